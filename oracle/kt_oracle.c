@@ -1,0 +1,440 @@
+/*
+ * kt_oracle.c - CPU restatement of kmertools' k-mer hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product path (kmertools_amd/, libkmertools_hip.so) never links or calls it.
+ *
+ * Parity pinning: the reference is pure Rust and cannot be built in this image
+ * (no cargo/rustc), so this restatement is pinned by the reference's committed
+ * fixtures and in-file known-answer tests (tests/golden/, tests/test_oracle_golden.py):
+ * expected_fa.kmers, expected_fa_batch_unnorm.kmers, expected_fa_header.kmers,
+ * expected_reads.k4.cgr, expected_counts.part_0_chunk_0, the merge fixtures,
+ * and the 70-entry k=31 list of kmer/src/kmer_minimisers.rs:216-288.
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose algorithm it follows.  The structure is deliberately the reference's
+ * (a serial rolling generator), NOT the GPU's position-parallel formulation,
+ * so that the two are independent derivations of the same contract.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* kmer/src/kmer.rs:6-15 (duplicated at kmer/src/lib.rs:7-16): byte -> code.
+ * A/a=0 C/c=1 G/g=2 T/t/U/u=3, raw bytes 0..3 map to themselves, rest = 4. */
+static uint8_t NT4[256];
+static pthread_once_t nt4_once = PTHREAD_ONCE_INIT;
+static void nt4_init(void) {
+    memset(NT4, 4, sizeof NT4);
+    NT4[0] = 0; NT4[1] = 1; NT4[2] = 2; NT4[3] = 3;
+    NT4['A'] = NT4['a'] = 0;
+    NT4['C'] = NT4['c'] = 1;
+    NT4['G'] = NT4['g'] = 2;
+    NT4['T'] = NT4['t'] = 3;
+    NT4['U'] = NT4['u'] = 3;
+}
+uint8_t kto_nt4(uint8_t c) {
+    pthread_once(&nt4_once, nt4_init);
+    return NT4[c];
+}
+
+/* ------------------------------------------------------------------------ */
+/* kmer/src/kmer.rs:18-41 KmerGenerator state + new() */
+typedef struct {
+    const uint8_t *seq;
+    uint64_t len_seq;
+    uint64_t fval, rval;
+    uint64_t len, pos, ksize;
+    uint64_t mask, shift;
+} kto_gen;
+
+void kto_gen_init(kto_gen *g, const uint8_t *seq, uint64_t n, uint64_t k) {
+    pthread_once(&nt4_once, nt4_init);
+    g->seq = seq; g->len_seq = n;
+    g->fval = g->rval = 0; g->len = 0; g->pos = 0; g->ksize = k;
+    g->mask = (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1); /* kmer.rs:38 (k<=31 in practice) */
+    g->shift = 2 * (k - 1);                                 /* kmer.rs:39 */
+}
+
+/* kmer/src/kmer.rs:80-106 Iterator::next.  Returns 1 and fills (f,r), or 0 at end. */
+int kto_gen_next(kto_gen *g, uint64_t *f, uint64_t *r) {
+    for (;;) {
+        if (g->pos == g->len_seq) return 0;                 /* :82-84 */
+        uint64_t fv = NT4[g->seq[g->pos]];                   /* :85-86 */
+        uint64_t rv = fv ^ 3;                                /* :87 */
+        g->pos += 1;                                         /* :88 */
+        if (fv < 4) {                                        /* :90-94 */
+            g->fval = ((g->fval << 2) | fv) & g->mask;
+            g->rval = (g->rval >> 2) | (rv << g->shift);
+            g->len += 1;
+        } else {
+            g->len = 0;                                      /* :95-98 */
+        }
+        if (g->len == g->ksize) {                            /* :100-103 */
+            g->len -= 1;
+            *f = g->fval; *r = g->rval;
+            return 1;
+        }
+    }
+}
+
+/* All (fwd,rev) pairs of one sequence in positional order; returns the count.
+ * `end_pos` (optional) receives the index of each k-mer's last base. */
+uint64_t kto_kmers(const uint8_t *seq, uint64_t n, uint64_t k,
+                   uint64_t *fwd, uint64_t *rev, uint64_t *end_pos) {
+    kto_gen g; kto_gen_init(&g, seq, n, k);
+    uint64_t f, r, c = 0;
+    while (kto_gen_next(&g, &f, &r)) {
+        if (fwd) fwd[c] = f;
+        if (rev) rev[c] = r;
+        if (end_pos) end_pos[c] = g.pos - 1;
+        c++;
+    }
+    return c;
+}
+
+/* kmer/src/kmer.rs:43-52 rev_comp */
+uint64_t kto_rev_comp(uint64_t kmer, uint64_t k) {
+    uint64_t rk = 0;
+    for (uint64_t i = 0; i < k; i++) {
+        rk <<= 2;
+        rk |= (kmer & 3) ^ 3;
+        kmer >>= 2;
+    }
+    return rk;
+}
+
+/* kmer/src/kmer.rs:54-73 kmer_pos_maps.
+ * min_mer_pos_map[4^k] (0 for non-canonical slots), pos_min_mer[count] (the
+ * HashMap pos->kmer as a dense array), returns count.  The reference collects
+ * min(kmer,rc) into a HashSet, sorts ascending, and numbers them. */
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) - (x < y);
+}
+uint64_t kto_pos_maps(uint64_t k, uint64_t *min_mer_pos_map, uint64_t *pos_min_mer) {
+    uint64_t n = 1ULL << (2 * k);
+    uint64_t *set = (uint64_t *)malloc(n * sizeof(uint64_t));
+    uint64_t cnt = 0;
+    for (uint64_t km = 0; km < n; km++) {
+        uint64_t rc = kto_rev_comp(km, k);
+        uint64_t mn = km < rc ? km : rc;
+        if (mn == km) set[cnt++] = km;   /* set membership: each canonical value once */
+        if (min_mer_pos_map) min_mer_pos_map[km] = 0;
+    }
+    qsort(set, cnt, sizeof(uint64_t), cmp_u64);
+    for (uint64_t pos = 0; pos < cnt; pos++) {
+        if (min_mer_pos_map) min_mer_pos_map[set[pos]] = pos;
+        if (pos_min_mer) pos_min_mer[pos] = set[pos];
+    }
+    free(set);
+    return cnt;
+}
+
+/* kmer/src/lib.rs:19-34 numeric_to_kmer (out must hold k+1 bytes) */
+void kto_numeric_to_kmer(uint64_t kmer, uint64_t k, char *out) {
+    static const char L[4] = {'A', 'C', 'G', 'T'};
+    for (uint64_t i = 0; i < k; i++) {
+        out[k - 1 - i] = L[kmer & 3];
+        kmer >>= 2;
+    }
+    out[k] = 0;
+}
+
+/* kmer/src/lib.rs:36-50 kmer_to_numeric (no validity check: 'N' contributes 4) */
+void kto_kmer_to_numeric(const char *s, uint64_t n, uint64_t *fwd, uint64_t *rev) {
+    pthread_once(&nt4_once, nt4_init);
+    uint64_t f = 0, r = 0;
+    uint64_t shift = 2 * (n - 1);
+    uint64_t mask = (n >= 32) ? ~0ULL : ((1ULL << (2 * n)) - 1);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t fv = NT4[(uint8_t)s[i]];
+        uint64_t rv = fv ^ 3;
+        f = ((f << 2) | fv) & mask;
+        r = (r >> 2) | (rv << shift);
+    }
+    *fwd = f; *rev = r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* composition/src/oligo.rs:231-259 vectorise_one (CLI crate, total_step=1)
+ * pybindings/src/oligo.rs:39-69   vectorise_one (python; raw mode total += 2)
+ * composition/src/oligocgr.rs:145-163 seq_to_kmer (== count_min=1)
+ * out has kcount (count_min) or 4^k (raw) doubles. */
+void kto_oligo_one(const uint8_t *seq, uint64_t n, uint64_t k, int count_min, int norm,
+                   double total_step, const uint64_t *pos_map, uint64_t bins, double *out) {
+    for (uint64_t i = 0; i < bins; i++) out[i] = 0.0;
+    double total = 0.0;
+    kto_gen g; kto_gen_init(&g, seq, n, k);
+    uint64_t f, r;
+    while (kto_gen_next(&g, &f, &r)) {
+        if (count_min) {
+            uint64_t mn = f < r ? f : r;           /* oligo.rs:243 */
+            out[pos_map[mn]] += 1.0;               /* :246-247 */
+            total += 1.0;                          /* :248 */
+        } else {
+            out[f] += 1.0;                         /* :250 */
+            total += total_step;                   /* :251 (1.0) / pybindings oligo.rs:61 (2.0) */
+        }
+    }
+    if (norm) {
+        double d = total > 1.0 ? total : 1.0;      /* f64::max(1, total) :255-257 */
+        for (uint64_t i = 0; i < bins; i++) out[i] /= d;
+    }
+}
+
+typedef struct {
+    const uint8_t *bases; const uint64_t *offsets; uint64_t n_reads; uint64_t k;
+    int count_min, norm; double total_step; const uint64_t *pos_map; uint64_t bins;
+    double *out; _Atomic uint64_t *next;
+} oligo_job;
+
+static void *oligo_worker(void *p) {
+    oligo_job *j = (oligo_job *)p;
+    for (;;) {
+        /* analogue of rayon par_iter over in-memory reads, pybindings/src/oligo.rs:77-81 */
+        uint64_t i0 = atomic_fetch_add(j->next, 256);
+        if (i0 >= j->n_reads) break;
+        uint64_t i1 = i0 + 256 < j->n_reads ? i0 + 256 : j->n_reads;
+        for (uint64_t i = i0; i < i1; i++)
+            kto_oligo_one(j->bases + j->offsets[i], j->offsets[i + 1] - j->offsets[i], j->k,
+                          j->count_min, j->norm, j->total_step, j->pos_map, j->bins,
+                          j->out + i * j->bins);
+    }
+    return NULL;
+}
+
+/* Batch over CSR reads into a preallocated n_reads x bins f64 matrix, `threads` workers. */
+int kto_oligo_batch(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t k,
+                    int count_min, int norm, double total_step, double *out, int threads) {
+    uint64_t n4k = 1ULL << (2 * k);
+    uint64_t *pos_map = (uint64_t *)malloc(n4k * sizeof(uint64_t));
+    uint64_t kcount = kto_pos_maps(k, pos_map, NULL);
+    uint64_t bins = count_min ? kcount : n4k;
+    _Atomic uint64_t next = 0;
+    oligo_job job = {bases, offsets, n_reads, k, count_min, norm, total_step, pos_map, bins, out, &next};
+    if (threads <= 1) {
+        oligo_worker(&job);
+    } else {
+        pthread_t *t = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+        for (int i = 0; i < threads; i++) pthread_create(&t[i], NULL, oligo_worker, &job);
+        for (int i = 0; i < threads; i++) pthread_join(t[i], NULL);
+        free(t);
+    }
+    free(pos_map);
+    return 0;
+}
+
+/* composition/src/oligocgr.rs:165-189 cgr_maps + :123-143 vectorise_one coordinate part.
+ * xy[2*i],xy[2*i+1] for canonical k-mer i (ascending numeric order); the coordinates
+ * are read-independent: start at centre, per base m = (corner + m)/2. */
+void kto_cgr_coords(uint64_t k, double vecsize, double *xy) {
+    uint64_t n4k = 1ULL << (2 * k);
+    uint64_t *pos_kmer = (uint64_t *)malloc(n4k * sizeof(uint64_t));
+    uint64_t kcount = kto_pos_maps(k, NULL, pos_kmer);
+    /* corners: A(0,0) T(vs,0) G(vs,vs) C(0,vs)  oligocgr.rs:166-170 ; codes A0 C1 G2 T3 */
+    const double cx[4] = {0.0, 0.0, vecsize, vecsize};
+    const double cy[4] = {0.0, vecsize, vecsize, 0.0};
+    char s[40];
+    for (uint64_t i = 0; i < kcount; i++) {
+        kto_numeric_to_kmer(pos_kmer[i], k, s);     /* oligocgr.rs:36-38 */
+        double mx = vecsize / 2.0, my = vecsize / 2.0;
+        for (uint64_t j = 0; j < k; j++) {          /* :129-134, string order = MSB base first */
+            int c = s[j] == 'A' ? 0 : s[j] == 'C' ? 1 : s[j] == 'G' ? 2 : 3;
+            mx = (cx[c] + mx) / 2.0;
+            my = (cy[c] + my) / 2.0;
+        }
+        xy[2 * i] = mx; xy[2 * i + 1] = my;
+    }
+    free(pos_kmer);
+}
+
+/* ------------------------------------------------------------------------ */
+/* counter/src/lib.rs:92-170 count_chunk + :172-234 merge, in memory.
+ * The reference keeps `n_parts` concurrent maps, owner = min_mer % n_parts
+ * (:100,:127), `entry(m).and_modify(+1).or_insert(1)` (:126-130), u32 counts.
+ * Here: n_parts open-addressing tables, each behind a mutex (the analogue of
+ * scc's bucket locks), worker-pull over reads (the analogue of
+ * records.lock().next(), :119). */
+typedef struct {
+    uint64_t *keys; uint32_t *vals; uint64_t cap, used; pthread_mutex_t mu;
+} kto_map;
+
+#define KTO_EMPTY 0xFFFFFFFFFFFFFFFFULL   /* canonical k-mers are < 2^62 (kmer.rs:38) */
+
+static inline uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+static void map_init(kto_map *m, uint64_t cap) {
+    m->cap = cap; m->used = 0;
+    m->keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    m->vals = (uint32_t *)calloc(cap, sizeof(uint32_t));
+    memset(m->keys, 0xFF, cap * sizeof(uint64_t));
+    pthread_mutex_init(&m->mu, NULL);
+}
+static void map_free(kto_map *m) { free(m->keys); free(m->vals); pthread_mutex_destroy(&m->mu); }
+
+static void map_add_nolock(kto_map *m, uint64_t key, uint32_t add);
+static void map_grow(kto_map *m) {
+    kto_map n; map_init(&n, m->cap * 2);
+    for (uint64_t i = 0; i < m->cap; i++)
+        if (m->keys[i] != KTO_EMPTY) map_add_nolock(&n, m->keys[i], m->vals[i]);
+    free(m->keys); free(m->vals);
+    m->keys = n.keys; m->vals = n.vals; m->cap = n.cap; m->used = n.used;
+    pthread_mutex_destroy(&n.mu);
+}
+static void map_add_nolock(kto_map *m, uint64_t key, uint32_t add) {
+    if ((m->used + 1) * 10 > m->cap * 7) map_grow(m);
+    uint64_t h = mix64(key) & (m->cap - 1);
+    for (;;) {
+        if (m->keys[h] == key) { m->vals[h] += add; return; }        /* and_modify / += (u32 wrap) */
+        if (m->keys[h] == KTO_EMPTY) { m->keys[h] = key; m->vals[h] = add; m->used++; return; } /* or_insert */
+        h = (h + 1) & (m->cap - 1);
+    }
+}
+
+typedef struct {
+    kto_map *parts; uint64_t n_parts;
+} kto_counter;
+
+kto_counter *kto_counter_new(uint64_t n_parts) {
+    kto_counter *c = (kto_counter *)malloc(sizeof(kto_counter));
+    c->n_parts = n_parts ? n_parts : 1;
+    c->parts = (kto_map *)malloc(sizeof(kto_map) * c->n_parts);
+    for (uint64_t i = 0; i < c->n_parts; i++) map_init(&c->parts[i], 1024);
+    return c;
+}
+void kto_counter_free(kto_counter *c) {
+    for (uint64_t i = 0; i < c->n_parts; i++) map_free(&c->parts[i]);
+    free(c->parts); free(c);
+}
+
+typedef struct {
+    kto_counter *c; const uint8_t *bases; const uint64_t *offsets; uint64_t n_reads, k;
+    _Atomic uint64_t *next;
+} count_job;
+
+static void *count_worker(void *p) {
+    count_job *j = (count_job *)p;
+    kto_counter *c = j->c;
+    for (;;) {
+        uint64_t i0 = atomic_fetch_add(j->next, 64);          /* records.lock().next() lib.rs:119 */
+        if (i0 >= j->n_reads) break;
+        uint64_t i1 = i0 + 64 < j->n_reads ? i0 + 64 : j->n_reads;
+        for (uint64_t i = i0; i < i1; i++) {
+            kto_gen g;
+            kto_gen_init(&g, j->bases + j->offsets[i], j->offsets[i + 1] - j->offsets[i], j->k);
+            uint64_t f, r;
+            while (kto_gen_next(&g, &f, &r)) {                /* lib.rs:123 */
+                uint64_t mn = f < r ? f : r;                   /* :124 */
+                kto_map *m = &c->parts[mn % c->n_parts];       /* :127 */
+                pthread_mutex_lock(&m->mu);
+                map_add_nolock(m, mn, 1);                      /* :128-130 */
+                pthread_mutex_unlock(&m->mu);
+            }
+        }
+    }
+    return NULL;
+}
+
+/* count_chunk's in-memory part: add every canonical k-mer of the reads. */
+int kto_counter_add_reads(kto_counter *c, const uint8_t *bases, const uint64_t *offsets,
+                          uint64_t n_reads, uint64_t k, int threads) {
+    pthread_once(&nt4_once, nt4_init);
+    _Atomic uint64_t next = 0;
+    count_job job = {c, bases, offsets, n_reads, k, &next};
+    if (threads <= 1) {
+        count_worker(&job);
+    } else {
+        pthread_t *t = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+        for (int i = 0; i < threads; i++) pthread_create(&t[i], NULL, count_worker, &job);
+        for (int i = 0; i < threads; i++) pthread_join(t[i], NULL);
+        free(t);
+    }
+    return 0;
+}
+
+/* merge's arithmetic (lib.rs:201-210): `*map.entry(kmer).or_insert(0) += count`. */
+int kto_counter_add_pairs(kto_counter *c, const uint64_t *keys, const uint32_t *counts, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++)
+        map_add_nolock(&c->parts[keys[i] % c->n_parts], keys[i], counts[i]);
+    return 0;
+}
+
+uint64_t kto_counter_size(const kto_counter *c) {
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < c->n_parts; i++) n += c->parts[i].used;
+    return n;
+}
+
+typedef struct { uint64_t k; uint32_t v; } kv_t;
+static int cmp_kv(const void *a, const void *b) {
+    uint64_t x = ((const kv_t *)a)->k, y = ((const kv_t *)b)->k;
+    return (x > y) - (x < y);
+}
+
+/* map.scan (lib.rs:162-165, :220-230).  The reference's line order is unspecified
+ * (its own tests sort); `sorted` != 0 returns keys ascending for comparisons. */
+uint64_t kto_counter_export(const kto_counter *c, uint64_t *keys, uint32_t *counts, int sorted) {
+    uint64_t n = kto_counter_size(c), o = 0;
+    kv_t *kv = (kv_t *)malloc((n ? n : 1) * sizeof(kv_t));
+    for (uint64_t p = 0; p < c->n_parts; p++) {
+        const kto_map *m = &c->parts[p];
+        for (uint64_t i = 0; i < m->cap; i++)
+            if (m->keys[i] != KTO_EMPTY) { kv[o].k = m->keys[i]; kv[o].v = m->vals[i]; o++; }
+    }
+    if (sorted) qsort(kv, n, sizeof(kv_t), cmp_kv);
+    for (uint64_t i = 0; i < n; i++) { keys[i] = kv[i].k; counts[i] = kv[i].v; }
+    free(kv);
+    return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic reads: NOT a reference algorithm - the build's own
+ * deterministic generator, mirrored bit-for-bit by the device generator
+ * (kmertools_amd/csrc/kt_synth.hip) so the oracle can regenerate any slice.
+ *   uniform   : base = mix64(seed + g) & 3, g = read*read_len + pos
+ *   genome    : reads sampled (both strands) from a genome_len-bp random genome
+ *               with 1 % substitution errors
+ *   noise     : base -> 'N' with p ~ 0.001, lower-cased with p ~ 0.01 */
+void kto_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint64_t read_len,
+                     int noise, uint64_t genome_len, uint8_t *bases) {
+    static const char L[4] = {'A', 'C', 'G', 'T'};
+    for (uint64_t i = 0; i < n_reads; i++) {
+        uint64_t rid = first_read + i;
+        uint64_t start = 0; int strand = 0;
+        if (genome_len) {
+            uint64_t hr = mix64(seed ^ 0x5eed5eed5eedULL ^ mix64(rid));
+            start = (hr >> 1) % (genome_len - read_len + 1);
+            strand = (int)(hr & 1);
+        }
+        for (uint64_t p = 0; p < read_len; p++) {
+            uint64_t g = rid * read_len + p;
+            uint64_t h = mix64(seed + g);
+            unsigned code;
+            if (genome_len) {
+                uint64_t j = strand ? start + (read_len - 1 - p) : start + p;
+                code = (unsigned)(mix64((seed ^ 0x67656e6f6d65ULL) + j) & 3);
+                if (strand) code = 3 - code;
+                if (((h >> 40) % 100) == 0) code = (code + 1 + (unsigned)((h >> 50) % 3)) & 3;
+            } else {
+                code = (unsigned)(h & 3);
+            }
+            uint8_t c = (uint8_t)L[code];
+            if (noise) {
+                if (((h >> 8) & 0xFFFFF) < 1049) c = 'N';
+                else if (((h >> 28) & 0xFFF) < 41) c = (uint8_t)(c | 0x20);
+            }
+            bases[i * read_len + p] = c;
+        }
+    }
+}

@@ -1,0 +1,156 @@
+"""Pins the CPU oracle (oracle/kt_oracle.c) to every fixture / known-answer test the
+reference holds for the hot path.  CPU only."""
+import numpy as np
+
+
+def _reads(oracle, golden, name="reads.fq"):
+    recs = oracle.read_records(golden / name)
+    return oracle.to_csr([s for _, s in recs]), recs
+
+
+def test_nt4_table(oracle):
+    # kmer/src/kmer.rs:6-15
+    valid = {ord(c): v for c, v in zip("ACGTUacgtu", [0, 1, 2, 3, 3, 0, 1, 2, 3, 3])}
+    valid.update({0: 0, 1: 1, 2: 2, 3: 3})
+    for c in range(256):
+        assert oracle.nt4(c) == valid.get(c, 4), c
+
+
+def test_kmer_pairs_inline(oracle, kat):
+    for case in kat["kmers"]:
+        f, r, _ = oracle.kmers(case["seq"], case["k"])
+        assert [[int(a), int(b)] for a, b in zip(f, r)] == case["pairs"], case["source"]
+
+
+def test_rev_comp_inline(oracle, kat):
+    for c in kat["rev_comp"]:
+        assert oracle.rev_comp(c["kmer"], c["k"]) == c["rc"]
+
+
+def test_pos_map_k4(oracle, kat):
+    m, pk, cnt = oracle.pos_maps(4)
+    e = kat["pos_map_k4"]
+    assert cnt == e["count"] and len(pk) == e["count"]
+    assert int((m > 0).sum()) == e["nonzero_entries"]
+    assert int(m.max()) < cnt
+    for idx, v in e["entries"].items():
+        assert int(m[int(idx)]) == v
+
+
+def test_kcount_formula(oracle):
+    # comment at kmer/src/kmer.rs:55
+    for k, want in [(3, 32), (4, 136), (5, 512), (6, 2080), (7, 8192)]:
+        assert oracle.pos_maps(k)[2] == want
+
+
+def test_numeric_roundtrip(oracle, kat):
+    for v, k, s in kat["numeric"]["to_acgt"]:
+        assert oracle.numeric_to_kmer(v, k) == s
+    for s, f, r in kat["numeric"]["to_numeric"]:
+        assert oracle.kmer_to_numeric(s) == (f, r)
+
+
+def test_py_kmers(oracle, kat):
+    c = kat["py_kmers"]
+    f, _, _ = oracle.kmers(c["seq"], c["k"])
+    assert [oracle.numeric_to_kmer(int(x), c["k"]) for x in f] == c["fwd_acgt"]
+
+
+def test_k31_canonical_kat(oracle, kat):
+    c = kat["k31"]
+    f, r, _ = oracle.kmers(c["seq"], 31)
+    got = [oracle.numeric_to_kmer(int(min(a, b)), 31) for a, b in zip(f, r)]
+    assert got == c["canonical_kmers_in_order"]
+    assert int(min(f[0], r[0])) == 0x0E6336CA6D8E889C
+
+
+def test_oligo_one_inline(oracle, kat):
+    c = kat["oligo_one"]
+    raw = oracle.oligo_one(c["seq"], 4, count_min=False)
+    assert len(raw) == c["raw_len"]
+    h = oracle.header(4, False)
+    assert h[0] == c["raw_header_first"] and h[-1] == c["raw_header_last"] and len(h) == len(raw)
+    assert oracle.oligo_one(c["seq"], 4, True, True)[0] == c["canon_norm_v0"]
+    un = oracle.oligo_one(c["seq"], 4, True, False)
+    assert un[0] == c["canon_unnorm_v0"] and un.sum() == c["canon_unnorm_sum"]
+    hc = oracle.header(4, True)
+    assert hc[0] == c["canon_header_0"] and hc[135] == c["canon_header_135"] and len(hc) == 136
+
+
+def test_oligo_files(oracle, golden):
+    (bases, offsets), _ = _reads(oracle, golden)
+    norm = oracle.oligo_batch(bases, offsets, 4, True, True)
+    assert oracle.oligo_text(norm, True) == (golden / "expected_fa.kmers").read_bytes()
+    cnt = oracle.oligo_batch(bases, offsets, 4, True, False)
+    assert oracle.oligo_text(cnt, False) == (golden / "expected_fa_batch_unnorm.kmers").read_bytes()
+    assert oracle.oligo_text(norm, True, header_line=oracle.header(4, True)) == \
+        (golden / "expected_fa_header.kmers").read_bytes()
+    # threaded worker-pull path gives identical rows (oligo.rs:327-368 repeats with 8 threads)
+    for _ in range(4):
+        assert np.array_equal(oracle.oligo_batch(bases, offsets, 4, True, True, threads=8), norm)
+
+
+def test_oligo_python_surface(oracle, golden):
+    # tests/test_oligo.py:8-25: round(x, 6) equality against expected_fa.kmers
+    (bases, offsets), _ = _reads(oracle, golden)
+    got = oracle.oligo_batch(bases, offsets, 4)
+    truth = [list(map(float, ln.split())) for ln in (golden / "expected_fa.kmers").read_text().splitlines()]
+    for g, t in zip(got, truth):
+        assert [round(float(x), 6) for x in g] == t
+
+
+def test_py_raw_total_quirk(oracle):
+    # pybindings/src/oligo.rs:61 -> normalised raw vectors sum to 0.5
+    v = oracle.oligo_one("ACGTACGTAC", 3, count_min=False, norm=True, total_step=2.0)
+    assert abs(v.sum() - 0.5) < 1e-15
+    v1 = oracle.oligo_one("ACGTACGTAC", 3, count_min=False, norm=True, total_step=1.0)
+    assert abs(v1.sum() - 1.0) < 1e-15
+
+
+def test_oligocgr(oracle, kat, golden):
+    c = kat["oligocgr_one"]
+    xy = oracle.cgr_coords(4, 16)
+    assert list(xy[0]) == c["first_point"]
+    assert oracle.oligo_one(c["seq"], 4, True, True)[0] == 1.0 / c["norm_first_freq_den"]
+    assert oracle.oligo_one(c["seq"], 4, True, False)[0] == c["unnorm_first_freq"]
+    (bases, offsets), _ = _reads(oracle, golden)
+    cnt = oracle.oligo_batch(bases, offsets, 4, True, False)
+    assert oracle.oligocgr_text(cnt, xy) == (golden / "expected_reads.k4.cgr").read_bytes()
+
+
+def test_counter_k15_file(oracle, golden):
+    (bases, offsets), _ = _reads(oracle, golden)
+    keys, counts = oracle.count_reads(bases, offsets, 15)
+    want = sorted((golden / "expected_counts.part_0_chunk_0").read_text().splitlines())
+    assert oracle.counts_lines(keys, counts) == want
+    # partitioned + threaded restatement agrees (n_parts only changes placement)
+    k2, c2 = oracle.count_reads(bases, offsets, 15, n_parts=3, threads=4)
+    assert np.array_equal(keys, k2) and np.array_equal(counts, c2)
+
+
+def test_counter_merge_fixtures(oracle, golden):
+    ctr = oracle.Counter(2)
+    for f in sorted((golden / "computed_counts_test").iterdir()):
+        rows = [ln.split("\t") for ln in f.read_text().splitlines() if ln.strip()]
+        ctr.add_pairs([int(a) for a, _ in rows], [int(b) for _, b in rows])
+    keys, counts = ctr.export()
+    assert oracle.counts_lines(keys, counts) == \
+        sorted((golden / "expected_counts_test.counts").read_text().splitlines())
+    assert oracle.counts_lines(keys, counts, k=15, acgt=True) == \
+        sorted((golden / "expected_counts_acgt_test.counts").read_text().splitlines())
+
+
+def test_reader_fixtures(oracle, kat, golden):
+    e = kat["reader"]
+    for name, ids in [("reads.fq", e["fq_ids"]), ("reads.fa", e["fa_ids"]), ("reads.fq.gz", e["fq_ids"])]:
+        recs = oracle.read_records(golden / name)
+        assert [r[0] for r in recs] == ids
+        assert [r[1].decode() for r in recs] == e["seqs"]
+        assert sum(len(r[1]) for r in recs) == e["total_length"]
+
+
+def test_display_format(oracle):
+    f = oracle.fmt_display
+    assert f(16.0) == "16" and f(0.5) == "0.5" and f(1 / 26) == "0.038461538461538464"
+    assert f(1e-7) == "0.0000001" and f(1e21) == "1000000000000000000000" and f(0.0) == "0"
+    assert f(1.5e-5) == "0.000015"
