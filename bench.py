@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X k-mer hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
+A "step" is one pass of the hot path over one batch of synthetic reads that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: `comp oligo k=4`,
+10 M x 150 bp reads, f64 rows (the reference's element type) on each GPU (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel: algorithmic bytes
+per launch (DESIGN.md "Measurement") / average launch duration measured with HIP events
+on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle (a C
+restatement of the reference's algorithm - the Rust reference cannot be built here)
+timed on this box's host cores on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 0x6b6d6572
+
+WORKLOADS = {
+    # name: kind, k, reads per GPU, read length, dtype, batch (reads per launch)
+    "comp_oligo_k4": dict(kind="oligo", k=4, n=10_000_000, L=150, dtype="f64", batch=10_000_000, cfg=1,
+                          desc="comp oligo k=4 canonical, 10M x 150bp synthetic reads per GPU, f64 rows"),
+    "comp_cgr_k7": dict(kind="oligo", k=7, n=10_000_000, L=150, dtype="f32", batch=1_000_000, cfg=4,
+                        desc="comp cgr k=7 (8192 canonical bins), 10M x 150bp per GPU, f32 rows, 1M-read output ring"),
+    "ctr_k15": dict(kind="ctr", k=15, n=50_000_000, L=150, cfg=2,
+                    desc="ctr k=15 canonical counts, 50M x 150bp per GPU, hash table in HBM"),
+    "ctr_k31": dict(kind="ctr", k=31, n=25_000_000, L=150, cfg=3,
+                    desc="ctr k=31 canonical counts, 25M x 150bp per GPU (200M over 8), hash-prefix sharded"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="comp_oligo_k4", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (debug; marks the line as reduced)")
+    ap.add_argument("--genome", type=int, default=0, help="ctr: sample reads from a random genome of this length")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline_oligo(k, L, seconds):
+    """CPU oracle (port of composition/src/oligo.rs:231-259 + rayon par_iter analogue) on host cores."""
+    from oracle import kt_oracle as oracle
+    cores = os.cpu_count() or 1
+    n = 100_000
+    hb, ho = oracle.synth_reads(SEED, n, L)
+    t0 = time.perf_counter()
+    oracle.oligo_batch(hb, ho, k, True, True, 1.0, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    n2 = int(min(max(n * seconds / dt, n), 4_000_000))
+    hb, ho = oracle.synth_reads(SEED, n2, L)
+    t0 = time.perf_counter()
+    oracle.oligo_batch(hb, ho, k, True, True, 1.0, threads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=n2 * L / dt / 1e9, unit="Gbases/s", cores=cores, kind="port",
+                sample="%d x %dbp synthetic reads, k=%d canonical f64 rows, %d threads, %.1f s"
+                       % (n2, L, k, cores, dt))
+
+
+def cpu_baseline_ctr(k, L, seconds, genome):
+    """CPU oracle (port of counter/src/lib.rs:100-131 sharded maps, in memory) on host cores."""
+    from oracle import kt_oracle as oracle
+    cores = os.cpu_count() or 1
+    n = 50_000
+    hb, ho = oracle.synth_reads(SEED, n, L, genome_len=genome)
+    t0 = time.perf_counter()
+    oracle.count_reads(hb, ho, k, n_parts=max(cores, 1) * 8, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    n2 = int(min(max(n * seconds / dt, n), 2_000_000))
+    hb, ho = oracle.synth_reads(SEED, n2, L, genome_len=genome)
+    c = oracle.Counter(max(cores, 1) * 8)
+    t0 = time.perf_counter()
+    c.add_reads(hb, ho, k, threads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=n2 * L / dt / 1e9, unit="Gbases/s", cores=cores, kind="port",
+                sample="%d x %dbp synthetic reads, k=%d, %d sharded maps, %d threads, %.1f s, in-memory count only"
+                       % (n2, L, k, cores * 8, cores, dt))
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from kmertools_amd import device
+
+    wl = dict(WORKLOADS[args.workload])
+    reduced = False
+    if args.reads:
+        wl["n"] = args.reads
+        wl["batch"] = min(wl.get("batch", args.reads), args.reads)
+        reduced = True
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream()
+    ctx = device.Context(local_rank, stream=stream.cuda_stream)
+    n, L, k = wl["n"], wl["L"], wl["k"]
+
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(SEED + wl["cfg"], n, L, bases, offsets, genome_len=args.genome, first_read=rank * n)
+    torch.cuda.synchronize()
+
+    launches_per_step = 1
+    if wl["kind"] == "oligo":
+        B = wl["batch"]
+        bins = device.bins(k, True)
+        tdt = torch.float64 if wl["dtype"] == "f64" else torch.float32
+        esz = 8 if wl["dtype"] == "f64" else 4
+        out = torch.empty((B, bins), dtype=tdt, device="cuda")
+        nb = (n + B - 1) // B
+        launches_per_step = nb
+        # per-batch views of the CSR arrays (offsets are absolute; each batch passes its slice base)
+        batch_args = []
+        for b in range(nb):
+            r0, r1 = b * B, min(n, (b + 1) * B)
+            if b == 0:
+                batch_args.append((bases, offsets, r1 - r0))
+            else:
+                # offsets slice must start at 0: rebase once, outside the timed region
+                o = (offsets[r0:r1 + 1] - offsets[r0]).contiguous()
+                batch_args.append((bases[r0 * L:], o, r1 - r0))
+        alg_bytes_per_launch = min(B, n) * (L + bins * esz)
+        dominant = "oligo_tile_kernel<k=%d,%s>" % (k, wl["dtype"])
+
+        def step():
+            for (bb, oo, cnt) in batch_args:
+                ctx.oligo(bb, oo, cnt, k, out, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+    else:
+        from kmertools_amd import dist as ktdist
+        kmers_per_read = L - k + 1
+        cap = 1 << max(20, (2 * n * kmers_per_read - 1).bit_length())
+        counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)
+        alg_bytes_per_launch = n * (L + kmers_per_read * 16)
+        dominant = "count_reads_kernel<k=%d>" % k
+
+        def step():
+            counter.clear()
+            counter.add_reads(bases, offsets, n)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n * L * args.steps / elapsed / 1e9
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
+    achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
+
+    extra = {}
+    if wl["kind"] == "ctr":
+        extra["distinct_rank0"] = counter.size_local()
+
+    if rank == 0:
+        line = {
+            "metric": "Gbases/s on comp-oligo k=4 and ctr k=31, 150bp synthetic reads, 1/2/4/8 GPU",
+            "value": round(value, 3),
+            "unit": "Gbases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": wl.get("dtype", "u64 keys / u32 counts"),
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "reads_per_gpu": n, "read_len": L, "k": k,
+                       "parallelism": "reads sharded by rank, no data-path collective" if wl["kind"] == "oligo"
+                       else "hash-prefix key ownership, RCCL all-to-all of routed k-mers",
+                       "reduced": reduced},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": dominant, "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu:
+            if wl["kind"] == "oligo":
+                line["cpu_baseline"] = cpu_baseline_oligo(k, L, args.cpu_seconds)
+            else:
+                line["cpu_baseline"] = cpu_baseline_ctr(k, L, args.cpu_seconds, args.genome)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

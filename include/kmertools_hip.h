@@ -1,0 +1,169 @@
+/*
+ * kmertools_hip.h - C ABI of libkmertools_hip.so, the MI355X (gfx950) drop-in for
+ * kmertools' k-mer hot path.
+ *
+ * The reference (anuradhawick/kmertools, pure Rust) has no FFI today; the entry
+ * points below are what a `extern "C"` block in the reference's crates would
+ * bind in place of the Rust functions cited on each declaration (paths relative
+ * to the reference root).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every input and output buffer;
+ *    the library owns device scratch inside kt_ctx / kt_ctr.
+ *  - every function returns KT_OK (0) or a KT_ERR_* code; kt_last_error() gives the
+ *    message for the calling thread.  Nothing aborts or throws across the ABI.
+ *  - read batches are CSR: `bases` = concatenated ASCII bytes (no separators),
+ *    `offsets` = uint64[n_reads + 1], read i = bases[offsets[i] .. offsets[i+1]).
+ *  - `mem` says where `bases`, `offsets` and the output buffers live:
+ *    KT_MEM_DEVICE = all are device (HBM) pointers, work is enqueued on the ctx
+ *    stream and the call returns without synchronising;
+ *    KT_MEM_HOST   = all are host pointers, the library stages them through its
+ *    own device scratch and returns after the results are back on the host.
+ *  - k-mers are uint64 (`type Kmer = u64`, kmer/src/lib.rs:4), 2 bits per base,
+ *    A=0 C=1 G=2 T=3, first base most significant.
+ */
+#ifndef KMERTOOLS_HIP_H
+#define KMERTOOLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KT_OK 0
+#define KT_ERR_ARG 1      /* bad argument (k out of range, null pointer, ...) */
+#define KT_ERR_HIP 2      /* a HIP runtime call failed; message has the HIP error */
+#define KT_ERR_NOMEM 3    /* device or host allocation failed */
+#define KT_ERR_FULL 4     /* k-mer table ran out of slots (raise capacity) */
+#define KT_ERR_NODEVICE 5 /* no usable gfx950 device */
+
+#define KT_MEM_HOST 0
+#define KT_MEM_DEVICE 1
+
+#define KT_F64 0 /* reference's element type (Vec<f64>) */
+#define KT_F32 1 /* BASELINE cfg5 output type */
+#define KT_U32 2 /* raw integer counts (norm must be 0) */
+
+#define KT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull /* never a k-mer: k <= 31 => key < 2^62 */
+
+typedef struct kt_ctx kt_ctx; /* one device + one stream; use from one host thread at a time */
+typedef struct kt_ctr kt_ctr; /* HBM-resident canonical k-mer count table */
+
+/* ---- library ----------------------------------------------------------------- */
+int kt_version(void);
+const char *kt_last_error(void);
+int kt_device_count(int *count);
+
+/* stream = a hipStream_t to enqueue on (e.g. the caller's / torch's current stream),
+ * or NULL to let the ctx create and own one. */
+int kt_ctx_create(int device, void *stream, kt_ctx **out);
+int kt_ctx_destroy(kt_ctx *ctx);
+int kt_ctx_sync(kt_ctx *ctx);
+
+/* ---- host-side helpers (no GPU work) ------------------------------------------ */
+
+/* number of output bins: canonical count (count_min != 0) or 4^k.
+ * replaces: `kcount` from KmerGenerator::kmer_pos_maps, kmer/src/kmer.rs:54-73;
+ *           the raw-mode size in composition/src/oligo.rs:232-236 */
+int kt_bins(int k, int count_min, uint64_t *bins);
+
+/* replaces: KmerGenerator::kmer_pos_maps, kmer/src/kmer.rs:54-73.
+ * min_mer_pos_map[4^k]: rank of canonical k-mer among canonicals (0 in non-canonical
+ * slots, as in the reference); pos_min_mer[kcount]: rank -> canonical k-mer (the
+ * reference's HashMap<pos,kmer> as a dense array).  Either may be NULL. */
+int kt_pos_map(int k, uint32_t *min_mer_pos_map, uint64_t *pos_min_mer, uint32_t *kcount);
+
+/* replaces: KmerGenerator::rev_comp, kmer/src/kmer.rs:43-52 */
+uint64_t kt_rev_comp(uint64_t kmer, int k);
+
+/* replaces: numeric_to_kmer, kmer/src/lib.rs:19-34 (out: k+1 bytes, NUL-terminated) */
+int kt_numeric_to_kmer(uint64_t kmer, int k, char *out);
+
+/* replaces: kmer_to_numeric, kmer/src/lib.rs:36-50 (no validity check, like the
+ * reference; len > 32 is KT_ERR_ARG = the ValueError of pybindings/src/kmer.rs:58-63) */
+int kt_kmer_to_numeric(const char *kmer, uint64_t len, uint64_t *fwd, uint64_t *rev);
+
+/* replaces: OligoCgrComputer::cgr_maps + the per-k-mer midpoint walk,
+ * composition/src/oligocgr.rs:165-189, :123-143.  xy[2*i], xy[2*i+1] = CGR point of
+ * canonical k-mer i; read-independent, so computed once on the host. */
+int kt_cgr_coords(int k, double vecsize, double *xy);
+
+/* ---- device hot path ----------------------------------------------------------- */
+
+/* replaces: KmerGenerator::new + Iterator::next, kmer/src/kmer.rs:30-41, :80-106
+ * (and pybindings/src/kmer.rs:22-41).  Position-parallel form: for every base index
+ * g in [0, offsets[n_reads]) valid[g] = 1 iff a k-mer ends at that base (its k bases
+ * lie in one read and are all ACGTU/acgtu/0..3), and then fwd[g], rev[g] hold the
+ * pair the reference's iterator yields at that position.  Iterating g in order and
+ * skipping valid[g]==0 reproduces the iterator.  1 <= k <= 31. */
+int kt_kmers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+             int k, uint64_t *fwd, uint64_t *rev, uint8_t *valid, int mem);
+
+/* replaces: OligoComputer::vectorise_one, composition/src/oligo.rs:231-259;
+ *           OligoCgrComputer::seq_to_kmer, composition/src/oligocgr.rs:145-163;
+ *           python OligoComputer.vectorise_one/_batch, pybindings/src/oligo.rs:39-81.
+ * out: n_reads x bins row-major (bins from kt_bins), element type out_dtype.
+ * count_min: merge reverse complements (canonical bins) / 0 = raw 4^k bins.
+ * norm: divide every bin by max(1, total), total = total_step * (#k-mers of the read).
+ * total_step: 1 (CLI crate, oligo.rs:248,251) or 2 (python raw mode, pybindings
+ * oligo.rs:61).  KT_F64 results are bit-identical to the reference (integer counts,
+ * one IEEE division).  3 <= k <= 7 (the CLI range, kmertools/src/args.rs:85). */
+int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                   int k, int count_min, int norm, int total_step, int out_dtype, void *out,
+                   int mem);
+
+/* replaces: CountComputer::new / count_chunk's table, counter/src/lib.rs:37-55, :100.
+ * One HBM-resident open-addressing table (u64 keys, u32 counts - the reference's
+ * types) takes the place of the reference's n_parts scc maps and chunk files.
+ * capacity_slots is rounded up to a power of two; keep distinct keys <= ~70 % of it. */
+int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out);
+int kt_ctr_destroy(kt_ctr *ctr);
+int kt_ctr_clear(kt_ctr *ctr);
+
+/* replaces: the hot loop of count_chunk, counter/src/lib.rs:119-131:
+ * for every k-mer of every read: table[min(fwd,rev)] += 1.  Repeatable (= chunks). */
+int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
+                     uint64_t n_reads, int mem);
+
+/* replaces: merge's arithmetic, counter/src/lib.rs:201-210: table[keys[i]] += counts[i]
+ * (counts == NULL means 1 each: raw canonical k-mers routed from another GPU). */
+int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, uint64_t n,
+                     int mem);
+
+/* number of distinct k-mers in the table (synchronises). KT_ERR_FULL if an insert overflowed. */
+int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct);
+
+/* replaces: map.scan, counter/src/lib.rs:162-165, :220-230.  Writes up to max_out
+ * (key,count) pairs in unspecified order (the reference's order is unspecified too,
+ * its tests sort); *n_out = number written.  Synchronises. */
+int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_out,
+                  uint64_t *n_out, int mem);
+
+/* Multi-GPU routing step (the reference's `min_mer % n_parts` partitioning,
+ * counter/src/lib.rs:127, re-expressed as hash-prefix ownership):
+ * writes every canonical k-mer of the reads into keys_out grouped by owner
+ * o = kt_owner_of(kmer, n_owners); owner_counts[o] = group sizes (groups are
+ * contiguous, in owner order).  keys_out needs room for offsets[n_reads] entries
+ * (upper bound).  owner_counts follows `mem`.  1 <= n_owners <= 64. */
+int kt_ctr_route(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                 int k, int n_owners, uint64_t *keys_out, uint64_t *owner_counts, int mem);
+
+/* owner rank of a canonical k-mer among n_owners (host helper, same function the
+ * device uses): high bits of a 64-bit mix, independent of the table's slot bits. */
+uint32_t kt_owner_of(uint64_t kmer, uint32_t n_owners);
+
+/* Synthetic reads for benchmarks/parity, generated in HBM:
+ * bases_dev[n_reads*read_len], offsets_dev[n_reads+1] (may be NULL).  Deterministic
+ * in (seed, first_read + i, pos); genome_len == 0: i.i.d. uniform ACGT, else reads
+ * sampled from a random genome_len-bp genome (both strands, 1 % substitutions);
+ * noise: ~0.1 % N, ~1 % lower case.  Device pointers only. */
+int kt_synth_reads(kt_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                   uint32_t read_len, int noise, uint64_t genome_len, uint8_t *bases_dev,
+                   uint64_t *offsets_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERTOOLS_HIP_H */

@@ -1,0 +1,487 @@
+// kt_ctr.hip - canonical k-mer counting in an HBM-resident table, plus the hash-prefix
+// routing step used when the table is sharded over several GPUs, plus the debug
+// k-mer generator surface (kt_kmers).
+//
+// Replaces CountComputer::count_chunk / merge (reference counter/src/lib.rs:92-234):
+// the reference's n_parts concurrent hash maps, chunked spill to text files and
+// per-partition re-merge collapse into one open-addressing table that stays in HBM
+// (u64 keys + u32 counts in separate arrays, so the increment is a plain 32-bit
+// atomic once a 64-bit CAS has claimed the slot).  HBM-bound random access; no MFMA.
+#include <vector>
+
+#include "kt_internal.hpp"
+#include "kt_segment.hpp"
+
+namespace {
+
+using ktseg::SegArgs;
+using ktseg::SegShared;
+
+constexpr int BLOCK = ktseg::BLOCK;
+
+// ---- table primitives -------------------------------------------------------------
+
+// table[key] += add.  Linear probing; a slot's key goes EMPTY -> key exactly once, so a
+// stale (cached) read can only show EMPTY for a slot that is now taken, and the CAS
+// (device scope, coherent across XCDs) settles that case.
+__device__ __forceinline__ bool table_add(uint64_t *__restrict__ keys, uint32_t *__restrict__ counts,
+                                          uint64_t mask, uint64_t key, uint32_t add) {
+    uint64_t slot = ktd::mix64(key) & mask;
+    for (uint64_t probe = 0; probe <= mask; probe++) {
+        uint64_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == KT_EMPTY_KEY) {
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[slot]),
+                                            (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key);
+            cur = (prev == KT_EMPTY_KEY) ? key : prev;
+        }
+        if (cur == key) {
+            atomicAdd(&counts[slot], add);
+            return true;
+        }
+        slot = (slot + 1) & mask;
+    }
+    return false;
+}
+
+struct TableRef {
+    uint64_t *keys;
+    uint32_t *counts;
+    uint64_t mask;
+    uint32_t *flags;
+};
+
+__global__ __launch_bounds__(BLOCK) void count_reads_kernel(SegArgs a, TableRef t) {
+    __shared__ SegShared sm;
+    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
+        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
+            const uint64_t m = f < r ? f : r;  // counter/src/lib.rs:124
+            if (!table_add(t.keys, t.counts, t.mask, m, 1u)) atomicOr(t.flags, 1u);
+        });
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void add_pairs_kernel(const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ counts, uint64_t n,
+                                                          TableRef t) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t key = keys[i];
+        const uint32_t c = counts ? counts[i] : 1u;
+        if (key == KT_EMPTY_KEY) continue;
+        if (!table_add(t.keys, t.counts, t.mask, key, c)) atomicOr(t.flags, 1u);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void table_size_kernel(const uint64_t *__restrict__ keys, uint64_t cap,
+                                                           uint64_t *__restrict__ out) {
+    uint64_t n = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK)
+        n += keys[i] != KT_EMPTY_KEY;
+    // wave reduction, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(reinterpret_cast<unsigned long long *>(out), (unsigned long long)n);
+}
+
+// stream the table, compact occupied slots: ballot + one cursor atomic per wave
+__global__ __launch_bounds__(BLOCK) void table_export_kernel(const uint64_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ counts, uint64_t cap,
+                                                             uint64_t *__restrict__ out_keys,
+                                                             uint32_t *__restrict__ out_counts, uint64_t max_out,
+                                                             uint64_t *__restrict__ cursor) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    const uint64_t rounds = (cap + stride - 1) / stride;
+    for (uint64_t it = 0; it < rounds; it++) {
+        const uint64_t i = it * stride + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+        uint64_t key = KT_EMPTY_KEY;
+        if (i < cap) key = keys[i];
+        const bool occ = key != KT_EMPTY_KEY;
+        const uint64_t bal = __ballot(occ);
+        if (bal == 0) continue;
+        uint64_t base = 0;
+        if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(cursor), (unsigned long long)__popcll(bal));
+        base = ktd::uniform64(base);
+        if (occ) {
+            const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < max_out) {
+                out_keys[pos] = key;
+                out_counts[pos] = counts[i];
+            }
+        }
+    }
+}
+
+// ---- routing (multi-GPU ownership) ------------------------------------------------------
+
+constexpr int MAX_OWNERS = 64;
+
+__global__ __launch_bounds__(BLOCK) void route_count_kernel(SegArgs a, uint32_t n_owners,
+                                                            uint64_t *__restrict__ owner_counts) {
+    __shared__ SegShared sm;
+    __shared__ uint32_t cnt[MAX_OWNERS];
+    if (threadIdx.x < MAX_OWNERS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
+        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
+            const uint64_t m = f < r ? f : r;
+            atomicAdd(&cnt[ktd::owner_of(m, n_owners)], 1u);
+        });
+        if (threadIdx.x < n_owners && cnt[threadIdx.x]) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&owner_counts[threadIdx.x]),
+                      (unsigned long long)cnt[threadIdx.x]);
+            cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// cursors[o] starts at the exclusive prefix of owner_counts; each workgroup reserves a
+// contiguous range per owner for its segment, then its lanes fill the range.
+__global__ __launch_bounds__(BLOCK) void route_scatter_kernel(SegArgs a, uint32_t n_owners,
+                                                              uint64_t *__restrict__ cursors,
+                                                              uint64_t *__restrict__ keys_out) {
+    __shared__ SegShared sm;
+    __shared__ uint32_t cnt[MAX_OWNERS];
+    __shared__ uint64_t base[MAX_OWNERS];
+    if (threadIdx.x < MAX_OWNERS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
+        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
+            const uint64_t m = f < r ? f : r;
+            atomicAdd(&cnt[ktd::owner_of(m, n_owners)], 1u);
+        });
+        if (threadIdx.x < n_owners) {
+            const uint32_t c = cnt[threadIdx.x];
+            base[threadIdx.x] = c ? atomicAdd(reinterpret_cast<unsigned long long *>(&cursors[threadIdx.x]),
+                                              (unsigned long long)c)
+                                  : 0;
+            cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
+            const uint64_t m = f < r ? f : r;
+            const uint32_t o = ktd::owner_of(m, n_owners);
+            const uint32_t slot = atomicAdd(&cnt[o], 1u);
+            keys_out[base[o] + slot] = m;
+        });
+        if (threadIdx.x < MAX_OWNERS) cnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+
+__global__ void route_prefix_kernel(const uint64_t *__restrict__ owner_counts, uint32_t n_owners,
+                                    uint64_t *__restrict__ cursors) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t acc = 0;
+        for (uint32_t o = 0; o < n_owners; o++) {
+            cursors[o] = acc;
+            acc += owner_counts[o];
+        }
+    }
+}
+
+// ---- debug surface -------------------------------------------------------------------------
+
+__global__ __launch_bounds__(BLOCK) void kmers_kernel(SegArgs a, uint64_t *__restrict__ fwd,
+                                                      uint64_t *__restrict__ rev, uint8_t *__restrict__ valid) {
+    __shared__ SegShared sm;
+    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
+        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t end) {
+            fwd[end] = f;
+            rev[end] = r;
+            valid[end] = 1;
+        });
+    }
+}
+
+// ---- host helpers ----------------------------------------------------------------------------
+
+uint32_t grid_for(const kt_ctx *ctx, uint64_t work_items, uint32_t per_cu) {
+    uint64_t g = (uint64_t)ctx->n_cu * per_cu;
+    if (g > work_items) g = work_items;
+    if (g < 1) g = 1;
+    return (uint32_t)g;
+}
+
+// Builds SegArgs for device-resident CSR input (seg_first lives in ctx scratch s_aux0).
+int make_seg_args(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                  uint64_t total_bases, int k, SegArgs *out) {
+    const uint64_t n_seg = (total_bases + ktseg::SEG - 1) / ktseg::SEG;
+    if (int rc = ctx->s_aux0.reserve((n_seg + 2) * sizeof(uint64_t))) return rc;
+    uint64_t *seg_first = (uint64_t *)ctx->s_aux0.p;
+    const uint64_t threads = n_reads + 1;
+    const uint32_t blocks = (uint32_t)((threads + 255) / 256);
+    hipLaunchKernelGGL(ktseg::seg_index_kernel, dim3(blocks), dim3(256), 0, ctx->stream, offsets, n_reads,
+                       seg_first, n_seg);
+    KT_HIP(hipGetLastError());
+    out->bases = bases;
+    out->offsets = offsets;
+    out->seg_first = seg_first;
+    out->n_reads = n_reads;
+    out->n_seg = n_seg;
+    out->k = (uint32_t)k;
+    return KT_OK;
+}
+
+// total number of bases = offsets[n_reads]; needs a read-back for device offsets
+int total_bases_of(kt_ctx *ctx, const uint64_t *offsets, uint64_t n_reads, int mem, uint64_t *total) {
+    if (mem == KT_MEM_HOST) {
+        *total = offsets[n_reads];
+        return KT_OK;
+    }
+    KT_HIP(hipMemcpyAsync(total, offsets + n_reads, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
+    return KT_OK;
+}
+
+// copies a host CSR batch into ctx scratch; returns device pointers
+int stage_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                const uint8_t **d_bases, const uint64_t **d_offsets) {
+    const uint64_t total = offsets[n_reads];
+    if (offsets[0] != 0) return kt::fail(KT_ERR_ARG, "offsets[0] must be 0");
+    if (int rc = ctx->s_bases.reserve(total + 64)) return rc;
+    if (int rc = ctx->s_offsets.reserve((n_reads + 1) * 8)) return rc;
+    if (total) KT_HIP(hipMemcpyAsync(ctx->s_bases.p, bases, total, hipMemcpyHostToDevice, ctx->stream));
+    KT_HIP(hipMemcpyAsync(ctx->s_offsets.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    *d_bases = (const uint8_t *)ctx->s_bases.p;
+    *d_offsets = (const uint64_t *)ctx->s_offsets.p;
+    return KT_OK;
+}
+
+int check_overflow(kt_ctr *ctr) {
+    uint32_t flag = 0;
+    KT_HIP(hipMemcpyAsync(&flag, ctr->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctr->ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctr->ctx->stream));
+    if (flag) return kt::fail(KT_ERR_FULL, "k-mer table is full: raise capacity_slots");
+    return KT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
+    if (!ctx || !out) return kt::fail(KT_ERR_ARG, "kt_ctr_create: null");
+    *out = nullptr;
+    if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_ctr_create: k must be in 1..31");
+    if (int rc = ctx->use()) return rc;
+    uint64_t cap = 1024;
+    while (cap < capacity_slots) cap <<= 1;
+    kt_ctr *c = new (std::nothrow) kt_ctr();
+    if (!c) return kt::fail(KT_ERR_NOMEM, "kt_ctr_create: host alloc");
+    c->ctx = ctx;
+    c->k = k;
+    c->cap = cap;
+    hipError_t e = hipMalloc((void **)&c->keys, cap * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->counts, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
+    if (e != hipSuccess) {
+        kt_ctr_destroy(c);
+        return kt::fail(KT_ERR_NOMEM, std::string("kt_ctr_create: hipMalloc: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return kt_ctr_clear(c);
+}
+
+int kt_ctr_destroy(kt_ctr *ctr) {
+    if (!ctr) return KT_OK;
+    if (ctr->ctx) {
+        (void)hipSetDevice(ctr->ctx->device);
+        (void)hipStreamSynchronize(ctr->ctx->stream);
+    }
+    if (ctr->keys) (void)hipFree(ctr->keys);
+    if (ctr->counts) (void)hipFree(ctr->counts);
+    if (ctr->flags) (void)hipFree(ctr->flags);
+    if (ctr->cursor) (void)hipFree(ctr->cursor);
+    delete ctr;
+    return KT_OK;
+}
+
+int kt_ctr_clear(kt_ctr *ctr) {
+    if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_clear: null");
+    if (int rc = ctr->ctx->use()) return rc;
+    KT_HIP(hipMemsetAsync(ctr->keys, 0xFF, ctr->cap * sizeof(uint64_t), ctr->ctx->stream));
+    KT_HIP(hipMemsetAsync(ctr->counts, 0, ctr->cap * sizeof(uint32_t), ctr->ctx->stream));
+    KT_HIP(hipMemsetAsync(ctr->flags, 0, 64, ctr->ctx->stream));
+    return KT_OK;
+}
+
+int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int mem) {
+    if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads: null ctr");
+    if (n_reads == 0) return KT_OK;
+    if (!offsets) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads: null offsets");
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    uint64_t total = 0;
+    if (int rc = total_bases_of(ctx, offsets, n_reads, mem, &total)) return rc;
+    if (total == 0) return KT_OK;
+    if (!bases) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads: null bases");
+    const uint8_t *d_bases = bases;
+    const uint64_t *d_offsets = offsets;
+    if (mem == KT_MEM_HOST) {
+        if (int rc = stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) return rc;
+    }
+    SegArgs a;
+    if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
+    TableRef t{ctr->keys, ctr->counts, ctr->cap - 1, ctr->flags};
+    hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t);
+    KT_HIP(hipGetLastError());
+    if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
+    return KT_OK;
+}
+
+int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, uint64_t n, int mem) {
+    if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_add_pairs: null ctr");
+    if (n == 0) return KT_OK;
+    if (!keys) return kt::fail(KT_ERR_ARG, "kt_ctr_add_pairs: null keys");
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    const uint64_t *d_keys = keys;
+    const uint32_t *d_counts = counts;
+    if (mem == KT_MEM_HOST) {
+        if (int rc = ctx->s_aux1.reserve(n * 8)) return rc;
+        KT_HIP(hipMemcpyAsync(ctx->s_aux1.p, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_keys = (const uint64_t *)ctx->s_aux1.p;
+        if (counts) {
+            if (int rc = ctx->s_aux2.reserve(n * 4)) return rc;
+            KT_HIP(hipMemcpyAsync(ctx->s_aux2.p, counts, n * 4, hipMemcpyHostToDevice, ctx->stream));
+            d_counts = (const uint32_t *)ctx->s_aux2.p;
+        }
+    }
+    TableRef t{ctr->keys, ctr->counts, ctr->cap - 1, ctr->flags};
+    hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
+                       ctx->stream, d_keys, d_counts, n, t);
+    KT_HIP(hipGetLastError());
+    if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
+    return KT_OK;
+}
+
+int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct) {
+    if (!ctr || !distinct) return kt::fail(KT_ERR_ARG, "kt_ctr_size: null");
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(table_size_kernel, dim3(grid_for(ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
+                       ctx->stream, ctr->keys, ctr->cap, ctr->cursor);
+    KT_HIP(hipGetLastError());
+    KT_HIP(hipMemcpyAsync(distinct, ctr->cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
+    return check_overflow(ctr);
+}
+
+int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_out, uint64_t *n_out, int mem) {
+    if (!ctr || !n_out) return kt::fail(KT_ERR_ARG, "kt_ctr_export: null");
+    if (max_out && (!keys || !counts)) return kt::fail(KT_ERR_ARG, "kt_ctr_export: null output");
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    if (int rc = check_overflow(ctr)) return rc;
+    uint64_t *d_keys = keys;
+    uint32_t *d_counts = counts;
+    if (mem == KT_MEM_HOST && max_out) {
+        if (int rc = ctx->s_aux1.reserve(max_out * 8)) return rc;
+        if (int rc = ctx->s_aux2.reserve(max_out * 4)) return rc;
+        d_keys = (uint64_t *)ctx->s_aux1.p;
+        d_counts = (uint32_t *)ctx->s_aux2.p;
+    }
+    KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
+                       ctx->stream, ctr->keys, ctr->counts, ctr->cap, d_keys, d_counts, max_out, ctr->cursor);
+    KT_HIP(hipGetLastError());
+    uint64_t n = 0;
+    KT_HIP(hipMemcpyAsync(&n, ctr->cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t written = n < max_out ? n : max_out;
+    if (mem == KT_MEM_HOST && written) {
+        KT_HIP(hipMemcpy(keys, d_keys, written * 8, hipMemcpyDeviceToHost));
+        KT_HIP(hipMemcpy(counts, d_counts, written * 4, hipMemcpyDeviceToHost));
+    }
+    *n_out = written;
+    if (n > max_out) return kt::fail(KT_ERR_ARG, "kt_ctr_export: max_out smaller than the table's size");
+    return KT_OK;
+}
+
+int kt_ctr_route(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k,
+                 int n_owners, uint64_t *keys_out, uint64_t *owner_counts, int mem) {
+    if (!ctx || !owner_counts) return kt::fail(KT_ERR_ARG, "kt_ctr_route: null");
+    if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_ctr_route: k must be in 1..31");
+    if (n_owners < 1 || n_owners > MAX_OWNERS) return kt::fail(KT_ERR_ARG, "kt_ctr_route: n_owners must be in 1..64");
+    if (int rc = ctx->use()) return rc;
+    // device scalars: [0..63] owner counts, [64..127] cursors
+    if (int rc = ctx->s_aux2.reserve(2 * MAX_OWNERS * 8)) return rc;
+    uint64_t *d_counts = (uint64_t *)ctx->s_aux2.p;
+    uint64_t *d_cursors = d_counts + MAX_OWNERS;
+    KT_HIP(hipMemsetAsync(d_counts, 0, 2 * MAX_OWNERS * 8, ctx->stream));
+    uint64_t total = 0;
+    if (n_reads) {
+        if (!offsets) return kt::fail(KT_ERR_ARG, "kt_ctr_route: null offsets");
+        if (int rc = total_bases_of(ctx, offsets, n_reads, mem, &total)) return rc;
+    }
+    uint64_t *d_keys = keys_out;
+    if (total) {
+        if (!bases || !keys_out) return kt::fail(KT_ERR_ARG, "kt_ctr_route: null buffer");
+        const uint8_t *d_bases = bases;
+        const uint64_t *d_offsets = offsets;
+        if (mem == KT_MEM_HOST) {
+            if (int rc = stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) return rc;
+            if (int rc = ctx->s_aux1.reserve(total * 8)) return rc;
+            d_keys = (uint64_t *)ctx->s_aux1.p;
+        }
+        SegArgs a;
+        if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, k, &a)) return rc;
+        const uint32_t grid = grid_for(ctx, a.n_seg, 8);
+        hipLaunchKernelGGL(route_count_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, a, (uint32_t)n_owners, d_counts);
+        hipLaunchKernelGGL(route_prefix_kernel, dim3(1), dim3(64), 0, ctx->stream, d_counts, (uint32_t)n_owners, d_cursors);
+        hipLaunchKernelGGL(route_scatter_kernel, dim3(grid), dim3(BLOCK), 0, ctx->stream, a, (uint32_t)n_owners,
+                           d_cursors, d_keys);
+        KT_HIP(hipGetLastError());
+    }
+    if (mem == KT_MEM_DEVICE) {
+        KT_HIP(hipMemcpyAsync(owner_counts, d_counts, n_owners * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return KT_OK;
+    }
+    KT_HIP(hipMemcpyAsync(owner_counts, d_counts, n_owners * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t n_keys = 0;
+    for (int o = 0; o < n_owners; o++) n_keys += owner_counts[o];
+    if (n_keys) KT_HIP(hipMemcpy(keys_out, d_keys, n_keys * 8, hipMemcpyDeviceToHost));
+    return KT_OK;
+}
+
+int kt_kmers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, uint64_t *fwd,
+             uint64_t *rev, uint8_t *valid, int mem) {
+    if (!ctx) return kt::fail(KT_ERR_ARG, "kt_kmers: null ctx");
+    if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_kmers: k must be in 1..31");
+    if (n_reads == 0) return KT_OK;
+    if (!offsets) return kt::fail(KT_ERR_ARG, "kt_kmers: null offsets");
+    if (int rc = ctx->use()) return rc;
+    uint64_t total = 0;
+    if (int rc = total_bases_of(ctx, offsets, n_reads, mem, &total)) return rc;
+    if (total == 0) return KT_OK;
+    if (!bases || !fwd || !rev || !valid) return kt::fail(KT_ERR_ARG, "kt_kmers: null buffer");
+    const uint8_t *d_bases = bases;
+    const uint64_t *d_offsets = offsets;
+    uint64_t *d_fwd = fwd, *d_rev = rev;
+    uint8_t *d_valid = valid;
+    if (mem == KT_MEM_HOST) {
+        if (int rc = stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) return rc;
+        if (int rc = ctx->s_out.reserve(total * 17)) return rc;
+        d_fwd = (uint64_t *)ctx->s_out.p;
+        d_rev = d_fwd + total;
+        d_valid = (uint8_t *)(d_rev + total);
+    }
+    KT_HIP(hipMemsetAsync(d_valid, 0, total, ctx->stream));
+    SegArgs a;
+    if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, k, &a)) return rc;
+    hipLaunchKernelGGL(kmers_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, d_fwd, d_rev,
+                       d_valid);
+    KT_HIP(hipGetLastError());
+    if (mem == KT_MEM_HOST) {
+        KT_HIP(hipMemcpyAsync(fwd, d_fwd, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipMemcpyAsync(rev, d_rev, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipMemcpyAsync(valid, d_valid, total, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return KT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Device-side building blocks shared by the gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ktd {
+
+constexpr int WAVE = 64;
+
+// byte -> 2-bit code + validity; arithmetic form of SEQ_NT4_TABLE (reference
+// kmer/src/kmer.rs:6-15): A/a 0, C/c 1, G/g 2, T/t/U/u 3, raw bytes 0..3 themselves.
+// Returns code | 4 for every other byte.
+__device__ __forceinline__ uint32_t nt4(uint32_t c) {
+    const uint32_t idx = (c & 0xDFu) - 0x41u;              // fold case; 'A' -> 0
+    // letters A(0) C(2) G(6) T(19) U(20)
+    const bool letter = idx < 21u && ((0x00180045u >> idx) & 1u);
+    const bool raw = c < 4u;
+    const uint32_t code = raw ? c : (((c >> 1) ^ (c >> 2)) & 3u);
+    return (letter || raw) ? code : (code | 4u);
+}
+
+// splitmix64 finaliser: table slot hash, owner hash and the synthetic-read generator
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+// owner of a canonical k-mer among n owners: top 32 bits of the mix, multiply-shift
+__host__ __device__ __forceinline__ uint32_t owner_of(uint64_t kmer, uint32_t n) {
+    return (uint32_t)(((mix64(kmer) >> 32) * (uint64_t)n) >> 32);
+}
+
+// reverse complement of a packed k-mer (2 bits/base) without a loop:
+// complement, reverse the 2-bit groups of the 64-bit word, shift down.
+__host__ __device__ __forceinline__ uint64_t rev_comp(uint64_t x, int k) {
+    x = ~x;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * k);
+}
+
+// lane l receives the value of lane l-1; lane 0 receives `fill` (DPP wave_shr:1, gfx9)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// uniform (scalar) broadcast of a 64-bit value held by all lanes
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+}  // namespace ktd

@@ -1,0 +1,261 @@
+// Host side of the C ABI: error reporting, ctx lifetime, and the integer helpers
+// (canonical-rank map, reverse complement, numeric<->ACGT, CGR coordinates).
+// Behaviour follows the reference functions cited in include/kmertools_hip.h; the
+// implementations are this library's own (enumeration in ascending order instead
+// of HashSet+sort, bit tricks instead of per-base loops).
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "kt_device.hpp"
+#include "kt_internal.hpp"
+
+namespace kt {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+int Scratch::reserve(size_t bytes) {
+    if (bytes <= cap) return KT_OK;
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        return fail(KT_ERR_NOMEM, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
+    }
+    cap = want;
+    return KT_OK;
+}
+void Scratch::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+uint64_t rev_comp_bits(uint64_t kmer, int k) { return ktd::rev_comp(kmer, k); }
+
+uint32_t build_canon_lut(int k, uint16_t *lut_full) {
+    const uint64_t n = 1ull << (2 * k);
+    // ascending enumeration visits canonical k-mers (km <= rc(km)) in sorted order,
+    // so their rank is a running counter; non-canonical k-mers take their partner's rank.
+    uint32_t rank = 0;
+    for (uint64_t km = 0; km < n; km++) {
+        uint64_t rc = ktd::rev_comp(km, k);
+        if (km <= rc) lut_full[km] = (uint16_t)rank++;
+    }
+    for (uint64_t km = 0; km < n; km++) {
+        uint64_t rc = ktd::rev_comp(km, k);
+        if (km > rc) lut_full[km] = lut_full[rc];
+    }
+    return rank;
+}
+
+}  // namespace kt
+
+int kt_ctx::use() {
+    KT_HIP(hipSetDevice(device));
+    return KT_OK;
+}
+
+int kt_ctx::canon_lut(int k, const uint16_t **out) {
+    if (k < 1 || k > kt::KT_MAX_OLIGO_K) return kt::fail(KT_ERR_ARG, "canon_lut: k out of range");
+    if (!lut_dev[k]) {
+        const size_t n = (size_t)1 << (2 * k);
+        std::vector<uint16_t> h(n);
+        kt::build_canon_lut(k, h.data());
+        uint16_t *d = nullptr;
+        KT_HIP(hipMalloc((void **)&d, n * sizeof(uint16_t)));
+        hipError_t e = hipMemcpy(d, h.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return kt::fail(KT_ERR_HIP, std::string("hipMemcpy lut: ") + hipGetErrorString(e));
+        }
+        lut_dev[k] = d;
+    }
+    *out = lut_dev[k];
+    return KT_OK;
+}
+
+extern "C" {
+
+int kt_version(void) { return 100; }
+
+const char *kt_last_error(void) { return kt::g_err.c_str(); }
+
+int kt_device_count(int *count) {
+    if (!count) return kt::fail(KT_ERR_ARG, "kt_device_count: null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return kt::fail(KT_ERR_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return KT_OK;
+}
+
+int kt_ctx_create(int device, void *stream, kt_ctx **out) {
+    if (!out) return kt::fail(KT_ERR_ARG, "kt_ctx_create: null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return kt::fail(KT_ERR_NODEVICE, std::string("no HIP device: ") +
+                                             (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
+    if (device < 0 || device >= n) return kt::fail(KT_ERR_ARG, "kt_ctx_create: device index out of range");
+    kt_ctx *c = new (std::nothrow) kt_ctx();
+    if (!c) return kt::fail(KT_ERR_NOMEM, "kt_ctx_create: out of host memory");
+    c->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if (e == hipSuccess) {
+        if (stream) {
+            c->stream = (hipStream_t)stream;
+        } else {
+            e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+            c->own_stream = (e == hipSuccess);
+        }
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return kt::fail(KT_ERR_HIP, std::string("kt_ctx_create: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return KT_OK;
+}
+
+int kt_ctx_destroy(kt_ctx *ctx) {
+    if (!ctx) return KT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->lut_dev)
+        if (p) (void)hipFree(p);
+    ctx->s_bases.release();
+    ctx->s_offsets.release();
+    ctx->s_out.release();
+    ctx->s_aux0.release();
+    ctx->s_aux1.release();
+    ctx->s_aux2.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return KT_OK;
+}
+
+int kt_ctx_sync(kt_ctx *ctx) {
+    if (!ctx) return kt::fail(KT_ERR_ARG, "kt_ctx_sync: null ctx");
+    if (int rc = ctx->use()) return rc;
+    KT_HIP(hipStreamSynchronize(ctx->stream));
+    return KT_OK;
+}
+
+int kt_bins(int k, int count_min, uint64_t *bins) {
+    if (!bins) return kt::fail(KT_ERR_ARG, "kt_bins: null");
+    if (k < 1 || k > 15) return kt::fail(KT_ERR_ARG, "kt_bins: k must be in 1..15");
+    const uint64_t n = 1ull << (2 * k);
+    // palindromes exist only for even k: (4^k + 4^(k/2)) / 2, else 4^k / 2  (kmer.rs:55)
+    *bins = count_min ? ((k & 1) ? n / 2 : (n + (1ull << k)) / 2) : n;
+    return KT_OK;
+}
+
+int kt_pos_map(int k, uint32_t *min_mer_pos_map, uint64_t *pos_min_mer, uint32_t *kcount) {
+    if (k < 1 || k > 12) return kt::fail(KT_ERR_ARG, "kt_pos_map: k must be in 1..12");
+    const uint64_t n = 1ull << (2 * k);
+    uint32_t rank = 0;
+    for (uint64_t km = 0; km < n; km++) {
+        const uint64_t rc = ktd::rev_comp(km, k);
+        if (km <= rc) {
+            if (min_mer_pos_map) min_mer_pos_map[km] = rank;
+            if (pos_min_mer) pos_min_mer[rank] = km;
+            rank++;
+        } else if (min_mer_pos_map) {
+            min_mer_pos_map[km] = 0;  // the reference leaves non-canonical slots at 0
+        }
+    }
+    if (kcount) *kcount = rank;
+    return KT_OK;
+}
+
+uint64_t kt_rev_comp(uint64_t kmer, int k) {
+    if (k < 1 || k > 32) return 0;
+    return ktd::rev_comp(kmer, k);
+}
+
+int kt_numeric_to_kmer(uint64_t kmer, int k, char *out) {
+    if (!out || k < 0 || k > 32) return kt::fail(KT_ERR_ARG, "kt_numeric_to_kmer: bad argument");
+    for (int i = 0; i < k; i++) out[i] = "ACGT"[(kmer >> (2 * (k - 1 - i))) & 3];
+    out[k] = 0;
+    return KT_OK;
+}
+
+int kt_kmer_to_numeric(const char *kmer, uint64_t len, uint64_t *fwd, uint64_t *rev) {
+    if (!kmer || !fwd || !rev) return kt::fail(KT_ERR_ARG, "kt_kmer_to_numeric: null");
+    if (len > 32)  // pybindings/src/kmer.rs:58-63
+        return kt::fail(KT_ERR_ARG, "Invalid k-mer length: " + std::to_string(len) + ", must be <= 32");
+    if (len == 0) return kt::fail(KT_ERR_ARG, "kt_kmer_to_numeric: empty k-mer");
+    // like the reference, no validity check: an invalid letter contributes code 4
+    // (lib.rs:42-47), i.e. it ORs into the next base's low bit.
+    const uint64_t mask = len >= 32 ? ~0ull : ((1ull << (2 * len)) - 1);
+    const uint64_t shift = 2 * (len - 1);
+    uint64_t f = 0, r = 0;
+    for (uint64_t i = 0; i < len; i++) {
+        const unsigned char c = (unsigned char)kmer[i];
+        uint64_t v;
+        switch (c) {
+            case 0: case 'A': case 'a': v = 0; break;
+            case 1: case 'C': case 'c': v = 1; break;
+            case 2: case 'G': case 'g': v = 2; break;
+            case 3: case 'T': case 't': case 'U': case 'u': v = 3; break;
+            default: v = 4; break;
+        }
+        f = ((f << 2) | v) & mask;
+        r = (r >> 2) | ((v ^ 3) << shift);
+    }
+    *fwd = f;
+    *rev = r;
+    return KT_OK;
+}
+
+int kt_cgr_coords(int k, double vecsize, double *xy) {
+    if (!xy) return kt::fail(KT_ERR_ARG, "kt_cgr_coords: null");
+    if (k < 1 || k > 12) return kt::fail(KT_ERR_ARG, "kt_cgr_coords: k must be in 1..12");
+    // corners (oligocgr.rs:166-170): A(0,0) C(0,vs) G(vs,vs) T(vs,0); start at the centre,
+    // one midpoint step per base, first (most significant) base first.
+    const double cx[4] = {0.0, 0.0, vecsize, vecsize};
+    const double cy[4] = {0.0, vecsize, vecsize, 0.0};
+    const uint64_t n = 1ull << (2 * k);
+    uint64_t i = 0;
+    for (uint64_t km = 0; km < n; km++) {
+        if (km > ktd::rev_comp(km, k)) continue;
+        double x = vecsize / 2.0, y = vecsize / 2.0;
+        for (int j = k - 1; j >= 0; j--) {
+            const int c = (int)((km >> (2 * j)) & 3);
+            x = (cx[c] + x) / 2.0;
+            y = (cy[c] + y) / 2.0;
+        }
+        xy[2 * i] = x;
+        xy[2 * i + 1] = y;
+        i++;
+    }
+    return KT_OK;
+}
+
+uint32_t kt_owner_of(uint64_t kmer, uint32_t n_owners) {
+    return n_owners ? ktd::owner_of(kmer, n_owners) : 0;
+}
+
+}  // extern "C"

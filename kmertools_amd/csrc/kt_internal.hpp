@@ -1,0 +1,61 @@
+// Internal (non-ABI) declarations shared by the translation units of libkmertools_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/kmertools_hip.h"
+
+namespace kt {
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define KT_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return kt::fail(KT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// growable device scratch owned by a ctx (only used by the KT_MEM_HOST staging path)
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+};
+
+constexpr int KT_MAX_OLIGO_K = 7;
+
+}  // namespace kt
+
+struct kt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    // device copies of the canonical-bin LUT (u16[4^k], lut[f] = rank(min(f, rc f))), k = 1..7
+    uint16_t *lut_dev[kt::KT_MAX_OLIGO_K + 1] = {};
+    kt::Scratch s_bases, s_offsets, s_out, s_aux0, s_aux1, s_aux2;
+    int use();  // hipSetDevice
+    int canon_lut(int k, const uint16_t **out);
+};
+
+struct kt_ctr {
+    kt_ctx *ctx = nullptr;
+    int k = 0;
+    uint64_t cap = 0;          // power of two
+    uint64_t *keys = nullptr;  // [cap], KT_EMPTY_KEY = free
+    uint32_t *counts = nullptr;
+    uint32_t *flags = nullptr; // [0] = overflow flag, device
+    uint64_t *cursor = nullptr; // device scalar for export / size
+};
+
+namespace kt {
+// host-side table builders (kt_host.cpp)
+uint64_t rev_comp_bits(uint64_t kmer, int k);
+// fills lut_full[4^k]: rank of the canonical form of every k-mer; returns kcount
+uint32_t build_canon_lut(int k, uint16_t *lut_full);
+}  // namespace kt

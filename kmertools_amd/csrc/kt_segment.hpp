@@ -1,0 +1,128 @@
+// kt_segment.hpp - flat "segment" front-end shared by the k-mer counting, routing and
+// debug kernels: canonical k-mers (1 <= k <= 31) of a CSR read batch, independent of
+// how long or how many the reads are.
+//
+// The concatenated bases are cut into fixed segments of SEG = 8192 bases; one
+// 256-thread workgroup owns one segment (grid-stride).  Per segment:
+//   stage     thread i encodes bases [32i, 32i+32) of the segment (+ one 32-base halo
+//             item) with two 16-byte loads into LDS: a 64-bit word of 2-bit codes
+//             (first base in the top bits) and a 32-bit mask of invalid bases.
+//   bounds    read starts that fall inside the segment are scattered into a third LDS
+//             bit mask (found through seg_first[], the per-segment lower bound of the
+//             offsets array built by seg_index_kernel) - a k-mer may not span one.
+//   k-mers    thread t walks window starts [32t, 32t+32) with a 128-bit shift register
+//             held in two VGPR pairs: fwd = top 2k bits, rev rolls like the reference's
+//             generator (kmer/src/kmer.rs:91-93) - but every start position is
+//             independent of the reads before it, so no serial scan.
+//   sink      a functor receives (fwd, rev, index of the k-mer's last base).
+#pragma once
+#include "kt_device.hpp"
+
+namespace ktseg {
+
+constexpr int BLOCK = 256;
+constexpr uint32_t PER_THREAD = 32;
+constexpr uint32_t SEG = BLOCK * PER_THREAD;  // 8192 bases
+constexpr uint32_t NITEM = BLOCK + 1;         // 32-base items incl. halo
+
+struct SegArgs {
+    const uint8_t *bases;
+    const uint64_t *offsets;  // n_reads + 1, offsets[0] == 0
+    const uint64_t *seg_first;  // n_seg + 1: first read r with offsets[r] >= g * SEG
+    uint64_t n_reads;
+    uint64_t n_seg;
+    uint32_t k;
+};
+
+// seg_first[g] = lower_bound(offsets[0..n_reads], g * SEG) for g in [0, n_seg]
+__global__ void seg_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads,
+                                 uint64_t *__restrict__ seg_first, uint64_t n_seg) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    const uint64_t cur = offsets[r];
+    uint64_t g_lo = (r == 0) ? 0 : offsets[r - 1] / SEG + 1;
+    uint64_t g_hi = cur / SEG;
+    if (r == n_reads) g_hi = n_seg;  // everything past the end maps to the sentinel
+    if (g_hi > n_seg) g_hi = n_seg;
+    for (uint64_t g = g_lo; g <= g_hi; g++) seg_first[g] = r;
+}
+
+struct SegShared {
+    uint64_t codes[NITEM + 1];
+    uint32_t inv[NITEM + 1];
+    uint32_t bnd[NITEM + 1];
+};
+
+// Runs `sink(fwd, rev, end_index)` for every valid k-mer of segment `g`.
+// Must be called by all 256 threads of the workgroup.
+template <class Sink>
+__device__ __forceinline__ void for_each_kmer(const SegArgs &a, uint64_t g, SegShared &sm, Sink &&sink) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = a.k;
+    const uint64_t total = a.offsets[a.n_reads];
+    const uint64_t B0 = g * SEG;
+
+    // ---- stage: 32 bases per item ------------------------------------------------
+    for (uint32_t i = tid; i < NITEM; i += BLOCK) {
+        const uint64_t b = B0 + 32ull * i;
+        uint64_t w = 0;
+        uint32_t iv = 0xFFFFFFFFu;
+        if (b < total) {
+            unsigned char raw[32];
+            if (b + 32 <= total) {
+                __builtin_memcpy(raw, a.bases + b, 32);
+            } else {
+                for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
+            }
+            iv = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t e = ktd::nt4(raw[j]);
+                w = (w << 2) | (e & 3u);
+                iv |= (e >> 2) << j;
+            }
+        }
+        sm.codes[i] = w;
+        sm.inv[i] = iv;
+        sm.bnd[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- read boundaries inside (B0, B0 + SEG + 32) ---------------------------------
+    {
+        const uint64_t lim = B0 + SEG + 32;
+        for (uint64_t r = a.seg_first[g] + tid; r < a.n_reads; r += BLOCK) {
+            const uint64_t o = a.offsets[r];
+            if (o >= lim) break;
+            const uint32_t rel = (uint32_t)(o - B0);
+            atomicOr(&sm.bnd[rel >> 5], 1u << (rel & 31u));
+        }
+    }
+    __syncthreads();
+
+    // ---- k-mers: 32 window starts per thread -------------------------------------------
+    {
+        uint64_t hi = sm.codes[tid], lo = sm.codes[tid + 1];
+        const uint64_t iv = (uint64_t)sm.inv[tid] | ((uint64_t)sm.inv[tid + 1] << 32);
+        const uint64_t bd = (uint64_t)sm.bnd[tid] | ((uint64_t)sm.bnd[tid + 1] << 32);
+        const uint32_t sh = 64u - 2u * k;
+        const uint64_t mk = (1ull << k) - 1ull;          // k bases
+        const uint64_t mk1 = (1ull << (k - 1)) - 1ull;   // the k-1 later bases
+        uint64_t f = hi >> sh;
+        uint64_t r = ktd::rev_comp(f, (int)k);
+        const uint64_t end0 = B0 + 32ull * tid + (k - 1);
+#pragma unroll 4
+        for (uint32_t j = 0; j < PER_THREAD; j++) {
+            const bool ok = (((iv >> j) & mk) == 0) && (((bd >> (j + 1)) & mk1) == 0);
+            if (ok) sink(f, r, end0 + j);
+            // slide one base: next code enters fwd at the bottom, its complement enters rev at the top
+            hi = (hi << 2) | (lo >> 62);
+            lo <<= 2;
+            f = hi >> sh;
+            r = (r >> 2) | ((uint64_t)(3u - (uint32_t)(f & 3u)) << (2u * (k - 1)));
+        }
+    }
+    __syncthreads();  // LDS is reused by the next segment
+}
+
+}  // namespace ktseg

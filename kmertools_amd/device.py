@@ -1,0 +1,227 @@
+"""Thin object layer over the C ABI: a Context (one GPU + one stream) and a Counter
+(HBM-resident k-mer table).  Two calling styles, same entry points:
+
+* host arrays (numpy): the library stages them through its own device scratch
+  (KT_MEM_HOST) - what the `pykmertools` mirror uses;
+* device tensors (anything with `.data_ptr()`, e.g. torch tensors on the GPU):
+  pointers are passed straight through (KT_MEM_DEVICE) and work is enqueued on the
+  context's stream without synchronising - what bench.py and the parity tests use.
+  torch is only plumbing here (allocation, streams, torch.distributed).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KT_F32, KT_F64, KT_MEM_DEVICE, KT_MEM_HOST, KT_U32, check
+
+_DT = {"f64": KT_F64, "f32": KT_F32, "u32": KT_U32, np.float64: KT_F64, np.float32: KT_F32, np.uint32: KT_U32}
+_NP = {KT_F64: np.float64, KT_F32: np.float32, KT_U32: np.uint32}
+
+
+def _ptr(x):
+    """device/host address of a numpy array, a tensor with data_ptr(), an int or None"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    return C.c_void_p(x.data_ptr())
+
+
+def bins(k, count_min=True):
+    out = C.c_uint64()
+    check(_lib.lib().kt_bins(k, int(bool(count_min)), C.byref(out)))
+    return out.value
+
+
+def pos_map(k):
+    """(min_mer_pos_map u32[4^k], pos_min_mer u64[kcount], kcount) - kmer.rs:54-73"""
+    n = 4 ** k
+    m = np.zeros(n, np.uint32)
+    pk = np.zeros(n, np.uint64)
+    cnt = C.c_uint32()
+    check(_lib.lib().kt_pos_map(k, _ptr(m), _ptr(pk), C.byref(cnt)))
+    return m, pk[: cnt.value].copy(), cnt.value
+
+
+def rev_comp(kmer, k):
+    return int(_lib.lib().kt_rev_comp(kmer, k))
+
+
+def numeric_to_kmer(kmer, k):
+    buf = C.create_string_buffer(k + 1)
+    check(_lib.lib().kt_numeric_to_kmer(kmer, k, buf))
+    return buf.value.decode()
+
+
+def kmer_to_numeric(s):
+    b = s.encode("latin-1") if isinstance(s, str) else bytes(s)
+    f, r = C.c_uint64(), C.c_uint64()
+    check(_lib.lib().kt_kmer_to_numeric(b, len(b), C.byref(f), C.byref(r)))
+    return f.value, r.value
+
+
+def cgr_coords(k, vecsize):
+    xy = np.zeros((bins(k, True), 2), np.float64)
+    check(_lib.lib().kt_cgr_coords(k, float(vecsize), _ptr(xy)))
+    return xy
+
+
+def owner_of(kmer, n_owners):
+    return int(_lib.lib().kt_owner_of(int(kmer), int(n_owners)))
+
+
+def to_csr(seqs):
+    """list[str|bytes] -> (bases u8[total], offsets u64[n+1])"""
+    bs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    joined = b"".join(bs)
+    bases = np.frombuffer(joined, dtype=np.uint8).copy() if joined else np.zeros(0, np.uint8)
+    return bases, offsets
+
+
+class Context:
+    """One device + one stream (kt_ctx).  `stream` is a raw hipStream_t handle
+    (e.g. torch.cuda.current_stream().cuda_stream) or None for a private stream."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        self.device = device
+        check(_lib.lib().kt_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().kt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(_lib.lib().kt_ctx_sync(self._h))
+
+    # -- comp oligo / comp cgr -k ------------------------------------------------------
+    def oligo(self, bases, offsets, n_reads, k, out, count_min=True, norm=True, total_step=1, dtype="f64",
+              mem=KT_MEM_DEVICE):
+        check(_lib.lib().kt_oligo_batch(self._h, _ptr(bases), _ptr(offsets), n_reads, k, int(bool(count_min)),
+                                        int(bool(norm)), int(total_step), _DT[dtype], _ptr(out), mem))
+        return out
+
+    def oligo_host(self, bases, offsets, k, count_min=True, norm=True, total_step=1, dtype="f64"):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, bins(k, count_min)), _NP[_DT[dtype]])
+        if n:
+            self.oligo(bases if bases.size else np.zeros(1, np.uint8), offsets, n, k, out, count_min, norm,
+                       total_step, dtype, KT_MEM_HOST)
+        return out
+
+    # -- KmerGenerator surface -----------------------------------------------------------
+    def kmers(self, bases, offsets, n_reads, k, fwd, rev, valid, mem=KT_MEM_DEVICE):
+        check(_lib.lib().kt_kmers(self._h, _ptr(bases), _ptr(offsets), n_reads, k, _ptr(fwd), _ptr(rev),
+                                  _ptr(valid), mem))
+
+    def kmers_host(self, bases, offsets, k):
+        """-> (fwd, rev, end_index) of every k-mer in positional order"""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        total = int(offsets[-1])
+        fwd = np.zeros(max(total, 1), np.uint64)
+        rev = np.zeros(max(total, 1), np.uint64)
+        valid = np.zeros(max(total, 1), np.uint8)
+        if total:
+            self.kmers(bases, offsets, len(offsets) - 1, k, fwd, rev, valid, KT_MEM_HOST)
+        idx = np.nonzero(valid[:total])[0]
+        return fwd[idx], rev[idx], idx.astype(np.uint64)
+
+    # -- ctr routing -------------------------------------------------------------------------
+    def route(self, bases, offsets, n_reads, k, n_owners, keys_out, owner_counts, mem=KT_MEM_DEVICE):
+        check(_lib.lib().kt_ctr_route(self._h, _ptr(bases), _ptr(offsets), n_reads, k, n_owners, _ptr(keys_out),
+                                      _ptr(owner_counts), mem))
+
+    def route_host(self, bases, offsets, k, n_owners):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        total = int(offsets[-1])
+        keys = np.zeros(max(total, 1), np.uint64)
+        counts = np.zeros(n_owners, np.uint64)
+        self.route(bases if bases.size else np.zeros(1, np.uint8), offsets, len(offsets) - 1, k, n_owners, keys,
+                   counts, KT_MEM_HOST)
+        return keys[: int(counts.sum())], counts
+
+    # -- synthetic reads (device only) ----------------------------------------------------------
+    def synth_reads(self, seed, n_reads, read_len, bases_dev, offsets_dev=None, noise=False, genome_len=0,
+                    first_read=0):
+        check(_lib.lib().kt_synth_reads(self._h, seed, first_read, n_reads, read_len, int(bool(noise)),
+                                        genome_len, _ptr(bases_dev), _ptr(offsets_dev)))
+
+
+class Counter:
+    """HBM-resident canonical k-mer table (kt_ctr) = the reference's CountComputer state."""
+
+    def __init__(self, ctx, k, capacity_slots):
+        self.ctx = ctx
+        self.k = k
+        self._h = C.c_void_p()
+        check(_lib.lib().kt_ctr_create(ctx._h, k, int(capacity_slots), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().kt_ctr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        check(_lib.lib().kt_ctr_clear(self._h))
+
+    def add_reads(self, bases, offsets, n_reads, mem=KT_MEM_DEVICE):
+        check(_lib.lib().kt_ctr_add_reads(self._h, _ptr(bases), _ptr(offsets), n_reads, mem))
+
+    def add_reads_host(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        self.add_reads(bases if bases.size else np.zeros(1, np.uint8), offsets, len(offsets) - 1, KT_MEM_HOST)
+
+    def add_pairs(self, keys, counts, n, mem=KT_MEM_DEVICE):
+        check(_lib.lib().kt_ctr_add_pairs(self._h, _ptr(keys), _ptr(counts), n, mem))
+
+    def add_pairs_host(self, keys, counts=None):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        if counts is not None:
+            counts = np.ascontiguousarray(counts, np.uint32)
+        if len(keys):
+            self.add_pairs(keys, counts, len(keys), KT_MEM_HOST)
+
+    def size(self):
+        n = C.c_uint64()
+        check(_lib.lib().kt_ctr_size(self._h, C.byref(n)))
+        return n.value
+
+    def export(self, keys, counts, max_out, mem=KT_MEM_DEVICE):
+        n = C.c_uint64()
+        check(_lib.lib().kt_ctr_export(self._h, _ptr(keys), _ptr(counts), max_out, C.byref(n), mem))
+        return n.value
+
+    def export_host(self, sort=True):
+        n = self.size()
+        keys = np.zeros(max(n, 1), np.uint64)
+        counts = np.zeros(max(n, 1), np.uint32)
+        got = self.export(keys, counts, n, KT_MEM_HOST) if n else 0
+        keys, counts = keys[:got], counts[:got]
+        if sort:
+            order = np.argsort(keys, kind="stable")
+            keys, counts = keys[order], counts[order]
+        return keys, counts

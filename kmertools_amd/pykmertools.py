@@ -1,0 +1,99 @@
+"""Mirror of the reference's `pykmertools` Python module (pybindings/src/{oligo,kmer}.rs,
+pip/src/lib.rs:31-40), running on the MI355X through libkmertools_hip.so.
+
+Same class names, argument names, defaults and error behaviour:
+
+    OligoComputer(ksize).vectorise_one(seq, norm=True, mins=True)      pybindings/src/oligo.rs:22,39
+                        .vectorise_batch(seqs, norm=True, mins=True)   :77
+                        .get_header(mins=True)                         :85
+    KmerGenerator(seq, ksize)  iterable of (fwd, rev)                  pybindings/src/kmer.rs:22,39
+                 .kmer_pos_maps()                                      :31
+    utils.to_acgt(kmer, ksize) / utils.to_numeric(kmer)                :49,:57
+
+Quirks kept on purpose: raw mode (`mins=False`) normalises by
+2x the k-mer count (pybindings/src/oligo.rs:61); `kmer_pos_maps()` returns
+(list[4^k], dict pos->kmer, count); `to_numeric` raises ValueError beyond 32 bases.
+"""
+import numpy as np
+
+from . import _lib, device
+
+_ctx = None
+
+
+def _context():
+    """process-wide Context on device 0 with a private stream (host-array calling style)"""
+    global _ctx
+    if _ctx is None:
+        _ctx = device.Context(0)
+    return _ctx
+
+
+class OligoComputer:
+    """Computer for generating oligonucleotide frequency vectors"""
+
+    def __init__(self, ksize):
+        self.ksize = int(ksize)
+        if not 3 <= self.ksize <= 7:
+            # the reference CLI restricts k to 3..=7 (kmertools/src/args.rs:85); the GPU
+            # kernels are instantiated for exactly that range
+            raise ValueError("ksize must be in 3..=7")
+        self.kcount = device.bins(self.ksize, True)
+
+    def vectorise_one(self, seq, norm=True, mins=True):
+        return self.vectorise_batch([seq], norm, mins)[0]
+
+    def vectorise_batch(self, seqs, norm=True, mins=True):
+        return self.vectorise_batch_numpy(seqs, norm, mins).tolist()
+
+    def vectorise_batch_numpy(self, seqs, norm=True, mins=True):
+        """extension: the same result as an (n, bins) float64 ndarray"""
+        bases, offsets = device.to_csr(seqs)
+        # CLI crate adds 1 per k-mer to `total`; the python binding adds 2 in raw mode
+        step = 1 if mins else 2
+        return _context().oligo_host(bases, offsets, self.ksize, count_min=mins, norm=norm, total_step=step)
+
+    def get_header(self, mins=True):
+        if mins:
+            _, pos_kmer, _ = device.pos_map(self.ksize)
+            return [device.numeric_to_kmer(int(x), self.ksize) for x in pos_kmer]
+        return [device.numeric_to_kmer(x, self.ksize) for x in range(4 ** self.ksize)]
+
+
+class KmerGenerator:
+    """Computer for generating k-mers: iterates (forward, reverse-complement) pairs"""
+
+    def __init__(self, seq, ksize):
+        self.ksize = int(ksize)
+        if not 1 <= self.ksize <= 31:
+            raise ValueError("ksize must be in 1..=31")
+        bases, offsets = device.to_csr([seq])
+        fwd, rev, _ = _context().kmers_host(bases, offsets, self.ksize)
+        self._it = iter(zip(fwd.tolist(), rev.tolist()))
+
+    def kmer_pos_maps(self):
+        m, pos_kmer, count = device.pos_map(self.ksize)
+        return m.tolist(), {i: int(x) for i, x in enumerate(pos_kmer)}, count
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._it)
+
+
+class _Utils:
+    @staticmethod
+    def to_acgt(kmer, ksize):
+        """Translate numeric k-mer to ACGT"""
+        return device.numeric_to_kmer(int(kmer), int(ksize))
+
+    @staticmethod
+    def to_numeric(kmer):
+        """Translate ACGT kmer to numeric pair"""
+        if len(kmer) > 32:
+            raise ValueError("Invalid k-mer length: %d, must be <= 32" % len(kmer))
+        return device.kmer_to_numeric(kmer)
+
+
+utils = _Utils()

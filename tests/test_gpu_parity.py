@@ -1,0 +1,385 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the reference's golden fixtures, and - at BASELINE sizes - through
+size-independent properties.  Integer results are compared bit-exactly; f64 rows are
+bit-exact too (one IEEE division of exact integers); f32 rows within 1e-6."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx(torch_mod):
+    from kmertools_amd import device
+    c = device.Context(0, stream=torch_mod.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def hctx():
+    """private-stream context used with host arrays"""
+    from kmertools_amd import device
+    c = device.Context(0)
+    yield c
+    c.close()
+
+
+def ragged_reads(seed, n, max_len=400, noise=True, special=True):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len, size=n)
+    if special and n >= 8:
+        lens[0] = 0
+        lens[1] = 1
+        lens[2] = 2
+        lens[3] = 31
+        lens[4] = 64
+        lens[5] = 0
+        lens[6] = 9000      # crosses a ctr segment and many oligo chunks
+        lens[7] = 8192
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seqs = []
+    for L in lens:
+        s = alpha[rng.integers(0, 4, size=L)].copy()
+        if noise and L:
+            m = rng.random(L)
+            s[m < 0.01] = ord("N")
+            low = (m > 0.01) & (m < 0.05)
+            s[low] |= 0x20
+            s[(m > 0.05) & (m < 0.055)] = ord("U")
+            s[(m > 0.055) & (m < 0.057)] = 2       # raw byte code (kmer.rs:7 first row)
+            s[(m > 0.057) & (m < 0.059)] = ord("R")  # IUPAC -> invalid
+        seqs.append(s.tobytes())
+    return seqs
+
+
+def oracle_kmers_batch(oracle, seqs, k):
+    fs, rs, es = [], [], []
+    off = 0
+    for s in seqs:
+        f, r, e = oracle.kmers(s, k)
+        fs.append(f)
+        rs.append(r)
+        es.append(e + np.uint64(off))
+        off += len(s)
+    return np.concatenate(fs), np.concatenate(rs), np.concatenate(es)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic generator
+
+@pytest.mark.parametrize("noise,genome", [(False, 0), (True, 0), (False, 5000), (True, 100000)])
+def test_synth_matches_oracle(torch_mod, ctx, oracle, noise, genome):
+    torch = torch_mod
+    n, L, seed, first = 777, 150, 0x6b6d6572, 12345
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(seed, n, L, bases, offsets, noise=noise, genome_len=genome, first_read=first)
+    torch.cuda.synchronize()
+    want, woff = oracle.synth_reads(seed, n, L, noise=noise, genome_len=genome, first_read=first)
+    assert np.array_equal(bases.cpu().numpy(), want)
+    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), woff)
+
+
+# ---------------------------------------------------------------------------------------------
+# KmerGenerator surface (kt_kmers)
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 15, 16, 17, 21, 30, 31])
+def test_kmers_vs_oracle(hctx, oracle, k):
+    from kmertools_amd import device
+    seqs = ragged_reads(100 + k, 300)
+    bases, offsets = device.to_csr(seqs)
+    f, r, e = hctx.kmers_host(bases, offsets, k)
+    wf, wr, we = oracle_kmers_batch(oracle, seqs, k)
+    assert np.array_equal(e, we)
+    assert np.array_equal(f, wf)
+    assert np.array_equal(r, wr)
+
+
+def test_kmers_golden(hctx, oracle, kat):
+    from kmertools_amd import device
+    for case in kat["kmers"]:
+        b, o = device.to_csr([case["seq"]])
+        f, r, _ = hctx.kmers_host(b, o, case["k"])
+        assert [[int(x), int(y)] for x, y in zip(f, r)] == case["pairs"]
+    c = kat["k31"]
+    b, o = device.to_csr([c["seq"]])
+    f, r, _ = hctx.kmers_host(b, o, 31)
+    got = [device.numeric_to_kmer(int(min(x, y)), 31) for x, y in zip(f, r)]
+    assert got == c["canonical_kmers_in_order"]
+
+
+def test_kmers_empty_and_short(hctx):
+    from kmertools_amd import device
+    for seqs in ([], [b""], [b"", b""], [b"AC"], [b"ACG", b"", b"T"]):
+        b, o = device.to_csr(seqs)
+        f, r, e = hctx.kmers_host(b, o, 4)
+        assert len(f) == 0 and len(r) == 0 and len(e) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# comp oligo / comp cgr -k  (kt_oligo_batch)
+
+@pytest.mark.parametrize("k", [3, 4, 5, 6, 7])
+@pytest.mark.parametrize("count_min", [True, False])
+def test_oligo_vs_oracle(hctx, oracle, k, count_min):
+    from kmertools_amd import device
+    n = 300 if k <= 5 else 60
+    seqs = ragged_reads(7 * k + count_min, n)
+    bases, offsets = device.to_csr(seqs)
+    for norm, step in [(True, 1), (False, 1), (True, 2)]:
+        want = oracle.oligo_batch(bases, offsets, k, count_min, norm, float(step))
+        got = hctx.oligo_host(bases, offsets, k, count_min, norm, step, "f64")
+        assert got.shape == want.shape
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (k, count_min, norm, step)
+    want = oracle.oligo_batch(bases, offsets, k, count_min, True, 1.0)
+    got32 = hctx.oligo_host(bases, offsets, k, count_min, True, 1, "f32")
+    assert got32.dtype == np.float32
+    assert np.max(np.abs(got32.astype(np.float64) - want)) <= 1e-6   # north_star tolerance
+    cnt = oracle.oligo_batch(bases, offsets, k, count_min, False, 1.0)
+    gotu = hctx.oligo_host(bases, offsets, k, count_min, False, 1, "u32")
+    assert np.array_equal(gotu.astype(np.float64), cnt)
+
+
+def test_oligo_golden_files(hctx, oracle, golden):
+    from kmertools_amd import device
+    recs = oracle.read_records(golden / "reads.fq")
+    bases, offsets = device.to_csr([s for _, s in recs])
+    norm = hctx.oligo_host(bases, offsets, 4, True, True)
+    assert oracle.oligo_text(norm, True) == (golden / "expected_fa.kmers").read_bytes()
+    cnt = hctx.oligo_host(bases, offsets, 4, True, False)
+    assert oracle.oligo_text(cnt, False) == (golden / "expected_fa_batch_unnorm.kmers").read_bytes()
+    hdr = [device.numeric_to_kmer(int(x), 4) for x in device.pos_map(4)[1]]
+    assert oracle.oligo_text(norm, True, header_line=hdr) == (golden / "expected_fa_header.kmers").read_bytes()
+    xy = device.cgr_coords(4, 16)
+    assert oracle.oligocgr_text(cnt, xy) == (golden / "expected_reads.k4.cgr").read_bytes()
+    # multi-line FASTA gives the same rows (ktio/src/seq.rs:165-233)
+    recs_fa = oracle.read_records(golden / "reads.fa")
+    b2, o2 = device.to_csr([s for _, s in recs_fa])
+    assert np.array_equal(hctx.oligo_host(b2, o2, 4, True, True), norm)
+
+
+def test_oligo_inline_kat(hctx, kat):
+    from kmertools_amd import device
+    c = kat["oligo_one"]
+    b, o = device.to_csr([c["seq"]])
+    assert hctx.oligo_host(b, o, 4, False, True).shape[1] == c["raw_len"]
+    assert hctx.oligo_host(b, o, 4, True, True)[0, 0] == c["canon_norm_v0"]
+    un = hctx.oligo_host(b, o, 4, True, False)[0]
+    assert un[0] == c["canon_unnorm_v0"] and un.sum() == c["canon_unnorm_sum"]
+    g = kat["oligocgr_one"]
+    b, o = device.to_csr([g["seq"]])
+    assert hctx.oligo_host(b, o, 4, True, True)[0, 0] == 1.0 / g["norm_first_freq_den"]
+
+
+def test_oligo_empty_inputs(hctx):
+    from kmertools_amd import device
+    for seqs in ([], [b""], [b"AC", b"", b"NNNNNNNN"]):
+        b, o = device.to_csr(seqs)
+        out = hctx.oligo_host(b, o, 4)
+        assert out.shape == (len(seqs), 136) and not out.any()   # total = 0 -> divisor 1 -> zero row
+
+
+def test_oligo_device_tensors_many_tiles(torch_mod, ctx, oracle):
+    """device-pointer path, several tiles per workgroup, noise reads, all dtypes"""
+    torch = torch_mod
+    n, L = 200_000, 150
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(42, n, L, bases, offsets, noise=True)
+    out = torch.empty((n, 136), dtype=torch.float64, device="cuda")
+    ctx.oligo(bases, offsets, n, 4, out)
+    torch.cuda.synchronize()
+    hb, ho = oracle.synth_reads(42, n, L, noise=True)
+    want = oracle.oligo_batch(hb, ho, 4, True, True, 1.0, threads=8)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want.view(np.uint64))
+    # determinism: repeated launches give identical bits
+    out2 = torch.empty_like(out)
+    ctx.oligo(bases, offsets, n, 4, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_pykmertools_surface(oracle, golden, kat):
+    """the reference's own python tests (tests/test_oligo.py, test_kmers.py, test_utils.py)"""
+    from kmertools_amd import pykmertools as kt
+    seqs = [s.decode() for _, s in oracle.read_records(golden / "reads.fq")]
+    gen = kt.OligoComputer(4)
+    got = [[round(x, 6) for x in row] for row in gen.vectorise_batch(seqs)]
+    truth = [list(map(float, ln.split())) for ln in (golden / "expected_fa.kmers").read_text().splitlines()]
+    assert got == truth
+    assert len(gen.get_header()) == 136 and len(gen.get_header(False)) == 256
+    assert gen.get_header()[0] == "AAAA" and gen.get_header()[135] == "TTAA"
+    kmers = list(kt.KmerGenerator("ACGTCC", 3))
+    assert [kt.utils.to_acgt(f, 3) for f, _ in kmers] == kat["py_kmers"]["fwd_acgt"]
+    assert kmers == [(6, 27), (27, 6), (45, 33), (53, 40)]
+    assert kt.utils.to_acgt(111, 5) == "ACGTT" and kt.utils.to_acgt(27, 5) == "AACGT"
+    assert kt.utils.to_numeric("ACGTT") == (111, 27)
+    with pytest.raises(ValueError):
+        kt.utils.to_numeric("A" * 33)
+    # python raw-mode quirk: normalised raw vectors sum to 0.5 (pybindings/src/oligo.rs:61)
+    v = gen.vectorise_one(seqs[0], norm=True, mins=False)
+    assert abs(sum(v) - 0.5) < 1e-12
+    want = oracle.oligo_one(seqs[0], 4, count_min=False, norm=True, total_step=2.0)
+    assert np.array_equal(np.array(v), want)
+    m, pos_kmer, count = kt.KmerGenerator("ACGT", 4).kmer_pos_maps()
+    assert count == 136 and len(m) == 256 and pos_kmer[135] == oracle.kmer_to_numeric("TTAA")[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# ctr (kt_ctr_*)
+
+@pytest.mark.parametrize("k", [4, 10, 15, 21, 31])
+def test_ctr_vs_oracle(hctx, oracle, k):
+    from kmertools_amd import device
+    seqs = ragged_reads(1000 + k, 400)
+    # repeat some reads (and a reverse-complemented copy) so counts > 1 occur at every k
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    seqs += seqs[10:60] + [s.translate(comp)[::-1] for s in seqs[20:40]]
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    ctr = device.Counter(hctx, k, max(4096, 3 * len(wk)))
+    ctr.add_reads_host(bases, offsets)
+    assert ctr.size() == len(wk)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    assert wc.max() > 1
+    # chunked adds (= the reference's chunks) give the same table
+    ctr.clear()
+    half = len(seqs) // 2
+    b1, o1 = device.to_csr(seqs[:half])
+    b2, o2 = device.to_csr(seqs[half:])
+    ctr.add_reads_host(b1, o1)
+    ctr.add_reads_host(b2, o2)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    ctr.close()
+
+
+def test_ctr_golden_files(hctx, oracle, golden):
+    from kmertools_amd import device
+    recs = oracle.read_records(golden / "reads.fq")
+    bases, offsets = device.to_csr([s for _, s in recs])
+    ctr = device.Counter(hctx, 15, 4096)
+    ctr.add_reads_host(bases, offsets)
+    k, c = ctr.export_host()
+    assert oracle.counts_lines(k, c) == sorted((golden / "expected_counts.part_0_chunk_0").read_text().splitlines())
+    ctr.close()
+    # merge fixtures: plain u32 sums per key (counter/src/lib.rs:201-210)
+    ctr = device.Counter(hctx, 15, 4096)
+    for f in sorted((golden / "computed_counts_test").iterdir()):
+        rows = [ln.split("\t") for ln in f.read_text().splitlines() if ln.strip()]
+        ctr.add_pairs_host([int(a) for a, _ in rows], [int(b) for _, b in rows])
+    k, c = ctr.export_host()
+    assert oracle.counts_lines(k, c) == sorted((golden / "expected_counts_test.counts").read_text().splitlines())
+    acgt = sorted("%s\t%d" % (device.numeric_to_kmer(int(a), 15), int(b)) for a, b in zip(k, c))
+    assert acgt == sorted((golden / "expected_counts_acgt_test.counts").read_text().splitlines())
+    ctr.close()
+
+
+def test_ctr_table_full_is_loud(hctx):
+    from kmertools_amd import _lib, device
+    seqs = ragged_reads(5, 200, special=False)
+    b, o = device.to_csr(seqs)
+    ctr = device.Counter(hctx, 21, 1024)
+    ctr.add_reads_host(b, o)
+    with pytest.raises(_lib.KmertoolsError) as ei:
+        ctr.size()
+    assert ei.value.code == _lib.KT_ERR_FULL
+    ctr.close()
+
+
+@pytest.mark.parametrize("n_owners", [1, 2, 3, 8])
+def test_route_partitions_by_owner(hctx, oracle, n_owners):
+    from kmertools_amd import device
+    k = 31
+    seqs = ragged_reads(77, 300)
+    bases, offsets = device.to_csr(seqs)
+    keys, counts = hctx.route_host(bases, offsets, k, n_owners)
+    wf, wr, _ = oracle_kmers_batch(oracle, seqs, k)
+    canon = np.minimum(wf, wr)
+    assert counts.sum() == len(canon)
+    assert np.array_equal(np.sort(keys), np.sort(canon))      # same multiset
+    start = 0
+    for o in range(n_owners):
+        grp = keys[start:start + int(counts[o])]
+        owners = {device.owner_of(int(x), n_owners) for x in grp[:2000]}
+        assert owners <= {o}
+        start += int(counts[o])
+    # routed keys counted by their owners == counting the reads directly
+    ctr = device.Counter(hctx, k, 4 * len(canon) + 1024)
+    ctr.add_pairs_host(keys, None)
+    gk, gc = ctr.export_host()
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    ctr.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE-size property checks (size-independent invariants, no oracle pass over the full set)
+
+def test_cfg2_full_size_properties(torch_mod, ctx, oracle):
+    """comp oligo k=4, 10 M x 150 bp: row sums, totals, sampled rows vs oracle"""
+    torch = torch_mod
+    n, L, k, seed = 10_000_000, 150, 4, 0x6b6d6572 + 1
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(seed, n, L, bases, offsets)
+    cnt = torch.empty((n, 136), dtype=torch.int32, device="cuda")
+    ctx.oligo(bases, offsets, n, k, cnt, norm=False, dtype="u32")
+    torch.cuda.synchronize()
+    # all-ACGT reads: every row holds exactly L-k+1 k-mers
+    assert bool((cnt.sum(dim=1) == L - k + 1).all())
+    del cnt
+    out = torch.empty((n, 136), dtype=torch.float64, device="cuda")
+    ctx.oligo(bases, offsets, n, k, out)
+    torch.cuda.synchronize()
+    s = out.sum(dim=1)
+    assert float((s - 1.0).abs().max()) < 1e-12
+    # sampled slices against the oracle, bit-exact
+    for first in (0, 1_234_567, n - 4096):
+        hb, ho = oracle.synth_reads(seed, 4096, L, first_read=first)
+        want = oracle.oligo_batch(hb, ho, k, True, True, 1.0, threads=4)
+        got = out[first:first + 4096].cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
+    """ctr k=31 on 0.5 M x 150 bp genome-sampled reads: distinct / sum(count) / sum(key*count)
+    checksums against the oracle, and export == re-import idempotence"""
+    torch = torch_mod
+    from kmertools_amd import device
+    n, L, k, seed, G = 500_000, 150, 31, 0x6b6d6572 + 3, 1_000_000
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(seed, n, L, bases, offsets, genome_len=G)
+    ctr = device.Counter(ctx, k, 1 << 27)
+    ctr.add_reads(bases, offsets, n)
+    distinct = ctr.size()
+    keys = torch.empty(distinct, dtype=torch.int64, device="cuda")
+    counts = torch.empty(distinct, dtype=torch.int32, device="cuda")
+    assert ctr.export(keys, counts, distinct) == distinct
+    total = int(counts.to(torch.int64).sum())
+    assert total == n * (L - k + 1)
+    hb, ho = oracle.synth_reads(seed, n, L, genome_len=G)
+    wk, wc = oracle.count_reads(hb, ho, k, n_parts=8, threads=8)
+    assert distinct == len(wk)
+    gk = keys.cpu().numpy().view(np.uint64)
+    gc = counts.cpu().numpy().view(np.uint32)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], wk) and np.array_equal(gc[order], wc)
+    # checksum of checksums (wraps mod 2^64 on both sides)
+    assert int((gk * gc.astype(np.uint64)).sum()) == int((wk * wc.astype(np.uint64)).sum())
+    # merge idempotence: importing the exported pairs into an empty table reproduces it
+    ctr2 = device.Counter(ctx, k, 1 << 27)
+    ctr2.add_pairs(keys, counts, distinct)
+    assert ctr2.size() == distinct
+    ctr.close()
+    ctr2.close()
