@@ -56,9 +56,10 @@ int kt_version(void);
 const char *kt_last_error(void);
 int kt_device_count(int *count);
 
-/* stream = a hipStream_t to enqueue on (e.g. the caller's / torch's current stream),
- * or NULL to let the ctx create and own one. */
-int kt_ctx_create(int device, void *stream, kt_ctx **out);
+/* own_stream == 0: enqueue on `stream`, a hipStream_t of the caller (e.g. torch's current
+ * stream; NULL is the device's default stream).  own_stream != 0: `stream` is ignored and
+ * the ctx creates and owns a private non-blocking stream. */
+int kt_ctx_create(int device, void *stream, int own_stream, kt_ctx **out);
 int kt_ctx_destroy(kt_ctx *ctx);
 int kt_ctx_sync(kt_ctx *ctx);
 

@@ -23,7 +23,7 @@ SYMBOLS = {
     "kt_version": (_i, []),
     "kt_last_error": (C.c_char_p, []),
     "kt_device_count": (_i, [C.POINTER(_i)]),
-    "kt_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "kt_ctx_create": (_i, [_i, _vp, _i, C.POINTER(_vp)]),
     "kt_ctx_destroy": (_i, [_vp]),
     "kt_ctx_sync": (_i, [_vp]),
     "kt_bins": (_i, [_i, _i, C.POINTER(_u64)]),
@@ -72,6 +72,13 @@ def lib():
             raise ImportError(
                 "%s is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C kmertools_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64; importing it first makes this library resolve to
+        # the same HIP runtime instance, so torch's streams/pointers are valid here (two
+        # runtimes in one process cannot both see the GPU).  Without torch, /opt/rocm's is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol

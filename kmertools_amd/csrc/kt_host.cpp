@@ -105,7 +105,7 @@ int kt_device_count(int *count) {
     return KT_OK;
 }
 
-int kt_ctx_create(int device, void *stream, kt_ctx **out) {
+int kt_ctx_create(int device, void *stream, int own_stream, kt_ctx **out) {
     if (!out) return kt::fail(KT_ERR_ARG, "kt_ctx_create: null out");
     *out = nullptr;
     int n = 0;
@@ -124,7 +124,7 @@ int kt_ctx_create(int device, void *stream, kt_ctx **out) {
         if (e == hipSuccess) c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     if (e == hipSuccess) {
-        if (stream) {
+        if (!own_stream) {
             c->stream = (hipStream_t)stream;
         } else {
             e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

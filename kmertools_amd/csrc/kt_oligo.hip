@@ -4,22 +4,30 @@
 // OligoCgrComputer::seq_to_kmer (composition/src/oligocgr.rs:145-163) and the python
 // binding's copy (pybindings/src/oligo.rs:39-69) for a whole CSR batch of reads.
 //
-// Shape of the problem (k=4, 150-bp reads, f64 rows): 150 B in, 1088 B out per read -
-// a streaming-store kernel.  HBM-bound; no MFMA (integer histogram).
+// Shape of the problem (k=4, 150-bp reads, f64 rows): 150 B in, 1088 B out per read - a
+// streaming-store kernel whose first version was VALU-bound (278 VALU instructions per
+// read, profiles/r1_oligo_v1_pmc.txt).  This version is built around instruction count:
 //
-// One 256-thread workgroup owns a *tile* of R consecutive reads:
-//   stage     the tile's bytes are contiguous in `bases`; all 256 lanes copy them to LDS
-//             with 16-byte coalesced loads (one wait per tile instead of one per read)
-//   positions work items are (read, 64-base chunk); chunk c of read r goes to wave
-//             (c + r) & 3, so short reads fill all four waves and a long read is spread
-//             over the workgroup.  Lane l holds base c*S + l, S = 64-(k-1); the k-1
-//             predecessors arrive by DPP wave_shr:1 (no LDS traffic); the k-mer is
-//             fwd(p) = sum code[p-j]*4^j - position-parallel, identical to the
-//             reference's rolling value.  bin = lut[fwd] (rank of the
-//             canonical form) or fwd; one ds_add_u32 into the read's LDS histogram.
-//   output    the R x bins counts are one contiguous block of the output matrix; the
-//             256 lanes stream it out as 16-byte stores with the normalising division
-//             fused, and clear the LDS histogram behind them.
+// One 256-thread workgroup owns a *tile* of R consecutive reads; their bases are one
+// contiguous byte range of `bases`, treated as a flat stream.
+//   positions  each wave takes 504-byte chunks of the stream; a lane owns 8 consecutive
+//              bases (one aligned 8-byte global load; lane 0 is the halo for lane 1).  The 8
+//              bytes are encoded with SWAR integer ops (4 bases per instruction: 2-bit codes
+//              by shifts/xor, validity by a v_perm_b32 table compare), packed to 16 bits of
+//              codes + 8 invalid flags, and the predecessor lane's pack arrives by one DPP
+//              wave_shr:1.  Each of the 8 k-mers ending in the lane is then a single
+//              v_bfe_u32 of that 32-bit window: fwd(p) = sum code[p-j]*4^j, identical to the
+//              reference's rolling value.  Which read a base belongs to is
+//              arithmetic for equal-length tiles and a binary search of the tile's offsets
+//              otherwise, so long reads spread over all lanes and waves.
+//              bin = lut[fwd] (rank of the canonical form, LDS) or fwd; one ds_add_u32 into
+//              the read's LDS histogram row.
+//   output     the R x bins counts are one contiguous block of the output matrix; the 256
+//              lanes stream it out as 16-byte stores and clear the LDS rows behind them.
+//              Normalisation c / d (d = max(1, total)) uses y = RN(1/d) computed once per
+//              read: q0 = c*y, r = fma(-q0, d, c), q = fma(r, y, q0).  For integers
+//              c <= d < 2^32 the residual r is exact and q is the correctly rounded
+//              quotient (Markstein), i.e. bit-identical to the reference's f64 division.
 #include "kt_device.hpp"
 #include "kt_internal.hpp"
 
@@ -27,6 +35,7 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int NWAVES = BLOCK / 64;
+constexpr uint32_t CHUNK = 63 * 8;  // new bases per wave-chunk (lane 0 is halo)
 
 template <int DT>
 struct OutVec;
@@ -50,118 +59,271 @@ struct OligoArgs {
     const uint8_t *bases;
     const uint64_t *offsets;
     uint64_t n_reads;
-    const uint16_t *lut;  // device, 4^k entries (canonical mode)
+    const uint16_t *lut;  // device, 4^k entries, or nullptr for raw bins
     void *out;
     uint32_t bins;
     uint32_t R;            // reads per tile
-    uint32_t stage_bytes;  // LDS bytes reserved for the tile's bases
     uint32_t norm;
     uint32_t total_step;
     uint32_t vec_per_row;  // bins / VEC
     uint32_t vec_magic;    // ceil(2^32 / vec_per_row)
 };
 
-template <int K, bool CANON, int DT>
-__global__ __launch_bounds__(BLOCK) void oligo_tile_kernel(OligoArgs a) {
+// 4 bases in one dword -> 2-bit codes packed big-endian in 8 bits (first base in bits 7:6)
+// and 4 invalid flags (first base in bit 3).  Letters ACGTU/acgtu only; raw bytes 0..3 are
+// reported through `raw` (nonzero => caller takes the per-byte path).
+__device__ __forceinline__ void swar4(uint32_t x, uint32_t &codes8, uint32_t &inv4, uint32_t &raw) {
+    x = __builtin_bswap32(x);  // first base -> top byte, so right-shift packing is big-endian
+    const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    const uint32_t y = x & 0xDFDFDFDFu;  // fold case
+    // expected letter for (code, bit0): keys 4..7 -> A C G U (S0 bytes), key 3 -> T (S1 byte 3)
+    const uint32_t key = c | ((x & 0x01010101u) << 2);
+    const uint32_t expect = __builtin_amdgcn_perm(0x55474341u, 0x54FFFFFFu, key);
+    const uint32_t diff = y ^ expect;
+    const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;  // 0x80 per bad byte
+    codes8 = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
+    inv4 = ((nz >> 7) | (nz >> 14) | (nz >> 21) | (nz >> 28)) & 0xFu;
+    const uint32_t t = x & 0xFCFCFCFCu;
+    raw = (t - 0x01010101u) & ~t & 0x80808080u;  // some byte < 4 (may over-report, never under)
+}
+
+// per-byte path (exact SEQ_NT4_TABLE semantics incl. raw bytes 0..3)
+__device__ __forceinline__ void bytes8(uint32_t lo, uint32_t hi, uint32_t &P, uint32_t &V) {
+    P = 0;
+    V = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t b = ((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xFFu;
+        const uint32_t e = ktd::nt4(b);
+        P |= (e & 3u) << (2 * (7 - i));
+        V |= (e >> 2) << (7 - i);
+    }
+}
+
+// number of reads r in [0, nr] with roff[r] <= T, minus one = the read containing T
+// (the last one starting at or before T, which skips empty reads)
+__device__ __forceinline__ uint32_t find_read(const uint64_t *roff, uint32_t nr, uint64_t T) {
+    uint32_t lo = 0, hi = nr;  // invariant: roff[lo] <= T, answer in [lo, hi]
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (roff[mid] <= T) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <int K, int DT>
+__global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VEC = OutVec<DT>::VEC;
     using vec_t = typename OutVec<DT>::type;
-    constexpr uint32_t S = 64 - (K - 1);
-    constexpr uint32_t NLUT = CANON ? (1u << (2 * K)) : 0u;
+    constexpr uint32_t NLUT = 1u << (2 * K);
+    constexpr uint32_t KMASK = NLUT - 1u;
 
     const uint32_t R = a.R, bins = a.bins;
+    const bool use_lut = a.lut != nullptr;
     // LDS carve (all offsets multiples of 16)
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);                      // R * bins
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);  // R * bins
     uint32_t off = R * bins * 4;
-    uint32_t *totals = reinterpret_cast<uint32_t *>(smem + off);              // 2 * R (double buffered)
-    off += ((2 * R * 4 + 15) & ~15u);
-    uint64_t *roff = reinterpret_cast<uint64_t *>(smem + off);                // R + 1
+    uint32_t *tot = reinterpret_cast<uint32_t *>(smem + off);  // R
+    off += ((R * 4 + 15) & ~15u);
+    double *dnm = reinterpret_cast<double *>(smem + off);  // R: divisor d
+    off += ((R * 8 + 15) & ~15u);
+    double *rcp = reinterpret_cast<double *>(smem + off);  // R: RN(1/d)
+    off += ((R * 8 + 15) & ~15u);
+    uint64_t *roff = reinterpret_cast<uint64_t *>(smem + off);  // R + 1
     off += (((R + 1) * 8 + 15) & ~15u);
-    uint16_t *lut = reinterpret_cast<uint16_t *>(smem + off);                 // 4^K
-    off += ((NLUT * 2 + 15) & ~15u);
-    unsigned char *stage = smem + off;                                        // stage_bytes
+    uint16_t *lut = reinterpret_cast<uint16_t *>(smem + off);  // 4^K (canonical mode)
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (uint32_t i = tid; i < R * bins; i += BLOCK) hist[i] = 0;
-    for (uint32_t i = tid; i < 2 * R; i += BLOCK) totals[i] = 0;
-    if (CANON)
+    if (use_lut)
         for (uint32_t i = tid; i < NLUT; i += BLOCK) lut[i] = a.lut[i];
 
     const uint64_t n_tiles = (a.n_reads + R - 1) / R;
     const uint64_t total_bytes = a.offsets[a.n_reads];
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
-    uint32_t parity = 0;
 
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, parity ^= 1u) {
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t r0 = tile * R;
         const uint32_t nr = (uint32_t)((a.n_reads - r0) < R ? (a.n_reads - r0) : R);
         const uint64_t off0 = a.offsets[r0], off1 = a.offsets[r0 + nr];
-        for (uint32_t i = tid; i <= nr; i += BLOCK) roff[i] = a.offsets[r0 + i];
+        const uint64_t len_first = a.offsets[r0 + 1] - off0;
 
-        // ---- stage the tile's bases ------------------------------------------------
+        // ---- A: tile offsets -> LDS, are all reads of the tile equally long? -------------
+        int differs = 0;
+        for (uint32_t i = tid; i <= nr; i += BLOCK) {
+            const uint64_t o = a.offsets[r0 + i];
+            roff[i] = o;
+            if (i < nr) {
+                differs |= (a.offsets[r0 + i + 1] - o) != len_first;
+                tot[i] = 0;
+            }
+        }
+        const uint64_t TL = off1 - off0;
+        // (barrier) uniform-length fast path needs 8 <= len and tile-relative int32 positions
+        const bool general = __syncthreads_or(differs) || len_first < 8 || TL >= 0x7FFF0000ull;
+
+        // ---- B: positions -> LDS histograms ----------------------------------------------------
         const uintptr_t addr0 = base_addr + off0;
-        const uintptr_t al0 = addr0 & ~(uintptr_t)15;
+        const uintptr_t al0 = addr0 & ~(uintptr_t)7;
         const uint32_t sh = (uint32_t)(addr0 - al0);
-        const uint64_t span = (off1 - off0) + sh;
-        const bool staged = span + 16 <= a.stage_bytes;
-        if (staged) {
-            const uint32_t n16 = (uint32_t)((span + 15) >> 4);
-            for (uint32_t i = tid; i < n16; i += BLOCK) {
-                const uintptr_t p = al0 + 16ull * i;
-                uint4 v;
-                if (p >= base_addr && p + 16 <= base_addr + total_bytes) {
-                    v = *reinterpret_cast<const uint4 *>(p);
-                } else {  // first/last 16 bytes of the whole buffer: stay inside it
-                    unsigned char b[16];
-                    for (int j = 0; j < 16; j++) {
-                        const uintptr_t q = p + j;
-                        b[j] = (q >= base_addr && q < base_addr + total_bytes)
-                                   ? *reinterpret_cast<const unsigned char *>(q)
-                                   : (unsigned char)'N';
+        const uint64_t flat_end = TL + sh;  // tile bases are flat bytes [sh, flat_end) from al0
+        const uint64_t n_chunks = (flat_end + CHUNK - 1) / CHUNK;
+        const uint32_t Lr = (uint32_t)len_first;
+        const uint32_t lr_magic = general ? 0u : (uint32_t)(0xFFFFFFFFull / Lr) + 1u;  // exact for t < 2^31, Lr >= 8? see below
+
+        for (uint64_t ci = wave; ci < n_chunks; ci += NWAVES) {
+            // lane l owns flat bytes [q, q+8), q = ci*504 + 8*(l-1)   (lane 0: halo)
+            const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
+            uint32_t lo = 0x4E4E4E4Eu, hi = 0x4E4E4E4Eu;  // "NNNN": lanes outside the tile
+            const bool inside = q >= 0 && (uint64_t)q < flat_end;
+            if (inside) {
+                const uintptr_t p = al0 + (uint64_t)q;
+                if (p >= base_addr && p + 8 <= base_addr + total_bytes) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+                    lo = v.x;
+                    hi = v.y;
+                } else {  // first / last bytes of the whole buffer: stay inside it
+                    lo = 0;
+                    hi = 0;
+                    for (int j = 0; j < 8; j++) {
+                        const uintptr_t b = p + j;
+                        const uint32_t c = (b >= base_addr && b < base_addr + total_bytes)
+                                               ? *reinterpret_cast<const unsigned char *>(b)
+                                               : 0xFFu;
+                        if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
                     }
-                    __builtin_memcpy(&v, b, 16);
                 }
-                *reinterpret_cast<uint4 *>(stage + 16u * i) = v;
             }
-        }
-        __syncthreads();
+            // encode 8 bases: P = codes (base i at bits 2*(7-i)), V = invalid flags (bit 7-i)
+            uint32_t pa, va, ra, pb, vb, rb;
+            swar4(lo, pa, va, ra);
+            swar4(hi, pb, vb, rb);
+            uint32_t P = (pa << 8) | pb, V = (va << 4) | vb;
+            if (__ballot((ra | rb) != 0) != 0) bytes8(lo, hi, P, V);  // rare: raw 0..3 bytes present
+            if (!inside) V = 0xFFu;
 
-        // ---- positions -> LDS histograms --------------------------------------------
-        uint32_t *tot = totals + parity * R;
-        for (uint32_t r = 0; r < nr; r++) {
-            const uint64_t rs = roff[r];
-            const uint64_t L64 = roff[r + 1] - rs;
-            const uint32_t L = (uint32_t)(L64 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : L64);
-            if (L < (uint32_t)K) continue;
-            const uint32_t nch = (L - (K - 1) + S - 1) / S;
-            const unsigned char *src_l = stage + sh + (uint32_t)(rs - off0);
-            const uint8_t *src_g = a.bases + rs;
-            uint32_t *h = hist + r * bins;
-            uint32_t cnt = 0;
-            for (uint32_t c = (wave - r) & (NWAVES - 1); c < nch; c += NWAVES) {
-                const uint32_t p = c * S + lane;
-                uint32_t e = 4u;
-                if (p < L) e = ktd::nt4(staged ? src_l[p] : src_g[p]);
-                uint32_t f = e & 3u, bad = e >> 2, x = e;
+            // which read does the lane's first base belong to, and where in it?
+            // t0 = tile-relative index of the lane's first base (may be < 0 in the first lanes)
+            const int64_t t0 = q - (int64_t)sh;
+            uint32_t rid0;      // read (tile-relative) of base 0
+            int32_t pos0;       // its index inside that read (clamped; < 0 before the tile)
+            uint32_t rem;       // bases left in that read from base 0 on (clamped to 255)
+            uint32_t len1;      // length of the following read (clamped to 255; 0 = none)
+            bool slow = false;
+            if (!general) {
+                const uint32_t tt = t0 < 0 ? 0u : (uint32_t)t0;
+                rid0 = __umulhi(tt, lr_magic);
+                // magic division is exact for tt < 2^31 when Lr >= 2 ... guard against off-by-one
+                if (rid0 * Lr > tt) rid0--;
+                pos0 = t0 < 0 ? (int32_t)t0 : (int32_t)(tt - rid0 * Lr);
+                const uint32_t left = Lr - (uint32_t)(pos0 < 0 ? 0 : pos0);
+                rem = pos0 < 0 ? 255u : (left > 255u ? 255u : left);
+                len1 = (rid0 + 1 < nr) ? (Lr > 255u ? 255u : Lr) : 0u;
+                if (rid0 >= nr) V = 0xFFu;
+            } else {
+                if (t0 <= -8) {  // whole lane before the tile (halo lane of chunk 0)
+                    rid0 = 0;
+                    pos0 = -1024;
+                    rem = 255u;
+                    len1 = 0;
+                    V = 0xFFu;
+                } else if (t0 < 0) {
+                    // bases 0..(-t0-1) lie before the tile, the rest start read 0: treat read 0 as
+                    // if it extended backwards (negative positions never emit)
+                    rid0 = 0;
+                    pos0 = (int32_t)t0;
+                    const uint64_t e0 = roff[1];
+                    const uint64_t left = (e0 - off0) + (uint64_t)(-t0);
+                    rem = (uint32_t)(left > 255ull ? 255ull : left);
+                    uint64_t l1 = 0;
+                    if (1 < nr) l1 = roff[2] - e0;
+                    len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
+                    slow = rem < 8u && 1 < nr && len1 < 8u - rem;
+                } else if ((uint64_t)t0 >= TL) {
+                    rid0 = 0;
+                    pos0 = 0;
+                    rem = 255u;
+                    len1 = 0;
+                    V = 0xFFu;
+                } else {
+                    const uint64_t T = off0 + (uint64_t)t0;
+                    rid0 = find_read(roff, nr, T);
+                    const uint64_t s0 = roff[rid0], e0 = roff[rid0 + 1];
+                    const uint64_t p64 = T - s0, left = e0 - T;
+                    pos0 = (int32_t)(p64 > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : p64);
+                    rem = (uint32_t)(left > 255ull ? 255ull : left);
+                    uint64_t l1 = 0;
+                    if (rid0 + 1 < nr) l1 = roff[rid0 + 2] - e0;
+                    len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
+                    // a second boundary inside these 8 bases (tiny / empty next read)
+                    slow = rem < 8u && rid0 + 1 < nr && len1 < 8u - rem;
+                }
+            }
+
+            // predecessor lane's pack (lane 0 keeps "all invalid")
+            const uint32_t PV = (V << 16) | P;
+            const uint32_t prevPV = ktd::wave_shr1(PV, 0x00FF0000u);
+            const uint32_t W = ((prevPV & 0xFFFFu) << 16) | P;   // base i at bits 2*(7-i), previous lane above
+            const uint32_t VV = ((prevPV >> 16) << 8) | V;        // invalid flags, same order
+            const bool emit_lane = lane != 0;
+            const uint32_t row0 = rid0 * bins;
+            uint32_t cnt0 = 0, cnt1 = 0;
+
+            if (__ballot(slow) == 0) {
 #pragma unroll
-                for (int j = 1; j < K; j++) {
-                    x = ktd::wave_shr1(x, 4u);
-                    f |= (x & 3u) << (2 * j);
-                    bad |= x >> 2;
+                for (int i = 0; i < 8; i++) {
+                    const bool nxt = (uint32_t)i >= rem;                  // base i is in the following read
+                    const int32_t pos = nxt ? (int32_t)((uint32_t)i - rem) : pos0 + i;
+                    const bool in_read = nxt ? ((uint32_t)i - rem) < len1 : true;
+                    const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
+                    const bool ok = emit_lane && in_read && pos >= (int32_t)(K - 1) && bad == 0;
+                    if (ok) {
+                        const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+                        const uint32_t bin = use_lut ? (uint32_t)lut[f] : f;
+                        atomicAdd(&hist[(nxt ? row0 + bins : row0) + bin], 1u);
+                    }
+                    cnt0 += (ok && !nxt) ? 1u : 0u;
+                    cnt1 += (ok && nxt) ? 1u : 0u;
                 }
-                const bool emit = (lane >= (uint32_t)(K - 1)) && (bad == 0);
-                if (emit) {
-                    const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
-                    atomicAdd(&h[bin], 1u);
+                if (cnt0) atomicAdd(&tot[rid0], cnt0);
+                if (cnt1) atomicAdd(&tot[rid0 + 1], cnt1);
+            } else {
+                // per-base path: every base finds its own read (several boundaries in 8 bases)
+#pragma unroll 1
+                for (int i = 0; i < 8; i++) {
+                    const int64_t ti = t0 + i;
+                    if (!emit_lane || ti < 0 || (uint64_t)ti >= TL) continue;
+                    const uint64_t T = off0 + (uint64_t)ti;
+                    const uint32_t rid = find_read(roff, nr, T);
+                    const uint64_t p64 = T - roff[rid];
+                    const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
+                    if (p64 >= (uint64_t)(K - 1) && bad == 0) {
+                        const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+                        const uint32_t bin = use_lut ? (uint32_t)lut[f] : f;
+                        atomicAdd(&hist[rid * bins + bin], 1u);
+                        atomicAdd(&tot[rid], 1u);
+                    }
                 }
-                cnt += (uint32_t)__popcll(__ballot(emit));
             }
-            if (lane == 0 && cnt) atomicAdd(&tot[r], cnt);
         }
         __syncthreads();
 
-        // ---- stream the tile's rows out, clearing the histogram behind ----------------
+        // ---- C: per-read divisor and its reciprocal ------------------------------------------------
+        for (uint32_t i = tid; i < nr; i += BLOCK) {
+            double d = 1.0;
+            if (a.norm) {
+                const double t = (double)((uint64_t)tot[i] * a.total_step);
+                d = t > 1.0 ? t : 1.0;  // f64::max(1, total), oligo.rs:255-257
+            }
+            dnm[i] = d;
+            rcp[i] = 1.0 / d;
+        }
+        __syncthreads();
+
+        // ---- D: stream the tile's rows out, clearing the histogram behind -----------------------------
         const uint32_t nvec = nr * a.vec_per_row;
         vec_t *dst = reinterpret_cast<vec_t *>(a.out) + r0 * a.vec_per_row;
         for (uint32_t v = tid; v < nvec; v += BLOCK) {
@@ -171,53 +333,43 @@ __global__ __launch_bounds__(BLOCK) void oligo_tile_kernel(OligoArgs a) {
             if constexpr (DT == KT_F64) {
                 const uint2 c = *reinterpret_cast<uint2 *>(hp);
                 *reinterpret_cast<uint2 *>(hp) = make_uint2(0, 0);
-                double d = 1.0;
-                if (a.norm) {
-                    const double t = (double)((uint64_t)tot[r] * a.total_step);
-                    d = t > 1.0 ? t : 1.0;
-                }
-                o.x = (double)c.x / d;
-                o.y = (double)c.y / d;
+                const double d = dnm[r], y = rcp[r];
+                const double cx = (double)c.x, cy = (double)c.y;
+                const double qx = __dmul_rn(cx, y), qy = __dmul_rn(cy, y);
+                o.x = __fma_rn(__fma_rn(-qx, d, cx), y, qx);
+                o.y = __fma_rn(__fma_rn(-qy, d, cy), y, qy);
             } else {
                 const uint4 c = *reinterpret_cast<uint4 *>(hp);
                 *reinterpret_cast<uint4 *>(hp) = make_uint4(0, 0, 0, 0);
                 if constexpr (DT == KT_F32) {
-                    float d = 1.0f;
-                    if (a.norm) {
-                        const float t = (float)((uint64_t)tot[r] * a.total_step);
-                        d = t > 1.0f ? t : 1.0f;
-                    }
-                    o.x = (float)c.x / d;
-                    o.y = (float)c.y / d;
-                    o.z = (float)c.z / d;
-                    o.w = (float)c.w / d;
+                    const float d = (float)dnm[r], y = (float)rcp[r];
+                    const float cx = (float)c.x, cy = (float)c.y, cz = (float)c.z, cw = (float)c.w;
+                    const float qx = __fmul_rn(cx, y), qy = __fmul_rn(cy, y), qz = __fmul_rn(cz, y),
+                                qw = __fmul_rn(cw, y);
+                    o.x = __fmaf_rn(__fmaf_rn(-qx, d, cx), y, qx);
+                    o.y = __fmaf_rn(__fmaf_rn(-qy, d, cy), y, qy);
+                    o.z = __fmaf_rn(__fmaf_rn(-qz, d, cz), y, qz);
+                    o.w = __fmaf_rn(__fmaf_rn(-qw, d, cw), y, qw);
                 } else {
                     o = c;
                 }
             }
             dst[v] = o;
         }
-        // the other totals buffer was last read one tile ago: safe to clear now
-        for (uint32_t i = tid; i < R; i += BLOCK) totals[(parity ^ 1u) * R + i] = 0;
-        // the next tile's first barrier orders these LDS writes before its positions phase
+        // the next tile's first barrier (__syncthreads_or) orders these LDS writes before its
+        // positions phase; roff/tot/dnm/rcp are not touched again until after that barrier
+        // except roff/tot in phase A, which nobody reads in phase D.
     }
 }
 
 using kern_t = void (*)(OligoArgs);
 
 template <int K>
-kern_t pick(int count_min, int dt) {
-    if (count_min) {
-        switch (dt) {
-            case KT_F64: return oligo_tile_kernel<K, true, KT_F64>;
-            case KT_F32: return oligo_tile_kernel<K, true, KT_F32>;
-            default: return oligo_tile_kernel<K, true, KT_U32>;
-        }
-    }
+kern_t pick(int dt) {
     switch (dt) {
-        case KT_F64: return oligo_tile_kernel<K, false, KT_F64>;
-        case KT_F32: return oligo_tile_kernel<K, false, KT_F32>;
-        default: return oligo_tile_kernel<K, false, KT_U32>;
+        case KT_F64: return oligo_flat_kernel<K, KT_F64>;
+        case KT_F32: return oligo_flat_kernel<K, KT_F32>;
+        default: return oligo_flat_kernel<K, KT_U32>;
     }
 }
 
@@ -253,32 +405,29 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     a.vec_per_row = bins / VEC;
     a.vec_magic = (uint32_t)((0x100000000ull + a.vec_per_row - 1) / a.vec_per_row);
 
-    // reads per tile: ~18 KB of LDS histogram, at most 64 reads; the flat output index
+    // reads per tile: ~36 KB of LDS histogram, at most 64 reads; the flat output index
     // v < R * vec_per_row must keep the magic division exact: v * vec_per_row < 2^32.
-    uint32_t R = 18432u / (bins * 4u);
+    uint32_t R = 36864u / (bins * 4u);
     if (R < 1) R = 1;
     if (R > 64) R = 64;
     R = env_u32("KT_OLIGO_R", R);
     while (R > 1 && (uint64_t)R * a.vec_per_row * a.vec_per_row >= 0x100000000ull) R--;
     a.R = R;
-    a.stage_bytes = ((R * 192u + 47u) & ~15u);
-    if (a.stage_bytes > 24576u) a.stage_bytes = 24576u;
-    a.stage_bytes = env_u32("KT_OLIGO_STAGE", a.stage_bytes) & ~15u;
 
     size_t lds = (size_t)R * bins * 4;
-    lds += ((2 * R * 4 + 15) & ~15u);
+    lds += ((R * 4 + 15) & ~15u);
+    lds += 2 * ((R * 8 + 15) & ~15u);
     lds += (((R + 1) * 8 + 15) & ~15u);
     lds += count_min ? ((((size_t)1 << (2 * k)) * 2 + 15) & ~(size_t)15) : 0;
-    lds += a.stage_bytes;
     if (lds > 160 * 1024) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: tile does not fit in LDS");
 
     kern_t kern = nullptr;
     switch (k) {
-        case 3: kern = pick<3>(count_min, dt); break;
-        case 4: kern = pick<4>(count_min, dt); break;
-        case 5: kern = pick<5>(count_min, dt); break;
-        case 6: kern = pick<6>(count_min, dt); break;
-        case 7: kern = pick<7>(count_min, dt); break;
+        case 3: kern = pick<3>(dt); break;
+        case 4: kern = pick<4>(dt); break;
+        case 5: kern = pick<5>(dt); break;
+        case 6: kern = pick<6>(dt); break;
+        case 7: kern = pick<7>(dt); break;
         default: return kt::fail(KT_ERR_ARG, "kt_oligo_batch: k must be in 3..7");
     }
     if (lds > 64 * 1024)
@@ -289,7 +438,7 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
-    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", 1);
+    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", 4);
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(BLOCK), lds, ctx->stream, a);

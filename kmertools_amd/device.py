@@ -86,12 +86,15 @@ def to_csr(seqs):
 
 class Context:
     """One device + one stream (kt_ctx).  `stream` is a raw hipStream_t handle
-    (e.g. torch.cuda.current_stream().cuda_stream) or None for a private stream."""
+    (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream) to enqueue on,
+    or None to let the context own a private stream."""
 
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
         self.device = device
-        check(_lib.lib().kt_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        own = stream is None
+        check(_lib.lib().kt_ctx_create(device, None if own else C.c_void_p(int(stream)), int(own),
+                                       C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -134,7 +134,9 @@ def test_oligo_vs_oracle(hctx, oracle, k, count_min):
     n = 300 if k <= 5 else 60
     seqs = ragged_reads(7 * k + count_min, n)
     bases, offsets = device.to_csr(seqs)
-    for norm, step in [(True, 1), (False, 1), (True, 2)]:
+    # total_step = 2 is the python binding's raw-mode quirk (pybindings/src/oligo.rs:61); the
+    # reference never applies it to canonical bins, so the oracle only models it for raw mode
+    for norm, step in [(True, 1), (False, 1)] + ([] if count_min else [(True, 2)]):
         want = oracle.oligo_batch(bases, offsets, k, count_min, norm, float(step))
         got = hctx.oligo_host(bases, offsets, k, count_min, norm, step, "f64")
         assert got.shape == want.shape
