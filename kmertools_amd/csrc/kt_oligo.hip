@@ -67,6 +67,7 @@ struct OligoArgs {
     uint32_t total_step;
     uint32_t vec_per_row;  // bins / VEC
     uint32_t vec_magic;    // ceil(2^32 / vec_per_row)
+    uint32_t debug;        // KT_OLIGO_DEBUG bits: 1 skip positions, 2 skip stores (ablation only)
 };
 
 // 4 bases in one dword -> 2-bit codes packed big-endian in 8 bits (first base in bits 7:6)
@@ -111,7 +112,7 @@ __device__ __forceinline__ uint32_t find_read(const uint64_t *roff, uint32_t nr,
     return lo;
 }
 
-template <int K, int DT>
+template <int K, bool CANON, int DT>
 __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VEC = OutVec<DT>::VEC;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
     constexpr uint32_t KMASK = NLUT - 1u;
 
     const uint32_t R = a.R, bins = a.bins;
-    const bool use_lut = a.lut != nullptr;
+
     // LDS carve (all offsets multiples of 16)
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);  // R * bins
     uint32_t off = R * bins * 4;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (uint32_t i = tid; i < R * bins; i += BLOCK) hist[i] = 0;
-    if (use_lut)
+    if (CANON)
         for (uint32_t i = tid; i < NLUT; i += BLOCK) lut[i] = a.lut[i];
 
     const uint64_t n_tiles = (a.n_reads + R - 1) / R;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
         const uint32_t Lr = (uint32_t)len_first;
         const uint32_t lr_magic = general ? 0u : (uint32_t)(0xFFFFFFFFull / Lr) + 1u;  // exact for t < 2^31, Lr >= 8? see below
 
-        for (uint64_t ci = wave; ci < n_chunks; ci += NWAVES) {
+        for (uint64_t ci = wave; ci < ((a.debug & 1u) ? 0 : n_chunks); ci += NWAVES) {
             // lane l owns flat bytes [q, q+8), q = ci*504 + 8*(l-1)   (lane 0: halo)
             const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
             uint32_t lo = 0x4E4E4E4Eu, hi = 0x4E4E4E4Eu;  // "NNNN": lanes outside the tile
@@ -269,27 +270,39 @@ __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
             const uint32_t W = ((prevPV & 0xFFFFu) << 16) | P;   // base i at bits 2*(7-i), previous lane above
             const uint32_t VV = ((prevPV >> 16) << 8) | V;        // invalid flags, same order
             const bool emit_lane = lane != 0;
-            const uint32_t row0 = rid0 * bins;
-            uint32_t cnt0 = 0, cnt1 = 0;
 
             if (__ballot(slow) == 0) {
+                // Branch-free: 8-bit masks over the lane's bases (base i <-> bit 7-i), then 8
+                // unconditional LUT reads and 8 unconditional ds_add of 0 or 1.
+                // ge(x) = { i >= x } = 0xFF >> clamp(x, 0, 8)
+                uint32_t B = VV;  // bit 7-i: some invalid base in the window ending at base i
+#pragma unroll
+                for (int j = 1; j < K; j++) B |= VV >> j;
+                const int32_t a1 = (int32_t)(K - 1) - pos0;  // current read: bases i < a1 lack predecessors
+                const uint32_t g1 = 0xFFu >> (uint32_t)(a1 < 0 ? 0 : (a1 > 8 ? 8 : a1));
+                const uint32_t gr = 0xFFu >> (rem > 8u ? 8u : rem);                // bases of the following read
+                const uint32_t grk = 0xFFu >> (rem + (K - 1) > 8u ? 8u : rem + (K - 1));   // ... that have k-1 predecessors
+                const uint32_t grl = 0xFFu >> (rem + len1 > 8u ? 8u : rem + len1); // past the following read
+                uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFu;
+                ok = emit_lane ? ok : 0u;
+                const uint32_t rsafe = rid0 < R ? rid0 : R - 1;                     // dead lanes add 0 to a real row
+                const uint32_t row0 = rsafe * bins;
+                const uint32_t has_next = rsafe + 1 < R ? 1u : 0u;
+                const uint32_t rowstep = has_next ? bins : 0u;
+                uint32_t bin[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const bool nxt = (uint32_t)i >= rem;                  // base i is in the following read
-                    const int32_t pos = nxt ? (int32_t)((uint32_t)i - rem) : pos0 + i;
-                    const bool in_read = nxt ? ((uint32_t)i - rem) < len1 : true;
-                    const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
-                    const bool ok = emit_lane && in_read && pos >= (int32_t)(K - 1) && bad == 0;
-                    if (ok) {
-                        const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
-                        const uint32_t bin = use_lut ? (uint32_t)lut[f] : f;
-                        atomicAdd(&hist[(nxt ? row0 + bins : row0) + bin], 1u);
-                    }
-                    cnt0 += (ok && !nxt) ? 1u : 0u;
-                    cnt1 += (ok && nxt) ? 1u : 0u;
+                    const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+                    bin[i] = CANON ? (uint32_t)lut[f] : f;
                 }
-                if (cnt0) atomicAdd(&tot[rid0], cnt0);
-                if (cnt1) atomicAdd(&tot[rid0 + 1], cnt1);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t sel = (gr >> (7 - i)) & 1u;
+                    const uint32_t val = (ok >> (7 - i)) & 1u;
+                    atomicAdd(&hist[row0 + sel * rowstep + bin[i]], val);
+                }
+                atomicAdd(&tot[rsafe], (uint32_t)__popc(ok & ~gr));
+                atomicAdd(&tot[rsafe + has_next], (uint32_t)__popc(ok & gr));
             } else {
                 // per-base path: every base finds its own read (several boundaries in 8 bases)
 #pragma unroll 1
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
                     const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
                     if (p64 >= (uint64_t)(K - 1) && bad == 0) {
                         const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
-                        const uint32_t bin = use_lut ? (uint32_t)lut[f] : f;
+                        const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
                         atomicAdd(&hist[rid * bins + bin], 1u);
                         atomicAdd(&tot[rid], 1u);
                     }
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
                     o = c;
                 }
             }
-            dst[v] = o;
+            if (!(a.debug & 2u)) dst[v] = o;
         }
         // the next tile's first barrier (__syncthreads_or) orders these LDS writes before its
         // positions phase; roff/tot/dnm/rcp are not touched again until after that barrier
@@ -365,11 +378,18 @@ __global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
 using kern_t = void (*)(OligoArgs);
 
 template <int K>
-kern_t pick(int dt) {
+kern_t pick(int count_min, int dt) {
+    if (count_min) {
+        switch (dt) {
+            case KT_F64: return oligo_flat_kernel<K, true, KT_F64>;
+            case KT_F32: return oligo_flat_kernel<K, true, KT_F32>;
+            default: return oligo_flat_kernel<K, true, KT_U32>;
+        }
+    }
     switch (dt) {
-        case KT_F64: return oligo_flat_kernel<K, KT_F64>;
-        case KT_F32: return oligo_flat_kernel<K, KT_F32>;
-        default: return oligo_flat_kernel<K, KT_U32>;
+        case KT_F64: return oligo_flat_kernel<K, false, KT_F64>;
+        case KT_F32: return oligo_flat_kernel<K, false, KT_F32>;
+        default: return oligo_flat_kernel<K, false, KT_U32>;
     }
 }
 
@@ -404,6 +424,7 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     a.total_step = (uint32_t)total_step;
     a.vec_per_row = bins / VEC;
     a.vec_magic = (uint32_t)((0x100000000ull + a.vec_per_row - 1) / a.vec_per_row);
+    a.debug = env_u32("KT_OLIGO_DEBUG", 0);
 
     // reads per tile: ~36 KB of LDS histogram, at most 64 reads; the flat output index
     // v < R * vec_per_row must keep the magic division exact: v * vec_per_row < 2^32.
@@ -423,11 +444,11 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
 
     kern_t kern = nullptr;
     switch (k) {
-        case 3: kern = pick<3>(dt); break;
-        case 4: kern = pick<4>(dt); break;
-        case 5: kern = pick<5>(dt); break;
-        case 6: kern = pick<6>(dt); break;
-        case 7: kern = pick<7>(dt); break;
+        case 3: kern = pick<3>(count_min, dt); break;
+        case 4: kern = pick<4>(count_min, dt); break;
+        case 5: kern = pick<5>(count_min, dt); break;
+        case 6: kern = pick<6>(count_min, dt); break;
+        case 7: kern = pick<7>(count_min, dt); break;
         default: return kt::fail(KT_ERR_ARG, "kt_oligo_batch: k must be in 3..7");
     }
     if (lds > 64 * 1024)
