@@ -5,37 +5,47 @@
 // binding's copy (pybindings/src/oligo.rs:39-69) for a whole CSR batch of reads.
 //
 // Shape of the problem (k=4, 150-bp reads, f64 rows): 150 B in, 1088 B out per read - a
-// streaming-store kernel whose first version was VALU-bound (278 VALU instructions per
-// read, profiles/r1_oligo_v1_pmc.txt).  This version is built around instruction count:
+// streaming-store kernel; HBM-bound, no MFMA (integer histogram).  The first version was
+// VALU-bound (278 VALU instructions per read) and the second serialised its compute and
+// store phases (profiles/r1_oligo_*), so this one is built around two things: instruction
+// count, and keeping the store stream busy while the next tile is being counted.
 //
-// One 256-thread workgroup owns a *tile* of R consecutive reads; their bases are one
-// contiguous byte range of `bases`, treated as a flat stream.
-//   positions  each wave takes 504-byte chunks of the stream; a lane owns 8 consecutive
-//              bases (one aligned 8-byte global load; lane 0 is the halo for lane 1).  The 8
-//              bytes are encoded with SWAR integer ops (4 bases per instruction: 2-bit codes
-//              by shifts/xor, validity by a v_perm_b32 table compare), packed to 16 bits of
-//              codes + 8 invalid flags, and the predecessor lane's pack arrives by one DPP
-//              wave_shr:1.  Each of the 8 k-mers ending in the lane is then a single
-//              v_bfe_u32 of that 32-bit window: fwd(p) = sum code[p-j]*4^j, identical to the
-//              reference's rolling value.  Which read a base belongs to is
-//              arithmetic for equal-length tiles and a binary search of the tile's offsets
-//              otherwise, so long reads spread over all lanes and waves.
-//              bin = lut[fwd] (rank of the canonical form, LDS) or fwd; one ds_add_u32 into
-//              the read's LDS histogram row.
-//   output     the R x bins counts are one contiguous block of the output matrix; the 256
-//              lanes stream it out as 16-byte stores and clear the LDS rows behind them.
-//              Normalisation c / d (d = max(1, total)) uses y = RN(1/d) computed once per
-//              read: q0 = c*y, r = fma(-q0, d, c), q = fma(r, y, q0).  For integers
-//              c <= d < 2^32 the residual r is exact and q is the correctly rounded
-//              quotient (Markstein), i.e. bit-identical to the reference's f64 division.
+// A 256-thread workgroup owns *tiles* of R consecutive reads; their bases are one contiguous
+// byte range of `bases`, treated as a flat stream.  Per tile:
+//
+//   B  positions: each wave takes 504-byte chunks of the stream; a lane owns 8 consecutive
+//      bases (one aligned 8-byte global load, issued one tile ahead; lane 0 is the halo for
+//      lane 1).  The 8 bytes are encoded with SWAR integer ops (4 bases per instruction:
+//      2-bit codes by shifts/xor, validity by a v_perm_b32 table compare), packed to 16 bits
+//      of codes + 8 invalid flags, and the predecessor lane's pack arrives by one DPP
+//      wave_shr:1.  Each of the 8 k-mers ending in the lane is then one bit-field extract of
+//      that 32-bit window: fwd(p) = sum code[p-j]*4^j, identical to the reference's rolling
+//      value.  Which read a base belongs to is arithmetic for equal-length
+//      tiles and a binary search of the tile's offsets otherwise, so long reads spread over
+//      all lanes and waves.  Validity (invalid base in the window, read boundary inside the
+//      window) is 8-bit mask arithmetic; the 8 LUT reads (rank of the canonical form, LDS)
+//      and the 8 ds_add_u32 into the reads' LDS histogram rows are unconditional (they add
+//      0 or 1): no branches.
+//   D  output: the R x bins counts are one contiguous block of the output matrix; each wave
+//      streams its rows out as 16-byte stores (4 in flight per lane) and clears the LDS
+//      rows behind.  Normalisation c / d (d = max(1, total)) uses y = RN(1/d) computed once
+//      per read: q0 = c*y, r = fma(-q0, d, c), q = fma(r, y, q0).  For integers
+//      c <= d < 2^32 the residual r is exact and q is the correctly rounded quotient
+//      (Markstein), i.e. bit-identical to the reference's f64 division.
+//
+// Two barriers per tile; the next tile's offsets and bases are loaded into registers
+// between B and D so HBM read latency hides under the store phase.  Structures that were
+// measured and dropped (double-buffered producer/consumer wave specialisation; the per-read
+// wave loop with k-1 DPP shifts) are in the git history and DESIGN.md.
 #include "kt_device.hpp"
 #include "kt_internal.hpp"
 
+#include <type_traits>
+
 namespace {
 
-constexpr int BLOCK = 256;
-constexpr int NWAVES = BLOCK / 64;
 constexpr uint32_t CHUNK = 63 * 8;  // new bases per wave-chunk (lane 0 is halo)
+constexpr uint32_t MAX_R = 64;      // reads per tile (one lane per read in the per-read steps)
 
 template <int DT>
 struct OutVec;
@@ -59,10 +69,10 @@ struct OligoArgs {
     const uint8_t *bases;
     const uint64_t *offsets;
     uint64_t n_reads;
-    const uint16_t *lut;  // device, 4^k entries, or nullptr for raw bins
+    const uint16_t *lut;  // device, 4^k entries (canonical mode)
     void *out;
     uint32_t bins;
-    uint32_t R;            // reads per tile
+    uint32_t R;            // reads per tile, <= MAX_R
     uint32_t norm;
     uint32_t total_step;
     uint32_t vec_per_row;  // bins / VEC
@@ -112,284 +122,424 @@ __device__ __forceinline__ uint32_t find_read(const uint64_t *roff, uint32_t nr,
     return lo;
 }
 
-template <int K, bool CANON, int DT>
-__global__ __launch_bounds__(BLOCK) void oligo_flat_kernel(OligoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+struct TileCtx {
+    uint64_t r0;       // first read of the tile
+    uint32_t nr;       // reads in the tile
+    uint64_t off0;     // base offset of its first read
+    uint64_t TL;       // number of bases of the tile
+};
+
+// What a producer wave knows about a tile once its offsets have arrived.
+struct ProdTile {
+    uint64_t r0, off0, TL;
+    uint32_t nr;
+    uintptr_t al0;      // 8-byte aligned address at or before the tile's first base
+    uint32_t sh;        // (address of first base) - al0
+    uint64_t flat_end;  // tile bases are flat bytes [sh, flat_end) from al0
+    uint64_t n_chunks;
+    uint32_t Lr, lr_magic;  // uniform read length and its magic reciprocal (fast path)
+    bool general;           // reads differ in length (or are tiny / huge): binary-search path
+};
+
+// lane i holds offsets[r0+i] and offsets[r0+i+1] of a tile (i < nr <= 64); issued two tiles ahead
+struct OffRegs {
+    uint64_t o, on;
+};
+
+__device__ __forceinline__ OffRegs load_offsets(const OligoArgs &a, uint64_t tile, uint32_t lane) {
+    OffRegs r{0, 0};
+    const uint64_t r0 = tile * a.R;
+    if (r0 < a.n_reads) {
+        const uint64_t nr = (a.n_reads - r0) < a.R ? (a.n_reads - r0) : a.R;
+        if (lane < nr) {
+            r.o = a.offsets[r0 + lane];
+            r.on = a.offsets[r0 + lane + 1];
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile, const OffRegs &r, uint32_t lane) {
+    ProdTile t;
+    t.r0 = tile * a.R;
+    t.nr = (uint32_t)((a.n_reads - t.r0) < a.R ? (a.n_reads - t.r0) : a.R);
+    t.off0 = readlane64(r.o, 0);
+    const uint64_t off1 = readlane64(r.on, t.nr - 1);
+    const uint64_t len_first = readlane64(r.on, 0) - t.off0;
+    t.TL = off1 - t.off0;
+    const bool differs = lane < t.nr && (r.on - r.o) != len_first;
+    // uniform-length fast path needs len >= 8 and tile-relative int32 positions
+    t.general = __ballot(differs) != 0 || len_first < 8 || t.TL >= 0x7FFF0000ull;
+    const uintptr_t addr0 = reinterpret_cast<uintptr_t>(a.bases) + t.off0;
+    t.al0 = addr0 & ~(uintptr_t)7;
+    t.sh = (uint32_t)(addr0 - t.al0);
+    t.flat_end = t.TL + t.sh;
+    t.n_chunks = (t.flat_end + CHUNK - 1) / CHUNK;
+    t.Lr = (uint32_t)len_first;
+    t.lr_magic = t.general ? 0u : (uint32_t)(0xFFFFFFFFull / t.Lr) + 1u;
+    return t;
+}
+
+// lane l of chunk ci owns flat bytes [q, q+8), q = ci*504 + 8*(l-1)   (lane 0: halo)
+__device__ __forceinline__ uint2 load_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint32_t lane,
+                                            uint64_t total_bytes) {
+    const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
+    const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
+    uint2 v = make_uint2(0x4E4E4E4Eu, 0x4E4E4E4Eu);  // "NNNN": lanes outside the tile
+    if (a.debug & 4u) return make_uint2(0x54474341u + lane, 0x41434754u);  // ablation: no global load
+    if (q >= 0 && (uint64_t)q < t.flat_end) {
+        const uintptr_t p = t.al0 + (uint64_t)q;
+        if (p >= base_addr && p + 8 <= base_addr + total_bytes) {
+            v = *reinterpret_cast<const uint2 *>(p);
+        } else {  // first / last bytes of the whole buffer: stay inside it
+            v = make_uint2(0, 0);
+            for (int j = 0; j < 8; j++) {
+                const uintptr_t b = p + j;
+                const uint32_t c = (b >= base_addr && b < base_addr + total_bytes)
+                                       ? *reinterpret_cast<const unsigned char *>(b)
+                                       : 0xFFu;
+                if (j < 4) v.x |= c << (8 * j); else v.y |= c << (8 * (j - 4));
+            }
+        }
+    }
+    return v;
+}
+
+// ---- producer: one 504-base chunk of a tile -> LDS histogram rows ---------------------------------
+template <int K, bool CANON>
+__device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint2 data,
+                                              uint32_t lane, const uint16_t *lut, uint32_t *hist, uint32_t *tot,
+                                              const uint64_t *roff) {
+    constexpr uint32_t KMASK = (1u << (2 * K)) - 1u;
+    const uint32_t R = a.R, bins = a.bins, nr = t.nr;
+    const uint64_t off0 = t.off0, TL = t.TL;
+    const uint32_t sh = t.sh, Lr = t.Lr, lr_magic = t.lr_magic;
+    const bool general = t.general;
+    {
+        const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
+        const uint32_t lo = data.x, hi = data.y;
+        const bool inside = q >= 0 && (uint64_t)q < t.flat_end;
+        // encode 8 bases: P = codes (base i at bits 2*(7-i)), V = invalid flags (bit 7-i)
+        uint32_t pa, va, ra, pb, vb, rb;
+        swar4(lo, pa, va, ra);
+        swar4(hi, pb, vb, rb);
+        uint32_t P = (pa << 8) | pb, V = (va << 4) | vb;
+        if (__ballot((ra | rb) != 0) != 0) bytes8(lo, hi, P, V);  // rare: raw 0..3 bytes present
+        if (!inside) V = 0xFFu;
+
+        // which read does the lane's first base belong to, and where in it?
+        // t0 = tile-relative index of the lane's first base (may be < 0 in the first lanes)
+        const int64_t t0 = q - (int64_t)sh;
+        uint32_t rid0;      // read (tile-relative) of base 0
+        int32_t pos0;       // its index inside that read (clamped; < 0 before the tile)
+        uint32_t rem;       // bases left in that read from base 0 on (clamped to 255)
+        uint32_t len1;      // length of the following read (clamped to 255; 0 = none)
+        bool slow = false;
+        if (!general) {
+            const uint32_t tt = t0 < 0 ? 0u : (uint32_t)t0;
+            rid0 = __umulhi(tt, lr_magic);
+            if (rid0 * Lr > tt) rid0--;  // the magic quotient can overshoot by one
+            pos0 = t0 < 0 ? (int32_t)t0 : (int32_t)(tt - rid0 * Lr);
+            const uint32_t left = Lr - (uint32_t)(pos0 < 0 ? 0 : pos0);
+            rem = pos0 < 0 ? 255u : (left > 255u ? 255u : left);
+            len1 = (rid0 + 1 < nr) ? (Lr > 255u ? 255u : Lr) : 0u;
+            if (rid0 >= nr) V = 0xFFu;
+        } else {
+            if (t0 <= -8) {  // whole lane before the tile (halo lane of chunk 0)
+                rid0 = 0;
+                pos0 = -1024;
+                rem = 255u;
+                len1 = 0;
+                V = 0xFFu;
+            } else if (t0 < 0) {
+                // bases 0..(-t0-1) lie before the tile, the rest start read 0: treat read 0 as
+                // if it extended backwards (negative positions never emit)
+                rid0 = 0;
+                pos0 = (int32_t)t0;
+                const uint64_t e0 = roff[1];
+                const uint64_t left = (e0 - off0) + (uint64_t)(-t0);
+                rem = (uint32_t)(left > 255ull ? 255ull : left);
+                uint64_t l1 = 0;
+                if (1 < nr) l1 = roff[2] - e0;
+                len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
+                slow = rem < 8u && 1 < nr && len1 < 8u - rem;
+            } else if ((uint64_t)t0 >= TL) {
+                rid0 = 0;
+                pos0 = 0;
+                rem = 255u;
+                len1 = 0;
+                V = 0xFFu;
+            } else {
+                const uint64_t T = off0 + (uint64_t)t0;
+                rid0 = find_read(roff, nr, T);
+                const uint64_t s0 = roff[rid0], e0 = roff[rid0 + 1];
+                const uint64_t p64 = T - s0, left = e0 - T;
+                pos0 = (int32_t)(p64 > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : p64);
+                rem = (uint32_t)(left > 255ull ? 255ull : left);
+                uint64_t l1 = 0;
+                if (rid0 + 1 < nr) l1 = roff[rid0 + 2] - e0;
+                len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
+                // a second boundary inside these 8 bases (tiny / empty next read)
+                slow = rem < 8u && rid0 + 1 < nr && len1 < 8u - rem;
+            }
+        }
+
+        // predecessor lane's pack (lane 0 keeps "all invalid")
+        const uint32_t PV = (V << 16) | P;
+        const uint32_t prevPV = ktd::wave_shr1(PV, 0x00FF0000u);
+        const uint32_t W = ((prevPV & 0xFFFFu) << 16) | P;   // base i at bits 2*(7-i), previous lane above
+        const uint32_t VV = ((prevPV >> 16) << 8) | V;        // invalid flags, same order
+        const bool emit_lane = lane != 0;
+
+        if (__ballot(slow) == 0) {
+            // Branch-free: 8-bit masks over the lane's bases (base i <-> bit 7-i), then 8
+            // unconditional LUT reads and 8 unconditional ds_add of 0 or 1.
+            // ge(x) = { i >= x } = 0xFF >> clamp(x, 0, 8)
+            uint32_t B = VV;  // bit 7-i: some invalid base in the window ending at base i
+#pragma unroll
+            for (int j = 1; j < K; j++) B |= VV >> j;
+            const int32_t a1 = (int32_t)(K - 1) - pos0;  // current read: bases i < a1 lack predecessors
+            const uint32_t g1 = 0xFFu >> (uint32_t)(a1 < 0 ? 0 : (a1 > 8 ? 8 : a1));
+            const uint32_t gr = 0xFFu >> (rem > 8u ? 8u : rem);                        // bases of the following read
+            const uint32_t grk = 0xFFu >> (rem + (K - 1) > 8u ? 8u : rem + (K - 1));  // ... with k-1 predecessors
+            const uint32_t grl = 0xFFu >> (rem + len1 > 8u ? 8u : rem + len1);        // past the following read
+            uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFu;
+            ok = emit_lane ? ok : 0u;
+            const uint32_t rsafe = rid0 < R ? rid0 : R - 1;  // dead lanes add 0 to a real row
+            const uint32_t row0 = rsafe * bins;
+            const uint32_t has_next = rsafe + 1 < R ? 1u : 0u;
+            const uint32_t rowstep = has_next ? bins : 0u;
+            uint32_t bin[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+                bin[i] = CANON ? (uint32_t)lut[f] : f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t sel = (gr >> (7 - i)) & 1u;
+                const uint32_t val = (ok >> (7 - i)) & 1u;
+                if (!(a.debug & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[i]], val);
+                else if (val + bin[i] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
+            }
+            atomicAdd(&tot[rsafe], (uint32_t)__popc(ok & ~gr));
+            atomicAdd(&tot[rsafe + has_next], (uint32_t)__popc(ok & gr));
+        } else {
+            // per-base path: every base finds its own read (several boundaries in 8 bases)
+#pragma unroll 1
+            for (int i = 0; i < 8; i++) {
+                const int64_t ti = t0 + i;
+                if (!emit_lane || ti < 0 || (uint64_t)ti >= TL) continue;
+                const uint64_t T = off0 + (uint64_t)ti;
+                const uint32_t rid = find_read(roff, nr, T);
+                const uint64_t p64 = T - roff[rid];
+                const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
+                if (p64 >= (uint64_t)(K - 1) && bad == 0) {
+                    const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+                    const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
+                    atomicAdd(&hist[rid * bins + bin], 1u);
+                    atomicAdd(&tot[rid], 1u);
+                }
+            }
+        }
+    }
+}
+
+// ---- consumer: finished histogram rows -> output matrix ------------------------------------------
+// Executed by NC consumer waves; wave `cw` streams the rows [cw*nr/NC, (cw+1)*nr/NC) out,
+// clears them and their totals.  dnm/rcp slots are per read, so consumer waves never share.
+template <int DT, int NC>
+__device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &t, uint32_t cw, uint32_t lane,
+                                             uint32_t *hist, uint32_t *tot, double *dnm, double *rcp) {
     constexpr int VEC = OutVec<DT>::VEC;
     using vec_t = typename OutVec<DT>::type;
-    constexpr uint32_t NLUT = 1u << (2 * K);
-    constexpr uint32_t KMASK = NLUT - 1u;
+    const uint32_t nr = t.nr;
+    const uint32_t row_lo = (uint32_t)(((uint64_t)cw * nr) / NC), row_hi = (uint32_t)(((uint64_t)(cw + 1) * nr) / NC);
+
+    // per-read divisor and its reciprocal (one lane per read; rows <= MAX_R = 64)
+    for (uint32_t i = row_lo + lane; i < row_hi; i += 64) {
+        double d = 1.0;
+        if (a.norm) {
+            const double tt = (double)((uint64_t)tot[i] * a.total_step);
+            d = tt > 1.0 ? tt : 1.0;  // f64::max(1, total), oligo.rs:255-257
+        }
+        tot[i] = 0;
+        dnm[i] = d;
+        rcp[i] = 1.0 / d;
+    }
+    // same wave wrote dnm/rcp; LDS executes a wave's accesses in order
+
+    const uint32_t v_lo = row_lo * a.vec_per_row, v_hi = row_hi * a.vec_per_row;
+    vec_t *dst = reinterpret_cast<vec_t *>(a.out) + t.r0 * a.vec_per_row;
+    // U independent 16-byte outputs per lane per trip: all LDS reads first, then the arithmetic,
+    // then the stores, so one wave keeps several KB of stores in flight.
+    constexpr int U = 4;
+    using cnt_t = typename std::conditional<DT == KT_F64, uint2, uint4>::type;
+    for (uint32_t vb = v_lo; vb < v_hi; vb += 64 * U) {
+        cnt_t c[U];
+        double d[U], y[U];
+        bool act[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t v = vb + u * 64 + lane;
+            act[u] = v < v_hi;
+            c[u] = cnt_t{};
+            d[u] = 1.0;
+            y[u] = 1.0;
+            if (act[u]) {
+                cnt_t *hp = reinterpret_cast<cnt_t *>(hist + v * VEC);
+                c[u] = *hp;
+                *hp = cnt_t{};
+                const uint32_t r = __umulhi(v, a.vec_magic);
+                d[u] = dnm[r];
+                y[u] = rcp[r];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            vec_t o;
+            if constexpr (DT == KT_F64) {
+                const double cx = (double)c[u].x, cy = (double)c[u].y;
+                const double qx = __dmul_rn(cx, y[u]), qy = __dmul_rn(cy, y[u]);
+                o.x = __fma_rn(__fma_rn(-qx, d[u], cx), y[u], qx);
+                o.y = __fma_rn(__fma_rn(-qy, d[u], cy), y[u], qy);
+            } else if constexpr (DT == KT_F32) {
+                const float df = (float)d[u], yf = (float)y[u];
+                const float cx = (float)c[u].x, cy = (float)c[u].y, cz = (float)c[u].z, cw4 = (float)c[u].w;
+                const float qx = __fmul_rn(cx, yf), qy = __fmul_rn(cy, yf), qz = __fmul_rn(cz, yf),
+                            qw = __fmul_rn(cw4, yf);
+                o.x = __fmaf_rn(__fmaf_rn(-qx, df, cx), yf, qx);
+                o.y = __fmaf_rn(__fmaf_rn(-qy, df, cy), yf, qy);
+                o.z = __fmaf_rn(__fmaf_rn(-qz, df, cz), yf, qz);
+                o.w = __fmaf_rn(__fmaf_rn(-qw, df, cw4), yf, qw);
+            } else {
+                o = c[u];
+            }
+            if (act[u] && !(a.debug & 2u)) dst[vb + u * 64 + lane] = o;
+        }
+    }
+}
+
+// Single-buffer variant: every wave counts its chunks of the tile (B), barrier, every wave
+// streams out its rows of the same tile (D), barrier.  Half the LDS of the double-buffered
+// kernel, so twice the resident workgroups; loads for the next tile are issued between the
+// phases so they are in flight while the rows are being stored.
+template <int K, bool CANON, int DT, int NW>
+__global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t NLUT = CANON ? (1u << (2 * K)) : 0u;
+    constexpr uint32_t NT = NW * 64;
+    constexpr int PF = 4;
 
     const uint32_t R = a.R, bins = a.bins;
-
-    // LDS carve (all offsets multiples of 16)
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);  // R * bins
-    uint32_t off = R * bins * 4;
-    uint32_t *tot = reinterpret_cast<uint32_t *>(smem + off);  // R
-    off += ((R * 4 + 15) & ~15u);
-    double *dnm = reinterpret_cast<double *>(smem + off);  // R: divisor d
-    off += ((R * 8 + 15) & ~15u);
-    double *rcp = reinterpret_cast<double *>(smem + off);  // R: RN(1/d)
-    off += ((R * 8 + 15) & ~15u);
-    uint64_t *roff = reinterpret_cast<uint64_t *>(smem + off);  // R + 1
-    off += (((R + 1) * 8 + 15) & ~15u);
-    uint16_t *lut = reinterpret_cast<uint16_t *>(smem + off);  // 4^K (canonical mode)
+    uint16_t *lut = reinterpret_cast<uint16_t *>(smem);
+    uint32_t off = (NLUT * 2 + 15) & ~15u;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + off);
+    off += R * bins * 4;
+    uint32_t *tot = reinterpret_cast<uint32_t *>(smem + off);
+    off += MAX_R * 4;
+    double *dnm = reinterpret_cast<double *>(smem + off);
+    off += MAX_R * 8;
+    double *rcp = reinterpret_cast<double *>(smem + off);
+    off += MAX_R * 8;
+    uint64_t *roff = reinterpret_cast<uint64_t *>(smem + off);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (uint32_t i = tid; i < R * bins; i += BLOCK) hist[i] = 0;
-    if (CANON)
-        for (uint32_t i = tid; i < NLUT; i += BLOCK) lut[i] = a.lut[i];
+    for (uint32_t i = tid; i < R * bins; i += NT) hist[i] = 0;
+    for (uint32_t i = tid; i < MAX_R; i += NT) tot[i] = 0;
+    for (uint32_t i = tid; i < NLUT; i += NT) lut[i] = a.lut[i];
+    __syncthreads();
 
     const uint64_t n_tiles = (a.n_reads + R - 1) / R;
     const uint64_t total_bytes = a.offsets[a.n_reads];
-    const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
+    if (blockIdx.x >= n_tiles) return;
+    const uint64_t nt = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    auto tile_of = [&](uint64_t j) { return (uint64_t)blockIdx.x + j * gridDim.x; };
 
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t r0 = tile * R;
-        const uint32_t nr = (uint32_t)((a.n_reads - r0) < R ? (a.n_reads - r0) : R);
-        const uint64_t off0 = a.offsets[r0], off1 = a.offsets[r0 + nr];
-        const uint64_t len_first = a.offsets[r0 + 1] - off0;
-
-        // ---- A: tile offsets -> LDS, are all reads of the tile equally long? -------------
-        int differs = 0;
-        for (uint32_t i = tid; i <= nr; i += BLOCK) {
-            const uint64_t o = a.offsets[r0 + i];
-            roff[i] = o;
-            if (i < nr) {
-                differs |= (a.offsets[r0 + i + 1] - o) != len_first;
-                tot[i] = 0;
+    OffRegs o_cur = load_offsets(a, tile_of(0), lane);
+    OffRegs o_nxt = nt > 1 ? load_offsets(a, tile_of(1), lane) : OffRegs{0, 0};
+    ProdTile t_cur = make_tile(a, tile_of(0), o_cur, lane);
+    uint2 c_cur[PF];
+#pragma unroll
+    for (int it = 0; it < PF; it++) {
+        c_cur[it] = make_uint2(0, 0);
+        const uint64_t ci = wave + (uint64_t)NW * it;
+        if (ci < t_cur.n_chunks) c_cur[it] = load_chunk(a, t_cur, ci, lane, total_bytes);
+    }
+    for (uint64_t j = 0; j < nt; j++) {
+        // ---- B: positions ------------------------------------------------------------------
+        if (!(a.debug & 1u)) {
+            if (lane < t_cur.nr) {
+                roff[lane] = o_cur.o;
+                roff[lane + 1] = o_cur.on;
             }
+#pragma unroll
+            for (int it = 0; it < PF; it++) {
+                const uint64_t ci = wave + (uint64_t)NW * it;
+                if (ci < t_cur.n_chunks) process_chunk<K, CANON>(a, t_cur, ci, c_cur[it], lane, lut, hist, tot, roff);
+            }
+            for (uint64_t ci = wave + (uint64_t)NW * PF; ci < t_cur.n_chunks; ci += NW)
+                process_chunk<K, CANON>(a, t_cur, ci, load_chunk(a, t_cur, ci, lane, total_bytes), lane, lut, hist,
+                                        tot, roff);
         }
-        const uint64_t TL = off1 - off0;
-        // (barrier) uniform-length fast path needs 8 <= len and tile-relative int32 positions
-        const bool general = __syncthreads_or(differs) || len_first < 8 || TL >= 0x7FFF0000ull;
-
-        // ---- B: positions -> LDS histograms ----------------------------------------------------
-        const uintptr_t addr0 = base_addr + off0;
-        const uintptr_t al0 = addr0 & ~(uintptr_t)7;
-        const uint32_t sh = (uint32_t)(addr0 - al0);
-        const uint64_t flat_end = TL + sh;  // tile bases are flat bytes [sh, flat_end) from al0
-        const uint64_t n_chunks = (flat_end + CHUNK - 1) / CHUNK;
-        const uint32_t Lr = (uint32_t)len_first;
-        const uint32_t lr_magic = general ? 0u : (uint32_t)(0xFFFFFFFFull / Lr) + 1u;  // exact for t < 2^31, Lr >= 8? see below
-
-        for (uint64_t ci = wave; ci < ((a.debug & 1u) ? 0 : n_chunks); ci += NWAVES) {
-            // lane l owns flat bytes [q, q+8), q = ci*504 + 8*(l-1)   (lane 0: halo)
-            const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
-            uint32_t lo = 0x4E4E4E4Eu, hi = 0x4E4E4E4Eu;  // "NNNN": lanes outside the tile
-            const bool inside = q >= 0 && (uint64_t)q < flat_end;
-            if (inside) {
-                const uintptr_t p = al0 + (uint64_t)q;
-                if (p >= base_addr && p + 8 <= base_addr + total_bytes) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(p);
-                    lo = v.x;
-                    hi = v.y;
-                } else {  // first / last bytes of the whole buffer: stay inside it
-                    lo = 0;
-                    hi = 0;
-                    for (int j = 0; j < 8; j++) {
-                        const uintptr_t b = p + j;
-                        const uint32_t c = (b >= base_addr && b < base_addr + total_bytes)
-                                               ? *reinterpret_cast<const unsigned char *>(b)
-                                               : 0xFFu;
-                        if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
-                    }
-                }
-            }
-            // encode 8 bases: P = codes (base i at bits 2*(7-i)), V = invalid flags (bit 7-i)
-            uint32_t pa, va, ra, pb, vb, rb;
-            swar4(lo, pa, va, ra);
-            swar4(hi, pb, vb, rb);
-            uint32_t P = (pa << 8) | pb, V = (va << 4) | vb;
-            if (__ballot((ra | rb) != 0) != 0) bytes8(lo, hi, P, V);  // rare: raw 0..3 bytes present
-            if (!inside) V = 0xFFu;
-
-            // which read does the lane's first base belong to, and where in it?
-            // t0 = tile-relative index of the lane's first base (may be < 0 in the first lanes)
-            const int64_t t0 = q - (int64_t)sh;
-            uint32_t rid0;      // read (tile-relative) of base 0
-            int32_t pos0;       // its index inside that read (clamped; < 0 before the tile)
-            uint32_t rem;       // bases left in that read from base 0 on (clamped to 255)
-            uint32_t len1;      // length of the following read (clamped to 255; 0 = none)
-            bool slow = false;
-            if (!general) {
-                const uint32_t tt = t0 < 0 ? 0u : (uint32_t)t0;
-                rid0 = __umulhi(tt, lr_magic);
-                // magic division is exact for tt < 2^31 when Lr >= 2 ... guard against off-by-one
-                if (rid0 * Lr > tt) rid0--;
-                pos0 = t0 < 0 ? (int32_t)t0 : (int32_t)(tt - rid0 * Lr);
-                const uint32_t left = Lr - (uint32_t)(pos0 < 0 ? 0 : pos0);
-                rem = pos0 < 0 ? 255u : (left > 255u ? 255u : left);
-                len1 = (rid0 + 1 < nr) ? (Lr > 255u ? 255u : Lr) : 0u;
-                if (rid0 >= nr) V = 0xFFu;
-            } else {
-                if (t0 <= -8) {  // whole lane before the tile (halo lane of chunk 0)
-                    rid0 = 0;
-                    pos0 = -1024;
-                    rem = 255u;
-                    len1 = 0;
-                    V = 0xFFu;
-                } else if (t0 < 0) {
-                    // bases 0..(-t0-1) lie before the tile, the rest start read 0: treat read 0 as
-                    // if it extended backwards (negative positions never emit)
-                    rid0 = 0;
-                    pos0 = (int32_t)t0;
-                    const uint64_t e0 = roff[1];
-                    const uint64_t left = (e0 - off0) + (uint64_t)(-t0);
-                    rem = (uint32_t)(left > 255ull ? 255ull : left);
-                    uint64_t l1 = 0;
-                    if (1 < nr) l1 = roff[2] - e0;
-                    len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
-                    slow = rem < 8u && 1 < nr && len1 < 8u - rem;
-                } else if ((uint64_t)t0 >= TL) {
-                    rid0 = 0;
-                    pos0 = 0;
-                    rem = 255u;
-                    len1 = 0;
-                    V = 0xFFu;
-                } else {
-                    const uint64_t T = off0 + (uint64_t)t0;
-                    rid0 = find_read(roff, nr, T);
-                    const uint64_t s0 = roff[rid0], e0 = roff[rid0 + 1];
-                    const uint64_t p64 = T - s0, left = e0 - T;
-                    pos0 = (int32_t)(p64 > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : p64);
-                    rem = (uint32_t)(left > 255ull ? 255ull : left);
-                    uint64_t l1 = 0;
-                    if (rid0 + 1 < nr) l1 = roff[rid0 + 2] - e0;
-                    len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
-                    // a second boundary inside these 8 bases (tiny / empty next read)
-                    slow = rem < 8u && rid0 + 1 < nr && len1 < 8u - rem;
-                }
-            }
-
-            // predecessor lane's pack (lane 0 keeps "all invalid")
-            const uint32_t PV = (V << 16) | P;
-            const uint32_t prevPV = ktd::wave_shr1(PV, 0x00FF0000u);
-            const uint32_t W = ((prevPV & 0xFFFFu) << 16) | P;   // base i at bits 2*(7-i), previous lane above
-            const uint32_t VV = ((prevPV >> 16) << 8) | V;        // invalid flags, same order
-            const bool emit_lane = lane != 0;
-
-            if (__ballot(slow) == 0) {
-                // Branch-free: 8-bit masks over the lane's bases (base i <-> bit 7-i), then 8
-                // unconditional LUT reads and 8 unconditional ds_add of 0 or 1.
-                // ge(x) = { i >= x } = 0xFF >> clamp(x, 0, 8)
-                uint32_t B = VV;  // bit 7-i: some invalid base in the window ending at base i
-#pragma unroll
-                for (int j = 1; j < K; j++) B |= VV >> j;
-                const int32_t a1 = (int32_t)(K - 1) - pos0;  // current read: bases i < a1 lack predecessors
-                const uint32_t g1 = 0xFFu >> (uint32_t)(a1 < 0 ? 0 : (a1 > 8 ? 8 : a1));
-                const uint32_t gr = 0xFFu >> (rem > 8u ? 8u : rem);                // bases of the following read
-                const uint32_t grk = 0xFFu >> (rem + (K - 1) > 8u ? 8u : rem + (K - 1));   // ... that have k-1 predecessors
-                const uint32_t grl = 0xFFu >> (rem + len1 > 8u ? 8u : rem + len1); // past the following read
-                uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFu;
-                ok = emit_lane ? ok : 0u;
-                const uint32_t rsafe = rid0 < R ? rid0 : R - 1;                     // dead lanes add 0 to a real row
-                const uint32_t row0 = rsafe * bins;
-                const uint32_t has_next = rsafe + 1 < R ? 1u : 0u;
-                const uint32_t rowstep = has_next ? bins : 0u;
-                uint32_t bin[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
-                    bin[i] = CANON ? (uint32_t)lut[f] : f;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t sel = (gr >> (7 - i)) & 1u;
-                    const uint32_t val = (ok >> (7 - i)) & 1u;
-                    atomicAdd(&hist[row0 + sel * rowstep + bin[i]], val);
-                }
-                atomicAdd(&tot[rsafe], (uint32_t)__popc(ok & ~gr));
-                atomicAdd(&tot[rsafe + has_next], (uint32_t)__popc(ok & gr));
-            } else {
-                // per-base path: every base finds its own read (several boundaries in 8 bases)
-#pragma unroll 1
-                for (int i = 0; i < 8; i++) {
-                    const int64_t ti = t0 + i;
-                    if (!emit_lane || ti < 0 || (uint64_t)ti >= TL) continue;
-                    const uint64_t T = off0 + (uint64_t)ti;
-                    const uint32_t rid = find_read(roff, nr, T);
-                    const uint64_t p64 = T - roff[rid];
-                    const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
-                    if (p64 >= (uint64_t)(K - 1) && bad == 0) {
-                        const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
-                        const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
-                        atomicAdd(&hist[rid * bins + bin], 1u);
-                        atomicAdd(&tot[rid], 1u);
-                    }
-                }
-            }
-        }
+        TileCtx tc;
+        tc.r0 = t_cur.r0;
+        tc.nr = t_cur.nr;
+        tc.off0 = 0;
+        tc.TL = 0;
         __syncthreads();
-
-        // ---- C: per-read divisor and its reciprocal ------------------------------------------------
-        for (uint32_t i = tid; i < nr; i += BLOCK) {
-            double d = 1.0;
-            if (a.norm) {
-                const double t = (double)((uint64_t)tot[i] * a.total_step);
-                d = t > 1.0 ? t : 1.0;  // f64::max(1, total), oligo.rs:255-257
+        // ---- prefetch the next tile while this one is stored -------------------------------------
+        if (j + 1 < nt) {
+            t_cur = make_tile(a, tile_of(j + 1), o_nxt, lane);
+            o_cur = o_nxt;
+#pragma unroll
+            for (int it = 0; it < PF; it++) {
+                const uint64_t ci = wave + (uint64_t)NW * it;
+                if (ci < t_cur.n_chunks) c_cur[it] = load_chunk(a, t_cur, ci, lane, total_bytes);
             }
-            dnm[i] = d;
-            rcp[i] = 1.0 / d;
+            if (j + 2 < nt) o_nxt = load_offsets(a, tile_of(j + 2), lane);
         }
+        // ---- D: rows out, histogram cleared behind ---------------------------------------------------
+        consume_tile<DT, NW>(a, tc, wave, lane, hist, tot, dnm, rcp);
         __syncthreads();
-
-        // ---- D: stream the tile's rows out, clearing the histogram behind -----------------------------
-        const uint32_t nvec = nr * a.vec_per_row;
-        vec_t *dst = reinterpret_cast<vec_t *>(a.out) + r0 * a.vec_per_row;
-        for (uint32_t v = tid; v < nvec; v += BLOCK) {
-            const uint32_t r = __umulhi(v, a.vec_magic);
-            uint32_t *hp = hist + v * VEC;
-            vec_t o;
-            if constexpr (DT == KT_F64) {
-                const uint2 c = *reinterpret_cast<uint2 *>(hp);
-                *reinterpret_cast<uint2 *>(hp) = make_uint2(0, 0);
-                const double d = dnm[r], y = rcp[r];
-                const double cx = (double)c.x, cy = (double)c.y;
-                const double qx = __dmul_rn(cx, y), qy = __dmul_rn(cy, y);
-                o.x = __fma_rn(__fma_rn(-qx, d, cx), y, qx);
-                o.y = __fma_rn(__fma_rn(-qy, d, cy), y, qy);
-            } else {
-                const uint4 c = *reinterpret_cast<uint4 *>(hp);
-                *reinterpret_cast<uint4 *>(hp) = make_uint4(0, 0, 0, 0);
-                if constexpr (DT == KT_F32) {
-                    const float d = (float)dnm[r], y = (float)rcp[r];
-                    const float cx = (float)c.x, cy = (float)c.y, cz = (float)c.z, cw = (float)c.w;
-                    const float qx = __fmul_rn(cx, y), qy = __fmul_rn(cy, y), qz = __fmul_rn(cz, y),
-                                qw = __fmul_rn(cw, y);
-                    o.x = __fmaf_rn(__fmaf_rn(-qx, d, cx), y, qx);
-                    o.y = __fmaf_rn(__fmaf_rn(-qy, d, cy), y, qy);
-                    o.z = __fmaf_rn(__fmaf_rn(-qz, d, cz), y, qz);
-                    o.w = __fmaf_rn(__fmaf_rn(-qw, d, cw), y, qw);
-                } else {
-                    o = c;
-                }
-            }
-            if (!(a.debug & 2u)) dst[v] = o;
-        }
-        // the next tile's first barrier (__syncthreads_or) orders these LDS writes before its
-        // positions phase; roff/tot/dnm/rcp are not touched again until after that barrier
-        // except roff/tot in phase A, which nobody reads in phase D.
     }
 }
 
 using kern_t = void (*)(OligoArgs);
 
-template <int K>
-kern_t pick(int count_min, int dt) {
+template <int K, int NW>
+kern_t pick_sb(int count_min, int dt) {
     if (count_min) {
         switch (dt) {
-            case KT_F64: return oligo_flat_kernel<K, true, KT_F64>;
-            case KT_F32: return oligo_flat_kernel<K, true, KT_F32>;
-            default: return oligo_flat_kernel<K, true, KT_U32>;
+            case KT_F64: return oligo_sb_kernel<K, true, KT_F64, NW>;
+            case KT_F32: return oligo_sb_kernel<K, true, KT_F32, NW>;
+            default: return oligo_sb_kernel<K, true, KT_U32, NW>;
         }
     }
     switch (dt) {
-        case KT_F64: return oligo_flat_kernel<K, false, KT_F64>;
-        case KT_F32: return oligo_flat_kernel<K, false, KT_F32>;
-        default: return oligo_flat_kernel<K, false, KT_U32>;
+        case KT_F64: return oligo_sb_kernel<K, false, KT_F64, NW>;
+        case KT_F32: return oligo_sb_kernel<K, false, KT_F32, NW>;
+        default: return oligo_sb_kernel<K, false, KT_U32, NW>;
+    }
+}
+
+template <int NW>
+kern_t pick_sb_k(int k, int count_min, int dt) {
+    switch (k) {
+        case 3: return pick_sb<3, NW>(count_min, dt);
+        case 4: return pick_sb<4, NW>(count_min, dt);
+        case 5: return pick_sb<5, NW>(count_min, dt);
+        case 6: return pick_sb<6, NW>(count_min, dt);
+        case 7: return pick_sb<7, NW>(count_min, dt);
+        default: return nullptr;
     }
 }
 
@@ -426,43 +576,47 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     a.vec_magic = (uint32_t)((0x100000000ull + a.vec_per_row - 1) / a.vec_per_row);
     a.debug = env_u32("KT_OLIGO_DEBUG", 0);
 
-    // reads per tile: ~36 KB of LDS histogram, at most 64 reads; the flat output index
-    // v < R * vec_per_row must keep the magic division exact: v * vec_per_row < 2^32.
-    uint32_t R = 36864u / (bins * 4u);
+    // reads per tile: ~22 KB of LDS histogram, at most 64 reads; the flat
+    // output index v < R * vec_per_row must keep the magic division exact: v * vec_per_row < 2^32.
+    // wave layout: 104 = 4 waves per workgroup, 108 = 8
+    const uint32_t shape = env_u32("KT_OLIGO_SHAPE", 104);
+    const uint32_t nbuf = 1;
+    uint32_t R = 22528u / (bins * 4u);
+    if (R >= 8) R &= ~3u;  // k=4: 40 reads = 12 wave-chunks of 150-bp reads, 6 workgroups per CU
     if (R < 1) R = 1;
-    if (R > 64) R = 64;
+    if (R > MAX_R) R = MAX_R;
     R = env_u32("KT_OLIGO_R", R);
+    if (R > MAX_R) R = MAX_R;
     while (R > 1 && (uint64_t)R * a.vec_per_row * a.vec_per_row >= 0x100000000ull) R--;
     a.R = R;
 
-    size_t lds = (size_t)R * bins * 4;
-    lds += ((R * 4 + 15) & ~15u);
-    lds += 2 * ((R * 8 + 15) & ~15u);
-    lds += (((R + 1) * 8 + 15) & ~15u);
-    lds += count_min ? ((((size_t)1 << (2 * k)) * 2 + 15) & ~(size_t)15) : 0;
+    size_t lds = count_min ? ((((size_t)1 << (2 * k)) * 2 + 15) & ~(size_t)15) : 0;
+    lds += nbuf * (size_t)R * bins * 4;
+    lds += 2 * MAX_R * 4 + 2 * MAX_R * 8 + (MAX_R + 1) * 8 + 8;
     if (lds > 160 * 1024) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: tile does not fit in LDS");
 
+    // wave specialisation: small rows are producer-heavy, big rows (k >= 6) are all output
     kern_t kern = nullptr;
-    switch (k) {
-        case 3: kern = pick<3>(count_min, dt); break;
-        case 4: kern = pick<4>(count_min, dt); break;
-        case 5: kern = pick<5>(count_min, dt); break;
-        case 6: kern = pick<6>(count_min, dt); break;
-        case 7: kern = pick<7>(count_min, dt); break;
-        default: return kt::fail(KT_ERR_ARG, "kt_oligo_batch: k must be in 3..7");
+    uint32_t nthreads = 256;
+    switch (shape) {
+        case 104: kern = pick_sb_k<4>(k, count_min, dt); nthreads = 256; break;
+        case 108: kern = pick_sb_k<8>(k, count_min, dt); nthreads = 512; break;
+        default: return kt::fail(KT_ERR_ARG, "kt_oligo_batch: unknown KT_OLIGO_SHAPE");
     }
+    if (!kern) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: k must be in 3..7");
     if (lds > 64 * 1024)
         KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     const uint64_t n_tiles = (n_reads + R - 1) / R;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
-    if (per_cu > 8) per_cu = 8;
+    const uint32_t by_waves = 2048 / nthreads;
+    if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", 4);
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
-    hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(BLOCK), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(nthreads), lds, ctx->stream, a);
     KT_HIP(hipGetLastError());
     return KT_OK;
 }
