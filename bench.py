@@ -156,7 +156,7 @@ def main():
                 o = (offsets[r0:r1 + 1] - offsets[r0]).contiguous()
                 batch_args.append((bases[r0 * L:], o, r1 - r0))
         alg_bytes_per_launch = min(B, n) * (L + bins * esz)
-        dominant = "oligo_tile_kernel<k=%d,%s>" % (k, wl["dtype"])
+        dominant = "oligo_sb_kernel<k=%d,canonical,%s,4 waves>" % (k, wl["dtype"])
 
         def step():
             for (bb, oo, cnt) in batch_args:
@@ -164,7 +164,9 @@ def main():
     else:
         from kmertools_amd import dist as ktdist
         kmers_per_read = L - k + 1
-        cap = 1 << max(20, (2 * n * kmers_per_read - 1).bit_length())
+        # slots: 2x the most distinct keys this rank can see (all instances, or all canonical k-mers)
+        max_distinct = min(n * kmers_per_read, (4 ** k + 2 ** k) // 2)
+        cap = 1 << max(20, (2 * max_distinct - 1).bit_length())
         counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
         dominant = "count_reads_kernel<k=%d>" % k
@@ -194,6 +196,16 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
     achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from PMC counters (collected in separate rocprofv3 --pmc passes and
+    # committed under profiles/; see profiles/traffic.json) - null when not collected
+    traffic = None
+    try:
+        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(args.workload)
+        if tj and not reduced and not args.genome:
+            traffic = int((tj["fetch_kib"] * tj.get("fetch_correction", 1) + tj["write_kib"]) * 1024)
+    except (OSError, ValueError, KeyError):
+        traffic = None
+
     extra = {}
     if wl["kind"] == "ctr":
         extra["distinct_rank0"] = counter.size_local()
@@ -217,7 +229,7 @@ def main():
                        else "hash-prefix key ownership, RCCL all-to-all of routed k-mers",
                        "reduced": reduced},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": dominant, "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch},
         }

@@ -7,7 +7,7 @@ import sys
 
 root = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].split("(")[0][-60:]
