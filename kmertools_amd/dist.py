@@ -32,15 +32,17 @@ def exchange_keys(keys, send_counts, group=None):
     world = dist.get_world_size(group)
     send = [int(x) for x in send_counts]
     assert len(send) == world
-    cnt_dev = keys.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    s = torch.tensor(send, dtype=torch.int64, device=cnt_dev)
-    r = torch.empty(world, dtype=torch.int64, device=cnt_dev)
+    on_gpu_fabric = dist.get_backend(group) == "nccl"
+    # gloo (CPU tests, or several ranks sharing one GPU) moves host memory: stage through it
+    xdev = keys.device if on_gpu_fabric else torch.device("cpu")
+    s = torch.tensor(send, dtype=torch.int64, device=xdev)
+    r = torch.empty(world, dtype=torch.int64, device=xdev)
     dist.all_to_all_single(r, s, group=group)
     recv = [int(x) for x in r.cpu()]
-    out = torch.empty(sum(recv), dtype=torch.int64, device=keys.device)
-    dist.all_to_all_single(out, keys[: sum(send)].contiguous(), output_split_sizes=recv,
-                           input_split_sizes=send, group=group)
-    return out, recv
+    src = keys[: sum(send)].contiguous().to(xdev)
+    out = torch.empty(sum(recv), dtype=torch.int64, device=xdev)
+    dist.all_to_all_single(out, src, output_split_sizes=recv, input_split_sizes=send, group=group)
+    return out.to(keys.device), recv
 
 
 class ShardedCounter:

@@ -385,3 +385,67 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
     assert ctr2.size() == distinct
     ctr.close()
     ctr2.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 path on one GPU: two ranks share cuda:0, route on the GPU, exchange (gloo, host-staged),
+# count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
+
+def _two_rank_worker(rank, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        from kmertools_amd import device, dist as ktdist
+        torch.cuda.set_device(0)
+        ctx = device.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        n, L, k = 20000, 150, 31
+        bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+        offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        ctx.synth_reads(4242, n, L, bases, offsets, noise=True, genome_len=200000, first_read=rank * n)
+        sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD)
+        sc.add_reads(bases, offsets, n)
+        sc.add_reads(bases[: 100 * L], offsets[:101], 100)      # a second "chunk"
+        keys, counts = sc.export_local()
+        total = sc.size_global()
+        q.put((rank, keys, counts, total))
+        sc.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_sharded_ctr(oracle):
+    import socket
+    import torch.multiprocessing as mp
+    from kmertools_amd import device
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, L, k = 20000, 150, 31
+    ctr = oracle.Counter(4)
+    for rank in range(2):
+        hb, ho = oracle.synth_reads(4242, n, L, noise=True, genome_len=200000, first_read=rank * n)
+        ctr.add_reads(hb, ho, k, threads=4)
+        ctr.add_reads(hb[: 100 * L], ho[:101], k)
+    wk, wc = ctr.export()
+    keys = np.concatenate([r[1] for r in res])
+    counts = np.concatenate([r[2] for r in res])
+    for rank, rk, _, total in res:
+        assert total == len(wk)
+        assert all(device.owner_of(int(x), 2) == rank for x in rk[:300])
+    order = np.argsort(keys)
+    assert np.array_equal(keys[order], wk) and np.array_equal(counts[order], wc)
