@@ -1,0 +1,90 @@
+// computers.hpp - C++ mirror of the reference's Rust-level operator API for the hot path:
+//   OligoComputer      composition/src/oligo.rs:15-93
+//   OligoCgrComputer   composition/src/oligocgr.rs:16-121
+//   CountComputer      counter/src/lib.rs:22-90, 172-234
+// Same constructor arguments, setters and entry points (vectorise / count / merge); the
+// per-read / per-k-mer work goes through the C ABI (include/kmertools_hip.h) to the GPU.
+// The reference's error style is kept: vectorise() returns "" on success or the message that
+// the CLI prints after "Error: ".
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../../include/kmertools_hip.h"
+
+namespace kthost {
+
+// Rust `format!("{:.6}", x)` (oligo.rs:132-134) and `Display` for f64 (shortest round-trip,
+// positional notation, integral values without ".0": oligo.rs:136, oligocgr.rs:95)
+void append_fixed6(std::string &out, double x);
+void append_display(std::string &out, double x);
+
+struct Device {  // one kt_ctx per computer, created on first use
+    int index = 0;
+    kt_ctx *ctx = nullptr;
+    ~Device();
+    std::string ensure();  // "" or error message
+};
+
+class OligoComputer {
+  public:
+    OligoComputer(std::string in_path, std::string out_path, int ksize, bool count_min);
+    void set_threads(int t) { threads_ = t; }
+    void set_norm(bool n) { norm_ = n; }
+    void set_delim(std::string d) { delim_ = std::move(d); }
+    void set_max_memory(uint64_t m) { memory_ = m; }
+    void set_header(bool h) { header_ = h; }
+    void set_device(int d) { dev_.index = d; }
+    std::vector<std::string> get_header() const;  // oligo.rs:69-83
+    std::string vectorise();                      // oligo.rs:88-93 (batch and mmap paths write identical bytes)
+
+  private:
+    std::string in_path_, out_path_, delim_ = " ";
+    int ksize_, threads_ = 0;
+    bool count_min_, norm_ = true, header_ = false;
+    uint64_t memory_ = 4ull << 30;  // GB_4, oligo.rs:13
+    Device dev_;
+};
+
+class OligoCgrComputer {
+  public:
+    OligoCgrComputer(std::string in_path, std::string out_path, int ksize, uint64_t vecsize);
+    void set_threads(int t) { threads_ = t; }
+    void set_norm(bool n) { norm_ = n; }
+    void set_device(int d) { dev_.index = d; }
+    std::string vectorise();  // oligocgr.rs:63-121
+
+  private:
+    std::string in_path_, out_path_;
+    int ksize_, threads_ = 0;
+    uint64_t vecsize_;
+    bool norm_ = true;
+    uint64_t memory_ = 4ull << 30;
+    Device dev_;
+};
+
+class CountComputer {
+  public:
+    CountComputer(std::string in_path, std::string out_dir, int ksize);
+    ~CountComputer();
+    void set_threads(int t) { threads_ = t; }
+    void set_max_memory(double gb) { memory_ceil_gb_ = gb; }  // accepted; the table is HBM-resident
+    void set_acgt_output(bool a) { acgt_ = a; }
+    void set_device(int d) { dev_.index = d; }
+    std::string count();             // counter/src/lib.rs:69-90 (no temp files: one resident table)
+    std::string merge(bool del);     // counter/src/lib.rs:172-234: writes {out_dir}/kmers.counts
+    uint64_t seq_count() const { return seq_count_; }
+
+  private:
+    std::string in_path_, out_dir_;
+    int ksize_, threads_ = 0;
+    double memory_ceil_gb_ = 6.0;
+    bool acgt_ = false;
+    uint64_t seq_count_ = 0, total_length_ = 0;
+    Device dev_;
+    kt_ctr *ctr_ = nullptr;
+};
+
+}  // namespace kthost

@@ -1,0 +1,76 @@
+// seqio.hpp - FASTA/FASTQ(/.gz/stdin) record reader producing CSR batches for the C ABI.
+//
+// Host-side counterpart of the reference's ktio::seq (ktio/src/seq.rs:12-155), which wraps
+// rust-bio 2.3.0's fasta/fastq readers (third-party, Cargo.lock:98; not in the reference tree -
+// behaviour restated from its documented format handling and pinned by the reference's reader
+// tests, ktio/src/seq.rs:165-233):
+//   * format: by file extension after stripping ".gz" (.fq/.fastq | .fasta/.fa/.fna,
+//     SeqFormat::get, seq.rs:30-41), else by the first byte ('>' = FASTA; the reference's batch
+//     paths sniff the same way, composition/src/oligo.rs:100-105)
+//   * ".gz" suffix => gzip (get_reader, seq.rs:141-155); "-" => stdin
+//   * FASTA: header '>' + id (first whitespace-delimited token); sequence lines are joined with
+//     trailing whitespace removed; bytes are otherwise untouched (case preserved)
+//   * FASTQ: '@' header, sequence lines up to the '+' line, then as many quality lines
+// Unlike the reference (one heap Sequence per record, single consumer behind a mutex) records
+// are appended straight into a reusable batch: `bases` (concatenated) + `offsets`.
+#pragma once
+#include <stdint.h>
+#include <zlib.h>
+
+#include <string>
+#include <vector>
+
+namespace kthost {
+
+enum class SeqFormat { Fasta, Fastq, Unknown };
+
+SeqFormat format_from_path(const std::string &path);  // SeqFormat::get
+
+struct Batch {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets;  // n + 1 entries, offsets[0] == 0
+    std::vector<std::string> ids;   // filled only when keep_ids
+    uint64_t first_record = 0;      // ordinal of the batch's first record (Sequence::n)
+    void clear() {
+        bases.clear();
+        offsets.assign(1, 0);
+        ids.clear();
+    }
+    uint64_t n_reads() const { return offsets.empty() ? 0 : offsets.size() - 1; }
+};
+
+class SeqReader {
+  public:
+    SeqReader() = default;
+    ~SeqReader();
+    SeqReader(const SeqReader &) = delete;
+    SeqReader &operator=(const SeqReader &) = delete;
+
+    // Opens `path` ("-" = stdin).  sniff = decide the format from the first byte instead of the
+    // extension.  Returns false and sets error() on failure ("Unable to open: {path}", seq.rs:147).
+    bool open(const std::string &path, bool sniff);
+    // Appends records until the batch holds >= max_bases bases or max_reads reads.
+    // Returns false at end of input (the batch may still hold records) or on a parse error.
+    bool next_batch(Batch &b, uint64_t max_bases, uint64_t max_reads, bool keep_ids = false);
+    bool failed() const { return !err_.empty(); }
+    const std::string &error() const { return err_; }
+    uint64_t records_read() const { return n_records_; }
+
+    // Sequences::seq_stats (seq.rs:69-94): record count and total length of a whole file
+    static bool seq_stats(const std::string &path, uint64_t &seq_count, uint64_t &total_length, std::string &err);
+
+  private:
+    bool fill();
+    bool read_line(std::string &line);  // without the trailing '\n'; false at EOF
+    bool peek(int &c);
+    gzFile gz_ = nullptr;  // zlib reads plain files transparently
+    std::vector<unsigned char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+    SeqFormat fmt_ = SeqFormat::Unknown;
+    std::string err_, line_, pending_;
+    bool have_pending_ = false;
+    uint64_t n_records_ = 0;
+};
+
+}  // namespace kthost

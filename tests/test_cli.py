@@ -1,0 +1,166 @@
+"""The C++ host side (kmertools_amd/csrc/host): reader behaviour and argument handling on CPU,
+and - with a GPU - byte-for-byte equality of the CLI's output files with the reference's
+golden files (the reference's own end-to-end tests: composition/src/oligo.rs:312-432,
+composition/src/oligocgr.rs:223-238, counter/src/lib.rs:260-276)."""
+import gzip
+import pathlib
+import subprocess
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+CLI = ROOT / "kmertools_amd" / "bin" / "kmertools"
+
+
+@pytest.fixture(scope="module")
+def cli():
+    if not CLI.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "kmertools_amd" / "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+    return str(CLI)
+
+
+def run(cli, *args, **kw):
+    return subprocess.run([cli, *map(str, args)], capture_output=True, text=True, timeout=300, **kw)
+
+
+def records(cli, path, *extra):
+    r = run(cli, "debug-read", path, *extra)
+    assert r.returncode == 0, r.stderr
+    recs, meta = [], {}
+    for ln in r.stdout.splitlines():
+        parts = ln.split("\t")
+        if ln.startswith("#"):
+            meta[parts[0]] = (int(parts[1]), int(parts[2]))
+        else:
+            recs.append((int(parts[0]), parts[1], parts[2] if len(parts) > 2 else ""))
+    return recs, meta
+
+
+def test_reader_fixtures(cli, golden, kat):
+    e = kat["reader"]
+    for name, ids in [("reads.fq", e["fq_ids"]), ("reads.fa", e["fa_ids"]), ("reads.fq.gz", e["fq_ids"])]:
+        recs, meta = records(cli, golden / name)
+        assert [r[1] for r in recs] == ids and [r[2] for r in recs] == e["seqs"]
+        assert [r[0] for r in recs] == [0, 1]                      # Sequence::n ordinals
+        assert meta["#records"] == (2, e["total_length"]) == meta["#seq_stats"]
+
+
+def test_reader_edge_cases(cli, tmp_path):
+    # multi-line FASTA/FASTQ, CRLF, blank lines, lower case preserved, descriptions dropped,
+    # empty sequence, no trailing newline, format sniffing of an unknown extension
+    fa = tmp_path / "x.fa"
+    fa.write_bytes(b">r1 some description\r\nACGT\r\nacgtn\r\n\r\n>r2\n>r3\tdesc\nTT\nGG")
+    recs, meta = records(cli, fa)
+    assert [(r[1], r[2]) for r in recs] == [("r1", "ACGTacgtn"), ("r2", ""), ("r3", "TTGG")]
+    assert meta["#records"] == (3, 13)
+    fq = tmp_path / "y.fastq"
+    fq.write_bytes(b"@q1 d\nACGT\nAC\n+\nIIII\nII\n@q2\nNN\n+q2\n##\n")
+    recs, _ = records(cli, fq)
+    assert [(r[1], r[2]) for r in recs] == [("q1", "ACGTAC"), ("q2", "NN")]
+    unk = tmp_path / "z.txt"
+    unk.write_bytes(b">a\nAC\n")
+    assert [(r[1], r[2]) for r in records(cli, unk)[0]] == [("a", "AC")]
+    big = tmp_path / "big.fa.gz"
+    seqs = ["ACGT" * (50 + i) for i in range(300)]
+    with gzip.open(big, "wb") as fh:
+        for i, s in enumerate(seqs):
+            fh.write((">s%d\n" % i).encode())
+            for j in range(0, len(s), 60):
+                fh.write((s[j:j + 60] + "\n").encode())
+    recs, meta = records(cli, big)
+    assert [r[2] for r in recs] == seqs and meta["#seq_stats"] == (300, sum(map(len, seqs)))
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@q\nACGT\n+\nII\n")
+    r = run(cli, "debug-read", bad)
+    assert r.returncode != 0 and "Unequal length" in r.stderr
+
+
+def test_cli_argument_handling(cli, golden, tmp_path):
+    r = run(cli, "comp", "oligo", "-i", golden / "reads.fa", "-o", tmp_path / "o", "-k", "8")
+    assert r.returncode == 2 and "is not in 3..=7" in r.stderr          # args.rs:85
+    r = run(cli, "ctr", "-i", golden / "reads.fq", "-o", tmp_path / "c")
+    assert r.returncode == 2 and "--k-size" in r.stderr                   # required, args.rs:219
+    r = run(cli, "ctr", "-i", golden / "reads.fq", "-o", tmp_path / "c", "-k", "9")
+    assert r.returncode == 2 and "10..=31" in r.stderr
+    r = run(cli, "ctr", "-i", golden / "reads.fq", "-o", tmp_path / "c", "-k", "21", "-m", "3")
+    assert r.returncode == 2 and "6..=128" in r.stderr
+    r = run(cli, "comp", "oligo", "-i", golden / "reads.fa", "-o", tmp_path / "o", "-p", "xml")
+    assert r.returncode == 2
+    r = run(cli, "comp", "cgr", "-i", golden / "reads.fa", "-o", tmp_path / "o", "-c")
+    assert "Error: cannot use counts in whole sequence CGR!" in r.stderr  # args.rs:284-287
+    assert run(cli, "--help").returncode == 0 and run(cli, "comp", "oligo", "--help").returncode == 0
+    assert run(cli, "cov").returncode == 2
+
+
+def test_cli_fails_loudly_without_gpu(cli, golden, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = run(cli, "comp", "oligo", "-i", golden / "reads.fa", "-o", tmp_path / "o", "-k", "4")
+    assert "Error: no HIP device" in r.stderr
+    assert not (tmp_path / "o").exists() or (tmp_path / "o").stat().st_size == 0
+
+
+@pytest.mark.gpu
+def test_cli_golden_outputs(cli, golden, tmp_path):
+    o = tmp_path / "fa.kmers"
+    for inp in ("reads.fq", "reads.fa", "reads.fq.gz"):
+        for t in (1, 8):
+            r = run(cli, "comp", "oligo", "-i", golden / inp, "-o", o, "-k", "4", "-t", t)
+            assert r.returncode == 0 and r.stderr == "", r.stderr
+            assert o.read_bytes() == (golden / "expected_fa.kmers").read_bytes()
+    run(cli, "comp", "oligo", "-i", golden / "reads.fq", "-o", o, "-k4", "--counts")
+    assert o.read_bytes() == (golden / "expected_fa_batch_unnorm.kmers").read_bytes()
+    run(cli, "comp", "oligo", "--input", golden / "reads.fq", "--output=%s" % o, "--k-size", "4", "-H")
+    assert o.read_bytes() == (golden / "expected_fa_header.kmers").read_bytes()
+    # stdin path (oligo.rs:89-91)
+    with open(golden / "reads.fq", "rb") as fh:
+        subprocess.run([cli, "comp", "oligo", "-i", "-", "-o", str(o), "-k", "4"], stdin=fh, check=True, timeout=300)
+    assert o.read_bytes() == (golden / "expected_fa.kmers").read_bytes()
+    # presets only change the delimiter
+    run(cli, "comp", "oligo", "-i", golden / "reads.fq", "-o", o, "-k", "4", "-p", "csv")
+    assert o.read_bytes() == (golden / "expected_fa.kmers").read_bytes().replace(b" ", b",")
+    # raw mode: 256 columns
+    run(cli, "comp", "oligo", "-i", golden / "reads.fq", "-o", o, "-k", "4", "-r", "-c")
+    rows = o.read_text().splitlines()
+    assert len(rows) == 2 and all(len(x.split()) == 256 for x in rows)
+    assert sum(map(int, rows[0].split())) == 72 - 4 + 1
+    # comp cgr -k 4 -c: default vecsize k^2 = 16 (args.rs:266-269)
+    c = tmp_path / "k4.cgr"
+    r = run(cli, "comp", "cgr", "-i", golden / "reads.fq", "-o", c, "-k", "4", "-c")
+    assert r.returncode == 0 and r.stderr == ""
+    assert c.read_bytes() == (golden / "expected_reads.k4.cgr").read_bytes()
+    # ctr -k 15: sorted lines equal the reference's chunk file (all counts 1)
+    d = tmp_path / "counts"
+    r = run(cli, "ctr", "-i", golden / "reads.fq", "-o", d, "-k", "15")
+    assert r.returncode == 0, r.stderr
+    got = sorted((d / "kmers.counts").read_text().splitlines())
+    assert got == sorted((golden / "expected_counts.part_0_chunk_0").read_text().splitlines())
+    r = run(cli, "ctr", "-i", golden / "reads.fq", "-o", d, "-k", "15", "-a")
+    lines = (d / "kmers.counts").read_text().splitlines()
+    assert len(lines) == len(got) and all(len(x.split("\t")[0]) == 15 for x in lines)
+    # unwritable output -> the reference's message, exit code 0 (args.rs:260-262)
+    r = run(cli, "comp", "oligo", "-i", golden / "reads.fq", "-o", tmp_path / "nodir" / "x", "-k", "4")
+    assert r.returncode == 0 and "Error: Unable to write to file" in r.stderr
+    r = run(cli, "comp", "oligo", "-i", tmp_path / "missing.fa", "-o", o, "-k", "4")
+    assert "Error: Unable to open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_larger_file_matches_oracle(cli, oracle, tmp_path):
+    """5000 ragged reads through file -> reader -> GPU -> text, vs the oracle's text"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGTNacgt"), size=int(L), p=[.24, .24, .24, .24, .01, .0075, .0075, .0075, .0075]))
+            for L in rng.integers(0, 700, size=5000)]
+    fa = tmp_path / "r.fasta"
+    fa.write_text("".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    bases, offsets = oracle.to_csr(seqs)
+    for k in (3, 5):
+        o = tmp_path / ("o%d" % k)
+        assert run(cli, "comp", "oligo", "-i", fa, "-o", o, "-k", k).stderr == ""
+        assert o.read_bytes() == oracle.oligo_text(oracle.oligo_batch(bases, offsets, k, True, True), True)
+    d = tmp_path / "c"
+    assert run(cli, "ctr", "-i", fa, "-o", d, "-k", "21").returncode == 0
+    keys, counts = oracle.count_reads(bases, offsets, 21)
+    assert sorted((d / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(keys, counts)
