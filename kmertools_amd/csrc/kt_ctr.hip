@@ -5,8 +5,10 @@
 // Replaces CountComputer::count_chunk / merge (reference counter/src/lib.rs:92-234):
 // the reference's n_parts concurrent hash maps, chunked spill to text files and
 // per-partition re-merge collapse into one open-addressing table that stays in HBM
-// (u64 keys + u32 counts in separate arrays, so the increment is a plain 32-bit
-// atomic once a 64-bit CAS has claimed the slot).  HBM-bound random access; no MFMA.
+// (16-byte slots {u64 key, u32 count, pad}: the 64-bit CAS that claims a slot and the 32-bit
+// atomic add that counts it touch the same 64-byte line, which halves the DRAM lines moved
+// per insert compared with separate key/count arrays - profiles/r1_ctr_*).  HBM-bound
+// random access; no MFMA.
 #include <vector>
 
 #include "kt_internal.hpp"
@@ -24,18 +26,33 @@ constexpr int BLOCK = ktseg::BLOCK;
 // table[key] += add.  Linear probing; a slot's key goes EMPTY -> key exactly once, so a
 // stale (cached) read can only show EMPTY for a slot that is now taken, and the CAS
 // (device scope, coherent across XCDs) settles that case.
-__device__ __forceinline__ bool table_add(uint64_t *__restrict__ keys, uint32_t *__restrict__ counts,
-                                          uint64_t mask, uint64_t key, uint32_t add) {
+struct Slot {
+    uint64_t key;    // KT_EMPTY_KEY = free
+    uint32_t count;  // occurrences - 1 (a claimed slot has been seen once)
+    uint32_t pad;
+};
+static_assert(sizeof(Slot) == 16, "slot layout");
+
+__device__ __forceinline__ bool table_add(Slot *__restrict__ slots, uint64_t mask, uint64_t key, uint32_t add) {
     uint64_t slot = ktd::mix64(key) & mask;
     for (uint64_t probe = 0; probe <= mask; probe++) {
-        uint64_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t cur = KT_EMPTY_KEY;
+#ifndef KT_CAS_FIRST
+        cur = __hip_atomic_load(&slots[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         if (cur == KT_EMPTY_KEY) {
-            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[slot]),
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[slot].key),
                                             (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key);
-            cur = (prev == KT_EMPTY_KEY) ? key : prev;
+            if (prev == KT_EMPTY_KEY) {
+                // the slot stores (occurrences - 1): claiming it already counts one occurrence,
+                // so a k-mer seen once costs one atomic (the CAS), not two
+                if (add > 1u) atomicAdd(&slots[slot].count, add - 1u);
+                return true;
+            }
+            cur = prev;
         }
         if (cur == key) {
-            atomicAdd(&counts[slot], add);
+            atomicAdd(&slots[slot].count, add);
             return true;
         }
         slot = (slot + 1) & mask;
@@ -44,8 +61,7 @@ __device__ __forceinline__ bool table_add(uint64_t *__restrict__ keys, uint32_t 
 }
 
 struct TableRef {
-    uint64_t *keys;
-    uint32_t *counts;
+    Slot *slots;
     uint64_t mask;
     uint32_t *flags;
 };
@@ -55,7 +71,7 @@ __global__ __launch_bounds__(BLOCK) void count_reads_kernel(SegArgs a, TableRef 
     for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
         ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
             const uint64_t m = f < r ? f : r;  // counter/src/lib.rs:124
-            if (!table_add(t.keys, t.counts, t.mask, m, 1u)) atomicOr(t.flags, 1u);
+            if (!table_add(t.slots, t.mask, m, 1u)) atomicOr(t.flags, 1u);
         });
     }
 }
@@ -67,23 +83,28 @@ __global__ __launch_bounds__(BLOCK) void add_pairs_kernel(const uint64_t *__rest
         const uint64_t key = keys[i];
         const uint32_t c = counts ? counts[i] : 1u;
         if (key == KT_EMPTY_KEY) continue;
-        if (!table_add(t.keys, t.counts, t.mask, key, c)) atomicOr(t.flags, 1u);
+        if (!table_add(t.slots, t.mask, key, c)) atomicOr(t.flags, 1u);
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void table_size_kernel(const uint64_t *__restrict__ keys, uint64_t cap,
+__global__ __launch_bounds__(BLOCK) void table_clear_kernel(Slot *__restrict__ slots, uint64_t cap) {
+    const uint4 empty = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK)
+        reinterpret_cast<uint4 *>(slots)[i] = empty;
+}
+
+__global__ __launch_bounds__(BLOCK) void table_size_kernel(const Slot *__restrict__ slots, uint64_t cap,
                                                            uint64_t *__restrict__ out) {
     uint64_t n = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK)
-        n += keys[i] != KT_EMPTY_KEY;
+        n += slots[i].key != KT_EMPTY_KEY;
     // wave reduction, one atomic per wave
     for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(reinterpret_cast<unsigned long long *>(out), (unsigned long long)n);
 }
 
 // stream the table, compact occupied slots: ballot + one cursor atomic per wave
-__global__ __launch_bounds__(BLOCK) void table_export_kernel(const uint64_t *__restrict__ keys,
-                                                             const uint32_t *__restrict__ counts, uint64_t cap,
+__global__ __launch_bounds__(BLOCK) void table_export_kernel(const Slot *__restrict__ slots, uint64_t cap,
                                                              uint64_t *__restrict__ out_keys,
                                                              uint32_t *__restrict__ out_counts, uint64_t max_out,
                                                              uint64_t *__restrict__ cursor) {
@@ -93,7 +114,12 @@ __global__ __launch_bounds__(BLOCK) void table_export_kernel(const uint64_t *__r
     for (uint64_t it = 0; it < rounds; it++) {
         const uint64_t i = it * stride + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
         uint64_t key = KT_EMPTY_KEY;
-        if (i < cap) key = keys[i];
+        uint32_t cnt = 0;
+        if (i < cap) {
+            const uint4 v = reinterpret_cast<const uint4 *>(slots)[i];
+            key = ((uint64_t)v.y << 32) | v.x;
+            cnt = v.z + 1u;  // stored value is occurrences - 1
+        }
         const bool occ = key != KT_EMPTY_KEY;
         const uint64_t bal = __ballot(occ);
         if (bal == 0) continue;
@@ -104,7 +130,7 @@ __global__ __launch_bounds__(BLOCK) void table_export_kernel(const uint64_t *__r
             const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
             if (pos < max_out) {
                 out_keys[pos] = key;
-                out_counts[pos] = counts[i];
+                out_counts[pos] = cnt;
             }
         }
     }
@@ -271,8 +297,7 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     c->ctx = ctx;
     c->k = k;
     c->cap = cap;
-    hipError_t e = hipMalloc((void **)&c->keys, cap * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->counts, cap * sizeof(uint32_t));
+    hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
     if (e != hipSuccess) {
@@ -289,8 +314,7 @@ int kt_ctr_destroy(kt_ctr *ctr) {
         (void)hipSetDevice(ctr->ctx->device);
         (void)hipStreamSynchronize(ctr->ctx->stream);
     }
-    if (ctr->keys) (void)hipFree(ctr->keys);
-    if (ctr->counts) (void)hipFree(ctr->counts);
+    if (ctr->slots) (void)hipFree(ctr->slots);
     if (ctr->flags) (void)hipFree(ctr->flags);
     if (ctr->cursor) (void)hipFree(ctr->cursor);
     delete ctr;
@@ -300,8 +324,9 @@ int kt_ctr_destroy(kt_ctr *ctr) {
 int kt_ctr_clear(kt_ctr *ctr) {
     if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_clear: null");
     if (int rc = ctr->ctx->use()) return rc;
-    KT_HIP(hipMemsetAsync(ctr->keys, 0xFF, ctr->cap * sizeof(uint64_t), ctr->ctx->stream));
-    KT_HIP(hipMemsetAsync(ctr->counts, 0, ctr->cap * sizeof(uint32_t), ctr->ctx->stream));
+    hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(ctr->ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
+                       ctr->ctx->stream, (Slot *)ctr->slots, ctr->cap);
+    KT_HIP(hipGetLastError());
     KT_HIP(hipMemsetAsync(ctr->flags, 0, 64, ctr->ctx->stream));
     return KT_OK;
 }
@@ -323,7 +348,7 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
     }
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
-    TableRef t{ctr->keys, ctr->counts, ctr->cap - 1, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, ctr->flags};
     hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t);
     KT_HIP(hipGetLastError());
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -348,7 +373,7 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
             d_counts = (const uint32_t *)ctx->s_aux2.p;
         }
     }
-    TableRef t{ctr->keys, ctr->counts, ctr->cap - 1, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctx->stream, d_keys, d_counts, n, t);
     KT_HIP(hipGetLastError());
@@ -362,7 +387,7 @@ int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct) {
     if (int rc = ctx->use()) return rc;
     KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
     hipLaunchKernelGGL(table_size_kernel, dim3(grid_for(ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
-                       ctx->stream, ctr->keys, ctr->cap, ctr->cursor);
+                       ctx->stream, (const Slot *)ctr->slots, ctr->cap, ctr->cursor);
     KT_HIP(hipGetLastError());
     KT_HIP(hipMemcpyAsync(distinct, ctr->cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
     KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -385,7 +410,7 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
     }
     KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
     hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
-                       ctx->stream, ctr->keys, ctr->counts, ctr->cap, d_keys, d_counts, max_out, ctr->cursor);
+                       ctx->stream, (const Slot *)ctr->slots, ctr->cap, d_keys, d_counts, max_out, ctr->cursor);
     KT_HIP(hipGetLastError());
     uint64_t n = 0;
     KT_HIP(hipMemcpyAsync(&n, ctr->cursor, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -47,8 +47,7 @@ struct kt_ctr {
     kt_ctx *ctx = nullptr;
     int k = 0;
     uint64_t cap = 0;          // power of two
-    uint64_t *keys = nullptr;  // [cap], KT_EMPTY_KEY = free
-    uint32_t *counts = nullptr;
+    void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}
     uint32_t *flags = nullptr; // [0] = overflow flag, device
     uint64_t *cursor = nullptr; // device scalar for export / size
 };
