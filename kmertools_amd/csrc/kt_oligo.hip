@@ -433,12 +433,15 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
 template <int K, bool CANON, int DT, int NW>
 __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t NLUT = CANON ? (1u << (2 * K)) : 0u;
+    // k <= 5: the canonical-rank LUT (<= 2 KB) lives in LDS; k >= 6 (8 / 32 KB) it is read through
+    // L2 instead, because there the LDS is better spent on resident tiles (rows are 8-64 KB)
+    constexpr bool LUT_LDS = CANON && K <= 5;
+    constexpr uint32_t NLUT = LUT_LDS ? (1u << (2 * K)) : 0u;
     constexpr uint32_t NT = NW * 64;
     constexpr int PF = 4;
 
     const uint32_t R = a.R, bins = a.bins;
-    uint16_t *lut = reinterpret_cast<uint16_t *>(smem);
+    const uint16_t *lut = LUT_LDS ? reinterpret_cast<const uint16_t *>(smem) : a.lut;
     uint32_t off = (NLUT * 2 + 15) & ~15u;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + off);
     off += R * bins * 4;
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
 
     for (uint32_t i = tid; i < R * bins; i += NT) hist[i] = 0;
     for (uint32_t i = tid; i < MAX_R; i += NT) tot[i] = 0;
-    for (uint32_t i = tid; i < NLUT; i += NT) lut[i] = a.lut[i];
+    for (uint32_t i = tid; i < NLUT; i += NT) reinterpret_cast<uint16_t *>(smem)[i] = a.lut[i];
     __syncthreads();
 
     const uint64_t n_tiles = (a.n_reads + R - 1) / R;
@@ -581,7 +584,9 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     // wave layout: 104 = 4 waves per workgroup, 108 = 8
     const uint32_t shape = env_u32("KT_OLIGO_SHAPE", 104);
     const uint32_t nbuf = 1;
-    uint32_t R = 22528u / (bins * 4u);
+    // small rows: ~22 KB of LDS rows (6 workgroups per CU); big rows (k >= 6, 8-64 KB each) are
+    // pure store streams and measured best with one large tile per CU (cfg5: R=4, 0.56 of peak)
+    uint32_t R = (bins <= 1024 ? 22528u : 131072u) / (bins * 4u);
     if (R >= 8) R &= ~3u;  // k=4: 40 reads = 12 wave-chunks of 150-bp reads, 6 workgroups per CU
     if (R < 1) R = 1;
     if (R > MAX_R) R = MAX_R;
@@ -590,7 +595,7 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     while (R > 1 && (uint64_t)R * a.vec_per_row * a.vec_per_row >= 0x100000000ull) R--;
     a.R = R;
 
-    size_t lds = count_min ? ((((size_t)1 << (2 * k)) * 2 + 15) & ~(size_t)15) : 0;
+    size_t lds = (count_min && k <= 5) ? ((((size_t)1 << (2 * k)) * 2 + 15) & ~(size_t)15) : 0;
     lds += nbuf * (size_t)R * bins * 4;
     lds += 2 * MAX_R * 4 + 2 * MAX_R * 8 + (MAX_R + 1) * 8 + 8;
     if (lds > 160 * 1024) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: tile does not fit in LDS");
