@@ -129,7 +129,7 @@ struct TileCtx {
     uint64_t TL;       // number of bases of the tile
 };
 
-// What a producer wave knows about a tile once its offsets have arrived.
+// What a wave knows about a tile once its offsets have arrived.
 struct ProdTile {
     uint64_t r0, off0, TL;
     uint32_t nr;
@@ -137,8 +137,11 @@ struct ProdTile {
     uint32_t sh;        // (address of first base) - al0
     uint64_t flat_end;  // tile bases are flat bytes [sh, flat_end) from al0
     uint64_t n_chunks;
-    uint32_t Lr, lr_magic;  // uniform read length and its magic reciprocal (fast path)
-    bool general;           // reads differ in length (or are tiny / huge): binary-search path
+    // fast path (all reads of the tile equally long, >= 8 bases, tile < 2^31 bytes): everything
+    // is 32-bit and read membership is a magic division
+    bool general;
+    uint32_t Lr, lr_magic;
+    int32_t safe_lo, safe_hi;  // flat range in which an 8-byte load stays inside the buffer
 };
 
 // lane i holds offsets[r0+i] and offsets[r0+i+1] of a tile (i < nr <= 64); issued two tiles ahead
@@ -165,7 +168,8 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile, const OffRegs &r, uint32_t lane) {
+__device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile, const OffRegs &r, uint32_t lane,
+                                              uint64_t total_bytes) {
     ProdTile t;
     t.r0 = tile * a.R;
     t.nr = (uint32_t)((a.n_reads - t.r0) < a.R ? (a.n_reads - t.r0) : a.R);
@@ -174,179 +178,213 @@ __device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile,
     const uint64_t len_first = readlane64(r.on, 0) - t.off0;
     t.TL = off1 - t.off0;
     const bool differs = lane < t.nr && (r.on - r.o) != len_first;
-    // uniform-length fast path needs len >= 8 and tile-relative int32 positions
     t.general = __ballot(differs) != 0 || len_first < 8 || t.TL >= 0x7FFF0000ull;
-    const uintptr_t addr0 = reinterpret_cast<uintptr_t>(a.bases) + t.off0;
+    const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
+    const uintptr_t addr0 = base_addr + t.off0;
     t.al0 = addr0 & ~(uintptr_t)7;
     t.sh = (uint32_t)(addr0 - t.al0);
     t.flat_end = t.TL + t.sh;
-    t.n_chunks = (t.flat_end + CHUNK - 1) / CHUNK;
     t.Lr = (uint32_t)len_first;
-    t.lr_magic = t.general ? 0u : (uint32_t)(0xFFFFFFFFull / t.Lr) + 1u;
+    t.lr_magic = 0;
+    t.safe_lo = 0;
+    t.safe_hi = 0;
+    if (t.general) {
+        t.n_chunks = (t.flat_end + CHUNK - 1) / CHUNK;
+    } else {
+        t.n_chunks = ((uint32_t)t.flat_end + CHUNK - 1) / CHUNK;
+        t.lr_magic = (uint32_t)(0xFFFFFFFFull / t.Lr) + 1u;
+        // flat coordinate q is loadable iff base <= al0 + q and al0 + q + 8 <= base + total
+        const int64_t lo = (int64_t)base_addr - (int64_t)t.al0;                 // <= 0 unless bases is unaligned
+        const int64_t hi = (int64_t)(base_addr + total_bytes) - (int64_t)t.al0;  // may exceed int32: clamp
+        t.safe_lo = (int32_t)(lo < -16 ? -16 : lo);
+        t.safe_hi = (int32_t)(hi > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : hi);
+    }
     return t;
+}
+
+// bytes [p, p+8) with everything outside the buffer replaced by 0xFF (first / last bytes only)
+__device__ __forceinline__ uint2 load8_guarded(uintptr_t p, uintptr_t base_addr, uint64_t total_bytes) {
+    uint2 v = make_uint2(0, 0);
+    for (int j = 0; j < 8; j++) {
+        const uintptr_t b = p + j;
+        const uint32_t c = (b >= base_addr && b < base_addr + total_bytes)
+                               ? *reinterpret_cast<const unsigned char *>(b)
+                               : 0xFFu;
+        if (j < 4) v.x |= c << (8 * j); else v.y |= c << (8 * (j - 4));
+    }
+    return v;
 }
 
 // lane l of chunk ci owns flat bytes [q, q+8), q = ci*504 + 8*(l-1)   (lane 0: halo)
 __device__ __forceinline__ uint2 load_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint32_t lane,
                                             uint64_t total_bytes) {
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
-    const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
     uint2 v = make_uint2(0x4E4E4E4Eu, 0x4E4E4E4Eu);  // "NNNN": lanes outside the tile
     if (a.debug & 4u) return make_uint2(0x54474341u + lane, 0x41434754u);  // ablation: no global load
-    if (q >= 0 && (uint64_t)q < t.flat_end) {
-        const uintptr_t p = t.al0 + (uint64_t)q;
-        if (p >= base_addr && p + 8 <= base_addr + total_bytes) {
-            v = *reinterpret_cast<const uint2 *>(p);
-        } else {  // first / last bytes of the whole buffer: stay inside it
-            v = make_uint2(0, 0);
-            for (int j = 0; j < 8; j++) {
-                const uintptr_t b = p + j;
-                const uint32_t c = (b >= base_addr && b < base_addr + total_bytes)
-                                       ? *reinterpret_cast<const unsigned char *>(b)
-                                       : 0xFFu;
-                if (j < 4) v.x |= c << (8 * j); else v.y |= c << (8 * (j - 4));
-            }
+    if (!t.general) {
+        const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + 8 * ((int32_t)lane - 1);
+        if (q >= 0 && q < (int32_t)(uint32_t)t.flat_end) {
+            const uintptr_t p = t.al0 + (uint32_t)q;
+            if (q >= t.safe_lo && q + 8 <= t.safe_hi) v = *reinterpret_cast<const uint2 *>(p);
+            else v = load8_guarded(p, base_addr, total_bytes);
+        }
+    } else {
+        const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
+        if (q >= 0 && (uint64_t)q < t.flat_end) {
+            const uintptr_t p = t.al0 + (uint64_t)q;
+            if (p >= base_addr && p + 8 <= base_addr + total_bytes) v = *reinterpret_cast<const uint2 *>(p);
+            else v = load8_guarded(p, base_addr, total_bytes);
         }
     }
     return v;
 }
 
-// ---- producer: one 504-base chunk of a tile -> LDS histogram rows ---------------------------------
+// encode the lane's 8 bases: P = codes (base i at bits 2*(7-i)), V = invalid flags (bit 7-i)
+__device__ __forceinline__ void encode8(uint2 data, uint32_t &P, uint32_t &V) {
+    uint32_t pa, va, ra, pb, vb, rb;
+    swar4(data.x, pa, va, ra);
+    swar4(data.y, pb, vb, rb);
+    P = (pa << 8) | pb;
+    V = (va << 4) | vb;
+    if (__ballot((ra | rb) != 0) != 0) bytes8(data.x, data.y, P, V);  // rare: raw 0..3 bytes present
+}
+
+// The lane's 8 k-mers -> histogram.  pos0 = index of base 0 in its read (< 0: before the tile),
+// rem = bases left in that read from base 0 on, len1 = length of the following read (0: none);
+// all clamped to small ranges by the caller.  Branch-free: 8-bit masks over the lane's bases
+// (base i <-> bit 7-i), 8 unconditional LUT reads, 8 unconditional ds_add of 0 or 1.
+template <int K, bool CANON>
+__device__ __forceinline__ void emit8(const OligoArgs &a, uint32_t P, uint32_t V, uint32_t lane, uint32_t rid0,
+                                      int32_t pos0, uint32_t rem, uint32_t len1, const uint16_t *lut,
+                                      uint32_t *hist, uint32_t *tot, uint32_t &W_out, uint32_t &VV_out) {
+    constexpr uint32_t KMASK = (1u << (2 * K)) - 1u;
+    const uint32_t R = a.R, bins = a.bins;
+    // predecessor lane's pack (lane 0 keeps "all invalid")
+    const uint32_t PV = (V << 16) | P;
+    const uint32_t prevPV = ktd::wave_shr1(PV, 0x00FF0000u);
+    const uint32_t W = ((prevPV & 0xFFFFu) << 16) | P;  // base i at bits 2*(7-i), previous lane above
+    const uint32_t VV = ((prevPV >> 16) << 8) | V;       // invalid flags, same order
+    W_out = W;
+    VV_out = VV;
+    // ge(x) = { i >= x } = 0xFF >> clamp(x, 0, 8)
+    uint32_t B = VV;  // bit 7-i: some invalid base in the window ending at base i
+#pragma unroll
+    for (int j = 1; j < K; j++) B |= VV >> j;
+    const int32_t a1 = (int32_t)(K - 1) - pos0;  // current read: bases i < a1 lack predecessors
+    const uint32_t g1 = 0xFFu >> (uint32_t)(a1 < 0 ? 0 : (a1 > 8 ? 8 : a1));
+    const uint32_t gr = 0xFFu >> (rem > 8u ? 8u : rem);                        // bases of the following read
+    const uint32_t grk = 0xFFu >> (rem + (K - 1) > 8u ? 8u : rem + (K - 1));  // ... with k-1 predecessors
+    const uint32_t grl = 0xFFu >> (rem + len1 > 8u ? 8u : rem + len1);        // past the following read
+    uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFu;
+    ok = lane != 0 ? ok : 0u;
+    const uint32_t rsafe = rid0 < R ? rid0 : R - 1;  // dead lanes add 0 to a real row
+    const uint32_t row0 = rsafe * bins;
+    const uint32_t has_next = rsafe + 1 < R ? 1u : 0u;
+    const uint32_t rowstep = has_next ? bins : 0u;
+    uint32_t bin[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+        bin[i] = CANON ? (uint32_t)lut[f] : f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t sel = (gr >> (7 - i)) & 1u;
+        const uint32_t val = (ok >> (7 - i)) & 1u;
+        if (!(a.debug & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[i]], val);
+        else if (val + bin[i] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
+    }
+    atomicAdd(&tot[rsafe], (uint32_t)__popc(ok & ~gr));
+    atomicAdd(&tot[rsafe + has_next], (uint32_t)__popc(ok & gr));
+}
+
+// ---- one 504-base chunk of a tile -> LDS histogram rows -------------------------------------------
 template <int K, bool CANON>
 __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint2 data,
                                               uint32_t lane, const uint16_t *lut, uint32_t *hist, uint32_t *tot,
                                               const uint64_t *roff) {
     constexpr uint32_t KMASK = (1u << (2 * K)) - 1u;
-    const uint32_t R = a.R, bins = a.bins, nr = t.nr;
+    const uint32_t bins = a.bins, nr = t.nr;
+    uint32_t P, V, W, VV;
+    encode8(data, P, V);
+    if (!t.general) {
+        // equal-length tile: 32-bit positions, membership by magic division, at most one read
+        // boundary inside the lane's 8 bases (len >= 8)
+        const uint32_t Lr = t.Lr;
+        const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + 8 * ((int32_t)lane - 1);
+        const int32_t t0 = q - (int32_t)t.sh;  // tile-relative index of base 0 (< 0 in the first lanes)
+        const uint32_t tt = t0 < 0 ? 0u : (uint32_t)t0;
+        uint32_t rid0 = __umulhi(tt, t.lr_magic);
+        if (rid0 * Lr > tt) rid0--;  // the magic quotient can overshoot by one
+        const int32_t pos0 = t0 < 0 ? t0 : (int32_t)(tt - rid0 * Lr);
+        const uint32_t left = Lr - (uint32_t)(pos0 < 0 ? 0 : pos0);
+        const uint32_t rem = pos0 < 0 ? 255u : (left > 255u ? 255u : left);
+        const uint32_t len1 = (rid0 + 1 < nr) ? (Lr > 255u ? 255u : Lr) : 0u;
+        if (q < 0 || q >= (int32_t)(uint32_t)t.flat_end || rid0 >= nr) V = 0xFFu;
+        emit8<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot, W, VV);
+        return;
+    }
+    // general tile: 64-bit positions, membership by binary search of the tile's offsets
     const uint64_t off0 = t.off0, TL = t.TL;
-    const uint32_t sh = t.sh, Lr = t.Lr, lr_magic = t.lr_magic;
-    const bool general = t.general;
+    const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
+    if (!(q >= 0 && (uint64_t)q < t.flat_end)) V = 0xFFu;
+    const int64_t t0 = q - (int64_t)t.sh;
+    uint32_t rid0 = 0, rem = 255u, len1 = 0;
+    int32_t pos0 = 0;
+    bool slow = false;
+    if (t0 <= -8) {  // whole lane before the tile (halo lane of chunk 0)
+        pos0 = -1024;
+        V = 0xFFu;
+    } else if (t0 < 0) {
+        // bases 0..(-t0-1) lie before the tile, the rest start read 0: treat read 0 as if it
+        // extended backwards (negative positions never emit)
+        pos0 = (int32_t)t0;
+        const uint64_t e0 = roff[1];
+        const uint64_t left = (e0 - off0) + (uint64_t)(-t0);
+        rem = (uint32_t)(left > 255ull ? 255ull : left);
+        uint64_t l1 = 0;
+        if (1 < nr) l1 = roff[2] - e0;
+        len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
+        slow = rem < 8u && 1 < nr && len1 < 8u - rem;
+    } else if ((uint64_t)t0 >= TL) {
+        V = 0xFFu;
+    } else {
+        const uint64_t T = off0 + (uint64_t)t0;
+        rid0 = find_read(roff, nr, T);
+        const uint64_t s0 = roff[rid0], e0 = roff[rid0 + 1];
+        const uint64_t p64 = T - s0, left = e0 - T;
+        pos0 = (int32_t)(p64 > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : p64);
+        rem = (uint32_t)(left > 255ull ? 255ull : left);
+        uint64_t l1 = 0;
+        if (rid0 + 1 < nr) l1 = roff[rid0 + 2] - e0;
+        len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
+        // a second boundary inside these 8 bases (tiny / empty next read)
+        slow = rem < 8u && rid0 + 1 < nr && len1 < 8u - rem;
+    }
+    if (__ballot(slow) == 0) {
+        emit8<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot, W, VV);
+        return;
+    }
+    // per-base path: every base finds its own read (several boundaries in 8 bases)
     {
-        const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
-        const uint32_t lo = data.x, hi = data.y;
-        const bool inside = q >= 0 && (uint64_t)q < t.flat_end;
-        // encode 8 bases: P = codes (base i at bits 2*(7-i)), V = invalid flags (bit 7-i)
-        uint32_t pa, va, ra, pb, vb, rb;
-        swar4(lo, pa, va, ra);
-        swar4(hi, pb, vb, rb);
-        uint32_t P = (pa << 8) | pb, V = (va << 4) | vb;
-        if (__ballot((ra | rb) != 0) != 0) bytes8(lo, hi, P, V);  // rare: raw 0..3 bytes present
-        if (!inside) V = 0xFFu;
-
-        // which read does the lane's first base belong to, and where in it?
-        // t0 = tile-relative index of the lane's first base (may be < 0 in the first lanes)
-        const int64_t t0 = q - (int64_t)sh;
-        uint32_t rid0;      // read (tile-relative) of base 0
-        int32_t pos0;       // its index inside that read (clamped; < 0 before the tile)
-        uint32_t rem;       // bases left in that read from base 0 on (clamped to 255)
-        uint32_t len1;      // length of the following read (clamped to 255; 0 = none)
-        bool slow = false;
-        if (!general) {
-            const uint32_t tt = t0 < 0 ? 0u : (uint32_t)t0;
-            rid0 = __umulhi(tt, lr_magic);
-            if (rid0 * Lr > tt) rid0--;  // the magic quotient can overshoot by one
-            pos0 = t0 < 0 ? (int32_t)t0 : (int32_t)(tt - rid0 * Lr);
-            const uint32_t left = Lr - (uint32_t)(pos0 < 0 ? 0 : pos0);
-            rem = pos0 < 0 ? 255u : (left > 255u ? 255u : left);
-            len1 = (rid0 + 1 < nr) ? (Lr > 255u ? 255u : Lr) : 0u;
-            if (rid0 >= nr) V = 0xFFu;
-        } else {
-            if (t0 <= -8) {  // whole lane before the tile (halo lane of chunk 0)
-                rid0 = 0;
-                pos0 = -1024;
-                rem = 255u;
-                len1 = 0;
-                V = 0xFFu;
-            } else if (t0 < 0) {
-                // bases 0..(-t0-1) lie before the tile, the rest start read 0: treat read 0 as
-                // if it extended backwards (negative positions never emit)
-                rid0 = 0;
-                pos0 = (int32_t)t0;
-                const uint64_t e0 = roff[1];
-                const uint64_t left = (e0 - off0) + (uint64_t)(-t0);
-                rem = (uint32_t)(left > 255ull ? 255ull : left);
-                uint64_t l1 = 0;
-                if (1 < nr) l1 = roff[2] - e0;
-                len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
-                slow = rem < 8u && 1 < nr && len1 < 8u - rem;
-            } else if ((uint64_t)t0 >= TL) {
-                rid0 = 0;
-                pos0 = 0;
-                rem = 255u;
-                len1 = 0;
-                V = 0xFFu;
-            } else {
-                const uint64_t T = off0 + (uint64_t)t0;
-                rid0 = find_read(roff, nr, T);
-                const uint64_t s0 = roff[rid0], e0 = roff[rid0 + 1];
-                const uint64_t p64 = T - s0, left = e0 - T;
-                pos0 = (int32_t)(p64 > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : p64);
-                rem = (uint32_t)(left > 255ull ? 255ull : left);
-                uint64_t l1 = 0;
-                if (rid0 + 1 < nr) l1 = roff[rid0 + 2] - e0;
-                len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
-                // a second boundary inside these 8 bases (tiny / empty next read)
-                slow = rem < 8u && rid0 + 1 < nr && len1 < 8u - rem;
-            }
-        }
-
-        // predecessor lane's pack (lane 0 keeps "all invalid")
         const uint32_t PV = (V << 16) | P;
         const uint32_t prevPV = ktd::wave_shr1(PV, 0x00FF0000u);
-        const uint32_t W = ((prevPV & 0xFFFFu) << 16) | P;   // base i at bits 2*(7-i), previous lane above
-        const uint32_t VV = ((prevPV >> 16) << 8) | V;        // invalid flags, same order
-        const bool emit_lane = lane != 0;
-
-        if (__ballot(slow) == 0) {
-            // Branch-free: 8-bit masks over the lane's bases (base i <-> bit 7-i), then 8
-            // unconditional LUT reads and 8 unconditional ds_add of 0 or 1.
-            // ge(x) = { i >= x } = 0xFF >> clamp(x, 0, 8)
-            uint32_t B = VV;  // bit 7-i: some invalid base in the window ending at base i
-#pragma unroll
-            for (int j = 1; j < K; j++) B |= VV >> j;
-            const int32_t a1 = (int32_t)(K - 1) - pos0;  // current read: bases i < a1 lack predecessors
-            const uint32_t g1 = 0xFFu >> (uint32_t)(a1 < 0 ? 0 : (a1 > 8 ? 8 : a1));
-            const uint32_t gr = 0xFFu >> (rem > 8u ? 8u : rem);                        // bases of the following read
-            const uint32_t grk = 0xFFu >> (rem + (K - 1) > 8u ? 8u : rem + (K - 1));  // ... with k-1 predecessors
-            const uint32_t grl = 0xFFu >> (rem + len1 > 8u ? 8u : rem + len1);        // past the following read
-            uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFu;
-            ok = emit_lane ? ok : 0u;
-            const uint32_t rsafe = rid0 < R ? rid0 : R - 1;  // dead lanes add 0 to a real row
-            const uint32_t row0 = rsafe * bins;
-            const uint32_t has_next = rsafe + 1 < R ? 1u : 0u;
-            const uint32_t rowstep = has_next ? bins : 0u;
-            uint32_t bin[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
-                bin[i] = CANON ? (uint32_t)lut[f] : f;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t sel = (gr >> (7 - i)) & 1u;
-                const uint32_t val = (ok >> (7 - i)) & 1u;
-                if (!(a.debug & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[i]], val);
-                else if (val + bin[i] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
-            }
-            atomicAdd(&tot[rsafe], (uint32_t)__popc(ok & ~gr));
-            atomicAdd(&tot[rsafe + has_next], (uint32_t)__popc(ok & gr));
-        } else {
-            // per-base path: every base finds its own read (several boundaries in 8 bases)
+        W = ((prevPV & 0xFFFFu) << 16) | P;
+        VV = ((prevPV >> 16) << 8) | V;
+    }
 #pragma unroll 1
-            for (int i = 0; i < 8; i++) {
-                const int64_t ti = t0 + i;
-                if (!emit_lane || ti < 0 || (uint64_t)ti >= TL) continue;
-                const uint64_t T = off0 + (uint64_t)ti;
-                const uint32_t rid = find_read(roff, nr, T);
-                const uint64_t p64 = T - roff[rid];
-                const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
-                if (p64 >= (uint64_t)(K - 1) && bad == 0) {
-                    const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
-                    const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
-                    atomicAdd(&hist[rid * bins + bin], 1u);
-                    atomicAdd(&tot[rid], 1u);
-                }
-            }
+    for (int i = 0; i < 8; i++) {
+        const int64_t ti = t0 + i;
+        if (lane == 0 || ti < 0 || (uint64_t)ti >= TL) continue;
+        const uint64_t T = off0 + (uint64_t)ti;
+        const uint32_t rid = find_read(roff, nr, T);
+        const uint64_t p64 = T - roff[rid];
+        const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
+        if (p64 >= (uint64_t)(K - 1) && bad == 0) {
+            const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+            const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
+            atomicAdd(&hist[rid * bins + bin], 1u);
+            atomicAdd(&tot[rid], 1u);
         }
     }
 }
@@ -379,7 +417,7 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
     vec_t *dst = reinterpret_cast<vec_t *>(a.out) + t.r0 * a.vec_per_row;
     // U independent 16-byte outputs per lane per trip: all LDS reads first, then the arithmetic,
     // then the stores, so one wave keeps several KB of stores in flight.
-    constexpr int U = 4;
+    constexpr int U = 2;
     using cnt_t = typename std::conditional<DT == KT_F64, uint2, uint4>::type;
     for (uint32_t vb = v_lo; vb < v_hi; vb += 64 * U) {
         cnt_t c[U];
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
     constexpr bool LUT_LDS = CANON && K <= 5;
     constexpr uint32_t NLUT = LUT_LDS ? (1u << (2 * K)) : 0u;
     constexpr uint32_t NT = NW * 64;
-    constexpr int PF = 4;
+    constexpr int PF = 3;  // chunk loads kept in flight per wave (R=40 x 150 bp = 12 chunks / 4 waves)
 
     const uint32_t R = a.R, bins = a.bins;
     const uint16_t *lut = LUT_LDS ? reinterpret_cast<const uint16_t *>(smem) : a.lut;
@@ -469,7 +507,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
 
     OffRegs o_cur = load_offsets(a, tile_of(0), lane);
     OffRegs o_nxt = nt > 1 ? load_offsets(a, tile_of(1), lane) : OffRegs{0, 0};
-    ProdTile t_cur = make_tile(a, tile_of(0), o_cur, lane);
+    ProdTile t_cur = make_tile(a, tile_of(0), o_cur, lane, total_bytes);
     uint2 c_cur[PF];
 #pragma unroll
     for (int it = 0; it < PF; it++) {
@@ -484,14 +522,22 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
                 roff[lane] = o_cur.o;
                 roff[lane + 1] = o_cur.on;
             }
+            // one rolled loop = one copy of the chunk body in the binary (the unrolled form was
+            // 37 KB of code and 100 VGPRs); the prefetched registers are picked by a select chain
+            uint32_t it = 0;
+#pragma unroll 1
+            for (uint64_t ci = wave; ci < t_cur.n_chunks; ci += NW, it++) {
+                uint2 d;
+                if (it < (uint32_t)PF) {
+                    d = c_cur[0];
 #pragma unroll
-            for (int it = 0; it < PF; it++) {
-                const uint64_t ci = wave + (uint64_t)NW * it;
-                if (ci < t_cur.n_chunks) process_chunk<K, CANON>(a, t_cur, ci, c_cur[it], lane, lut, hist, tot, roff);
+                    for (int u = 1; u < PF; u++)
+                        if (it == (uint32_t)u) d = c_cur[u];
+                } else {
+                    d = load_chunk(a, t_cur, ci, lane, total_bytes);
+                }
+                process_chunk<K, CANON>(a, t_cur, ci, d, lane, lut, hist, tot, roff);
             }
-            for (uint64_t ci = wave + (uint64_t)NW * PF; ci < t_cur.n_chunks; ci += NW)
-                process_chunk<K, CANON>(a, t_cur, ci, load_chunk(a, t_cur, ci, lane, total_bytes), lane, lut, hist,
-                                        tot, roff);
         }
         TileCtx tc;
         tc.r0 = t_cur.r0;
@@ -501,7 +547,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
         __syncthreads();
         // ---- prefetch the next tile while this one is stored -------------------------------------
         if (j + 1 < nt) {
-            t_cur = make_tile(a, tile_of(j + 1), o_nxt, lane);
+            t_cur = make_tile(a, tile_of(j + 1), o_nxt, lane, total_bytes);
             o_cur = o_nxt;
 #pragma unroll
             for (int it = 0; it < PF; it++) {
@@ -511,7 +557,11 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
             if (j + 2 < nt) o_nxt = load_offsets(a, tile_of(j + 2), lane);
         }
         // ---- D: rows out, histogram cleared behind ---------------------------------------------------
+        // the store stream is what must never starve: waves in this phase outrank the waves of
+        // other workgroups that are still counting (-5 % wall, profiles/r1_oligo_ablation.txt)
+        if (!(a.debug & 16u)) __builtin_amdgcn_s_setprio(3);
         consume_tile<DT, NW>(a, tc, wave, lane, hist, tot, dnm, rcp);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
 }
