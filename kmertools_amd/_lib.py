@@ -9,7 +9,7 @@ import pathlib
 import subprocess
 
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libkmertools_hip.so"
+LIB_PATH = pathlib.Path(os.environ.get("KT_LIB", _HERE / "libkmertools_hip.so"))  # KT_LIB: A/B builds
 
 KT_OK = 0
 KT_ERR_ARG, KT_ERR_HIP, KT_ERR_NOMEM, KT_ERR_FULL, KT_ERR_NODEVICE = 1, 2, 3, 4, 5

@@ -13,21 +13,22 @@
 // A 256-thread workgroup owns *tiles* of R consecutive reads; their bases are one contiguous
 // byte range of `bases`, treated as a flat stream.  Per tile:
 //
-//   B  positions: each wave takes 504-byte chunks of the stream; a lane owns 8 consecutive
-//      bases (one aligned 8-byte global load, issued one tile ahead; lane 0 is the halo for
-//      lane 1).  The 8 bytes are encoded with SWAR integer ops (4 bases per instruction:
-//      2-bit codes by shifts/xor, validity by a v_perm_b32 table compare), packed to 16 bits
-//      of codes + 8 invalid flags, and the predecessor lane's pack arrives by one DPP
-//      wave_shr:1.  Each of the 8 k-mers ending in the lane is then one bit-field extract of
-//      that 32-bit window: fwd(p) = sum code[p-j]*4^j, identical to the reference's rolling
+//   B  positions: each wave takes 1008-byte chunks of the stream; a lane owns 16 consecutive
+//      bases (one aligned 16-byte global load, issued one tile ahead; lane 0 is the halo for
+//      lane 1).  The 16 bytes are encoded with SWAR integer ops (4 bases per instruction:
+//      2-bit codes by shifts/xor, validity by a v_perm_b32 table compare), packed to 32 bits
+//      of codes + 16 invalid flags, and the predecessor lane's last 8 bases arrive by one DPP
+//      wave_shr:1.  Each of the 16 k-mers ending in the lane is then one v_alignbit of that
+//      48-bit window: fwd(p) = sum code[p-j]*4^j, identical to the reference's rolling
 //      value.  Which read a base belongs to is arithmetic for equal-length
 //      tiles and a binary search of the tile's offsets otherwise, so long reads spread over
 //      all lanes and waves.  Validity (invalid base in the window, read boundary inside the
-//      window) is 8-bit mask arithmetic; the 8 LUT reads (rank of the canonical form, LDS)
-//      and the 8 ds_add_u32 into the reads' LDS histogram rows are unconditional (they add
-//      0 or 1): no branches.
+//      window) is 16-bit mask arithmetic; the 16 LUT reads (rank of the canonical form, LDS)
+//      and the 16 ds_add_u32 into the reads' LDS histogram rows are unconditional (they add
+//      0 or 1): no branches.  (16 rather than 8 bases per lane halves the lanes of one read
+//      that meet in one ds_add, i.e. the same-address conflicts, and the per-lane overhead.)
 //   D  output: the R x bins counts are one contiguous block of the output matrix; each wave
-//      streams its rows out as 16-byte stores (4 in flight per lane) and clears the LDS
+//      streams its rows out as 16-byte stores (2 in flight per lane) and clears the LDS
 //      rows behind.  Normalisation c / d (d = max(1, total)) uses y = RN(1/d) computed once
 //      per read: q0 = c*y, r = fma(-q0, d, c), q = fma(r, y, q0).  For integers
 //      c <= d < 2^32 the residual r is exact and q is the correctly rounded quotient
@@ -44,7 +45,8 @@
 
 namespace {
 
-constexpr uint32_t CHUNK = 63 * 8;  // new bases per wave-chunk (lane 0 is halo)
+constexpr uint32_t NB = 16;          // bases per lane (one aligned 16-byte load)
+constexpr uint32_t CHUNK = 63 * NB;  // new bases per wave-chunk (lane 0 is halo)
 constexpr uint32_t MAX_R = 64;      // reads per tile (one lane per read in the per-read steps)
 
 template <int DT>
@@ -98,19 +100,6 @@ __device__ __forceinline__ void swar4(uint32_t x, uint32_t &codes8, uint32_t &in
     raw = (t - 0x01010101u) & ~t & 0x80808080u;  // some byte < 4 (may over-report, never under)
 }
 
-// per-byte path (exact SEQ_NT4_TABLE semantics incl. raw bytes 0..3)
-__device__ __forceinline__ void bytes8(uint32_t lo, uint32_t hi, uint32_t &P, uint32_t &V) {
-    P = 0;
-    V = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t b = ((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xFFu;
-        const uint32_t e = ktd::nt4(b);
-        P |= (e & 3u) << (2 * (7 - i));
-        V |= (e >> 2) << (7 - i);
-    }
-}
-
 // number of reads r in [0, nr] with roff[r] <= T, minus one = the read containing T
 // (the last one starting at or before T, which skips empty reads)
 __device__ __forceinline__ uint32_t find_read(const uint64_t *roff, uint32_t nr, uint64_t T) {
@@ -133,15 +122,15 @@ struct TileCtx {
 struct ProdTile {
     uint64_t r0, off0, TL;
     uint32_t nr;
-    uintptr_t al0;      // 8-byte aligned address at or before the tile's first base
+    uintptr_t al0;      // NB-byte aligned address at or before the tile's first base
     uint32_t sh;        // (address of first base) - al0
     uint64_t flat_end;  // tile bases are flat bytes [sh, flat_end) from al0
     uint64_t n_chunks;
-    // fast path (all reads of the tile equally long, >= 8 bases, tile < 2^31 bytes): everything
+    // fast path (all reads of the tile equally long, >= NB bases, tile < 2^31 bytes): everything
     // is 32-bit and read membership is a magic division
     bool general;
     uint32_t Lr, lr_magic;
-    int32_t safe_lo, safe_hi;  // flat range in which an 8-byte load stays inside the buffer
+    int32_t safe_lo, safe_hi;  // flat range in which an NB-byte load stays inside the buffer
 };
 
 // lane i holds offsets[r0+i] and offsets[r0+i+1] of a tile (i < nr <= 64); issued two tiles ahead
@@ -178,10 +167,10 @@ __device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile,
     const uint64_t len_first = readlane64(r.on, 0) - t.off0;
     t.TL = off1 - t.off0;
     const bool differs = lane < t.nr && (r.on - r.o) != len_first;
-    t.general = __ballot(differs) != 0 || len_first < 8 || t.TL >= 0x7FFF0000ull;
+    t.general = __ballot(differs) != 0 || len_first < NB || t.TL >= 0x7FFF0000ull;
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     const uintptr_t addr0 = base_addr + t.off0;
-    t.al0 = addr0 & ~(uintptr_t)7;
+    t.al0 = addr0 & ~(uintptr_t)(NB - 1);
     t.sh = (uint32_t)(addr0 - t.al0);
     t.flat_end = t.TL + t.sh;
     t.Lr = (uint32_t)len_first;
@@ -193,125 +182,146 @@ __device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile,
     } else {
         t.n_chunks = ((uint32_t)t.flat_end + CHUNK - 1) / CHUNK;
         t.lr_magic = (uint32_t)(0xFFFFFFFFull / t.Lr) + 1u;
-        // flat coordinate q is loadable iff base <= al0 + q and al0 + q + 8 <= base + total
+        // flat coordinate q is loadable iff base <= al0 + q and al0 + q + NB <= base + total
         const int64_t lo = (int64_t)base_addr - (int64_t)t.al0;                 // <= 0 unless bases is unaligned
         const int64_t hi = (int64_t)(base_addr + total_bytes) - (int64_t)t.al0;  // may exceed int32: clamp
-        t.safe_lo = (int32_t)(lo < -16 ? -16 : lo);
+        t.safe_lo = (int32_t)(lo < -64 ? -64 : lo);
         t.safe_hi = (int32_t)(hi > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : hi);
     }
     return t;
 }
 
-// bytes [p, p+8) with everything outside the buffer replaced by 0xFF (first / last bytes only)
-__device__ __forceinline__ uint2 load8_guarded(uintptr_t p, uintptr_t base_addr, uint64_t total_bytes) {
-    uint2 v = make_uint2(0, 0);
-    for (int j = 0; j < 8; j++) {
+// bytes [p, p+16) with everything outside the buffer replaced by 0xFF (first / last bytes only)
+__device__ __forceinline__ uint4 load_guarded(uintptr_t p, uintptr_t base_addr, uint64_t total_bytes) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int j = 0; j < (int)NB; j++) {
         const uintptr_t b = p + j;
         const uint32_t c = (b >= base_addr && b < base_addr + total_bytes)
                                ? *reinterpret_cast<const unsigned char *>(b)
                                : 0xFFu;
-        if (j < 4) v.x |= c << (8 * j); else v.y |= c << (8 * (j - 4));
+        w[j >> 2] |= c << (8 * (j & 3));
     }
-    return v;
+    return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// lane l of chunk ci owns flat bytes [q, q+8), q = ci*504 + 8*(l-1)   (lane 0: halo)
-__device__ __forceinline__ uint2 load_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint32_t lane,
+// lane l of chunk ci owns flat bytes [q, q+NB), q = ci*CHUNK + NB*(l-1)   (lane 0: halo)
+__device__ __forceinline__ uint4 load_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint32_t lane,
                                             uint64_t total_bytes) {
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
-    uint2 v = make_uint2(0x4E4E4E4Eu, 0x4E4E4E4Eu);  // "NNNN": lanes outside the tile
-    if (a.debug & 4u) return make_uint2(0x54474341u + lane, 0x41434754u);  // ablation: no global load
+    uint4 v = make_uint4(0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu);  // "NNNN": lanes outside the tile
+    if (a.debug & 4u) return make_uint4(0x54474341u + lane, 0x41434754u, 0x47474343u, 0x41544154u);  // ablation
     if (!t.general) {
-        const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + 8 * ((int32_t)lane - 1);
+        const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + (int32_t)NB * ((int32_t)lane - 1);
         if (q >= 0 && q < (int32_t)(uint32_t)t.flat_end) {
             const uintptr_t p = t.al0 + (uint32_t)q;
-            if (q >= t.safe_lo && q + 8 <= t.safe_hi) v = *reinterpret_cast<const uint2 *>(p);
-            else v = load8_guarded(p, base_addr, total_bytes);
+            if (q >= t.safe_lo && q + (int32_t)NB <= t.safe_hi) v = *reinterpret_cast<const uint4 *>(p);
+            else v = load_guarded(p, base_addr, total_bytes);
         }
     } else {
-        const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
+        const int64_t q = (int64_t)(ci * CHUNK) + (int64_t)NB * ((int64_t)lane - 1);
         if (q >= 0 && (uint64_t)q < t.flat_end) {
             const uintptr_t p = t.al0 + (uint64_t)q;
-            if (p >= base_addr && p + 8 <= base_addr + total_bytes) v = *reinterpret_cast<const uint2 *>(p);
-            else v = load8_guarded(p, base_addr, total_bytes);
+            if (p >= base_addr && p + NB <= base_addr + total_bytes) v = *reinterpret_cast<const uint4 *>(p);
+            else v = load_guarded(p, base_addr, total_bytes);
         }
     }
     return v;
 }
 
-// encode the lane's 8 bases: P = codes (base i at bits 2*(7-i)), V = invalid flags (bit 7-i)
-__device__ __forceinline__ void encode8(uint2 data, uint32_t &P, uint32_t &V) {
-    uint32_t pa, va, ra, pb, vb, rb;
+// encode the lane's 16 bases: P = codes (base i at bits 2*(15-i)), V = invalid flags (bit 15-i)
+__device__ __forceinline__ void encode16(uint4 data, uint32_t &P, uint32_t &V) {
+    uint32_t pa, va, ra, pb, vb, rb, pc, vc, rc, pd, vd, rd;
     swar4(data.x, pa, va, ra);
     swar4(data.y, pb, vb, rb);
-    P = (pa << 8) | pb;
-    V = (va << 4) | vb;
-    if (__ballot((ra | rb) != 0) != 0) bytes8(data.x, data.y, P, V);  // rare: raw 0..3 bytes present
+    swar4(data.z, pc, vc, rc);
+    swar4(data.w, pd, vd, rd);
+    P = (pa << 24) | (pb << 16) | (pc << 8) | pd;
+    V = (va << 12) | (vb << 8) | (vc << 4) | vd;
+    if (__ballot((ra | rb | rc | rd) != 0) != 0) {  // rare: raw 0..3 bytes present -> per-byte path
+        const uint32_t w[4] = {data.x, data.y, data.z, data.w};
+        P = 0;
+        V = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t e = ktd::nt4((w[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+            P |= (e & 3u) << (2 * (15 - i));
+            V |= (e >> 2) << (15 - i);
+        }
+    }
 }
 
-// The lane's 8 k-mers -> histogram.  pos0 = index of base 0 in its read (< 0: before the tile),
+// window = the lane's 16 bases preceded by the previous lane's last 8 (one DPP): base i of this
+// lane sits at bits 2*(15-i) of (Whi:P); invalid flags at bit 15-i of VV, previous lane above
+__device__ __forceinline__ void halo(uint32_t P, uint32_t V, uint32_t &Whi, uint32_t &VV) {
+    const uint32_t PV = (V << 16) | (P & 0xFFFFu);
+    const uint32_t prevPV = ktd::wave_shr1(PV, 0xFFFF0000u);  // lane 0: "all invalid"
+    Whi = prevPV & 0xFFFFu;
+    VV = (prevPV & 0xFFFF0000u) | V;
+}
+
+// The lane's 16 k-mers -> histogram.  pos0 = index of base 0 in its read (< 0: before the tile),
 // rem = bases left in that read from base 0 on, len1 = length of the following read (0: none);
-// all clamped to small ranges by the caller.  Branch-free: 8-bit masks over the lane's bases
-// (base i <-> bit 7-i), 8 unconditional LUT reads, 8 unconditional ds_add of 0 or 1.
+// all clamped to small ranges by the caller.  Branch-free: 16-bit masks over the lane's bases
+// (base i <-> bit 15-i), 16 unconditional LUT reads, 16 unconditional ds_add of 0 or 1.
 template <int K, bool CANON>
-__device__ __forceinline__ void emit8(const OligoArgs &a, uint32_t P, uint32_t V, uint32_t lane, uint32_t rid0,
-                                      int32_t pos0, uint32_t rem, uint32_t len1, const uint16_t *lut,
-                                      uint32_t *hist, uint32_t *tot, uint32_t &W_out, uint32_t &VV_out) {
+__device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t V, uint32_t lane, uint32_t rid0,
+                                       int32_t pos0, uint32_t rem, uint32_t len1, const uint16_t *lut,
+                                       uint32_t *hist, uint32_t *tot) {
     constexpr uint32_t KMASK = (1u << (2 * K)) - 1u;
     const uint32_t R = a.R, bins = a.bins;
-    // predecessor lane's pack (lane 0 keeps "all invalid")
-    const uint32_t PV = (V << 16) | P;
-    const uint32_t prevPV = ktd::wave_shr1(PV, 0x00FF0000u);
-    const uint32_t W = ((prevPV & 0xFFFFu) << 16) | P;  // base i at bits 2*(7-i), previous lane above
-    const uint32_t VV = ((prevPV >> 16) << 8) | V;       // invalid flags, same order
-    W_out = W;
-    VV_out = VV;
-    // ge(x) = { i >= x } = 0xFF >> clamp(x, 0, 8)
-    uint32_t B = VV;  // bit 7-i: some invalid base in the window ending at base i
+    uint32_t Whi, VV;
+    halo(P, V, Whi, VV);
+    // ge(x) = { i >= x } = 0xFFFF >> clamp(x, 0, 16)
+    uint32_t B = VV;  // bit 15-i: some invalid base in the window ending at base i
 #pragma unroll
     for (int j = 1; j < K; j++) B |= VV >> j;
     const int32_t a1 = (int32_t)(K - 1) - pos0;  // current read: bases i < a1 lack predecessors
-    const uint32_t g1 = 0xFFu >> (uint32_t)(a1 < 0 ? 0 : (a1 > 8 ? 8 : a1));
-    const uint32_t gr = 0xFFu >> (rem > 8u ? 8u : rem);                        // bases of the following read
-    const uint32_t grk = 0xFFu >> (rem + (K - 1) > 8u ? 8u : rem + (K - 1));  // ... with k-1 predecessors
-    const uint32_t grl = 0xFFu >> (rem + len1 > 8u ? 8u : rem + len1);        // past the following read
-    uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFu;
+    const uint32_t g1 = 0xFFFFu >> (uint32_t)(a1 < 0 ? 0 : (a1 > 16 ? 16 : a1));
+    const uint32_t gr = 0xFFFFu >> (rem > 16u ? 16u : rem);                        // bases of the following read
+    const uint32_t grk = 0xFFFFu >> (rem + (K - 1) > 16u ? 16u : rem + (K - 1));  // ... with k-1 predecessors
+    const uint32_t grl = 0xFFFFu >> (rem + len1 > 16u ? 16u : rem + len1);        // past the following read
+    uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFFFu;
     ok = lane != 0 ? ok : 0u;
     const uint32_t rsafe = rid0 < R ? rid0 : R - 1;  // dead lanes add 0 to a real row
     const uint32_t row0 = rsafe * bins;
     const uint32_t has_next = rsafe + 1 < R ? 1u : 0u;
     const uint32_t rowstep = has_next ? bins : 0u;
-    uint32_t bin[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
-        bin[i] = CANON ? (uint32_t)lut[f] : f;
-    }
+    for (int h = 0; h < 2; h++) {  // two batches of 8: LUT reads first, then the adds
+        uint32_t bin[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t sel = (gr >> (7 - i)) & 1u;
-        const uint32_t val = (ok >> (7 - i)) & 1u;
-        if (!(a.debug & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[i]], val);
-        else if (val + bin[i] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
+        for (int j = 0; j < 8; j++) {
+            const int i = h * 8 + j;
+            const uint32_t f = __builtin_amdgcn_alignbit(Whi, P, 2 * (15 - i)) & KMASK;
+            bin[j] = CANON ? (uint32_t)lut[f] : f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = h * 8 + j;
+            const uint32_t sel = (gr >> (15 - i)) & 1u;
+            const uint32_t val = (ok >> (15 - i)) & 1u;
+            if (!(a.debug & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[j]], val);
+            else if (val + bin[j] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
+        }
     }
     atomicAdd(&tot[rsafe], (uint32_t)__popc(ok & ~gr));
     atomicAdd(&tot[rsafe + has_next], (uint32_t)__popc(ok & gr));
 }
 
-// ---- one 504-base chunk of a tile -> LDS histogram rows -------------------------------------------
+// ---- one 1008-base chunk of a tile -> LDS histogram rows ------------------------------------------
 template <int K, bool CANON>
-__device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint2 data,
+__device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint4 data,
                                               uint32_t lane, const uint16_t *lut, uint32_t *hist, uint32_t *tot,
                                               const uint64_t *roff) {
     constexpr uint32_t KMASK = (1u << (2 * K)) - 1u;
     const uint32_t bins = a.bins, nr = t.nr;
-    uint32_t P, V, W, VV;
-    encode8(data, P, V);
+    uint32_t P, V;
+    encode16(data, P, V);
     if (!t.general) {
         // equal-length tile: 32-bit positions, membership by magic division, at most one read
-        // boundary inside the lane's 8 bases (len >= 8)
+        // boundary inside the lane's 16 bases (len >= 16)
         const uint32_t Lr = t.Lr;
-        const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + 8 * ((int32_t)lane - 1);
+        const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + (int32_t)NB * ((int32_t)lane - 1);
         const int32_t t0 = q - (int32_t)t.sh;  // tile-relative index of base 0 (< 0 in the first lanes)
         const uint32_t tt = t0 < 0 ? 0u : (uint32_t)t0;
         uint32_t rid0 = __umulhi(tt, t.lr_magic);
@@ -320,21 +330,21 @@ __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile
         const uint32_t left = Lr - (uint32_t)(pos0 < 0 ? 0 : pos0);
         const uint32_t rem = pos0 < 0 ? 255u : (left > 255u ? 255u : left);
         const uint32_t len1 = (rid0 + 1 < nr) ? (Lr > 255u ? 255u : Lr) : 0u;
-        if (q < 0 || q >= (int32_t)(uint32_t)t.flat_end || rid0 >= nr) V = 0xFFu;
-        emit8<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot, W, VV);
+        if (q < 0 || q >= (int32_t)(uint32_t)t.flat_end || rid0 >= nr) V = 0xFFFFu;
+        emit16<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot);
         return;
     }
     // general tile: 64-bit positions, membership by binary search of the tile's offsets
     const uint64_t off0 = t.off0, TL = t.TL;
-    const int64_t q = (int64_t)(ci * CHUNK) + 8 * ((int64_t)lane - 1);
-    if (!(q >= 0 && (uint64_t)q < t.flat_end)) V = 0xFFu;
+    const int64_t q = (int64_t)(ci * CHUNK) + (int64_t)NB * ((int64_t)lane - 1);
+    if (!(q >= 0 && (uint64_t)q < t.flat_end)) V = 0xFFFFu;
     const int64_t t0 = q - (int64_t)t.sh;
     uint32_t rid0 = 0, rem = 255u, len1 = 0;
     int32_t pos0 = 0;
     bool slow = false;
-    if (t0 <= -8) {  // whole lane before the tile (halo lane of chunk 0)
+    if (t0 <= -(int64_t)NB) {  // whole lane before the tile (halo lane of chunk 0)
         pos0 = -1024;
-        V = 0xFFu;
+        V = 0xFFFFu;
     } else if (t0 < 0) {
         // bases 0..(-t0-1) lie before the tile, the rest start read 0: treat read 0 as if it
         // extended backwards (negative positions never emit)
@@ -345,9 +355,9 @@ __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile
         uint64_t l1 = 0;
         if (1 < nr) l1 = roff[2] - e0;
         len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
-        slow = rem < 8u && 1 < nr && len1 < 8u - rem;
+        slow = rem < NB && 1 < nr && len1 < NB - rem;
     } else if ((uint64_t)t0 >= TL) {
-        V = 0xFFu;
+        V = 0xFFFFu;
     } else {
         const uint64_t T = off0 + (uint64_t)t0;
         rid0 = find_read(roff, nr, T);
@@ -358,30 +368,26 @@ __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile
         uint64_t l1 = 0;
         if (rid0 + 1 < nr) l1 = roff[rid0 + 2] - e0;
         len1 = (uint32_t)(l1 > 255ull ? 255ull : l1);
-        // a second boundary inside these 8 bases (tiny / empty next read)
-        slow = rem < 8u && rid0 + 1 < nr && len1 < 8u - rem;
+        // a second boundary inside these 16 bases (tiny / empty next read)
+        slow = rem < NB && rid0 + 1 < nr && len1 < NB - rem;
     }
     if (__ballot(slow) == 0) {
-        emit8<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot, W, VV);
+        emit16<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot);
         return;
     }
-    // per-base path: every base finds its own read (several boundaries in 8 bases)
-    {
-        const uint32_t PV = (V << 16) | P;
-        const uint32_t prevPV = ktd::wave_shr1(PV, 0x00FF0000u);
-        W = ((prevPV & 0xFFFFu) << 16) | P;
-        VV = ((prevPV >> 16) << 8) | V;
-    }
+    // per-base path: every base finds its own read (several boundaries in 16 bases)
+    uint32_t Whi, VV;
+    halo(P, V, Whi, VV);
 #pragma unroll 1
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < (int)NB; i++) {
         const int64_t ti = t0 + i;
         if (lane == 0 || ti < 0 || (uint64_t)ti >= TL) continue;
         const uint64_t T = off0 + (uint64_t)ti;
         const uint32_t rid = find_read(roff, nr, T);
         const uint64_t p64 = T - roff[rid];
-        const uint32_t bad = (VV >> (7 - i)) & ((1u << K) - 1u);
+        const uint32_t bad = (VV >> (15 - i)) & ((1u << K) - 1u);
         if (p64 >= (uint64_t)(K - 1) && bad == 0) {
-            const uint32_t f = (W >> (2 * (7 - i))) & KMASK;
+            const uint32_t f = (uint32_t)((((uint64_t)Whi << 32) | P) >> (2 * (15 - i))) & KMASK;
             const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
             atomicAdd(&hist[rid * bins + bin], 1u);
             atomicAdd(&tot[rid], 1u);
@@ -414,53 +420,63 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
     // same wave wrote dnm/rcp; LDS executes a wave's accesses in order
 
     const uint32_t v_lo = row_lo * a.vec_per_row, v_hi = row_hi * a.vec_per_row;
-    vec_t *dst = reinterpret_cast<vec_t *>(a.out) + t.r0 * a.vec_per_row;
-    // U independent 16-byte outputs per lane per trip: all LDS reads first, then the arithmetic,
-    // then the stores, so one wave keeps several KB of stores in flight.
-    constexpr int U = 2;
+    // tile-local 32-bit byte offsets from a wave-uniform base: one scalar base + a VGPR offset
+    char *dstb = reinterpret_cast<char *>(reinterpret_cast<vec_t *>(a.out) + t.r0 * a.vec_per_row);
     using cnt_t = typename std::conditional<DT == KT_F64, uint2, uint4>::type;
-    for (uint32_t vb = v_lo; vb < v_hi; vb += 64 * U) {
+
+    auto convert = [&](const cnt_t &c, double d, double y) {
+        vec_t o;
+        if constexpr (DT == KT_F64) {
+            const double cx = (double)c.x, cy = (double)c.y;
+            const double qx = __dmul_rn(cx, y), qy = __dmul_rn(cy, y);
+            o.x = __fma_rn(__fma_rn(-qx, d, cx), y, qx);
+            o.y = __fma_rn(__fma_rn(-qy, d, cy), y, qy);
+        } else if constexpr (DT == KT_F32) {
+            const float df = (float)d, yf = (float)y;
+            const float cx = (float)c.x, cy = (float)c.y, cz = (float)c.z, cw4 = (float)c.w;
+            const float qx = __fmul_rn(cx, yf), qy = __fmul_rn(cy, yf), qz = __fmul_rn(cz, yf),
+                        qw = __fmul_rn(cw4, yf);
+            o.x = __fmaf_rn(__fmaf_rn(-qx, df, cx), yf, qx);
+            o.y = __fmaf_rn(__fmaf_rn(-qy, df, cy), yf, qy);
+            o.z = __fmaf_rn(__fmaf_rn(-qz, df, cz), yf, qz);
+            o.w = __fmaf_rn(__fmaf_rn(-qw, df, cw4), yf, qw);
+        } else {
+            o = c;
+        }
+        return o;
+    };
+
+    // U independent 16-byte outputs per lane per trip, unpredicated: all LDS reads first, then
+    // the arithmetic, then the stores; a predicated tail finishes the wave's rows.
+    constexpr int U = 2;
+    uint32_t vb = v_lo;
+    for (; vb + 64 * U <= v_hi; vb += 64 * U) {
         cnt_t c[U];
         double d[U], y[U];
-        bool act[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t v = vb + u * 64 + lane;
-            act[u] = v < v_hi;
-            c[u] = cnt_t{};
-            d[u] = 1.0;
-            y[u] = 1.0;
-            if (act[u]) {
-                cnt_t *hp = reinterpret_cast<cnt_t *>(hist + v * VEC);
-                c[u] = *hp;
-                *hp = cnt_t{};
-                const uint32_t r = __umulhi(v, a.vec_magic);
-                d[u] = dnm[r];
-                y[u] = rcp[r];
-            }
+            cnt_t *hp = reinterpret_cast<cnt_t *>(hist + v * VEC);
+            c[u] = *hp;
+            *hp = cnt_t{};
+            const uint32_t r = __umulhi(v, a.vec_magic);
+            d[u] = dnm[r];
+            y[u] = rcp[r];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            vec_t o;
-            if constexpr (DT == KT_F64) {
-                const double cx = (double)c[u].x, cy = (double)c[u].y;
-                const double qx = __dmul_rn(cx, y[u]), qy = __dmul_rn(cy, y[u]);
-                o.x = __fma_rn(__fma_rn(-qx, d[u], cx), y[u], qx);
-                o.y = __fma_rn(__fma_rn(-qy, d[u], cy), y[u], qy);
-            } else if constexpr (DT == KT_F32) {
-                const float df = (float)d[u], yf = (float)y[u];
-                const float cx = (float)c[u].x, cy = (float)c[u].y, cz = (float)c[u].z, cw4 = (float)c[u].w;
-                const float qx = __fmul_rn(cx, yf), qy = __fmul_rn(cy, yf), qz = __fmul_rn(cz, yf),
-                            qw = __fmul_rn(cw4, yf);
-                o.x = __fmaf_rn(__fmaf_rn(-qx, df, cx), yf, qx);
-                o.y = __fmaf_rn(__fmaf_rn(-qy, df, cy), yf, qy);
-                o.z = __fmaf_rn(__fmaf_rn(-qz, df, cz), yf, qz);
-                o.w = __fmaf_rn(__fmaf_rn(-qw, df, cw4), yf, qw);
-            } else {
-                o = c[u];
-            }
-            if (act[u] && !(a.debug & 2u)) dst[vb + u * 64 + lane] = o;
+            const vec_t o = convert(c[u], d[u], y[u]);
+            const uint32_t v = vb + u * 64 + lane;
+            if (!(a.debug & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
         }
+    }
+    for (uint32_t v = vb + lane; v < v_hi; v += 64) {
+        cnt_t *hp = reinterpret_cast<cnt_t *>(hist + v * VEC);
+        const cnt_t c = *hp;
+        *hp = cnt_t{};
+        const uint32_t r = __umulhi(v, a.vec_magic);
+        const vec_t o = convert(c, dnm[r], rcp[r]);
+        if (!(a.debug & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
     }
 }
 
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
     constexpr bool LUT_LDS = CANON && K <= 5;
     constexpr uint32_t NLUT = LUT_LDS ? (1u << (2 * K)) : 0u;
     constexpr uint32_t NT = NW * 64;
-    constexpr int PF = 3;  // chunk loads kept in flight per wave (R=40 x 150 bp = 12 chunks / 4 waves)
+    constexpr int PF = 2;  // chunk loads kept in flight per wave (R=52 x 150 bp = 8 chunks / 4 waves)
 
     const uint32_t R = a.R, bins = a.bins;
     const uint16_t *lut = LUT_LDS ? reinterpret_cast<const uint16_t *>(smem) : a.lut;
@@ -508,10 +524,10 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
     OffRegs o_cur = load_offsets(a, tile_of(0), lane);
     OffRegs o_nxt = nt > 1 ? load_offsets(a, tile_of(1), lane) : OffRegs{0, 0};
     ProdTile t_cur = make_tile(a, tile_of(0), o_cur, lane, total_bytes);
-    uint2 c_cur[PF];
+    uint4 c_cur[PF];
 #pragma unroll
     for (int it = 0; it < PF; it++) {
-        c_cur[it] = make_uint2(0, 0);
+        c_cur[it] = make_uint4(0, 0, 0, 0);
         const uint64_t ci = wave + (uint64_t)NW * it;
         if (ci < t_cur.n_chunks) c_cur[it] = load_chunk(a, t_cur, ci, lane, total_bytes);
     }
@@ -527,7 +543,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
             uint32_t it = 0;
 #pragma unroll 1
             for (uint64_t ci = wave; ci < t_cur.n_chunks; ci += NW, it++) {
-                uint2 d;
+                uint4 d;
                 if (it < (uint32_t)PF) {
                     d = c_cur[0];
 #pragma unroll
@@ -636,8 +652,8 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     const uint32_t nbuf = 1;
     // small rows: ~22 KB of LDS rows (6 workgroups per CU); big rows (k >= 6, 8-64 KB each) are
     // pure store streams and measured best with one large tile per CU (cfg5: R=4, 0.56 of peak)
-    uint32_t R = (bins <= 1024 ? 22528u : 131072u) / (bins * 4u);
-    if (R >= 8) R &= ~3u;  // k=4: 40 reads = 12 wave-chunks of 150-bp reads, 6 workgroups per CU
+    uint32_t R = (bins <= 1024 ? 28672u : 131072u) / (bins * 4u);
+    if (R >= 8) R &= ~3u;  // k=4: 52 reads = 8 wave-chunks (1008 B) of 150-bp reads, 5 workgroups per CU
     if (R < 1) R = 1;
     if (R > MAX_R) R = MAX_R;
     R = env_u32("KT_OLIGO_R", R);
