@@ -10,7 +10,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0][-60:]
+        name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
         per[(name, row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])
     for (name, _), cs in per.items():
         for c, v in cs.items():
