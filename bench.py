@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (debug; marks the line as reduced)")
     ap.add_argument("--genome", type=int, default=0, help="ctr: sample reads from a random genome of this length")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cap-log2", type=int, default=0, help="ctr: override log2 of the table capacity (experiments)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -164,9 +165,12 @@ def main():
     else:
         from kmertools_amd import dist as ktdist
         kmers_per_read = L - k + 1
-        # slots: 2x the most distinct keys this rank can see (all instances, or all canonical k-mers)
+        # slots: a power of two above the most distinct keys this rank can see
         max_distinct = min(n * kmers_per_read, (4 ** k + 2 ** k) // 2)
+        # (2x: short probe chains in the LDS build; measured faster than 1.3x despite the bigger table)
         cap = 1 << max(20, (2 * max_distinct - 1).bit_length())
+        if args.cap_log2:
+            cap = 1 << args.cap_log2
         counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
         dominant = "count_reads_kernel<k=%d>" % k

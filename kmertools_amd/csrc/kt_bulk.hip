@@ -1,0 +1,461 @@
+// kt_bulk.hip - bulk construction of the k-mer table from a whole read batch without global
+// atomics.
+//
+// Why: global atomics on this chip are capped at ~27 G/s wherever they land
+// (tools/ubench/atomic_region.hip, profiles/r1_ctr_notes.txt), so the incremental path
+// (one CAS or atomic add per k-mer, kt_ctr.hip) cannot exceed ~20 G k-mers/s.  An EMPTY table
+// can instead be built by streaming passes:
+//
+//   hist1     persistent workgroups run the segment front end over their reads and count
+//             k-mers per level-1 bucket d1 = top b1 bits of mix64(key)   (LDS counters)
+//   scan1     exact output offset of every (workgroup, d1) pair - no reservation atomics
+//   scatter1  same front end again; each segment's <= 8192 keys are counting-sorted by d1 in
+//             LDS and every d1 run is copied to its bucket with coalesced stores
+//   part2     one workgroup per level-1 bucket: histogram of d2 (next b2 hash bits), then the
+//             bucket is re-read in 4096-key chunks, each chunk counting-sorted in LDS and its
+//             runs appended to the fine buckets
+//   build     one workgroup per fine bucket (d1,d2): its keys are counted in an LDS
+//             open-addressing table that *is* the image of the global slot range
+//             [(d1,d2) * S, +S) (home slot = top log2(cap) hash bits, kt_table.hpp), and the
+//             4096 slots are written out with 16-byte coalesced stores - including the empty
+//             ones, so the bulk build needs no cleared table.  Keys that would probe past the
+//             end of their range go to a small spill list and are inserted afterwards through
+//             the ordinary (probing, atomic) path.
+//
+// Traffic ~ 1 B/base x 2 + 8 B/k-mer x 5 + 16 B/slot, all streaming.
+#include <stdlib.h>
+
+#include "kt_segment.hpp"
+#include "kt_table.hpp"
+
+namespace {
+
+using ktseg::SegArgs;
+using ktseg::SegShared;
+using kttab::Slot;
+using kttab::TableRef;
+
+constexpr int BLOCK = ktseg::BLOCK;       // 256
+constexpr uint32_t LOG2_S = 12;           // slots per fine bucket
+constexpr uint32_t S = 1u << LOG2_S;      // 4096 slots = 64 KB of table per fine bucket
+constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
+constexpr uint32_t CHUNK2 = 4096;         // keys sorted at a time in part2
+
+struct Plan {
+    uint32_t n;       // log2(cap)
+    uint32_t b1, b2;  // hash bits per level; b1 + b2 + LOG2_S == n
+    uint32_t B1, B2;
+    uint32_t G;       // persistent workgroups of hist1 / scatter1
+};
+
+struct Meta {           // device arrays carved from ctr->b_meta
+    uint32_t *H;        // [G][B1] k-mers of workgroup g in bucket d1
+    uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
+    uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
+    uint64_t *fstart;   // [B1 * B2 + 1] fine bucket boundaries in keys2
+    uint64_t *spill_n;  // [1]
+    uint64_t *spill_keys;
+    uint32_t *spill_counts;
+    uint64_t spill_cap;
+};
+
+__device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) {
+    return (uint32_t)(ktd::mix64(key) >> (64 - p.b1));
+}
+__device__ __forceinline__ uint32_t digit2(uint64_t key, const Plan &p) {
+    return (uint32_t)(ktd::mix64(key) >> (64 - p.b1 - p.b2)) & (p.B2 - 1);
+}
+
+// exclusive prefix sum of cnt[0..B) into out[0..B) (LDS arrays), B <= MAX_B; returns the total.
+// All 256 threads must call; tmp is a 256-entry LDS scratch.  Thread sums are scanned inside
+// each wave with shuffles and across the 4 waves through tmp: 2 barriers.
+__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_t *out, uint32_t B, uint32_t *tmp) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (B + BLOCK - 1) / BLOCK;  // <= 8
+    const uint32_t lo = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; i++)
+        if (lo + i < B) sum += cnt[lo + i];
+    uint32_t inc = sum;  // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += v;
+    }
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BLOCK / 64; w++) {
+        const uint32_t t = tmp[w];
+        if (w < wave) wbase += t;
+        total += t;
+    }
+    uint32_t run = wbase + inc - sum;  // exclusive prefix of this thread's group
+    for (uint32_t i = 0; i < per; i++) {
+        if (lo + i < B) {
+            const uint32_t c = cnt[lo + i];
+            out[lo + i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// ---- hist1 --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void hist1_kernel(SegArgs a, Plan p, uint32_t *__restrict__ H) {
+    __shared__ SegShared sm;
+    __shared__ uint32_t cnt[MAX_B];
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
+        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
+            const uint64_t m = f < r ? f : r;
+            atomicAdd(&cnt[digit1(m, p)], 1u);
+        });
+    }
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) H[(uint64_t)blockIdx.x * p.B1 + i] = cnt[i];
+}
+
+// ---- scan1: O[g][d] = (k-mers in buckets < d) + (k-mers of workgroups < g in bucket d) ------------
+__global__ __launch_bounds__(1024) void scan1_kernel(const uint32_t *__restrict__ H, Plan p, uint64_t *__restrict__ O,
+                                                     uint64_t *__restrict__ bstart) {
+    __shared__ uint64_t tot[MAX_B];
+    for (uint32_t d = threadIdx.x; d < p.B1; d += blockDim.x) {
+        uint64_t run = 0;
+        for (uint32_t g = 0; g < p.G; g++) {
+            O[(uint64_t)g * p.B1 + d] = run;
+            run += H[(uint64_t)g * p.B1 + d];
+        }
+        tot[d] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (uint32_t d = 0; d < p.B1; d++) {
+            const uint64_t c = tot[d];
+            tot[d] = run;
+            bstart[d] = run;
+            run += c;
+        }
+        bstart[p.B1] = run;
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < p.B1; d += blockDim.x) {
+        const uint64_t base = tot[d];
+        for (uint32_t g = 0; g < p.G; g++) O[(uint64_t)g * p.B1 + d] += base;
+    }
+}
+
+// ---- scatter1 ----------------------------------------------------------------------------------------
+constexpr uint32_t HALF = ktseg::SEG / 2;  // keys sorted at a time (two rounds per segment)
+
+struct Scatter1Shared {
+    SegShared seg;
+    uint64_t sorted[HALF];
+    uint64_t cursor[MAX_B];
+    uint32_t cnt[MAX_B];
+    uint32_t start[MAX_B];
+    uint32_t fill[MAX_B];
+    uint32_t tmp[BLOCK];
+};
+
+__global__ __launch_bounds__(BLOCK) void scatter1_kernel(SegArgs a, Plan p, const uint64_t *__restrict__ O,
+                                                         uint64_t *__restrict__ keys1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Scatter1Shared &sm = *reinterpret_cast<Scatter1Shared *>(smem_raw);
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cursor[i] = O[(uint64_t)blockIdx.x * p.B1 + i];
+    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
+        // one front-end pass: the thread's 32 canonical k-mers stay in registers
+        uint64_t keys[ktseg::PER_THREAD];
+        uint32_t ok;
+        ktseg::collect_kmers(a, g, sm.seg, keys, ok);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cnt[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if ((ok >> (half * 16 + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * 16 + j], p)], 1u);
+            __syncthreads();
+            const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
+            for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.fill[i] = sm.start[i];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if ((ok >> (half * 16 + j)) & 1u) {
+                    const uint64_t m = keys[half * 16 + j];
+                    const uint32_t pos = atomicAdd(&sm.fill[digit1(m, p)], 1u);
+                    sm.sorted[pos] = m;
+                }
+            }
+            __syncthreads();
+            // runs of equal d1 are contiguous in `sorted`: consecutive lanes -> consecutive addresses
+            for (uint32_t i = threadIdx.x; i < nk; i += BLOCK) {
+                const uint64_t key = sm.sorted[i];
+                const uint32_t d = digit1(key, p);
+                keys1[sm.cursor[d] + (i - sm.start[d])] = key;
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cursor[i] += sm.cnt[i];
+            __syncthreads();
+        }
+    }
+}
+
+// ---- part2: one workgroup per level-1 bucket -----------------------------------------------------------
+struct Part2Shared {
+    uint64_t sorted[CHUNK2];
+    uint64_t cursor[MAX_B];
+    uint32_t cnt[MAX_B];
+    uint32_t start[MAX_B];
+    uint32_t fill[MAX_B];
+    uint32_t tmp[BLOCK];
+};
+
+__global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict__ keys1,
+                                                      const uint64_t *__restrict__ bstart, Plan p,
+                                                      uint64_t *__restrict__ keys2, uint64_t *__restrict__ fstart) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Part2Shared &sm = *reinterpret_cast<Part2Shared *>(smem_raw);
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
+        const uint64_t lo = bstart[j], hi = bstart[j + 1];
+        // whole-bucket histogram of d2 -> fine bucket boundaries
+        for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cnt[i] = 0;
+        __syncthreads();
+        for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)BLOCK * 8) {  // 8 loads in flight per thread
+            uint64_t kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t i = i0 + (uint64_t)u * BLOCK;
+                kk[u] = i < hi ? keys1[i] : KT_EMPTY_KEY;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (kk[u] != KT_EMPTY_KEY) atomicAdd(&sm.cnt[digit2(kk[u], p)], 1u);
+        }
+        __syncthreads();
+        // bucket sizes can exceed 32 bits only for > 4 G keys in one level-1 bucket: not supported
+        block_excl_scan(sm.cnt, sm.start, p.B2, sm.tmp);
+        for (uint32_t i = tid; i < p.B2; i += BLOCK) {
+            const uint64_t pos = lo + sm.start[i];
+            sm.cursor[i] = pos;
+            fstart[(uint64_t)j * p.B2 + i] = pos;
+        }
+        if (j == p.B1 - 1 && tid == 0) fstart[(uint64_t)p.B1 * p.B2] = hi;
+        __syncthreads();
+        // chunks of CHUNK2 keys: counting sort in LDS, runs appended to the fine buckets
+        constexpr int PER = CHUNK2 / BLOCK;  // 16 keys per thread, held in registers
+        for (uint64_t c0 = lo; c0 < hi; c0 += CHUNK2) {
+            const uint64_t n64 = hi - c0;
+            const uint32_t nc = n64 < CHUNK2 ? (uint32_t)n64 : CHUNK2;
+            for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cnt[i] = 0;
+            __syncthreads();
+            uint64_t kreg[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint32_t i = (uint32_t)u * BLOCK + tid;
+                kreg[u] = i < nc ? keys1[c0 + i] : KT_EMPTY_KEY;
+                if (i < nc) atomicAdd(&sm.cnt[digit2(kreg[u], p)], 1u);
+            }
+            __syncthreads();
+            block_excl_scan(sm.cnt, sm.start, p.B2, sm.tmp);
+            for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.fill[i] = sm.start[i];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                if (kreg[u] != KT_EMPTY_KEY) {
+                    const uint32_t pos = atomicAdd(&sm.fill[digit2(kreg[u], p)], 1u);
+                    sm.sorted[pos] = kreg[u];
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < nc; i += BLOCK) {
+                const uint64_t key = sm.sorted[i];
+                const uint32_t d = digit2(key, p);
+                keys2[sm.cursor[d] + (i - sm.start[d])] = key;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cursor[i] += sm.cnt[i];
+            __syncthreads();
+        }
+    }
+}
+
+// ---- build: one workgroup per fine bucket ------------------------------------------------------------------
+struct BuildShared {
+    uint64_t keys[S];
+    uint32_t counts[S];
+};
+
+constexpr int BUILD_T = 1024;  // 16 waves per fine bucket: short serial probe chains, full occupancy
+
+__global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restrict__ keys2,
+                                                      const uint64_t *__restrict__ fstart, Plan p,
+                                                      Slot *__restrict__ slots, uint64_t *__restrict__ spill_n,
+                                                      uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
+                                                      uint32_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    BuildShared &sm = *reinterpret_cast<BuildShared *>(smem_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
+    const uint32_t shift = 64 - p.n;
+    for (uint64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
+        for (uint32_t i = tid; i < S; i += BUILD_T) {
+            sm.keys[i] = KT_EMPTY_KEY;
+            sm.counts[i] = 0;
+        }
+        __syncthreads();
+        const uint64_t lo = fstart[fb], hi = fstart[fb + 1];
+        for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)BUILD_T * 4) {  // 4 loads in flight per thread
+          uint64_t kk[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+              const uint64_t i = i0 + (uint64_t)u * BUILD_T;
+              kk[u] = i < hi ? keys2[i] : KT_EMPTY_KEY;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint64_t key = kk[u];
+            if (key == KT_EMPTY_KEY) continue;
+            uint32_t s = (uint32_t)(ktd::mix64(key) >> shift) & (S - 1);
+            bool placed = false;
+            for (; s < S; s++) {  // forward only: never wrap inside the range (kt_table.hpp invariant)
+                uint64_t cur = sm.keys[s];
+                if (cur == KT_EMPTY_KEY) {
+                    const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&sm.keys[s]),
+                                                    (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key);
+                    if (prev == KT_EMPTY_KEY) {  // claimed: first occurrence, stored count stays 0
+                        placed = true;
+                        break;
+                    }
+                    cur = prev;
+                }
+                if (cur == key) {
+                    atomicAdd(&sm.counts[s], 1u);
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) {  // ran off the end of the range: goes through the probing path afterwards
+                const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
+                if (at < spill_cap) spill_keys[at] = key;
+                else atomicOr(flags, 1u);
+            }
+          }
+        }
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * S);
+        for (uint32_t i = tid; i < S; i += BUILD_T) {
+            const uint64_t key = sm.keys[i];
+            dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), sm.counts[i], 0u);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void spill_insert_kernel(const uint64_t *__restrict__ spill_n,
+                                                             const uint64_t *__restrict__ spill_keys,
+                                                             uint64_t spill_cap, TableRef t) {
+    uint64_t n = *spill_n;
+    if (n > spill_cap) n = spill_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK)
+        if (!kttab::table_add(t, spill_keys[i], 1u)) atomicOr(t.flags, 1u);
+}
+
+uint64_t env_u64(const char *name, uint64_t dflt) {
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    return strtoull(s, nullptr, 10);
+}
+
+}  // namespace
+
+int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                  uint64_t total_bases, int *done) {
+    *done = 0;
+    kt_ctx *ctx = ctr->ctx;
+    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
+    if (total_bases < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
+    Plan p{};
+    p.n = ctr->log2cap;
+    if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
+    const uint32_t fb = p.n - LOG2_S;
+    p.b1 = (fb + 1) / 2;
+    if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
+    p.b2 = fb - p.b1;
+    if (p.b2 > 11) return KT_OK;
+    p.B1 = 1u << p.b1;
+    p.B2 = 1u << p.b2;
+    const uint64_t n_seg = (total_bases + ktseg::SEG - 1) / ktseg::SEG;
+    uint64_t G = (uint64_t)ctx->n_cu * 2;
+    if (G > n_seg) G = n_seg;
+    p.G = (uint32_t)G;
+
+    // buffers: two key arrays (upper bound: one k-mer per base) + metadata; if HBM is short,
+    // fall back to the incremental path
+    const uint64_t spill_cap = total_bases / 64 + (1u << 16);
+    size_t meta = 0;
+    const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
+    const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_bs = meta;      meta += ((size_t)(p.B1 + 1) * 8 + 255) & ~(size_t)255;
+    const size_t off_fs = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
+    const size_t off_sn = meta;      meta += 256;
+    const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
+    if (ctr->b_keys1.reserve(total_bases * 8) != KT_OK || ctr->b_keys2.reserve(total_bases * 8) != KT_OK ||
+        ctr->b_meta.reserve(meta) != KT_OK) {
+        ctr->b_keys1.release();
+        ctr->b_keys2.release();
+        ctr->b_meta.release();
+        kt::set_error("");
+        return KT_OK;  // not enough HBM for the bulk buffers: incremental path
+    }
+    char *mb = (char *)ctr->b_meta.p;
+    Meta m{};
+    m.H = (uint32_t *)(mb + off_H);
+    m.O = (uint64_t *)(mb + off_O);
+    m.bstart = (uint64_t *)(mb + off_bs);
+    m.fstart = (uint64_t *)(mb + off_fs);
+    m.spill_n = (uint64_t *)(mb + off_sn);
+    m.spill_keys = (uint64_t *)(mb + off_sk);
+    m.spill_cap = spill_cap;
+    uint64_t *keys1 = (uint64_t *)ctr->b_keys1.p, *keys2 = (uint64_t *)ctr->b_keys2.p;
+
+    // the segment index (seg_first) lives in ctx scratch; same helper kernel as the other paths
+    const uint64_t n_seg_alloc = n_seg + 2;
+    if (int rc = ctx->s_aux0.reserve(n_seg_alloc * sizeof(uint64_t))) return rc;
+    uint64_t *seg_first = (uint64_t *)ctx->s_aux0.p;
+    hipLaunchKernelGGL(ktseg::seg_index_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_offsets, n_reads, seg_first, n_seg);
+    SegArgs a;
+    a.bases = d_bases;
+    a.offsets = d_offsets;
+    a.seg_first = seg_first;
+    a.n_reads = n_reads;
+    a.n_seg = n_seg;
+    a.k = (uint32_t)ctr->k;
+
+    KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(hist1_kernel, dim3(p.G), dim3(BLOCK), 0, ctx->stream, a, p, m.H);
+    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.H, p, m.O, m.bstart);
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared)));
+    hipLaunchKernelGGL(scatter1_kernel, dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared), ctx->stream, a, p, m.O, keys1);
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Part2Shared)));
+    hipLaunchKernelGGL(part2_kernel, dim3(p.B1), dim3(BLOCK), sizeof(Part2Shared), ctx->stream, keys1, m.bstart, p, keys2,
+                       m.fstart);
+    const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
+    uint64_t gb = (uint64_t)ctx->n_cu * 2 * 2;
+    if (gb > n_fine) gb = n_fine;
+    hipLaunchKernelGGL(build_kernel, dim3((uint32_t)gb), dim3(BUILD_T), sizeof(BuildShared), ctx->stream, keys2, m.fstart, p,
+                       (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, ctr->flags);
+    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, 64 - ctr->log2cap, ctr->flags};
+    hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
+                       m.spill_cap, t);
+    KT_HIP(hipGetLastError());
+    *done = 1;
+    return KT_OK;
+}

@@ -13,6 +13,7 @@
 
 #include "kt_internal.hpp"
 #include "kt_segment.hpp"
+#include "kt_table.hpp"
 
 namespace {
 
@@ -21,57 +22,18 @@ using ktseg::SegShared;
 
 constexpr int BLOCK = ktseg::BLOCK;
 
-// ---- table primitives -------------------------------------------------------------
+// ---- table primitives: kt_table.hpp -------------------------------------------------
 
-// table[key] += add.  Linear probing; a slot's key goes EMPTY -> key exactly once, so a
-// stale (cached) read can only show EMPTY for a slot that is now taken, and the CAS
-// (device scope, coherent across XCDs) settles that case.
-struct Slot {
-    uint64_t key;    // KT_EMPTY_KEY = free
-    uint32_t count;  // occurrences - 1 (a claimed slot has been seen once)
-    uint32_t pad;
-};
-static_assert(sizeof(Slot) == 16, "slot layout");
-
-__device__ __forceinline__ bool table_add(Slot *__restrict__ slots, uint64_t mask, uint64_t key, uint32_t add) {
-    uint64_t slot = ktd::mix64(key) & mask;
-    for (uint64_t probe = 0; probe <= mask; probe++) {
-        uint64_t cur = KT_EMPTY_KEY;
-#ifndef KT_CAS_FIRST
-        cur = __hip_atomic_load(&slots[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-        if (cur == KT_EMPTY_KEY) {
-            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[slot].key),
-                                            (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key);
-            if (prev == KT_EMPTY_KEY) {
-                // the slot stores (occurrences - 1): claiming it already counts one occurrence,
-                // so a k-mer seen once costs one atomic (the CAS), not two
-                if (add > 1u) atomicAdd(&slots[slot].count, add - 1u);
-                return true;
-            }
-            cur = prev;
-        }
-        if (cur == key) {
-            atomicAdd(&slots[slot].count, add);
-            return true;
-        }
-        slot = (slot + 1) & mask;
-    }
-    return false;
-}
-
-struct TableRef {
-    Slot *slots;
-    uint64_t mask;
-    uint32_t *flags;
-};
+using kttab::Slot;
+using kttab::TableRef;
+using kttab::table_add;
 
 __global__ __launch_bounds__(BLOCK) void count_reads_kernel(SegArgs a, TableRef t) {
     __shared__ SegShared sm;
     for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
         ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
             const uint64_t m = f < r ? f : r;  // counter/src/lib.rs:124
-            if (!table_add(t.slots, t.mask, m, 1u)) atomicOr(t.flags, 1u);
+            if (!table_add(t, m, 1u)) atomicOr(t.flags, 1u);
         });
     }
 }
@@ -83,7 +45,7 @@ __global__ __launch_bounds__(BLOCK) void add_pairs_kernel(const uint64_t *__rest
         const uint64_t key = keys[i];
         const uint32_t c = counts ? counts[i] : 1u;
         if (key == KT_EMPTY_KEY) continue;
-        if (!table_add(t.slots, t.mask, key, c)) atomicOr(t.flags, 1u);
+        if (!table_add(t, key, c)) atomicOr(t.flags, 1u);
     }
 }
 
@@ -297,6 +259,8 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     c->ctx = ctx;
     c->k = k;
     c->cap = cap;
+    c->log2cap = 0;
+    while ((1ull << c->log2cap) < cap) c->log2cap++;
     hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
@@ -317,17 +281,30 @@ int kt_ctr_destroy(kt_ctr *ctr) {
     if (ctr->slots) (void)hipFree(ctr->slots);
     if (ctr->flags) (void)hipFree(ctr->flags);
     if (ctr->cursor) (void)hipFree(ctr->cursor);
+    ctr->b_keys1.release();
+    ctr->b_keys2.release();
+    ctr->b_meta.release();
     delete ctr;
+    return KT_OK;
+}
+
+// Clearing is deferred: the bulk build (kt_bulk.hip) overwrites every slot, so a clear that is
+// followed by a whole-batch kt_ctr_add_reads never has to touch the table.
+static int ensure_cleared(kt_ctr *ctr) {
+    if (!ctr->needs_clear) return KT_OK;
+    hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(ctr->ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
+                       ctr->ctx->stream, (Slot *)ctr->slots, ctr->cap);
+    KT_HIP(hipGetLastError());
+    ctr->needs_clear = false;
     return KT_OK;
 }
 
 int kt_ctr_clear(kt_ctr *ctr) {
     if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_clear: null");
     if (int rc = ctr->ctx->use()) return rc;
-    hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(ctr->ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
-                       ctr->ctx->stream, (Slot *)ctr->slots, ctr->cap);
-    KT_HIP(hipGetLastError());
     KT_HIP(hipMemsetAsync(ctr->flags, 0, 64, ctr->ctx->stream));
+    ctr->needs_clear = true;
+    ctr->empty = true;
     return KT_OK;
 }
 
@@ -346,9 +323,22 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
     if (mem == KT_MEM_HOST) {
         if (int rc = stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) return rc;
     }
+    if (ctr->empty) {
+        // a whole batch into an empty table: partition + LDS build, no global atomics
+        int done = 0;
+        if (int rc = kt_bulk_build(ctr, d_bases, d_offsets, n_reads, total, &done)) return rc;
+        if (done) {
+            ctr->empty = false;
+            ctr->needs_clear = false;  // every slot was written
+            if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
+            return KT_OK;
+        }
+    }
+    ctr->empty = false;
+    if (int rc = ensure_cleared(ctr)) return rc;
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
-    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, (uint32_t)(64 - ctr->log2cap), ctr->flags};
     hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t);
     KT_HIP(hipGetLastError());
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -373,7 +363,9 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
             d_counts = (const uint32_t *)ctx->s_aux2.p;
         }
     }
-    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, ctr->flags};
+    ctr->empty = false;
+    if (int rc = ensure_cleared(ctr)) return rc;
+    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, (uint32_t)(64 - ctr->log2cap), ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctx->stream, d_keys, d_counts, n, t);
     KT_HIP(hipGetLastError());
@@ -385,6 +377,7 @@ int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct) {
     if (!ctr || !distinct) return kt::fail(KT_ERR_ARG, "kt_ctr_size: null");
     kt_ctx *ctx = ctr->ctx;
     if (int rc = ctx->use()) return rc;
+    if (int rc = ensure_cleared(ctr)) return rc;
     KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
     hipLaunchKernelGGL(table_size_kernel, dim3(grid_for(ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctx->stream, (const Slot *)ctr->slots, ctr->cap, ctr->cursor);
@@ -399,6 +392,7 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
     if (max_out && (!keys || !counts)) return kt::fail(KT_ERR_ARG, "kt_ctr_export: null output");
     kt_ctx *ctx = ctr->ctx;
     if (int rc = ctx->use()) return rc;
+    if (int rc = ensure_cleared(ctr)) return rc;
     if (int rc = check_overflow(ctr)) return rc;
     uint64_t *d_keys = keys;
     uint32_t *d_counts = counts;

@@ -27,9 +27,10 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-// owner of a canonical k-mer among n owners: top 32 bits of the mix, multiply-shift
+// owner of a canonical k-mer among n owners: LOW 32 bits of the mix, multiply-shift (the
+// table's home slot uses the top bits of the same hash, kt_table.hpp)
 __host__ __device__ __forceinline__ uint32_t owner_of(uint64_t kmer, uint32_t n) {
-    return (uint32_t)(((mix64(kmer) >> 32) * (uint64_t)n) >> 32);
+    return (uint32_t)(((mix64(kmer) & 0xFFFFFFFFull) * (uint64_t)n) >> 32);
 }
 
 // reverse complement of a packed k-mer (2 bits/base) without a loop:

@@ -47,6 +47,10 @@ struct kt_ctr {
     kt_ctx *ctx = nullptr;
     int k = 0;
     uint64_t cap = 0;          // power of two
+    uint32_t log2cap = 0;
+    bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
+    bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
+    kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls
     void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}
     uint32_t *flags = nullptr; // [0] = overflow flag, device
     uint64_t *cursor = nullptr; // device scalar for export / size

@@ -35,7 +35,7 @@ struct SegArgs {
 };
 
 // seg_first[g] = lower_bound(offsets[0..n_reads], g * SEG) for g in [0, n_seg]
-__global__ void seg_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads,
+static __global__ void seg_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads,
                                  uint64_t *__restrict__ seg_first, uint64_t n_seg) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > n_reads) return;
@@ -121,6 +121,72 @@ __device__ __forceinline__ void for_each_kmer(const SegArgs &a, uint64_t g, SegS
             f = hi >> sh;
             r = (r >> 2) | ((uint64_t)(3u - (uint32_t)(f & 3u)) << (2u * (k - 1)));
         }
+    }
+    __syncthreads();  // LDS is reused by the next segment
+}
+
+// Same walk, but the thread's 32 canonical k-mers stay in registers: keys[j] = min(fwd, rev) of
+// window start 32*tid + j, bit j of `ok` says whether that window is a valid k-mer.  Fully
+// unrolled so the array is register-allocated; lets a caller make several passes over the
+// segment's k-mers (count, place) after a single front-end pass.
+__device__ __forceinline__ void collect_kmers(const SegArgs &a, uint64_t g, SegShared &sm, uint64_t (&keys)[PER_THREAD],
+                                              uint32_t &ok_mask) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k = a.k;
+    const uint64_t total = a.offsets[a.n_reads];
+    const uint64_t B0 = g * SEG;
+    for (uint32_t i = tid; i < NITEM; i += BLOCK) {
+        const uint64_t b = B0 + 32ull * i;
+        uint64_t w = 0;
+        uint32_t iv = 0xFFFFFFFFu;
+        if (b < total) {
+            unsigned char raw[32];
+            if (b + 32 <= total) {
+                __builtin_memcpy(raw, a.bases + b, 32);
+            } else {
+                for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
+            }
+            iv = 0;
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t e = ktd::nt4(raw[j]);
+                w = (w << 2) | (e & 3u);
+                iv |= (e >> 2) << j;
+            }
+        }
+        sm.codes[i] = w;
+        sm.inv[i] = iv;
+        sm.bnd[i] = 0;
+    }
+    __syncthreads();
+    {
+        const uint64_t lim = B0 + SEG + 32;
+        for (uint64_t r = a.seg_first[g] + tid; r < a.n_reads; r += BLOCK) {
+            const uint64_t o = a.offsets[r];
+            if (o >= lim) break;
+            const uint32_t rel = (uint32_t)(o - B0);
+            atomicOr(&sm.bnd[rel >> 5], 1u << (rel & 31u));
+        }
+    }
+    __syncthreads();
+    uint64_t hi = sm.codes[tid], lo = sm.codes[tid + 1];
+    const uint64_t iv = (uint64_t)sm.inv[tid] | ((uint64_t)sm.inv[tid + 1] << 32);
+    const uint64_t bd = (uint64_t)sm.bnd[tid] | ((uint64_t)sm.bnd[tid + 1] << 32);
+    const uint32_t sh = 64u - 2u * k;
+    const uint64_t mk = (1ull << k) - 1ull;
+    const uint64_t mk1 = (1ull << (k - 1)) - 1ull;
+    uint64_t f = hi >> sh;
+    uint64_t r = ktd::rev_comp(f, (int)k);
+    ok_mask = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER_THREAD; j++) {
+        const bool ok = (((iv >> j) & mk) == 0) && (((bd >> (j + 1)) & mk1) == 0);
+        ok_mask |= (ok ? 1u : 0u) << j;
+        keys[j] = f < r ? f : r;
+        hi = (hi << 2) | (lo >> 62);
+        lo <<= 2;
+        f = hi >> sh;
+        r = (r >> 2) | ((uint64_t)(3u - (uint32_t)(f & 3u)) << (2u * (k - 1)));
     }
     __syncthreads();  // LDS is reused by the next segment
 }

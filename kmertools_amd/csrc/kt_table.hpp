@@ -1,0 +1,66 @@
+// kt_table.hpp - the HBM-resident canonical k-mer table shared by the incremental (atomic)
+// path in kt_ctr.hip and the bulk (partition + LDS build) path in kt_bulk.hip.
+//
+// Layout: cap = 2^n slots of 16 bytes {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks
+// a free slot.  Home slot = TOP n bits of mix64(key), linear probing forward (wrapping at
+// cap).  Using the top bits makes "all keys of hash prefix p" one contiguous slot range, which
+// is what lets the bulk path build the table range by range in LDS.  GPU ownership
+// (ktd::owner_of) uses the LOW 32 bits of the same hash, so a shard's keys still spread over
+// its whole table.
+#pragma once
+#include "kt_device.hpp"
+#include "kt_internal.hpp"
+
+namespace kttab {
+
+struct Slot {
+    uint64_t key;    // KT_EMPTY_KEY = free
+    uint32_t count;  // occurrences - 1 (a claimed slot has been seen once)
+    uint32_t pad;
+};
+static_assert(sizeof(Slot) == 16, "slot layout");
+
+struct TableRef {
+    Slot *slots;
+    uint64_t mask;   // cap - 1
+    uint32_t shift;  // 64 - log2(cap)
+    uint32_t *flags; // [0] = overflow flag
+};
+
+__host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, uint32_t shift) {
+    return shift >= 64 ? 0 : (ktd::mix64(key) >> shift);
+}
+
+// table[key] += add.  A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe
+// can only show EMPTY for a slot that is now taken, and the CAS (device scope, coherent across
+// XCDs) settles that case.  A k-mer seen once costs one probing load + one CAS (claiming the
+// slot is its first count); a repeat costs one load + one 32-bit atomic add.
+__device__ __forceinline__ bool table_add(const TableRef &t, uint64_t key, uint32_t add) {
+    uint64_t slot = home_slot(key, t.shift);
+    for (uint64_t probe = 0; probe <= t.mask; probe++) {
+        uint64_t cur = __hip_atomic_load(&t.slots[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == KT_EMPTY_KEY) {
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.slots[slot].key),
+                                            (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key);
+            if (prev == KT_EMPTY_KEY) {
+                if (add > 1u) atomicAdd(&t.slots[slot].count, add - 1u);
+                return true;
+            }
+            cur = prev;
+        }
+        if (cur == key) {
+            atomicAdd(&t.slots[slot].count, add);
+            return true;
+        }
+        slot = (slot + 1) & t.mask;
+    }
+    return false;
+}
+
+}  // namespace kttab
+
+// kt_bulk.hip: builds an EMPTY table from a whole read batch without global atomics.
+// Returns KT_OK, or an error; `*done` = 0 when the batch / table shape is not eligible and
+// the caller must use the incremental path.
+int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                  uint64_t total_bases, int *done);

@@ -449,3 +449,56 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle):
         assert all(device.owner_of(int(x), 2) == rank for x in rk[:300])
     order = np.argsort(keys)
     assert np.array_equal(keys[order], wk) and np.array_equal(counts[order], wc)
+
+
+# ---------------------------------------------------------------------------------------------
+# bulk table construction (kt_bulk.hip): partition + LDS build must give exactly the table the
+# incremental (atomic) path gives, and incremental adds must keep working on top of it
+
+@pytest.mark.parametrize("k,log2cap", [(31, 17), (21, 18), (15, 19), (4, 14), (31, 20)])
+def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap):
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")       # force the bulk path on a small batch
+    seqs = ragged_reads(4000 + k + log2cap, 500)
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    seqs += seqs[10:80] + [s.translate(comp)[::-1] for s in seqs[20:60]] + [b"A" * 3000, b"ACGT" * 700]
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    assert len(wk) < 0.6 * (1 << log2cap)
+    ctr = device.Counter(hctx, k, 1 << log2cap)
+    ctr.add_reads_host(bases, offsets)                  # bulk (table empty)
+    assert ctr.size() == len(wk)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    assert wc.max() > 100                               # heavy hitters (poly-A, repeats) went through
+    # incremental adds on top of a bulk-built table: lookups must find the bulk-placed keys
+    ctr.add_reads_host(bases, offsets)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+    # clear + bulk again (no explicit table clear happens in between)
+    ctr.clear()
+    half = len(seqs) // 2
+    b1, o1 = device.to_csr(seqs[:half])
+    b2, o2 = device.to_csr(seqs[half:])
+    ctr.add_reads_host(b1, o1)                          # bulk
+    ctr.add_reads_host(b2, o2)                          # incremental
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    ctr.close()
+
+
+def test_ctr_bulk_overfull_ranges_spill(hctx, oracle, monkeypatch):
+    """load factor ~0.85: many keys run off the end of their 4096-slot range -> spill path"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seqs = [alpha[rng.integers(0, 4, size=150)].tobytes() for _ in range(470)]   # ~56 k distinct 31-mers
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, 31)
+    ctr = device.Counter(hctx, 31, 1 << 16)
+    assert 0.8 < len(wk) / (1 << 16) < 0.95
+    ctr.add_reads_host(bases, offsets)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    ctr.close()
