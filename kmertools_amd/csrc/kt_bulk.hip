@@ -36,7 +36,7 @@ using kttab::Slot;
 using kttab::TableRef;
 
 constexpr int BLOCK = ktseg::BLOCK;       // 256
-constexpr uint32_t LOG2_S = 12;           // slots per fine bucket
+constexpr uint32_t LOG2_S = 13;           // slots per fine bucket
 constexpr uint32_t S = 1u << LOG2_S;      // 4096 slots = 64 KB of table per fine bucket
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 constexpr uint32_t CHUNK2 = 4096;         // keys sorted at a time in part2
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(SegArgs a, Plan p, cons
 // ---- part2: one workgroup per level-1 bucket -----------------------------------------------------------
 struct Part2Shared {
     uint64_t sorted[CHUNK2];
+    uint16_t sdig[CHUNK2];
     uint64_t cursor[MAX_B];
     uint32_t cnt[MAX_B];
     uint32_t start[MAX_B];
@@ -246,19 +247,29 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
         }
         if (j == p.B1 - 1 && tid == 0) fstart[(uint64_t)p.B1 * p.B2] = hi;
         __syncthreads();
-        // chunks of CHUNK2 keys: counting sort in LDS, runs appended to the fine buckets
+        // chunks of CHUNK2 keys: counting sort in LDS, runs appended to the fine buckets.  The next
+        // chunk's keys are loaded while the current one is sorted; digits are hashed once.
         constexpr int PER = CHUNK2 / BLOCK;  // 16 keys per thread, held in registers
+        uint64_t kcur[PER], knxt[PER];
+        auto load_chunk = [&](uint64_t c0, uint64_t (&dst)[PER]) {
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const uint64_t i = c0 + (uint64_t)u * BLOCK + tid;
+                dst[u] = i < hi ? keys1[i] : KT_EMPTY_KEY;
+            }
+        };
+        if (lo < hi) load_chunk(lo, kcur);
         for (uint64_t c0 = lo; c0 < hi; c0 += CHUNK2) {
             const uint64_t n64 = hi - c0;
             const uint32_t nc = n64 < CHUNK2 ? (uint32_t)n64 : CHUNK2;
+            if (c0 + CHUNK2 < hi) load_chunk(c0 + CHUNK2, knxt);
             for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cnt[i] = 0;
             __syncthreads();
-            uint64_t kreg[PER];
+            uint16_t dg[PER];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint32_t i = (uint32_t)u * BLOCK + tid;
-                kreg[u] = i < nc ? keys1[c0 + i] : KT_EMPTY_KEY;
-                if (i < nc) atomicAdd(&sm.cnt[digit2(kreg[u], p)], 1u);
+                dg[u] = (uint16_t)digit2(kcur[u], p);
+                if (kcur[u] != KT_EMPTY_KEY) atomicAdd(&sm.cnt[dg[u]], 1u);
             }
             __syncthreads();
             block_excl_scan(sm.cnt, sm.start, p.B2, sm.tmp);
@@ -266,21 +277,24 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                if (kreg[u] != KT_EMPTY_KEY) {
-                    const uint32_t pos = atomicAdd(&sm.fill[digit2(kreg[u], p)], 1u);
-                    sm.sorted[pos] = kreg[u];
+                if (kcur[u] != KT_EMPTY_KEY) {
+                    const uint32_t pos = atomicAdd(&sm.fill[dg[u]], 1u);
+                    sm.sorted[pos] = kcur[u];
+                    sm.sdig[pos] = dg[u];
                 }
             }
             __syncthreads();
             for (uint32_t i = tid; i < nc; i += BLOCK) {
-                const uint64_t key = sm.sorted[i];
-                const uint32_t d = digit2(key, p);
-                keys2[sm.cursor[d] + (i - sm.start[d])] = key;
+                const uint32_t d = sm.sdig[i];
+                keys2[sm.cursor[d] + (i - sm.start[d])] = sm.sorted[i];
             }
             __syncthreads();
             for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cursor[i] += sm.cnt[i];
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
+            // (the next iteration's first barrier orders the cursor update before its use)
         }
+        __syncthreads();
     }
 }
 
@@ -450,6 +464,8 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 2 * 2;
     if (gb > n_fine) gb = n_fine;
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)sizeof(BuildShared)));
     hipLaunchKernelGGL(build_kernel, dim3((uint32_t)gb), dim3(BUILD_T), sizeof(BuildShared), ctx->stream, keys2, m.fstart, p,
                        (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, ctr->flags);
     TableRef t{(Slot *)ctr->slots, ctr->cap - 1, 64 - ctr->log2cap, ctr->flags};
