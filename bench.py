@@ -173,7 +173,7 @@ def main():
             cap = 1 << args.cap_log2
         counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
-        dominant = "count_reads_kernel<k=%d>" % k
+        dominant = "ctr k=%d step: bulk table build (hist1 + scatter1 + part2 + build kernels)" % k
 
         def step():
             counter.clear()
