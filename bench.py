@@ -37,6 +37,9 @@ WORKLOADS = {
                     desc="ctr k=15 canonical counts, 50M x 150bp per GPU, hash table in HBM"),
     "ctr_k31": dict(kind="ctr", k=31, n=25_000_000, L=150, cfg=3,
                     desc="ctr k=31 canonical counts, 25M x 150bp per GPU (200M over 8), hash-prefix sharded"),
+    # next row of SURVEY.md 8f: per-read coverage histograms against the resident table (table build untimed)
+    "cov_k15": dict(kind="cov", k=15, n=10_000_000, L=150, dtype="f64", cfg=5, bin_size=16, bin_count=16,
+                    desc="cov k=15 bin_size 16 x 16 bins, 10M x 150bp per GPU against the table of the same reads, f64 rows"),
 }
 
 
@@ -95,6 +98,25 @@ def cpu_baseline_ctr(k, L, seconds, genome):
     return dict(value=n2 * L / dt / 1e9, unit="Gbases/s", cores=cores, kind="port",
                 sample="%d x %dbp synthetic reads, k=%d, %d sharded maps, %d threads, %.1f s, in-memory count only"
                        % (n2, L, k, cores * 8, cores, dt))
+
+
+def cpu_baseline_cov(k, L, seconds, genome, bin_size, bin_count):
+    """CPU oracle (port of coverage/src/lib.rs:165-184) on one host core per call, table prebuilt."""
+    from oracle import kt_oracle as oracle
+    n = 400_000
+    hb, ho = oracle.synth_reads(SEED, n, L, genome_len=genome)
+    c = oracle.Counter(1)
+    c.add_reads(hb, ho, k)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        c.cov_batch(hb, ho, k, bin_size, bin_count, True)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or reps >= 200:
+            break
+    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
+                sample="%d passes over %d x %dbp synthetic reads, k=%d, lookups in a prebuilt table, 1 thread, %.1f s"
+                       % (reps, n, L, k, dt))
 
 
 def main():
@@ -162,6 +184,19 @@ def main():
         def step():
             for (bb, oo, cnt) in batch_args:
                 ctx.oligo(bb, oo, cnt, k, out, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+    elif wl["kind"] == "cov":
+        kmers_per_read = L - k + 1
+        max_distinct = min(n * kmers_per_read, (4 ** k + 2 ** k) // 2)
+        cap = 1 << max(20, (2 * max_distinct - 1).bit_length())
+        table = device.Counter(ctx, k, cap)
+        table.add_reads(bases, offsets, n)   # untimed: the step is the lookup pass
+        bc = wl["bin_count"]
+        out = torch.empty((n, bc), dtype=torch.float64, device="cuda")
+        alg_bytes_per_launch = n * (L + kmers_per_read * 16 + bc * 8)
+        dominant = "cov_kernel k=%d (one 16-byte table probe per k-mer)" % k
+
+        def step():
+            table.cov(bases, offsets, n, wl["bin_size"], bc, out, norm=True, dtype="f64")
     else:
         from kmertools_amd import dist as ktdist
         kmers_per_read = L - k + 1
@@ -211,6 +246,8 @@ def main():
         traffic = None
 
     extra = {}
+    if wl["kind"] == "cov":
+        extra["distinct_rank0"] = table.size()
     if wl["kind"] == "ctr":
         extra["distinct_rank0"] = counter.size_local()
 
@@ -230,6 +267,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "reads_per_gpu": n, "read_len": L, "k": k,
                        "parallelism": "reads sharded by rank, no data-path collective" if wl["kind"] == "oligo"
+                       else "reads sharded by rank, each rank probes the table of its own reads" if wl["kind"] == "cov"
                        else "hash-prefix key ownership, RCCL all-to-all of routed k-mers",
                        "reduced": reduced},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -241,6 +279,8 @@ def main():
         if world == 1 and not args.no_cpu:
             if wl["kind"] == "oligo":
                 line["cpu_baseline"] = cpu_baseline_oligo(k, L, args.cpu_seconds)
+            elif wl["kind"] == "cov":
+                line["cpu_baseline"] = cpu_baseline_cov(k, L, args.cpu_seconds, args.genome, wl["bin_size"], wl["bin_count"])
             else:
                 line["cpu_baseline"] = cpu_baseline_ctr(k, L, args.cpu_seconds, args.genome)
         print(json.dumps(line), flush=True)

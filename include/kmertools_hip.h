@@ -142,6 +142,17 @@ int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct);
 int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_out,
                   uint64_t *n_out, int mem);
 
+/* replaces: CovComputer::vectorise_one, coverage/src/lib.rs:165-184 (and the HashMap
+ * re-load of kmers.counts at :82-92: the table is probed where kt_ctr_add_reads left it).
+ * For every canonical k-mer of a read (k = the table's k): count = table[kmer] or 0,
+ * bin = min(count / bin_size, bin_count - 1); out row = histogram of the bins, divided
+ * by max(1, #k-mers of the read) when norm != 0.  out: n_reads x bin_count row-major,
+ * element type out_dtype (KT_U32 needs norm = 0).  KT_F64 results are bit-identical to
+ * the reference (integer counts, one IEEE division).  bin_size, bin_count >= 1. */
+int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                 uint64_t bin_size, uint64_t bin_count, int norm, int out_dtype, void *out,
+                 int mem);
+
 /* Multi-GPU routing step (the reference's `min_mer % n_parts` partitioning,
  * counter/src/lib.rs:127, re-expressed as hash-prefix ownership):
  * writes every canonical k-mer of the reads into keys_out grouped by owner

@@ -276,4 +276,65 @@ std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
     return "";
 }
 
+// ---------------------------------------------------------------------------------------------
+CovComputer::CovComputer(std::string in_path, std::string out_dir, int ksize, uint64_t bin_size, uint64_t bin_count)
+    : in_path_(in_path), in_path_kmer_(std::move(in_path)), out_dir_(std::move(out_dir)), ksize_(ksize),
+      bin_size_(bin_size), bin_count_(bin_count) {}
+
+CovComputer::~CovComputer() { delete ctr_; }
+
+std::string CovComputer::build_table() {
+    delete ctr_;
+    ctr_ = new CountComputer(in_path_kmer_, out_dir_, ksize_);
+    ctr_->set_threads(threads_);
+    ctr_->set_max_memory(memory_ceil_gb_);
+    ctr_->set_device(device_);
+    std::string e = ctr_->count();
+    if (e.empty()) e = ctr_->merge(true);  // the reference leaves kmers.counts behind as well
+    return e;
+}
+
+std::string CovComputer::compute_coverages() {
+    // the reference parses kmers.counts back into a HashMap (:82-92); the table is still in HBM here
+    if (!ctr_ || !ctr_->table()) return "build_table() has not run";
+    SeqReader reader;
+    if (!reader.open(in_path_, false)) return reader.error();
+    const std::string path = out_dir_ + "/kmers.vectors";
+    FILE *out = fopen(path.c_str(), "wb");
+    if (!out) return "Unable to write to file: " + path;
+    Batch b;
+    std::vector<double> rows;
+    std::vector<std::string> pieces;
+    std::string err;
+    const uint64_t bins = bin_count_;
+    for (;;) {
+        const uint64_t max_reads = bins >= 2048 ? 8192 : 1ull << 20;
+        const bool more = reader.next_batch(b, 256ull << 20, max_reads);
+        const uint64_t n = b.n_reads();
+        if (n) {
+            rows.resize(n * bins);
+            if (kt_cov_batch(ctr_->table(), b.bases.empty() ? (const uint8_t *)"" : b.bases.data(), b.offsets.data(), n,
+                             bin_size_, bin_count_, norm_, KT_F64, rows.data(), KT_MEM_HOST) != KT_OK) {
+                err = kt_last_error();
+                break;
+            }
+            const bool norm = norm_;
+            const std::string &delim = delim_;
+            format_rows(n, threads_, pieces, [&](uint64_t r, std::string &s) {
+                const double *row = rows.data() + r * bins;
+                for (uint64_t i = 0; i < bins; i++) {
+                    if (i) s += delim;
+                    if (norm) append_fixed6(s, row[i]); else append_display(s, row[i]);  // :116-120
+                }
+                s += '\n';
+            });
+            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+        }
+        if (!more) break;
+    }
+    if (err.empty() && reader.failed()) err = reader.error();
+    fclose(out);
+    return err;
+}
+
 }  // namespace kthost

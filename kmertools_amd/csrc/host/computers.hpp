@@ -2,6 +2,7 @@
 //   OligoComputer      composition/src/oligo.rs:15-93
 //   OligoCgrComputer   composition/src/oligocgr.rs:16-121
 //   CountComputer      counter/src/lib.rs:22-90, 172-234
+//   CovComputer        coverage/src/lib.rs:14-184
 // Same constructor arguments, setters and entry points (vectorise / count / merge); the
 // per-read / per-k-mer work goes through the C ABI (include/kmertools_hip.h) to the GPU.
 // The reference's error style is kept: vectorise() returns "" on success or the message that
@@ -76,6 +77,7 @@ class CountComputer {
     std::string count();             // counter/src/lib.rs:69-90 (no temp files: one resident table)
     std::string merge(bool del);     // counter/src/lib.rs:172-234: writes {out_dir}/kmers.counts
     uint64_t seq_count() const { return seq_count_; }
+    kt_ctr *table() const { return ctr_; }  // the resident table (valid after count())
 
   private:
     std::string in_path_, out_dir_;
@@ -85,6 +87,32 @@ class CountComputer {
     uint64_t seq_count_ = 0, total_length_ = 0;
     Device dev_;
     kt_ctr *ctr_ = nullptr;
+};
+
+class CovComputer {
+  public:
+    CovComputer(std::string in_path, std::string out_dir, int ksize, uint64_t bin_size, uint64_t bin_count);
+    void set_threads(int t) { threads_ = t; }
+    void set_norm(bool n) { norm_ = n; }
+    void set_delim(std::string d) { delim_ = std::move(d); }
+    void set_kmer_path(std::string p) { in_path_kmer_ = std::move(p); }
+    void set_max_memory(double gb) { memory_ceil_gb_ = gb; }
+    void set_device(int d) { device_ = d; }
+    std::string build_table();        // coverage/src/lib.rs:69-77: count + merge -> {out_dir}/kmers.counts
+    std::string compute_coverages();  // coverage/src/lib.rs:79-163: writes {out_dir}/kmers.vectors
+
+  private:
+    std::string in_path_, in_path_kmer_, out_dir_, delim_ = " ";
+    int ksize_, threads_ = 0, device_ = 0;
+    uint64_t bin_size_, bin_count_;
+    bool norm_ = true;
+    double memory_ceil_gb_ = 6.0;
+    CountComputer *ctr_ = nullptr;  // owns the HBM table the coverages are looked up in
+
+  public:
+    ~CovComputer();
+    CovComputer(const CovComputer &) = delete;
+    CovComputer &operator=(const CovComputer &) = delete;
 };
 
 }  // namespace kthost

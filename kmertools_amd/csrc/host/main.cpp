@@ -1,8 +1,8 @@
 // kmertools (GPU drop-in) - command line with the reference's `comp oligo`, `comp cgr -k` and
-// `ctr` flags (kmertools/src/args.rs:70-130, 208-236; dispatcher :239-368).  clap conventions
-// are kept: kebab-case long flags, the auto-derived short flags, `--flag=value`, `-k4`.
-// `cov`, `min` and whole-sequence `comp cgr` (no -k) are outside this build's scope
-//  and say so.
+// `ctr` flags (kmertools/src/args.rs:70-130, 208-236; dispatcher :239-368) and `cov`
+// (args.rs:132-172, :299-325).  clap conventions are kept: kebab-case long flags, the
+// auto-derived short flags, `--flag=value`, `-k4`.  `min` and whole-sequence `comp cgr` (no -k)
+// are outside this build's scope and say so.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -120,11 +120,11 @@ std::string required_str(const std::map<std::string, std::string> &f, const char
 const char *HELP_MAIN =
     "kmertools: DNA vectorisation\n\n"
     "k-mer based vectorisation for DNA sequences for\nmetagenomics and AI/ML applications\n"
-    "(MI355X build: comp oligo, comp cgr -k and ctr run on the GPU)\n\n"
+    "(MI355X build: comp oligo, comp cgr -k, cov and ctr run on the GPU)\n\n"
     "Usage: kmertools <COMMAND>\n\n"
     "Commands:\n"
     "  comp  Generate sequence composition based features\n"
-    "  cov   Generates coverage histogram based on the reads (not in this build)\n"
+    "  cov   Generates coverage histogram based on the reads\n"
     "  min   Bin reads using minimisers (not in this build)\n"
     "  ctr   Count k-mers\n"
     "  help  Print this message or the help of the given subcommand(s)\n\n"
@@ -170,6 +170,74 @@ const char *HELP_CTR =
     "  -t, --threads <THREADS>  Thread count for computations 0=auto [default: 0]\n"
     "      --device <DEVICE>    GPU index [default: 0]\n"
     "  -h, --help               Print help\n";
+
+const char *HELP_COV =
+    "Generates coverage histogram based on the reads\n\n"
+    "Usage: kmertools cov [OPTIONS] --input <INPUT> --output <OUTPUT>\n\n"
+    "Options:\n"
+    "  -i, --input <INPUT>          Input file path\n"
+    "  -a, --alt-input <ALT_INPUT>  Input file path, for k-mer counting\n"
+    "  -o, --output <OUTPUT>        Output directory path\n"
+    "  -k, --k-size <K_SIZE>        K size for the coverage histogram [default: 15]\n"
+    "  -p, --preset <PRESET>        Output type to write [default: spc] [possible values: csv, tsv, spc]\n"
+    "  -s, --bin-size <BIN_SIZE>    Bin size for the coverage histogram [default: 16]\n"
+    "  -c, --bin-count <BIN_COUNT>  Number of bins for the coverage histogram [default: 16]\n"
+    "  -m, --memory <MEMORY>        Max memory in GB [default: 6] (accepted; the table lives in HBM)\n"
+    "      --counts                 Disable normalisation and output raw counts\n"
+    "  -t, --threads <THREADS>      Thread count for computations 0=auto [default: 0]\n"
+    "      --device <DEVICE>        GPU index [default: 0]\n"
+    "  -h, --help                   Print help\n";
+
+int make_out_dir(const std::string &out) {
+    // create_directory(&command.output).unwrap()  (args.rs:300, :354)
+    if (mkdir(out.c_str(), 0777) != 0) {
+        struct stat st;
+        if (stat(out.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) {
+            fprintf(stderr, "Error: unable to create directory: %s\n", out.c_str());
+            return 101;  // the reference panics here
+        }
+    }
+    return 0;
+}
+
+int cmd_cov(int argc, char **argv, int from) {
+    const std::vector<Spec> specs = {{'i', "input", true},    {'a', "alt-input", true}, {'o', "output", true},
+                                     {'k', "k-size", true},   {'p', "preset", true},    {'s', "bin-size", true},
+                                     {'c', "bin-count", true}, {'m', "memory", true},   {0, "counts", false},
+                                     {'t', "threads", true},  {0, "device", true}};
+    const auto f = parse_flags(argc, argv, from, specs, HELP_COV);
+    const std::string in = required_str(f, "input"), out = required_str(f, "output");
+    const int k = (int)ranged(f, "k-size", 7, 31, false, 15);
+    const uint64_t bin_size = ranged(f, "bin-size", 5, ~0ull, false, 16);
+    const uint64_t bin_count = ranged(f, "bin-count", 5, ~0ull, false, 16);
+    const uint64_t mem = ranged(f, "memory", 6, 128, false, 6);
+    const int threads = (int)ranged(f, "threads", 0, 1 << 20, false, 0);
+    std::string preset = f.count("preset") ? f.at("preset") : "spc";
+    if (preset != "csv" && preset != "tsv" && preset != "spc")
+        usage_error("invalid value '" + preset + "' for '--preset <PRESET>'\n  [possible values: csv, tsv, spc]");
+    if (int rc = make_out_dir(out)) return rc;
+    const std::string kin = f.count("alt-input") ? f.at("alt-input") : in;
+    for (const std::string &p : {in, kin}) {
+        if (format_from_path(p) == SeqFormat::Unknown && p != "-") {
+            fprintf(stderr, "Error: unsupported input extension (expected .fa/.fasta/.fna/.fq/.fastq[.gz]): %s\n", p.c_str());
+            return 101;  // SeqFormat::get(...).unwrap()
+        }
+    }
+    CovComputer cov(in, out, k, bin_size, bin_count);
+    if (threads > 0) cov.set_threads(threads);
+    if (f.count("alt-input")) cov.set_kmer_path(kin);
+    if (f.count("counts")) cov.set_norm(false);
+    cov.set_max_memory((double)mem);
+    cov.set_delim(preset == "csv" ? "," : preset == "tsv" ? "\t" : " ");
+    cov.set_device((int)ranged(f, "device", 0, 63, false, 0));
+    std::string e = cov.build_table();
+    if (e.empty()) e = cov.compute_coverages();
+    if (!e.empty()) {
+        fprintf(stderr, "Error: %s\n", e.c_str());
+        return 101;  // build_table().unwrap() / unwraps inside compute_coverages
+    }
+    return 0;
+}
 
 int cmd_oligo(int argc, char **argv, int from) {
     const std::vector<Spec> specs = {{'i', "input", true},    {'o', "output", true},  {'c', "counts", false},
@@ -231,14 +299,7 @@ int cmd_ctr(int argc, char **argv, int from) {
     const int k = (int)ranged(f, "k-size", 10, 31, true, 0);
     const uint64_t mem = ranged(f, "memory", 6, 128, false, 6);
     const int threads = (int)ranged(f, "threads", 0, 1 << 20, false, 0);
-    // create_directory(&command.output).unwrap()  (args.rs:354)
-    if (mkdir(out.c_str(), 0777) != 0) {
-        struct stat st;
-        if (stat(out.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) {
-            fprintf(stderr, "Error: unable to create directory: %s\n", out.c_str());
-            return 101;  // the reference panics here
-        }
-    }
+    if (int rc = make_out_dir(out)) return rc;
     if (format_from_path(in) == SeqFormat::Unknown && in != "-") {
         // CountComputer::new unwraps SeqFormat::get (counter/src/lib.rs:38): unknown extension panics
         fprintf(stderr, "Error: unsupported input extension (expected .fa/.fasta/.fna/.fq/.fastq[.gz]): %s\n", in.c_str());
@@ -316,7 +377,8 @@ int main(int argc, char **argv) {
     }
     if (cmd == "ctr") return cmd_ctr(argc, argv, 2);
     if (cmd == "debug-read") return cmd_debug_read(argc, argv, 2);
-    if (cmd == "cov" || cmd == "min") {
+    if (cmd == "cov") return cmd_cov(argc, argv, 2);
+    if (cmd == "min") {
         fprintf(stderr, "Error: `kmertools %s` is outside the scope of this GPU build (see DESIGN.md section 7)\n", cmd.c_str());
         return 2;
     }

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kt_internal.hpp"
+#include "kt_launch.hpp"
 #include "kt_segment.hpp"
 #include "kt_table.hpp"
 
@@ -181,6 +182,18 @@ __global__ __launch_bounds__(BLOCK) void kmers_kernel(SegArgs a, uint64_t *__res
     }
 }
 
+int check_overflow(kt_ctr *ctr) {
+    uint32_t flag = 0;
+    KT_HIP(hipMemcpyAsync(&flag, ctr->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctr->ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctr->ctx->stream));
+    if (flag) return kt::fail(KT_ERR_FULL, "k-mer table is full: raise capacity_slots");
+    return KT_OK;
+}
+
+}  // namespace
+
+namespace ktl {
+
 // ---- host helpers ----------------------------------------------------------------------------
 
 uint32_t grid_for(const kt_ctx *ctx, uint64_t work_items, uint32_t per_cu) {
@@ -235,15 +248,9 @@ int stage_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint
     return KT_OK;
 }
 
-int check_overflow(kt_ctr *ctr) {
-    uint32_t flag = 0;
-    KT_HIP(hipMemcpyAsync(&flag, ctr->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctr->ctx->stream));
-    KT_HIP(hipStreamSynchronize(ctr->ctx->stream));
-    if (flag) return kt::fail(KT_ERR_FULL, "k-mer table is full: raise capacity_slots");
-    return KT_OK;
-}
+}  // namespace ktl
 
-}  // namespace
+using namespace ktl;
 
 extern "C" {
 
@@ -298,6 +305,12 @@ static int ensure_cleared(kt_ctr *ctr) {
     ctr->needs_clear = false;
     return KT_OK;
 }
+}  // extern "C"
+int ktl::table_ready(kt_ctr *ctr) {
+    if (int rc = ensure_cleared(ctr)) return rc;
+    return check_overflow(ctr);
+}
+extern "C" {
 
 int kt_ctr_clear(kt_ctr *ctr) {
     if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_clear: null");

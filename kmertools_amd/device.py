@@ -218,6 +218,22 @@ class Counter:
         check(_lib.lib().kt_ctr_export(self._h, _ptr(keys), _ptr(counts), max_out, C.byref(n), mem))
         return n.value
 
+    # -- cov: per-read coverage histograms against this table ---------------------------------
+    def cov(self, bases, offsets, n_reads, bin_size, bin_count, out, norm=True, dtype="f64", mem=KT_MEM_DEVICE):
+        check(_lib.lib().kt_cov_batch(self._h, _ptr(bases), _ptr(offsets), n_reads, int(bin_size), int(bin_count),
+                                      int(bool(norm)), _DT[dtype], _ptr(out), mem))
+        return out
+
+    def cov_host(self, bases, offsets, bin_size, bin_count, norm=True, dtype="f64"):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        out = np.zeros((n, int(bin_count)), _NP[_DT[dtype]])
+        if n:
+            self.cov(bases if bases.size else np.zeros(1, np.uint8), offsets, n, bin_size, bin_count, out, norm,
+                     dtype, KT_MEM_HOST)
+        return out
+
     def export_host(self, sort=True):
         n = self.size()
         keys = np.zeros(max(n, 1), np.uint64)

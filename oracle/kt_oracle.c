@@ -399,6 +399,46 @@ uint64_t kto_counter_export(const kto_counter *c, uint64_t *keys, uint32_t *coun
 }
 
 /* ------------------------------------------------------------------------ */
+/* coverage/src/lib.rs:165-184 CovComputer::vectorise_one over a CSR batch:
+ * per k-mer: count = table[min(f,r)] or 0 (:171), bin = min(floor(count / bin_size),
+ * bin_count - 1) (:172-173), vec[bin] += 1, total += 1; norm: /= max(1, total) (:180-182). */
+static uint32_t counter_get(const kto_counter *c, uint64_t key) {
+    const kto_map *m = &c->parts[key % c->n_parts];
+    uint64_t h = mix64(key) & (m->cap - 1);
+    for (;;) {
+        if (m->keys[h] == key) return m->vals[h];
+        if (m->keys[h] == KTO_EMPTY) return 0;
+        h = (h + 1) & (m->cap - 1);
+    }
+}
+
+int kto_cov_batch(const kto_counter *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                  uint64_t k, uint64_t bin_size, uint64_t bin_count, int norm, double *out) {
+    pthread_once(&nt4_once, nt4_init);
+    for (uint64_t i = 0; i < n_reads; i++) {
+        double *vec = out + i * bin_count;
+        for (uint64_t b = 0; b < bin_count; b++) vec[b] = 0.0;
+        double total = 0.0;
+        kto_gen g;
+        kto_gen_init(&g, bases + offsets[i], offsets[i + 1] - offsets[i], k);
+        uint64_t f, r;
+        while (kto_gen_next(&g, &f, &r)) {
+            uint64_t mn = f < r ? f : r;
+            uint32_t count = counter_get(c, mn);
+            uint64_t kmer_bin = (uint64_t)((double)count / (double)bin_size); /* floor of a non-negative f64 */
+            uint64_t vb = kmer_bin < bin_count - 1 ? kmer_bin : bin_count - 1;
+            vec[vb] += 1.0;
+            total += 1.0;
+        }
+        if (norm) {
+            double d = total > 1.0 ? total : 1.0;
+            for (uint64_t b = 0; b < bin_count; b++) vec[b] /= d;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Synthetic reads: NOT a reference algorithm - the build's own
  * deterministic generator, mirrored bit-for-bit by the device generator
  * (kmertools_amd/csrc/kt_synth.hip) so the oracle can regenerate any slice.

@@ -70,6 +70,8 @@ def lib():
         L.kto_counter_size.argtypes = [C.c_void_p]
         L.kto_counter_export.restype = C.c_uint64
         L.kto_counter_export.argtypes = [C.c_void_p, u64p, u32p, C.c_int]
+        L.kto_cov_batch.restype = C.c_int
+        L.kto_cov_batch.argtypes = [C.c_void_p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, f64p]
         L.kto_synth_reads.restype = None
         L.kto_synth_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
                                       C.c_uint64, u8p]
@@ -189,6 +191,14 @@ class Counter:
 
     def size(self):
         return int(lib().kto_counter_size(self.h))
+
+    def cov_batch(self, bases, offsets, k, bin_size, bin_count, norm=True):
+        """coverage/src/lib.rs:165-184 over a CSR batch -> (n_reads, bin_count) f64"""
+        n = len(offsets) - 1
+        out = np.zeros((n, bin_count), np.float64)
+        bb = bases if bases.size else np.zeros(1, np.uint8)
+        lib().kto_cov_batch(self.h, _p(bb, u8p), _p(offsets, u64p), n, k, bin_size, bin_count, int(norm), _p(out, f64p))
+        return out
 
     def export(self, sorted_=True):
         n = self.size()

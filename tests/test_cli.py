@@ -139,6 +139,13 @@ def test_cli_golden_outputs(cli, golden, tmp_path):
     r = run(cli, "ctr", "-i", golden / "reads.fq", "-o", d, "-k", "15", "-a")
     lines = (d / "kmers.counts").read_text().splitlines()
     assert len(lines) == len(got) and all(len(x.split("\t")[0]) == 15 for x in lines)
+    # cov: the reference's test uses k=4 / bin_size 2 / bin_count 3 through the library API, which the
+    # CLI's clap ranges (k 7..=31, bins >= 5) cannot express -> check the CLI against the oracle in
+    # test_cli_larger_file_matches_oracle and the flag ranges here
+    r = run(cli, "cov", "-i", golden / "reads.fq", "-o", tmp_path / "cv", "-k", "4")
+    assert r.returncode == 2 and "is not in 7..=31" in r.stderr
+    r = run(cli, "cov", "-i", golden / "reads.fq", "-o", tmp_path / "cv", "-s", "4")
+    assert r.returncode == 2 and "--bin-size" in r.stderr
     # unwritable output -> the reference's message, exit code 0 (args.rs:260-262)
     r = run(cli, "comp", "oligo", "-i", golden / "reads.fq", "-o", tmp_path / "nodir" / "x", "-k", "4")
     assert r.returncode == 0 and "Error: Unable to write to file" in r.stderr
@@ -164,3 +171,19 @@ def test_cli_larger_file_matches_oracle(cli, oracle, tmp_path):
     assert run(cli, "ctr", "-i", fa, "-o", d, "-k", "21").returncode == 0
     keys, counts = oracle.count_reads(bases, offsets, 21)
     assert sorted((d / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(keys, counts)
+    # cov -k 15 (table from the same file) and cov -a (table from another file), every preset
+    cv = tmp_path / "cv"
+    assert run(cli, "cov", "-i", fa, "-o", cv, "-k", "15", "-s", "5", "-c", "6").returncode == 0
+    want_ctr = oracle.Counter(1)
+    want_ctr.add_reads(bases, offsets, 15)
+    assert (cv / "kmers.vectors").read_bytes() == oracle.oligo_text(want_ctr.cov_batch(bases, offsets, 15, 5, 6, True), True)
+    k15, c15 = want_ctr.export()
+    assert sorted((cv / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(k15, c15)
+    fa2 = tmp_path / "r2.fasta"
+    fa2.write_text("".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(seqs[:2000] * 3)))
+    b2, o2 = oracle.to_csr(seqs[:2000] * 3)
+    alt = oracle.Counter(1)
+    alt.add_reads(b2, o2, 11)
+    assert run(cli, "cov", "-i", fa, "-a", fa2, "-o", cv, "-k", "11", "--counts", "-p", "csv", "--bin-size=5").returncode == 0
+    assert (cv / "kmers.vectors").read_bytes() == \
+        oracle.oligo_text(alt.cov_batch(bases, offsets, 11, 5, 16, False), False).replace(b" ", b",")

@@ -502,3 +502,100 @@ def test_ctr_bulk_overfull_ranges_spill(hctx, oracle, monkeypatch):
     gk, gc = ctr.export_host()
     assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
     ctr.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# cov (kt_cov_batch): coverage/src/lib.rs:165-184 against the resident table
+def test_cov_golden_files(hctx, oracle, golden):
+    """k=4, bin_size 2, bin_count 3 on reads.fq = the reference's own test (coverage/src/lib.rs:196-242)"""
+    from kmertools_amd import device
+    recs = oracle.read_records(golden / "reads.fq")
+    bases, offsets = oracle.to_csr([s for _, s in recs])
+    ctr = device.Counter(hctx, 4, 4096)
+    ctr.add_reads_host(bases, offsets)
+    norm = ctr.cov_host(bases, offsets, 2, 3, True)
+    assert oracle.oligo_text(norm, True) == (golden / "expected_counts.vectors").read_bytes()
+    cnt = ctr.cov_host(bases, offsets, 2, 3, False)
+    assert oracle.oligo_text(cnt, False) == (golden / "expected_counts_unnorm.vectors").read_bytes()
+    u = ctr.cov_host(bases, offsets, 2, 3, False, dtype="u32")
+    assert np.array_equal(u.astype(np.float64), cnt)
+    ctr.close()
+
+
+@pytest.mark.parametrize("k,bin_size,bin_count", [(7, 1, 5), (11, 2, 16), (15, 16, 16), (21, 3, 7), (31, 5, 64),
+                                                   (9, 1, 1), (13, 1 << 33, 4), (12, 2, 700)])
+def test_cov_vs_oracle(hctx, oracle, k, bin_size, bin_count):
+    """ragged reads (empty, 1-base, N runs, lower case, >1 segment) counted from a DIFFERENT read set
+    than the one that is vectorised, so absent k-mers (count 0) and repeats both occur"""
+    from kmertools_amd import device
+    table_reads = ragged_reads(100 + k, 300, max_len=600)
+    query = table_reads[::2] + ragged_reads(200 + k, 200, max_len=300) + table_reads[:40] * 3
+    tb, to = oracle.to_csr(table_reads * 2)  # every table k-mer at least twice
+    qb, qo = oracle.to_csr(query)
+    want_ctr = oracle.Counter(3)
+    want_ctr.add_reads(tb, to, k)
+    ctr = device.Counter(hctx, k, 1 << 20)
+    ctr.add_reads_host(tb, to)
+    for norm in (True, False):
+        want = want_ctr.cov_batch(qb, qo, k, bin_size, bin_count, norm)
+        got = ctr.cov_host(qb, qo, bin_size, bin_count, norm)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), (k, bin_size, bin_count, norm)
+    got32 = ctr.cov_host(qb, qo, bin_size, bin_count, True, dtype="f32")
+    assert np.abs(got32.astype(np.float64) - want_ctr.cov_batch(qb, qo, k, bin_size, bin_count, True)).max() <= 1e-6
+    ctr.close()
+
+
+def test_cov_tiny_reads_and_empty_table(hctx, oracle):
+    """segments holding more bin cells than the LDS image (thousands of k-length reads) take the
+    direct path; an empty table puts every k-mer in bin 0"""
+    from kmertools_amd import device
+    rng = np.random.default_rng(9)
+    k = 9
+    seqs = ["".join(rng.choice(list("ACGT"), size=int(L))) for L in rng.integers(0, 14, size=6000)]
+    b, o = oracle.to_csr(seqs)
+    want_ctr = oracle.Counter(1)
+    want_ctr.add_reads(b, o, k)
+    ctr = device.Counter(hctx, k, 1 << 18)
+    got0 = ctr.cov_host(b, o, 1, 8, False)
+    nk = np.array([max(0, len(s) - k + 1) for s in seqs], np.float64)
+    assert np.array_equal(got0[:, 0], nk) and not got0[:, 1:].any()
+    ctr.add_reads_host(b, o)
+    for bc in (8, 40):
+        assert np.array_equal(ctr.cov_host(b, o, 1, bc, True), want_ctr.cov_batch(b, o, k, 1, bc, True))
+    with pytest.raises(Exception):
+        ctr.cov_host(b, o, 0, 8)
+    with pytest.raises(Exception):
+        ctr.cov_host(b, o, 1, 0)
+    with pytest.raises(Exception):
+        ctr.cov_host(b, o, 1, 8, True, dtype="u32")
+    assert ctr.cov_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 1, 8).shape == (0, 8)
+    ctr.close()
+
+
+def test_cov_full_size_properties(torch_mod, ctx):
+    """2 M x 150 bp genome-sampled reads, k=15: every row of raw counts sums to the read's k-mer
+    count (136 here: ACGT-only reads), a read set vectorised against its own table never lands in
+    bin 0 with bin_size 1, and the normalised rows are the raw rows / 136 bit-for-bit"""
+    from kmertools_amd import device
+    torch = torch_mod
+    n, L, k = 2_000_000, 150, 15
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(11, n, L, bases, offsets, noise=False, genome_len=1 << 22)
+    ctr = device.Counter(ctx, k, 1 << 26)
+    ctr.add_reads(bases, offsets, n)
+    raw = torch.empty((n, 16), dtype=torch.int32, device="cuda")
+    ctr.cov(bases, offsets, n, 1, 16, raw, norm=False, dtype="u32")
+    nrm = torch.empty((n, 16), dtype=torch.float64, device="cuda")
+    ctr.cov(bases, offsets, n, 1, 16, nrm, norm=True)
+    ctx.sync()
+    assert bool((raw.sum(dim=1) == L - k + 1).all())
+    assert int(raw[:, 0].sum()) == 0
+    den = torch.full((1, 1), float(L - k + 1), dtype=torch.float64, device="cuda")  # tensor divisor: a true division
+    assert torch.equal(nrm, raw.to(torch.float64) / den)
+    # a wide bin collapses everything into bin 0
+    ctr.cov(bases, offsets, n, 1 << 40, 16, raw, norm=False, dtype="u32")
+    ctx.sync()
+    assert bool((raw[:, 0] == L - k + 1).all()) and int(raw[:, 1:].sum()) == 0
+    ctr.close()

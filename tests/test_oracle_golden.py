@@ -154,3 +154,14 @@ def test_display_format(oracle):
     assert f(16.0) == "16" and f(0.5) == "0.5" and f(1 / 26) == "0.038461538461538464"
     assert f(1e-7) == "0.0000001" and f(1e21) == "1000000000000000000000" and f(0.0) == "0"
     assert f(1.5e-5) == "0.000015"
+
+
+def test_coverage_fixtures(oracle, golden):
+    # coverage/src/lib.rs:196-242: k=4, bin_size 2, bin_count 3 on reads.fq
+    (bases, offsets), _ = _reads(oracle, golden)
+    ctr = oracle.Counter(1)
+    ctr.add_reads(bases, offsets, 4)
+    norm = ctr.cov_batch(bases, offsets, 4, 2, 3, True)
+    assert oracle.oligo_text(norm, True) == (golden / "expected_counts.vectors").read_bytes()
+    cnt = ctr.cov_batch(bases, offsets, 4, 2, 3, False)
+    assert oracle.oligo_text(cnt, False) == (golden / "expected_counts_unnorm.vectors").read_bytes()
