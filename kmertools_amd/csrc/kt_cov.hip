@@ -6,8 +6,8 @@
 // re-reads kmers.counts into a host HashMap; here the table built by kt_ctr_add_reads is
 // probed where it lies.  HBM-bound random 16-byte reads; no MFMA.
 //
-// Same segment front-end as the counting kernels.  A thread keeps its 32 canonical k-mers in
-// registers, issues the home-slot loads four at a time, and adds into a per-segment LDS image
+// Same segment front-end as the counting kernels.  A thread walks its 32 window starts in groups:
+// generate GROUP canonical k-mers, issue their home-slot loads together, then add into a per-segment LDS image
 // of the bin rows of the reads that touch the segment (row = read id - first read of the
 // segment); the image is flushed with one global atomic per non-zero cell, so a read that
 // straddles segments is still summed exactly.  Segments made of very many tiny reads (image
@@ -17,6 +17,10 @@
 #include "kt_segment.hpp"
 #include "kt_table.hpp"
 
+#ifndef KT_COV_GROUP
+#define KT_COV_GROUP 8
+#endif
+
 namespace {
 
 using ktseg::SegArgs;
@@ -24,6 +28,7 @@ using ktseg::SegShared;
 using kttab::Slot;
 
 constexpr int BLOCK = ktseg::BLOCK;
+constexpr uint32_t GROUP = KT_COV_GROUP;  // table probes in flight per thread
 constexpr uint32_t ROWS_LDS = 6144;  // u32 cells of bin rows staged per segment (24 KB)
 
 struct CovArgs {
@@ -59,9 +64,10 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
     const uint32_t last_bin = c.bin_count - 1u;
 
     for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
-        uint64_t keys[ktseg::PER_THREAD];
-        uint32_t ok;
-        ktseg::collect_kmers(a, g, sm, keys, ok);  // barriers inside order the rows[] zeroing
+        ktseg::stage_segment(a, g, sm);  // its barriers also order the rows[] zeroing
+        ktseg::Window w(sm, tid, a.k);
+        uint32_t ok = 0;
+        for (uint32_t j = 0; j < ktseg::PER_THREAD; j++) ok |= (w.ok(j) ? 1u : 0u) << j;
 
         // reads that can own a k-mer starting in this segment: [rbase, r_hi)
         const uint64_t B0 = g * ktseg::SEG;
@@ -84,19 +90,22 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
             }
             uint64_t rid = lo;
             uint64_t next = a.offsets[rid + 1];
+            // GROUP probes in flight per thread; rolled so the k-mers never sit in registers all at once
+#pragma unroll 1
+            for (uint32_t jj = 0; jj < ktseg::PER_THREAD; jj += GROUP) {
+                uint64_t key[GROUP], sl[GROUP];
+                uint4 v[GROUP];
 #pragma unroll
-            for (uint32_t jj = 0; jj < ktseg::PER_THREAD; jj += 4) {
-                uint64_t sl[4];
-                uint4 v[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
-                    sl[u] = kttab::home_slot(keys[jj + u], c.shift);
+                for (uint32_t u = 0; u < GROUP; u++) {
+                    key[u] = w.f < w.r ? w.f : w.r;
+                    w.step();
+                    sl[u] = kttab::home_slot(key[u], c.shift);
                     v[u] = load_slot(c.slots, sl[u]);
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
+                for (uint32_t u = 0; u < GROUP; u++) {
                     if (!((ok >> (jj + u)) & 1u)) continue;
-                    const uint32_t cnt = resolve_count(c, v[u], sl[u], keys[jj + u]);
+                    const uint32_t cnt = resolve_count(c, v[u], sl[u], key[u]);
                     uint32_t bin = c.bin_size ? cnt / c.bin_size : 0u;  // coverage/src/lib.rs:172
                     bin = bin < last_bin ? bin : last_bin;              // :173
                     const uint64_t s = s0 + jj + u;
@@ -108,8 +117,8 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
                 }
             }
         }
+        __syncthreads();  // sm is restaged by the next segment; rows[] is complete
         if (in_lds) {
-            __syncthreads();
             uint32_t *dst = c.counts + rbase * c.bin_count;
             for (uint32_t i = tid; i < (uint32_t)cells; i += BLOCK) {
                 const uint32_t n = rows[i];

@@ -11,9 +11,8 @@
 //             bit mask (found through seg_first[], the per-segment lower bound of the
 //             offsets array built by seg_index_kernel) - a k-mer may not span one.
 //   k-mers    thread t walks window starts [32t, 32t+32) with a 128-bit shift register
-//             held in two VGPR pairs: fwd = top 2k bits, rev rolls like the reference's
-//             generator (kmer/src/kmer.rs:91-93) - but every start position is
-//             independent of the reads before it, so no serial scan.
+//             (struct Window) - every start position is independent of the reads before
+//             it, so no serial scan.
 //   sink      a functor receives (fwd, rev, index of the k-mer's last base).
 #pragma once
 #include "kt_device.hpp"
@@ -53,12 +52,11 @@ struct SegShared {
     uint32_t bnd[NITEM + 1];
 };
 
-// Runs `sink(fwd, rev, end_index)` for every valid k-mer of segment `g`.
-// Must be called by all 256 threads of the workgroup.
-template <class Sink>
-__device__ __forceinline__ void for_each_kmer(const SegArgs &a, uint64_t g, SegShared &sm, Sink &&sink) {
+// Stages segment `g` into LDS (codes, invalid-base mask, read-boundary mask).  Must be called by
+// all 256 threads; ends with a barrier.  The caller needs another barrier before the next
+// stage_segment() reuses the LDS (for_each_kmer / collect_kmers do that themselves).
+__device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegShared &sm) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t k = a.k;
     const uint64_t total = a.offsets[a.n_reads];
     const uint64_t B0 = g * SEG;
 
@@ -99,27 +97,51 @@ __device__ __forceinline__ void for_each_kmer(const SegArgs &a, uint64_t g, SegS
         }
     }
     __syncthreads();
+}
 
-    // ---- k-mers: 32 window starts per thread -------------------------------------------
+// The thread's walk over its 32 window starts [32*tid, 32*tid + 32) of a staged segment: a
+// 128-bit shift register held in two VGPR pairs: fwd = top 2k bits, rev rolls like the
+// reference's generator (kmer/src/kmer.rs:91-93).
+struct Window {
+    uint64_t hi, lo, iv, bd, mk, mk1, f, r;
+    uint32_t sh, rsh;
+    __device__ __forceinline__ Window(const SegShared &sm, uint32_t tid, uint32_t k) {
+        hi = sm.codes[tid];
+        lo = sm.codes[tid + 1];
+        iv = (uint64_t)sm.inv[tid] | ((uint64_t)sm.inv[tid + 1] << 32);
+        bd = (uint64_t)sm.bnd[tid] | ((uint64_t)sm.bnd[tid + 1] << 32);
+        sh = 64u - 2u * k;
+        rsh = 2u * (k - 1);
+        mk = (1ull << k) - 1ull;          // k bases
+        mk1 = (1ull << (k - 1)) - 1ull;   // the k-1 later bases
+        f = hi >> sh;
+        r = ktd::rev_comp(f, (int)k);
+    }
+    // is window start j (0..31) a k-mer: k valid bases, no read start among the k-1 later ones
+    __device__ __forceinline__ bool ok(uint32_t j) const {
+        return (((iv >> j) & mk) == 0) && (((bd >> (j + 1)) & mk1) == 0);
+    }
+    // slide one base: the next code enters fwd at the bottom, its complement enters rev at the top
+    __device__ __forceinline__ void step() {
+        hi = (hi << 2) | (lo >> 62);
+        lo <<= 2;
+        f = hi >> sh;
+        r = (r >> 2) | ((uint64_t)(3u - (uint32_t)(f & 3u)) << rsh);
+    }
+};
+
+// Runs `sink(fwd, rev, end_index)` for every valid k-mer of segment `g`.
+// Must be called by all 256 threads of the workgroup.
+template <class Sink>
+__device__ __forceinline__ void for_each_kmer(const SegArgs &a, uint64_t g, SegShared &sm, Sink &&sink) {
+    stage_segment(a, g, sm);
     {
-        uint64_t hi = sm.codes[tid], lo = sm.codes[tid + 1];
-        const uint64_t iv = (uint64_t)sm.inv[tid] | ((uint64_t)sm.inv[tid + 1] << 32);
-        const uint64_t bd = (uint64_t)sm.bnd[tid] | ((uint64_t)sm.bnd[tid + 1] << 32);
-        const uint32_t sh = 64u - 2u * k;
-        const uint64_t mk = (1ull << k) - 1ull;          // k bases
-        const uint64_t mk1 = (1ull << (k - 1)) - 1ull;   // the k-1 later bases
-        uint64_t f = hi >> sh;
-        uint64_t r = ktd::rev_comp(f, (int)k);
-        const uint64_t end0 = B0 + 32ull * tid + (k - 1);
+        Window w(sm, threadIdx.x, a.k);
+        const uint64_t end0 = g * SEG + 32ull * threadIdx.x + (a.k - 1);
 #pragma unroll 4
         for (uint32_t j = 0; j < PER_THREAD; j++) {
-            const bool ok = (((iv >> j) & mk) == 0) && (((bd >> (j + 1)) & mk1) == 0);
-            if (ok) sink(f, r, end0 + j);
-            // slide one base: next code enters fwd at the bottom, its complement enters rev at the top
-            hi = (hi << 2) | (lo >> 62);
-            lo <<= 2;
-            f = hi >> sh;
-            r = (r >> 2) | ((uint64_t)(3u - (uint32_t)(f & 3u)) << (2u * (k - 1)));
+            if (w.ok(j)) sink(w.f, w.r, end0 + j);
+            w.step();
         }
     }
     __syncthreads();  // LDS is reused by the next segment
@@ -131,62 +153,14 @@ __device__ __forceinline__ void for_each_kmer(const SegArgs &a, uint64_t g, SegS
 // segment's k-mers (count, place) after a single front-end pass.
 __device__ __forceinline__ void collect_kmers(const SegArgs &a, uint64_t g, SegShared &sm, uint64_t (&keys)[PER_THREAD],
                                               uint32_t &ok_mask) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t k = a.k;
-    const uint64_t total = a.offsets[a.n_reads];
-    const uint64_t B0 = g * SEG;
-    for (uint32_t i = tid; i < NITEM; i += BLOCK) {
-        const uint64_t b = B0 + 32ull * i;
-        uint64_t w = 0;
-        uint32_t iv = 0xFFFFFFFFu;
-        if (b < total) {
-            unsigned char raw[32];
-            if (b + 32 <= total) {
-                __builtin_memcpy(raw, a.bases + b, 32);
-            } else {
-                for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
-            }
-            iv = 0;
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const uint32_t e = ktd::nt4(raw[j]);
-                w = (w << 2) | (e & 3u);
-                iv |= (e >> 2) << j;
-            }
-        }
-        sm.codes[i] = w;
-        sm.inv[i] = iv;
-        sm.bnd[i] = 0;
-    }
-    __syncthreads();
-    {
-        const uint64_t lim = B0 + SEG + 32;
-        for (uint64_t r = a.seg_first[g] + tid; r < a.n_reads; r += BLOCK) {
-            const uint64_t o = a.offsets[r];
-            if (o >= lim) break;
-            const uint32_t rel = (uint32_t)(o - B0);
-            atomicOr(&sm.bnd[rel >> 5], 1u << (rel & 31u));
-        }
-    }
-    __syncthreads();
-    uint64_t hi = sm.codes[tid], lo = sm.codes[tid + 1];
-    const uint64_t iv = (uint64_t)sm.inv[tid] | ((uint64_t)sm.inv[tid + 1] << 32);
-    const uint64_t bd = (uint64_t)sm.bnd[tid] | ((uint64_t)sm.bnd[tid + 1] << 32);
-    const uint32_t sh = 64u - 2u * k;
-    const uint64_t mk = (1ull << k) - 1ull;
-    const uint64_t mk1 = (1ull << (k - 1)) - 1ull;
-    uint64_t f = hi >> sh;
-    uint64_t r = ktd::rev_comp(f, (int)k);
+    stage_segment(a, g, sm);
+    Window w(sm, threadIdx.x, a.k);
     ok_mask = 0;
 #pragma unroll
     for (uint32_t j = 0; j < PER_THREAD; j++) {
-        const bool ok = (((iv >> j) & mk) == 0) && (((bd >> (j + 1)) & mk1) == 0);
-        ok_mask |= (ok ? 1u : 0u) << j;
-        keys[j] = f < r ? f : r;
-        hi = (hi << 2) | (lo >> 62);
-        lo <<= 2;
-        f = hi >> sh;
-        r = (r >> 2) | ((uint64_t)(3u - (uint32_t)(f & 3u)) << (2u * (k - 1)));
+        ok_mask |= (w.ok(j) ? 1u : 0u) << j;
+        keys[j] = w.f < w.r ? w.f : w.r;
+        w.step();
     }
     __syncthreads();  // LDS is reused by the next segment
 }
