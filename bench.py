@@ -57,10 +57,26 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cores():
+    """host threads this process may really use: os.cpu_count() capped by the cgroup CPU quota"""
+    n = os.cpu_count() or 1
+    try:
+        q, p = pathlib.Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return n
+
+
 def cpu_baseline_oligo(k, L, seconds):
     """CPU oracle (port of composition/src/oligo.rs:231-259 + rayon par_iter analogue) on host cores."""
     from oracle import kt_oracle as oracle
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     n = 100_000
     hb, ho = oracle.synth_reads(SEED, n, L)
     t0 = time.perf_counter()
@@ -83,7 +99,7 @@ def cpu_baseline_oligo(k, L, seconds):
 def cpu_baseline_ctr(k, L, seconds, genome):
     """CPU oracle (port of counter/src/lib.rs:100-131 sharded maps, in memory) on host cores."""
     from oracle import kt_oracle as oracle
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     n = 50_000
     hb, ho = oracle.synth_reads(SEED, n, L, genome_len=genome)
     t0 = time.perf_counter()

@@ -1,23 +1,70 @@
 #include "computers.hpp"
 
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <charconv>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "seqio.hpp"
 
 namespace kthost {
 
+// ---- text formats ------------------------------------------------------------------------------
+// Rust's `{:.6}` rounds the EXACT binary value half-to-even (core::num::flt2dec dragon
+// format_exact), which is also what glibc's "%.6f" does; snprintf costs ~150 ns and serialises
+// threads on locale state, so the common range is done by hand: N = round_half_even(x * 10^6)
+// exactly, from the rounded product p and its exact error e (Dekker two-product; 10^6 has 20
+// significant bits so only x needs splitting), then "<N / 10^6>.<6 digits>".
+static const char DIGIT_PAIRS[] =
+    "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+    "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+
+size_t format_fixed6(char *buf, double x) {
+    if (!(x >= 0.0) || x >= 4.0e9) return (size_t)snprintf(buf, FIXED6_BUF, "%.6f", x);  // negative, NaN, inf, huge
+    const double p = x * 1e6;
+    const double c = 134217729.0 * x;  // 2^27 + 1
+    const double xh = c - (c - x), xl = x - xh;
+    const double e = (xh * 1e6 - p) + xl * 1e6;  // x * 10^6 == p + e exactly
+    const double n = floor(p);
+    const double d = (p - n) - 0.5;  // exact: p < 2^52, so p - n and 0.5 are multiples of ulp(p); |e| <= ulp(p)/2
+    uint64_t N = (uint64_t)n;
+    if (d > 0.0 || (d == 0.0 && (e > 0.0 || (e == 0.0 && (N & 1ull))))) N += 1;
+    const uint64_t ip = N / 1000000ull;
+    const uint32_t fp = (uint32_t)(N % 1000000ull);
+    char *q = buf;
+    if (ip < 10) {
+        *q++ = (char)('0' + ip);
+    } else {
+        q = std::to_chars(q, q + 24, ip).ptr;
+    }
+    *q++ = '.';
+    memcpy(q, DIGIT_PAIRS + 2 * (fp / 10000u), 2);
+    memcpy(q + 2, DIGIT_PAIRS + 2 * ((fp / 100u) % 100u), 2);
+    memcpy(q + 4, DIGIT_PAIRS + 2 * (fp % 100u), 2);
+    return (size_t)(q + 6 - buf);
+}
+
 void append_fixed6(std::string &out, double x) {
-    char buf[64];
-    const int n = snprintf(buf, sizeof buf, "%.6f", x);  // exact, correctly rounded like Rust's {:.6}
-    out.append(buf, (size_t)n);
+    char buf[FIXED6_BUF];
+    out.append(buf, format_fixed6(buf, x));
 }
 
 void append_display(std::string &out, double x) {
     char buf[400];
+    if (x >= 0.0 && x < 9.0e15 && !signbit(x) && x == (double)(uint64_t)x) {  // counts: integral values print bare
+        const auto r = std::to_chars(buf, buf + sizeof buf, (uint64_t)x);
+        out.append(buf, (size_t)(r.ptr - buf));
+        return;
+    }
     const auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::fixed);  // shortest round-trip
     out.append(buf, (size_t)(r.ptr - buf));
 }
@@ -32,32 +79,225 @@ std::string Device::ensure() {
     return "";
 }
 
+// KT_CLI_TIMING=1: busy seconds of each stage on stderr (the stages overlap, see run_pipeline)
+struct PhaseTimer {
+    const char *what;
+    double t[4] = {0, 0, 0, 0};  // read, device, format, write - each owned by one thread
+    bool on;
+    explicit PhaseTimer(const char *w) : what(w), on(getenv("KT_CLI_TIMING") != nullptr) {}
+    ~PhaseTimer() {
+        if (on) fprintf(stderr, "[timing] %s: read %.3f s, device %.3f s, format %.3f s, write %.3f s\n", what, t[0], t[1], t[2], t[3]);
+    }
+};
+struct Lap {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double operator()() {
+        const auto now = std::chrono::steady_clock::now();
+        const double d = std::chrono::duration<double>(now - t0).count();
+        t0 = now;
+        return d;
+    }
+};
+
+// CPUs this process may actually use: the hardware count capped by the cgroup CPU quota (a
+// container with a 16-CPU quota on a 256-thread host is throttled, not sped up, by 256 workers)
+static int effective_cpus() {
+    static const int cached = [] {
+        unsigned h = std::thread::hardware_concurrency();
+        long n = h ? (long)h : 1;
+        long quota = -1, period = -1;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+            char q[32];
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+            if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *pf = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(pf, "%ld", &period) != 1) period = -1;
+                fclose(pf);
+            }
+        }
+        if (quota > 0 && period > 0) {
+            const long c = (quota + period - 1) / period;
+            if (c < n) n = c;
+        }
+        return (int)(n < 1 ? 1 : n);
+    }();
+    return cached;
+}
+
 static int worker_count(int threads) {
-    if (threads > 0) return threads;
-    const unsigned h = std::thread::hardware_concurrency();
-    return h ? (int)h : 1;
+    if (threads > 0) return threads;  // -t: the caller's explicit choice
+    return effective_cpus();
 }
 
 // format rows [0, n) with `fn(row, out)` on `threads` workers, return the pieces in row order
 template <class F>
-static void format_rows(uint64_t n, int threads, std::vector<std::string> &pieces, F fn) {
+static void format_rows(uint64_t n, int threads, size_t bytes_per_row, std::vector<std::string> &pieces, F fn) {
     int t = worker_count(threads);
-    if ((uint64_t)t > n) t = n ? (int)n : 1;
-    pieces.assign((size_t)t, std::string());
+    const uint64_t min_rows = 2048;  // a thread is not worth starting for less
+    if ((uint64_t)t > (n + min_rows - 1) / min_rows) t = (int)((n + min_rows - 1) / min_rows);
+    if (t < 1) t = 1;
+    pieces.resize((size_t)t);
+    auto work = [&](int w) {
+        const uint64_t lo = n * (uint64_t)w / (uint64_t)t, hi = n * (uint64_t)(w + 1) / (uint64_t)t;
+        // build in a thread-local object: the string headers in `pieces` share cache lines, and every
+        // append updates its header (measured: 8 threads slower than 1 when appending in place)
+        std::string s;
+        s.swap(pieces[(size_t)w]);  // keeps the capacity of the previous batch
+        s.clear();
+        s.reserve((hi - lo) * bytes_per_row);
+        for (uint64_t r = lo; r < hi; r++) fn(r, s);
+        s.swap(pieces[(size_t)w]);
+    };
+    // every share runs on a spawned thread: a share run on the calling thread was measured 6x slower than
+    // its siblings on the GPU box (new threads start on the caller's CPU and crowd it until they migrate)
     std::vector<std::thread> pool;
-    for (int w = 0; w < t; w++) {
-        pool.emplace_back([&, w] {
-            const uint64_t lo = n * (uint64_t)w / (uint64_t)t, hi = n * (uint64_t)(w + 1) / (uint64_t)t;
-            std::string &s = pieces[(size_t)w];
-            for (uint64_t r = lo; r < hi; r++) fn(r, s);
-        });
-    }
+    for (int w = 0; w < t; w++) pool.emplace_back(work, w);
     for (auto &th : pool) th.join();
 }
 
+// ---- read -> device -> text pipeline ---------------------------------------------------------
+// The three stages of every vectoriser (parse a batch of records; one C-ABI call that stages the
+// batch to the GPU and brings the rows back; format + write the rows) run on their own threads
+// over three rotating work items, so the file costs max(stage) instead of sum(stage).  Output
+// order is the input order (one emit thread, FIFO hand-off).
+struct Work {
+    Batch b;
+    std::vector<double> rows;
+};
+
+template <class T>
+class Channel {
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    bool closed_ = false;
+
+  public:
+    void push(T v) {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            q_.push_back(v);
+        }
+        cv_.notify_one();
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            closed_ = true;
+        }
+        cv_.notify_all();
+    }
+    bool pop(T &v) {  // false once closed and drained
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = q_.front();
+        q_.pop_front();
+        return true;
+    }
+};
+
+// device(w): fills w.rows from w.b, returns "" or an error message.  emit(w): writes the text.
+static std::string run_pipeline(SeqReader &reader, uint64_t max_bases, uint64_t max_reads, PhaseTimer &pt,
+                                const std::function<std::string(Work &)> &device,
+                                const std::function<void(Work &)> &emit) {
+    constexpr int DEPTH = 3;
+    Work items[DEPTH];
+    Channel<Work *> free_q, read_q, done_q;
+    for (auto &w : items) free_q.push(&w);
+    std::atomic<bool> stop{false};
+    std::thread reader_thread([&] {
+        Work *w = nullptr;
+        bool more = true;
+        Lap lap;
+        while (more && !stop.load() && free_q.pop(w)) {
+            lap();
+            more = reader.next_batch(w->b, max_bases, max_reads);
+            pt.t[0] += lap();
+            if (w->b.n_reads()) read_q.push(w); else free_q.push(w);
+        }
+        read_q.close();
+    });
+    std::thread emit_thread([&] {
+        Work *w = nullptr;
+        while (done_q.pop(w)) {
+            emit(*w);
+            free_q.push(w);
+        }
+    });
+    std::string err;
+    Work *w = nullptr;
+    while (read_q.pop(w)) {
+        if (err.empty()) {
+            Lap lap;
+            err = device(*w);
+            pt.t[1] += lap();
+        }
+        if (!err.empty()) {  // drain: let the reader see `stop` and finish
+            stop.store(true);
+            free_q.push(w);
+            continue;
+        }
+        done_q.push(w);
+    }
+    done_q.close();
+    reader_thread.join();
+    emit_thread.join();
+    if (err.empty() && reader.failed()) err = reader.error();
+    return err;
+}
+
 static uint64_t batch_bases(uint64_t memory) {
-    const uint64_t cap = 256ull << 20;  // keeps the f64 output slab of a batch bounded
+    const uint64_t cap = 64ull << 20;  // small enough that a file of a few batches still overlaps its stages
     return memory < cap ? (memory ? memory : 1) : cap;
+}
+
+static const uint8_t *bases_ptr(const Batch &b) { return b.bases.empty() ? (const uint8_t *)"" : b.bases.data(); }
+
+// writes `rows` (n x bins) as delimited text: {:.6} when normalised, Display otherwise
+static void emit_matrix(FILE *out, const Work &w, uint64_t bins, bool norm, const std::string &delim, int threads,
+                        std::vector<std::string> &pieces, PhaseTimer &pt) {
+    Lap lap;
+    const double *rows = w.rows.data();
+    format_rows(w.b.n_reads(), threads, bins * (norm ? 9 : 4) + 1, pieces, [&](uint64_t r, std::string &s) {
+        const double *row = rows + r * bins;
+        char buf[FIXED6_BUF];
+        for (uint64_t i = 0; i < bins; i++) {
+            if (i) s += delim;
+            if (norm) s.append(buf, format_fixed6(buf, row[i])); else append_display(s, row[i]);
+        }
+        s += '\n';
+    });
+    pt.t[2] += lap();
+    for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+    pt.t[3] += lap();
+}
+
+// hidden `kmertools debug-emit`: times the text stage alone on fabricated count-ratio rows
+double debug_emit_bench(uint64_t n_rows, uint64_t bins, bool norm, int threads, int reps) {
+    Work w;
+    w.b.clear();
+    for (uint64_t r = 0; r < n_rows; r++) w.b.offsets.push_back(r + 1);
+    w.rows.resize(n_rows * bins);
+    for (uint64_t i = 0; i < n_rows * bins; i++) {
+        const double c = (double)((i * 2654435761ull >> 7) % 5);
+        w.rows[i] = norm ? c / 147.0 : c;
+    }
+    FILE *out = fopen("/dev/null", "wb");
+    std::vector<std::string> pieces;
+    PhaseTimer pt("debug-emit");
+    double best = 1e30;
+    for (int i = 0; i < reps; i++) {
+        Lap lap;
+        emit_matrix(out, w, bins, norm, " ", threads, pieces, pt);
+        const double d = lap();
+        if (d < best) best = d;
+    }
+    fclose(out);
+    return best;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -110,35 +350,19 @@ std::string OligoComputer::vectorise() {
         line += "\n";
         fwrite(line.data(), 1, line.size(), out);
     }
-    Batch b;
-    std::vector<double> rows;
     std::vector<std::string> pieces;
-    std::string err;
-    for (;;) {
-        const bool more = reader.next_batch(b, batch_bases(memory_), 1ull << 20);
-        const uint64_t n = b.n_reads();
-        if (n) {
-            rows.resize(n * bins);
-            if (kt_oligo_batch(dev_.ctx, b.bases.empty() ? (const uint8_t *)"" : b.bases.data(), b.offsets.data(), n,
-                               ksize_, count_min_, norm_, 1, KT_F64, rows.data(), KT_MEM_HOST) != KT_OK) {
-                err = kt_last_error();
-                break;
-            }
-            const bool norm = norm_;
-            const std::string &delim = delim_;
-            format_rows(n, threads_, pieces, [&](uint64_t r, std::string &s) {
-                const double *row = rows.data() + r * bins;
-                for (uint64_t i = 0; i < bins; i++) {
-                    if (i) s += delim;
-                    if (norm) append_fixed6(s, row[i]); else append_display(s, row[i]);
-                }
-                s += '\n';
-            });
-            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
-        }
-        if (!more) break;
-    }
-    if (err.empty() && reader.failed()) err = reader.error();
+    PhaseTimer pt("comp oligo");
+    const std::string err = run_pipeline(
+        reader, batch_bases(memory_), 1ull << 19, pt,
+        [&](Work &w) -> std::string {
+            const uint64_t n = w.b.n_reads();
+            w.rows.resize(n * bins);
+            if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, count_min_, norm_, 1, KT_F64,
+                               w.rows.data(), KT_MEM_HOST) != KT_OK)
+                return kt_last_error();
+            return "";
+        },
+        [&](Work &w) { emit_matrix(out, w, bins, norm_, delim_, threads_, pieces, pt); });
     fclose(out);
     return err;
 }
@@ -170,24 +394,25 @@ std::string OligoCgrComputer::vectorise() {
         append_display(p, xy[2 * i + 1]);
         p += ",";
     }
-    Batch b;
-    std::vector<double> rows;
     std::vector<std::string> pieces;
-    std::string err;
-    for (;;) {
-        // rows are 8 * bins bytes each: bound the batch by reads as well
-        const uint64_t max_reads = bins >= 2048 ? 8192 : 262144;
-        const bool more = reader.next_batch(b, batch_bases(memory_), max_reads);
-        const uint64_t n = b.n_reads();
-        if (n) {
-            rows.resize(n * bins);
-            if (kt_oligo_batch(dev_.ctx, b.bases.empty() ? (const uint8_t *)"" : b.bases.data(), b.offsets.data(), n,
-                               ksize_, 1, norm_, 1, KT_F64, rows.data(), KT_MEM_HOST) != KT_OK) {
-                err = kt_last_error();
-                break;
-            }
-            format_rows(n, threads_, pieces, [&](uint64_t r, std::string &s) {
-                const double *row = rows.data() + r * bins;
+    PhaseTimer pt("comp cgr -k");
+    // rows are 8 * bins bytes each: bound the batch by reads as well
+    const uint64_t max_reads = bins >= 2048 ? 8192 : 262144;
+    const std::string err = run_pipeline(
+        reader, batch_bases(memory_), max_reads, pt,
+        [&](Work &w) -> std::string {
+            const uint64_t n = w.b.n_reads();
+            w.rows.resize(n * bins);
+            if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, 1, norm_, 1, KT_F64, w.rows.data(),
+                               KT_MEM_HOST) != KT_OK)
+                return kt_last_error();
+            return "";
+        },
+        [&](Work &w) {
+            Lap lap;
+            const double *rows = w.rows.data();
+            format_rows(w.b.n_reads(), threads_, bins * 24, pieces, [&](uint64_t r, std::string &s) {
+                const double *row = rows + r * bins;
                 for (uint64_t i = 0; i < bins; i++) {
                     if (i) s += ' ';
                     s += prefix[i];
@@ -196,11 +421,10 @@ std::string OligoCgrComputer::vectorise() {
                 }
                 s += '\n';
             });
+            pt.t[2] += lap();
             for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
-        }
-        if (!more) break;
-    }
-    if (err.empty() && reader.failed()) err = reader.error();
+            pt.t[3] += lap();
+        });
     fclose(out);
     return err;
 }
@@ -217,8 +441,11 @@ std::string CountComputer::count() {
     // init(): pre-pass for record count and total length (counter/src/lib.rs:236-249); here it
     // sizes the HBM table instead of the reference's partition count
     std::string err;
+    Lap setup;
     if (!SeqReader::seq_stats(in_path_, seq_count_, total_length_, err)) return err;
+    const double t_stats = setup();
     if (std::string e = dev_.ensure(); !e.empty()) return e;
+    const double t_dev = setup();
     uint64_t max_distinct = total_length_;
     if (ksize_ <= 15) {
         const uint64_t n4k = 1ull << (2 * ksize_);
@@ -228,15 +455,22 @@ std::string CountComputer::count() {
     uint64_t cap = 1024;
     while (cap < 2 * max_distinct) cap <<= 1;
     if (kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_) != KT_OK) return kt_last_error();
+    if (getenv("KT_CLI_TIMING"))
+        fprintf(stderr, "[timing] ctr setup: seq_stats pre-pass %.3f s, device init %.3f s, table of %llu slots %.3f s\n", t_stats,
+                t_dev, (unsigned long long)cap, setup());
     SeqReader reader;
     if (!reader.open(in_path_, false)) return reader.error();
     Batch b;
+    PhaseTimer pt("ctr count (after the seq_stats pre-pass)");
+    Lap lap;
     for (;;) {
         const bool more = reader.next_batch(b, 256ull << 20, 1ull << 22);
+        pt.t[0] += lap();
         if (b.n_reads() && !b.bases.empty()) {
             if (kt_ctr_add_reads(ctr_, b.bases.data(), b.offsets.data(), b.n_reads(), KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
         }
+        pt.t[1] += lap();
         if (!more) break;
     }
     if (reader.failed()) return reader.error();
@@ -245,19 +479,22 @@ std::string CountComputer::count() {
 
 std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
     if (!ctr_) return "count() has not run";
+    PhaseTimer pt("ctr merge");
+    Lap lap;
     uint64_t n = 0;
     if (kt_ctr_size(ctr_, &n) != KT_OK) return kt_last_error();
     std::vector<uint64_t> keys(n ? n : 1);
     std::vector<uint32_t> counts(n ? n : 1);
     uint64_t got = 0;
     if (n && kt_ctr_export(ctr_, keys.data(), counts.data(), n, &got, KT_MEM_HOST) != KT_OK) return kt_last_error();
+    pt.t[1] += lap();
     const std::string path = out_dir_ + "/kmers.counts";
     FILE *out = fopen(path.c_str(), "wb");
     if (!out) return "Unable to write to file: " + path;
     std::vector<std::string> pieces;
     const bool acgt = acgt_;
     const int k = ksize_;
-    format_rows(got, threads_, pieces, [&](uint64_t i, std::string &s) {
+    format_rows(got, threads_, acgt_ ? (size_t)ksize_ + 4 : 24, pieces, [&](uint64_t i, std::string &s) {
         char buf[40];
         if (acgt) {
             kt_numeric_to_kmer(keys[i], k, buf);  // counter/src/lib.rs:221-226
@@ -271,8 +508,10 @@ std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
         s.append(buf, (size_t)(r2.ptr - buf));
         s += '\n';
     });
+    pt.t[2] += lap();
     for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
     fclose(out);
+    pt.t[3] += lap();
     return "";
 }
 
@@ -302,37 +541,20 @@ std::string CovComputer::compute_coverages() {
     const std::string path = out_dir_ + "/kmers.vectors";
     FILE *out = fopen(path.c_str(), "wb");
     if (!out) return "Unable to write to file: " + path;
-    Batch b;
-    std::vector<double> rows;
     std::vector<std::string> pieces;
-    std::string err;
     const uint64_t bins = bin_count_;
-    for (;;) {
-        const uint64_t max_reads = bins >= 2048 ? 8192 : 1ull << 20;
-        const bool more = reader.next_batch(b, 256ull << 20, max_reads);
-        const uint64_t n = b.n_reads();
-        if (n) {
-            rows.resize(n * bins);
-            if (kt_cov_batch(ctr_->table(), b.bases.empty() ? (const uint8_t *)"" : b.bases.data(), b.offsets.data(), n,
-                             bin_size_, bin_count_, norm_, KT_F64, rows.data(), KT_MEM_HOST) != KT_OK) {
-                err = kt_last_error();
-                break;
-            }
-            const bool norm = norm_;
-            const std::string &delim = delim_;
-            format_rows(n, threads_, pieces, [&](uint64_t r, std::string &s) {
-                const double *row = rows.data() + r * bins;
-                for (uint64_t i = 0; i < bins; i++) {
-                    if (i) s += delim;
-                    if (norm) append_fixed6(s, row[i]); else append_display(s, row[i]);  // :116-120
-                }
-                s += '\n';
-            });
-            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
-        }
-        if (!more) break;
-    }
-    if (err.empty() && reader.failed()) err = reader.error();
+    PhaseTimer pt("cov");
+    const std::string err = run_pipeline(
+        reader, batch_bases(256ull << 20), bins >= 2048 ? 8192 : 1ull << 19, pt,
+        [&](Work &w) -> std::string {
+            const uint64_t n = w.b.n_reads();
+            w.rows.resize(n * bins);
+            if (kt_cov_batch(ctr_->table(), bases_ptr(w.b), w.b.offsets.data(), n, bin_size_, bin_count_, norm_, KT_F64,
+                             w.rows.data(), KT_MEM_HOST) != KT_OK)
+                return kt_last_error();
+            return "";
+        },
+        [&](Work &w) { emit_matrix(out, w, bins, norm_, delim_, threads_, pieces, pt); });  // :112-124
     fclose(out);
     return err;
 }

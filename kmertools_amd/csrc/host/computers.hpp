@@ -19,8 +19,12 @@ namespace kthost {
 
 // Rust `format!("{:.6}", x)` (oligo.rs:132-134) and `Display` for f64 (shortest round-trip,
 // positional notation, integral values without ".0": oligo.rs:136, oligocgr.rs:95)
+constexpr size_t FIXED6_BUF = 352;  // "%.6f" of DBL_MAX is 316 characters
+size_t format_fixed6(char *buf, double x);  // buf holds FIXED6_BUF bytes; returns the length written
 void append_fixed6(std::string &out, double x);
 void append_display(std::string &out, double x);
+
+double debug_emit_bench(uint64_t n_rows, uint64_t bins, bool norm, int threads, int reps);
 
 struct Device {  // one kt_ctx per computer, created on first use
     int index = 0;

@@ -3,6 +3,7 @@
 // (args.rs:132-172, :299-325).  clap conventions are kept: kebab-case long flags, the
 // auto-derived short flags, `--flag=value`, `-k4`.  `min` and whole-sequence `comp cgr` (no -k)
 // are outside this build's scope and say so.
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -352,6 +353,45 @@ int cmd_debug_read(int argc, char **argv, int from) {
     return 0;
 }
 
+// hidden: checks the hand-written {:.6} formatter against snprintf("%.6f") (both round the exact
+// binary value half-to-even) on count ratios, exact ties, and random doubles
+int cmd_debug_fixed6(int argc, char **argv, int from) {
+    const uint64_t n = from < argc ? strtoull(argv[from], nullptr, 10) : 1000000;
+    uint64_t state = 0x9e3779b97f4a7c15ull, checked = 0, bad = 0;
+    auto next = [&]() {
+        state += 0x9e3779b97f4a7c15ull;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto check = [&](double x) {
+        char a[FIXED6_BUF], b[FIXED6_BUF];
+        const size_t la = format_fixed6(a, x);
+        const int lb = snprintf(b, sizeof b, "%.6f", x);
+        checked++;
+        if (la != (size_t)lb || memcmp(a, b, la) != 0) {
+            if (bad++ < 10) fprintf(stderr, "mismatch: %.17g -> '%.*s' vs '%s'\n", x, (int)la, a, b);
+        }
+    };
+    const double specials[] = {0.0, 1.0, 0.5, 1e-7, 5e-7, 4.9999999999999998e-7, 5.0000000000000004e-7, 0.9999995, 0.99999949999999994,
+                               1.0 / 128, 3.0 / 128, 1.0 / 64, 123456.7890125, 3999999999.9999995, 4.0e9, 1e300, -1.5, 2.5e-6, 1.5e-6,
+                               0.1, 0.2, 0.3, 1.0 / 3.0, 2.0 / 3.0, 1e-300, 5e-324};
+    for (double x : specials) check(x);
+    for (uint64_t d = 1; d <= 1200; d++)             // every count ratio of a read with up to 1200 k-mers
+        for (uint64_t c = 0; c <= d; c++) check((double)c / (double)d);
+    for (int m = 1; m <= 40; m++)                     // dyadic values: the only exact ties
+        for (uint64_t c = 1; c < 400; c += 2) check(ldexp((double)c, -m));
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t r = next();
+        check((double)(r >> 11) * 0x1p-53);                                        // uniform [0,1)
+        check((double)(r >> 11) * 0x1p-53 * pow(10.0, (double)(next() % 19) - 9));   // wide range
+        check((double)(next() % 2000000001ull) / 2000000.0 + 0.00000025);          // near half-way digits
+    }
+    printf("checked %llu mismatches %llu\n", (unsigned long long)checked, (unsigned long long)bad);
+    return bad ? 1 : 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -377,6 +417,14 @@ int main(int argc, char **argv) {
     }
     if (cmd == "ctr") return cmd_ctr(argc, argv, 2);
     if (cmd == "debug-read") return cmd_debug_read(argc, argv, 2);
+    if (cmd == "debug-fixed6") return cmd_debug_fixed6(argc, argv, 2);
+    if (cmd == "debug-emit") {  // debug-emit <rows> <bins> <norm 0|1> <threads> <reps>
+        if (argc < 7) return 2;
+        const double s = debug_emit_bench(strtoull(argv[2], nullptr, 10), strtoull(argv[3], nullptr, 10), atoi(argv[4]) != 0,
+                                          atoi(argv[5]), atoi(argv[6]));
+        printf("best %.3f s\n", s);
+        return 0;
+    }
     if (cmd == "cov") return cmd_cov(argc, argv, 2);
     if (cmd == "min") {
         fprintf(stderr, "Error: `kmertools %s` is outside the scope of this GPU build (see DESIGN.md section 7)\n", cmd.c_str());

@@ -75,6 +75,14 @@ def test_reader_edge_cases(cli, tmp_path):
     assert r.returncode != 0 and "Unequal length" in r.stderr
 
 
+def test_fixed6_formatter_matches_printf(cli):
+    """the hand-written Rust-{:.6} formatter vs snprintf("%.6f") on every count ratio c/d (d <= 1200),
+    the dyadic exact ties and a few hundred thousand random doubles"""
+    r = run(cli, "debug-fixed6", "100000")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches 0" in r.stdout
+
+
 def test_cli_argument_handling(cli, golden, tmp_path):
     r = run(cli, "comp", "oligo", "-i", golden / "reads.fa", "-o", tmp_path / "o", "-k", "8")
     assert r.returncode == 2 and "is not in 3..=7" in r.stderr          # args.rs:85
