@@ -40,6 +40,9 @@ WORKLOADS = {
     # next row of SURVEY.md 8f: per-read coverage histograms against the resident table (table build untimed)
     "cov_k15": dict(kind="cov", k=15, n=10_000_000, L=150, dtype="f64", cfg=5, bin_size=16, bin_count=16,
                     desc="cov k=15 bin_size 16 x 16 bins, 10M x 150bp per GPU against the table of the same reads, f64 rows"),
+    # whole-sequence chaos game walk, 16 bytes of f64 points per base
+    "cgr_whole": dict(kind="cgr", k=0, n=10_000_000, L=150, dtype="f64", cfg=6,
+                      desc="comp cgr (no -k) whole-sequence walk, vecsize 1, 10M x 150bp per GPU, (x,y) f64 per base"),
 }
 
 
@@ -114,6 +117,23 @@ def cpu_baseline_ctr(k, L, seconds, genome):
     return dict(value=n2 * L / dt / 1e9, unit="Gbases/s", cores=cores, kind="port",
                 sample="%d x %dbp synthetic reads, k=%d, %d sharded maps, %d threads, %.1f s, in-memory count only"
                        % (n2, L, k, cores * 8, cores, dt))
+
+
+def cpu_baseline_cgr(L, seconds):
+    """CPU oracle (port of composition/src/cgr.rs:127-144) over a CSR batch on one host core."""
+    from oracle import kt_oracle as oracle
+    n = 1_000_000
+    hb, ho = oracle.synth_reads(SEED, n, L)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.cgr_batch(hb, ho, 1)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or reps >= 200:
+            break
+    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
+                sample="%d passes over %d x %dbp synthetic reads, 1 thread, %.1f s (includes allocating the 2.4 GB result)"
+                       % (reps, n, L, dt))
 
 
 def cpu_baseline_cov(k, L, seconds, genome, bin_size, bin_count):
@@ -200,6 +220,14 @@ def main():
         def step():
             for (bb, oo, cnt) in batch_args:
                 ctx.oligo(bb, oo, cnt, k, out, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+    elif wl["kind"] == "cgr":
+        out = torch.empty((n * L, 2), dtype=torch.float64, device="cuda")
+        bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+        alg_bytes_per_launch = n * (L * 17 + 8)
+        dominant = "cgr_kernel (128-base chunks per lane, bracketing start, LDS-transposed stores)"
+
+        def step():
+            ctx.cgr(bases, offsets, n, 1, out, bad)
     elif wl["kind"] == "cov":
         kmers_per_read = L - k + 1
         max_distinct = min(n * kmers_per_read, (4 ** k + 2 ** k) // 2)
@@ -283,6 +311,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "reads_per_gpu": n, "read_len": L, "k": k,
                        "parallelism": "reads sharded by rank, no data-path collective" if wl["kind"] == "oligo"
+                       else "reads sharded by rank, no data-path collective" if wl["kind"] == "cgr"
                        else "reads sharded by rank, each rank probes the table of its own reads" if wl["kind"] == "cov"
                        else "hash-prefix key ownership, RCCL all-to-all of routed k-mers",
                        "reduced": reduced},
@@ -295,6 +324,8 @@ def main():
         if world == 1 and not args.no_cpu:
             if wl["kind"] == "oligo":
                 line["cpu_baseline"] = cpu_baseline_oligo(k, L, args.cpu_seconds)
+            elif wl["kind"] == "cgr":
+                line["cpu_baseline"] = cpu_baseline_cgr(L, args.cpu_seconds)
             elif wl["kind"] == "cov":
                 line["cpu_baseline"] = cpu_baseline_cov(k, L, args.cpu_seconds, args.genome, wl["bin_size"], wl["bin_count"])
             else:

@@ -38,6 +38,7 @@ extern "C" {
 #define KT_ERR_NOMEM 3    /* device or host allocation failed */
 #define KT_ERR_FULL 4     /* k-mer table ran out of slots (raise capacity) */
 #define KT_ERR_NODEVICE 5 /* no usable gfx950 device */
+#define KT_ERR_BADNT 6    /* kt_cgr_points: a byte outside ACGTUacgtu ("Bad nucleotide, unable to proceed") */
 
 #define KT_MEM_HOST 0
 #define KT_MEM_DEVICE 1
@@ -141,6 +142,18 @@ int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct);
  * its tests sort); *n_out = number written.  Synchronises. */
 int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_out,
                   uint64_t *n_out, int mem);
+
+/* replaces: CgrComputer::vectorise_one, composition/src/cgr.rs:127-144 (corners from cgr_maps,
+ * :12-36) and python CgrComputer.vectorise_one/_batch, pybindings/src/cgr.rs:38-62.
+ * Whole-sequence chaos game walk: xy[2*g], xy[2*g+1] = marker after base g of the batch
+ * (g = global base index, so read i owns xy[2*offsets[i] .. 2*offsets[i+1])); every read
+ * starts from (vecsize/2, vecsize/2).  Bit-identical to the reference's serial f64 walk.
+ * A byte outside ACGTUacgtu is an error for the whole call, as in the reference:
+ * *bad_pos (may be NULL) = lowest offending base index, UINT64_MAX if none.  KT_MEM_HOST:
+ * returns KT_ERR_BADNT in that case; KT_MEM_DEVICE: bad_pos is a device pointer the caller
+ * inspects after synchronising (the call itself returns KT_OK). */
+int kt_cgr_points(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                  double vecsize, double *xy, uint64_t *bad_pos, int mem);
 
 /* replaces: CovComputer::vectorise_one, coverage/src/lib.rs:165-184 (and the HashMap
  * re-load of kmers.counts at :82-92: the table is probed where kt_ctr_add_reads left it).

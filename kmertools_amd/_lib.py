@@ -12,7 +12,7 @@ _HERE = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("KT_LIB", _HERE / "libkmertools_hip.so"))  # KT_LIB: A/B builds
 
 KT_OK = 0
-KT_ERR_ARG, KT_ERR_HIP, KT_ERR_NOMEM, KT_ERR_FULL, KT_ERR_NODEVICE = 1, 2, 3, 4, 5
+KT_ERR_ARG, KT_ERR_HIP, KT_ERR_NOMEM, KT_ERR_FULL, KT_ERR_NODEVICE, KT_ERR_BADNT = 1, 2, 3, 4, 5, 6
 KT_MEM_HOST, KT_MEM_DEVICE = 0, 1
 KT_F64, KT_F32, KT_U32 = 0, 1, 2
 KT_EMPTY_KEY = 0xFFFFFFFFFFFFFFFF
@@ -41,6 +41,7 @@ SYMBOLS = {
     "kt_ctr_add_pairs": (_i, [_vp, _vp, _vp, _u64, _i]),
     "kt_ctr_size": (_i, [_vp, C.POINTER(_u64)]),
     "kt_ctr_export": (_i, [_vp, _vp, _vp, _u64, C.POINTER(_u64), _i]),
+    "kt_cgr_points": (_i, [_vp, _vp, _vp, _u64, C.c_double, _vp, _vp, _i]),
     "kt_cov_batch": (_i, [_vp, _vp, _vp, _u64, _u64, _u64, _i, _i, _vp, _i]),
     "kt_ctr_route": (_i, [_vp, _vp, _vp, _u64, _i, _i, _vp, _vp, _i]),
     "kt_owner_of": (_u32, [_u64, _u32]),

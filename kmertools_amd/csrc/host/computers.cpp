@@ -430,6 +430,57 @@ std::string OligoCgrComputer::vectorise() {
 }
 
 // ---------------------------------------------------------------------------------------------
+CgrComputer::CgrComputer(std::string in_path, std::string out_path, uint64_t vecsize)
+    : in_path_(std::move(in_path)), out_path_(std::move(out_path)), vecsize_(vecsize) {}
+
+std::string CgrComputer::vectorise() {
+    SeqReader reader;
+    if (!reader.open(in_path_, true)) return reader.error();  // cgr.rs:68-76 sniffs '>'
+    FILE *out = fopen(out_path_.c_str(), "wb");
+    if (!out) return "Unable to write to file: " + out_path_;
+    if (std::string e = dev_.ensure(); !e.empty()) {
+        fclose(out);
+        return e;
+    }
+    std::vector<std::string> pieces;
+    PhaseTimer pt("comp cgr (whole sequence)");
+    // 16 bytes of points and ~40 bytes of text per base: keep the batches small
+    const std::string err = run_pipeline(
+        reader, 16ull << 20, 1ull << 18, pt,
+        [&](Work &w) -> std::string {
+            const uint64_t n = w.b.n_reads();
+            w.rows.resize(2 * w.b.bases.size() + 2);
+            if (kt_cgr_points(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, (double)vecsize_, w.rows.data(), nullptr,
+                              KT_MEM_HOST) != KT_OK)
+                return kt_last_error();
+            return "";
+        },
+        [&](Work &w) {
+            Lap lap;
+            const double *xy = w.rows.data();
+            const uint64_t *off = w.b.offsets.data();
+            const uint64_t n = w.b.n_reads();
+            const size_t per_row = n ? (size_t)(w.b.bases.size() / n + 1) * 44 : 1;
+            format_rows(n, threads_, per_row, pieces, [&](uint64_t r, std::string &s) {
+                for (uint64_t g = off[r]; g < off[r + 1]; g++) {  // "({},{})" joined by " " (:97-102)
+                    if (g != off[r]) s += ' ';
+                    s += '(';
+                    append_display(s, xy[2 * g]);
+                    s += ',';
+                    append_display(s, xy[2 * g + 1]);
+                    s += ')';
+                }
+                s += '\n';
+            });
+            pt.t[2] += lap();
+            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+            pt.t[3] += lap();
+        });
+    fclose(out);
+    return err;
+}
+
+// ---------------------------------------------------------------------------------------------
 CountComputer::CountComputer(std::string in_path, std::string out_dir, int ksize)
     : in_path_(std::move(in_path)), out_dir_(std::move(out_dir)), ksize_(ksize) {}
 

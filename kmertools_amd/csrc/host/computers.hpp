@@ -1,6 +1,7 @@
 // computers.hpp - C++ mirror of the reference's Rust-level operator API for the hot path:
 //   OligoComputer      composition/src/oligo.rs:15-93
 //   OligoCgrComputer   composition/src/oligocgr.rs:16-121
+//   CgrComputer        composition/src/cgr.rs:42-144
 //   CountComputer      counter/src/lib.rs:22-90, 172-234
 //   CovComputer        coverage/src/lib.rs:14-184
 // Same constructor arguments, setters and entry points (vectorise / count / merge); the
@@ -67,6 +68,22 @@ class OligoCgrComputer {
     uint64_t vecsize_;
     bool norm_ = true;
     uint64_t memory_ = 4ull << 30;
+    Device dev_;
+};
+
+class CgrComputer {
+  public:
+    CgrComputer(std::string in_path, std::string out_path, uint64_t vecsize);
+    void set_threads(int t) { threads_ = t; }
+    void set_device(int d) { dev_.index = d; }
+    // cgr.rs:67-125.  "" on success; "Bad nucleotide, unable to proceed" where the reference's
+    // worker unwraps that Err (:95) and the process dies
+    std::string vectorise();
+
+  private:
+    std::string in_path_, out_path_;
+    uint64_t vecsize_;
+    int threads_ = 0;
     Device dev_;
 };
 

@@ -1,8 +1,8 @@
 // kmertools (GPU drop-in) - command line with the reference's `comp oligo`, `comp cgr -k` and
 // `ctr` flags (kmertools/src/args.rs:70-130, 208-236; dispatcher :239-368) and `cov`
 // (args.rs:132-172, :299-325).  clap conventions are kept: kebab-case long flags, the
-// auto-derived short flags, `--flag=value`, `-k4`.  `min` and whole-sequence `comp cgr` (no -k)
-// are outside this build's scope and say so.
+// auto-derived short flags, `--flag=value`, `-k4`.  `min` is outside this build's scope
+//  and says so.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -277,7 +277,17 @@ int cmd_cgr(int argc, char **argv, int from) {
             fprintf(stderr, "Error: cannot use counts in whole sequence CGR!\n");
             return 0;
         }
-        fprintf(stderr, "Error: whole-sequence CGR (no --k-size) is not part of this GPU build; pass -k 3..7\n");
+        // args.rs:288-296: vecsize defaults to 1
+        CgrComputer cgr(in, out, has_v ? v : 1);
+        if (threads > 0) cgr.set_threads(threads);
+        cgr.set_device((int)ranged(f, "device", 0, 63, false, 0));
+        const std::string e = cgr.vectorise();
+        if (e == "Bad nucleotide, unable to proceed") {
+            // the reference unwraps this Err inside its worker (cgr.rs:95) and the process panics
+            fprintf(stderr, "Error: %s\n", e.c_str());
+            return 101;
+        }
+        if (!e.empty()) fprintf(stderr, "Error: %s\n", e.c_str());
         return 0;
     }
     // default vecsize = (k as f64).powf(4.0).powf(0.5) as u64 = k^2   (args.rs:266-269)

@@ -127,6 +127,23 @@ class Context:
                        total_step, dtype, KT_MEM_HOST)
         return out
 
+    # -- comp cgr (whole sequence) ---------------------------------------------------------------
+    def cgr(self, bases, offsets, n_reads, vecsize, xy, bad_pos=None, mem=KT_MEM_DEVICE):
+        """xy: 2 f64 per base; bad_pos: u64 scalar (device pointer in device mode) or None"""
+        check(_lib.lib().kt_cgr_points(self._h, _ptr(bases), _ptr(offsets), n_reads, float(vecsize), _ptr(xy),
+                                       _ptr(bad_pos), mem))
+        return xy
+
+    def cgr_host(self, bases, offsets, vecsize=1):
+        """-> (total_bases, 2) f64; raises KmertoolsError(KT_ERR_BADNT) on a byte outside ACGTUacgtu"""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        total = int(offsets[-1])
+        xy = np.zeros((max(total, 1), 2), np.float64)
+        self.cgr(bases if bases.size else np.zeros(1, np.uint8), offsets, len(offsets) - 1, vecsize, xy, None,
+                 KT_MEM_HOST)
+        return xy[:total]
+
     # -- KmerGenerator surface -----------------------------------------------------------
     def kmers(self, bases, offsets, n_reads, k, fwd, rev, valid, mem=KT_MEM_DEVICE):
         check(_lib.lib().kt_kmers(self._h, _ptr(bases), _ptr(offsets), n_reads, k, _ptr(fwd), _ptr(rev),

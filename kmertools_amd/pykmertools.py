@@ -6,6 +6,7 @@ Same class names, argument names, defaults and error behaviour:
     OligoComputer(ksize).vectorise_one(seq, norm=True, mins=True)      pybindings/src/oligo.rs:22,39
                         .vectorise_batch(seqs, norm=True, mins=True)   :77
                         .get_header(mins=True)                         :85
+    CgrComputer(vecsize).vectorise_one(seq) / .vectorise_batch(seqs)   pybindings/src/cgr.rs:22,38,60
     KmerGenerator(seq, ksize)  iterable of (fwd, rev)                  pybindings/src/kmer.rs:22,39
                  .kmer_pos_maps()                                      :31
     utils.to_acgt(kmer, ksize) / utils.to_numeric(kmer)                :49,:57
@@ -58,6 +59,31 @@ class OligoComputer:
             _, pos_kmer, _ = device.pos_map(self.ksize)
             return [device.numeric_to_kmer(int(x), self.ksize) for x in pos_kmer]
         return [device.numeric_to_kmer(x, self.ksize) for x in range(4 ** self.ksize)]
+
+
+class CgrComputer:
+    """Computer for generating chaos game representation (cgr)"""
+
+    def __init__(self, vecsize):
+        self.vecsize = int(vecsize)
+        if self.vecsize < 0:
+            raise OverflowError("can't convert negative int to unsigned")  # pyo3's usize extraction
+
+    def vectorise_one(self, seq):
+        return self.vectorise_batch([seq])[0]
+
+    def vectorise_batch(self, seqs):
+        """list of sequences -> list of lists of (x, y) tuples; ValueError("Bad nucleotide, unable to
+        proceed") if any sequence holds a byte outside ACGTUacgtu (pybindings/src/cgr.rs:47-49)"""
+        bases, offsets = device.to_csr(seqs)
+        try:
+            xy = _context().cgr_host(bases, offsets, self.vecsize)
+        except _lib.KmertoolsError as e:
+            if e.code == _lib.KT_ERR_BADNT:
+                raise ValueError("Bad nucleotide, unable to proceed") from None
+            raise
+        pts = list(map(tuple, xy.tolist()))
+        return [pts[int(offsets[i]):int(offsets[i + 1])] for i in range(len(offsets) - 1)]
 
 
 class KmerGenerator:

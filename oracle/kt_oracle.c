@@ -399,6 +399,40 @@ uint64_t kto_counter_export(const kto_counter *c, uint64_t *keys, uint32_t *coun
 }
 
 /* ------------------------------------------------------------------------ */
+/* composition/src/cgr.rs:12-36 cgr_maps + :127-144 CgrComputer::vectorise_one (same loop in
+ * pybindings/src/cgr.rs:38-54): whole-sequence chaos game walk.  Corners A=(0,0) T/U=(V,0)
+ * G=(V,V) C=(0,V), either case; marker starts at (V/2, V/2); every base moves the marker half
+ * way to its corner and emits it.  Any other byte is an error (returns the index of the first
+ * bad byte + 1, 0 on success).  out = 2 doubles per base. */
+uint64_t kto_cgr_one(const uint8_t *seq, uint64_t n, double vecsize, double *out) {
+    double mx = vecsize / 2.0, my = vecsize / 2.0;
+    for (uint64_t i = 0; i < n; i++) {
+        double cx, cy;
+        switch (seq[i]) {
+            case 'A': case 'a': cx = 0.0; cy = 0.0; break;
+            case 'T': case 't': case 'U': case 'u': cx = vecsize; cy = 0.0; break;
+            case 'G': case 'g': cx = vecsize; cy = vecsize; break;
+            case 'C': case 'c': cx = 0.0; cy = vecsize; break;
+            default: return i + 1;                 /* cgr.rs:139-141 */
+        }
+        mx = (cx + mx) / 2.0;                      /* :134-137 */
+        my = (cy + my) / 2.0;
+        out[2 * i] = mx;
+        out[2 * i + 1] = my;
+    }
+    return 0;
+}
+
+/* the same walk over a CSR batch (the par_iter of cgr.rs:92-106, serial here); out = 2 doubles per base */
+uint64_t kto_cgr_batch(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, double vecsize, double *out) {
+    for (uint64_t i = 0; i < n_reads; i++) {
+        uint64_t bad = kto_cgr_one(bases + offsets[i], offsets[i + 1] - offsets[i], vecsize, out + 2 * offsets[i]);
+        if (bad) return offsets[i] + bad;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* coverage/src/lib.rs:165-184 CovComputer::vectorise_one over a CSR batch:
  * per k-mer: count = table[min(f,r)] or 0 (:171), bin = min(floor(count / bin_size),
  * bin_count - 1) (:172-173), vec[bin] += 1, total += 1; norm: /= max(1, total) (:180-182). */

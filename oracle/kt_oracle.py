@@ -70,6 +70,10 @@ def lib():
         L.kto_counter_size.argtypes = [C.c_void_p]
         L.kto_counter_export.restype = C.c_uint64
         L.kto_counter_export.argtypes = [C.c_void_p, u64p, u32p, C.c_int]
+        L.kto_cgr_one.restype = C.c_uint64
+        L.kto_cgr_one.argtypes = [u8p, C.c_uint64, C.c_double, f64p]
+        L.kto_cgr_batch.restype = C.c_uint64
+        L.kto_cgr_batch.argtypes = [u8p, u64p, C.c_uint64, C.c_double, f64p]
         L.kto_cov_batch.restype = C.c_int
         L.kto_cov_batch.argtypes = [C.c_void_p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, f64p]
         L.kto_synth_reads.restype = None
@@ -171,6 +175,37 @@ def cgr_coords(k, vecsize):
     xy = np.zeros((c, 2), dtype=np.float64)
     lib().kto_cgr_coords(k, float(vecsize), _p(xy, f64p))
     return xy
+
+
+def cgr_points(seq, vecsize=1):
+    """composition/src/cgr.rs:127-144: (n, 2) f64 points; ValueError on a byte outside ACGTUacgtu"""
+    b = np.frombuffer(seq.encode("latin-1") if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+    n = len(b)
+    buf = np.zeros(max(n, 1), np.uint8)
+    buf[:n] = b
+    out = np.zeros((max(n, 1), 2), np.float64)
+    bad = lib().kto_cgr_one(_p(buf, u8p), n, float(vecsize), _p(out, f64p))
+    if bad:
+        raise ValueError("Bad nucleotide, unable to proceed")
+    return out[:n].copy()
+
+
+def cgr_batch(bases, offsets, vecsize=1):
+    """all reads of a CSR batch -> (total_bases, 2) f64"""
+    total = int(offsets[-1])
+    out = np.zeros((max(total, 1), 2), np.float64)
+    bb = bases if bases.size else np.zeros(1, np.uint8)
+    if lib().kto_cgr_batch(_p(bb, u8p), _p(offsets, u64p), len(offsets) - 1, float(vecsize), _p(out, f64p)):
+        raise ValueError("Bad nucleotide, unable to proceed")
+    return out[:total]
+
+
+def cgr_text(point_rows):
+    """composition/src/cgr.rs:97-104: "(x,y)" joined by " ", one line per read"""
+    lines = []
+    for pts in point_rows:
+        lines.append(" ".join("(%s,%s)" % (fmt_display(float(x)), fmt_display(float(y))) for x, y in pts) + "\n")
+    return "".join(lines).encode()
 
 
 class Counter:

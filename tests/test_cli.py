@@ -147,6 +147,17 @@ def test_cli_golden_outputs(cli, golden, tmp_path):
     r = run(cli, "ctr", "-i", golden / "reads.fq", "-o", d, "-k", "15", "-a")
     lines = (d / "kmers.counts").read_text().splitlines()
     assert len(lines) == len(got) and all(len(x.split("\t")[0]) == 15 for x in lines)
+    # whole-sequence CGR (no -k): vecsize defaults to 1 -> the reference's fixture (cgr.rs:189-199)
+    w = tmp_path / "whole.cgr"
+    r = run(cli, "comp", "cgr", "-i", golden / "reads.fq", "-o", w)
+    assert r.returncode == 0 and r.stderr == ""
+    assert w.read_bytes() == (golden / "expected_reads.cgr").read_bytes()
+    r = run(cli, "comp", "cgr", "-i", golden / "reads.fq", "-o", w, "-c")
+    assert r.returncode == 0 and "cannot use counts in whole sequence CGR" in r.stderr
+    nfa = tmp_path / "n.fa"
+    nfa.write_text(">a\nACGT\n>b\nACNT\n")
+    r = run(cli, "comp", "cgr", "-i", nfa, "-o", w)
+    assert r.returncode == 101 and "Bad nucleotide, unable to proceed" in r.stderr
     # cov: the reference's test uses k=4 / bin_size 2 / bin_count 3 through the library API, which the
     # CLI's clap ranges (k 7..=31, bins >= 5) cannot express -> check the CLI against the oracle in
     # test_cli_larger_file_matches_oracle and the flag ranges here
@@ -195,3 +206,10 @@ def test_cli_larger_file_matches_oracle(cli, oracle, tmp_path):
     assert run(cli, "cov", "-i", fa, "-a", fa2, "-o", cv, "-k", "11", "--counts", "-p", "csv", "--bin-size=5").returncode == 0
     assert (cv / "kmers.vectors").read_bytes() == \
         oracle.oligo_text(alt.cov_batch(bases, offsets, 11, 5, 16, False), False).replace(b" ", b",")
+    # whole-sequence CGR needs clean letters: strip N from the reads, vec-size 16
+    clean = [s.replace("N", "") for s in seqs[:1500]]
+    fa3 = tmp_path / "r3.fasta"
+    fa3.write_text("".join(">s%d\n%s\n" % (i, s) for i, s in enumerate(clean)))
+    w = tmp_path / "whole.cgr"
+    assert run(cli, "comp", "cgr", "-i", fa3, "-o", w, "-v", "16").stderr == ""
+    assert w.read_bytes() == oracle.cgr_text([oracle.cgr_points(s, 16) for s in clean])
