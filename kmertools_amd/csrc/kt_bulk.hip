@@ -83,7 +83,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_
         if (lane >= (uint32_t)off) inc += v;
     }
     if (lane == 63) tmp[wave] = inc;
-    __syncthreads();
+    ktd::lds_barrier();
     uint32_t wbase = 0, total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < BLOCK / 64; w++) {
@@ -99,7 +99,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_
             run += c;
         }
     }
-    __syncthreads();
+    ktd::lds_barrier();
     return total;
 }
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BLOCK) void hist1_kernel(SegArgs a, Plan p, uint32_
     __shared__ SegShared sm;
     __shared__ uint32_t cnt[MAX_B];
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) cnt[i] = 0;
-    __syncthreads();
+    ktd::lds_barrier();
     for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
         ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
             const uint64_t m = f < r ? f : r;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(1024) void scan1_kernel(const uint32_t *__restrict_
         }
         tot[d] = run;
     }
-    __syncthreads();
+    ktd::lds_barrier();
     if (threadIdx.x == 0) {
         uint64_t run = 0;
         for (uint32_t d = 0; d < p.B1; d++) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(1024) void scan1_kernel(const uint32_t *__restrict_
         }
         bstart[p.B1] = run;
     }
-    __syncthreads();
+    ktd::lds_barrier();
     for (uint32_t d = threadIdx.x; d < p.B1; d += blockDim.x) {
         const uint64_t base = tot[d];
         for (uint32_t g = 0; g < p.G; g++) O[(uint64_t)g * p.B1 + d] += base;
@@ -174,14 +174,14 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(SegArgs a, Plan p, cons
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cnt[i] = 0;
-            __syncthreads();
+            ktd::lds_barrier();
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 if ((ok >> (half * 16 + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * 16 + j], p)], 1u);
-            __syncthreads();
+            ktd::lds_barrier();
             const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.fill[i] = sm.start[i];
-            __syncthreads();
+            ktd::lds_barrier();
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 if ((ok >> (half * 16 + j)) & 1u) {
@@ -190,16 +190,16 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(SegArgs a, Plan p, cons
                     sm.sorted[pos] = m;
                 }
             }
-            __syncthreads();
+            ktd::lds_barrier();
             // runs of equal d1 are contiguous in `sorted`: consecutive lanes -> consecutive addresses
             for (uint32_t i = threadIdx.x; i < nk; i += BLOCK) {
                 const uint64_t key = sm.sorted[i];
                 const uint32_t d = digit1(key, p);
                 keys1[sm.cursor[d] + (i - sm.start[d])] = key;
             }
-            __syncthreads();
+            ktd::lds_barrier();
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cursor[i] += sm.cnt[i];
-            __syncthreads();
+            ktd::lds_barrier();
         }
     }
 }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
         const uint64_t lo = bstart[j], hi = bstart[j + 1];
         // whole-bucket histogram of d2 -> fine bucket boundaries
         for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cnt[i] = 0;
-        __syncthreads();
+        ktd::lds_barrier();
         for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)BLOCK * 8) {  // 8 loads in flight per thread
             uint64_t kk[8];
 #pragma unroll
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
             for (int u = 0; u < 8; u++)
                 if (kk[u] != KT_EMPTY_KEY) atomicAdd(&sm.cnt[digit2(kk[u], p)], 1u);
         }
-        __syncthreads();
+        ktd::lds_barrier();
         // bucket sizes can exceed 32 bits only for > 4 G keys in one level-1 bucket: not supported
         block_excl_scan(sm.cnt, sm.start, p.B2, sm.tmp);
         for (uint32_t i = tid; i < p.B2; i += BLOCK) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
             fstart[(uint64_t)j * p.B2 + i] = pos;
         }
         if (j == p.B1 - 1 && tid == 0) fstart[(uint64_t)p.B1 * p.B2] = hi;
-        __syncthreads();
+        ktd::lds_barrier();
         // chunks of CHUNK2 keys: counting sort in LDS, runs appended to the fine buckets.  The next
         // chunk's keys are loaded while the current one is sorted; digits are hashed once.
         constexpr int PER = CHUNK2 / BLOCK;  // 16 keys per thread, held in registers
@@ -264,17 +264,17 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
             const uint32_t nc = n64 < CHUNK2 ? (uint32_t)n64 : CHUNK2;
             if (c0 + CHUNK2 < hi) load_chunk(c0 + CHUNK2, knxt);
             for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cnt[i] = 0;
-            __syncthreads();
+            ktd::lds_barrier();
             uint16_t dg[PER];
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 dg[u] = (uint16_t)digit2(kcur[u], p);
                 if (kcur[u] != KT_EMPTY_KEY) atomicAdd(&sm.cnt[dg[u]], 1u);
             }
-            __syncthreads();
+            ktd::lds_barrier();
             block_excl_scan(sm.cnt, sm.start, p.B2, sm.tmp);
             for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.fill[i] = sm.start[i];
-            __syncthreads();
+            ktd::lds_barrier();
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 if (kcur[u] != KT_EMPTY_KEY) {
@@ -283,18 +283,18 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
                     sm.sdig[pos] = dg[u];
                 }
             }
-            __syncthreads();
+            ktd::lds_barrier();
             for (uint32_t i = tid; i < nc; i += BLOCK) {
                 const uint32_t d = sm.sdig[i];
                 keys2[sm.cursor[d] + (i - sm.start[d])] = sm.sorted[i];
             }
-            __syncthreads();
+            ktd::lds_barrier();
             for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cursor[i] += sm.cnt[i];
 #pragma unroll
             for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
             // (the next iteration's first barrier orders the cursor update before its use)
         }
-        __syncthreads();
+        ktd::lds_barrier();
     }
 }
 
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
             sm.keys[i] = KT_EMPTY_KEY;
             sm.counts[i] = 0;
         }
-        __syncthreads();
+        ktd::lds_barrier();
         const uint64_t lo = fstart[fb], hi = fstart[fb + 1];
         for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)BUILD_T * 4) {  // 4 loads in flight per thread
           uint64_t kk[4];
@@ -360,13 +360,13 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
             }
           }
         }
-        __syncthreads();
+        ktd::lds_barrier();
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * S);
         for (uint32_t i = tid; i < S; i += BUILD_T) {
             const uint64_t key = sm.keys[i];
             dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), sm.counts[i], 0u);
         }
-        __syncthreads();
+        ktd::lds_barrier();
     }
 }
 

@@ -45,6 +45,23 @@ __host__ __device__ __forceinline__ uint64_t rev_comp(uint64_t x, int k) {
     return x >> (64 - 2 * k);
 }
 
+#ifndef KT_LBAR
+#define KT_LBAR 1
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt == 0, i.e. for every
+// global store just issued and every global load just prefetched by the wave - which is exactly what the
+// kernels here want to leave in flight across the barrier.  Only valid where threads of a workgroup
+// communicate through LDS alone (true for every kernel in this library).
+__device__ __forceinline__ void lds_barrier() {
+#if KT_LBAR
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __syncthreads();
+#endif
+}
+
 // lane l receives the value of lane l-1; lane 0 receives `fill` (DPP wave_shr:1, gfx9)
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);

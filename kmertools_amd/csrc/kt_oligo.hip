@@ -191,6 +191,39 @@ __device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile,
     return t;
 }
 
+#ifndef KT_OLIGO_GLOAD
+#define KT_OLIGO_GLOAD 1
+#endif
+#ifndef KT_OLIGO_LBAR
+#define KT_OLIGO_LBAR 1
+#endif
+
+// 16 bytes at integer address p.  The address space is spelled out: through a generic pointer this is a
+// FLAT load, which counts against lgkmcnt as well as vmcnt, so every later wait for an LDS result would
+// also wait for the prefetched chunks.
+__device__ __forceinline__ uint4 load16(uintptr_t p) {
+#if KT_OLIGO_GLOAD
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(1))) *gptr;
+    const u32x4 v = *(gptr)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, i.e. it would wait for the
+// rows just stored (and the chunks just prefetched) to complete before the next phase may start.
+__device__ __forceinline__ void lds_barrier() {
+#if KT_OLIGO_LBAR
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __syncthreads();
+#endif
+}
+
 // bytes [p, p+16) with everything outside the buffer replaced by 0xFF (first / last bytes only)
 __device__ __forceinline__ uint4 load_guarded(uintptr_t p, uintptr_t base_addr, uint64_t total_bytes) {
     uint32_t w[4] = {0, 0, 0, 0};
@@ -214,14 +247,14 @@ __device__ __forceinline__ uint4 load_chunk(const OligoArgs &a, const ProdTile &
         const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + (int32_t)NB * ((int32_t)lane - 1);
         if (q >= 0 && q < (int32_t)(uint32_t)t.flat_end) {
             const uintptr_t p = t.al0 + (uint32_t)q;
-            if (q >= t.safe_lo && q + (int32_t)NB <= t.safe_hi) v = *reinterpret_cast<const uint4 *>(p);
+            if (q >= t.safe_lo && q + (int32_t)NB <= t.safe_hi) v = load16(p);
             else v = load_guarded(p, base_addr, total_bytes);
         }
     } else {
         const int64_t q = (int64_t)(ci * CHUNK) + (int64_t)NB * ((int64_t)lane - 1);
         if (q >= 0 && (uint64_t)q < t.flat_end) {
             const uintptr_t p = t.al0 + (uint64_t)q;
-            if (p >= base_addr && p + NB <= base_addr + total_bytes) v = *reinterpret_cast<const uint4 *>(p);
+            if (p >= base_addr && p + NB <= base_addr + total_bytes) v = load16(p);
             else v = load_guarded(p, base_addr, total_bytes);
         }
     }
@@ -560,7 +593,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
         tc.nr = t_cur.nr;
         tc.off0 = 0;
         tc.TL = 0;
-        __syncthreads();
+        lds_barrier();
         // ---- prefetch the next tile while this one is stored -------------------------------------
         if (j + 1 < nt) {
             t_cur = make_tile(a, tile_of(j + 1), o_nxt, lane, total_bytes);
@@ -578,7 +611,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
         if (!(a.debug & 16u)) __builtin_amdgcn_s_setprio(3);
         consume_tile<DT, NW>(a, tc, wave, lane, hist, tot, dnm, rcp);
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -684,7 +717,7 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     const uint32_t by_waves = 2048 / nthreads;
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
-    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", 4);
+    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", 64);
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(nthreads), lds, ctx->stream, a);

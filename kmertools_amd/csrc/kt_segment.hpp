@@ -84,7 +84,7 @@ __device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegS
         sm.inv[i] = iv;
         sm.bnd[i] = 0;
     }
-    __syncthreads();
+    ktd::lds_barrier();
 
     // ---- read boundaries inside (B0, B0 + SEG + 32) ---------------------------------
     {
@@ -96,7 +96,7 @@ __device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegS
             atomicOr(&sm.bnd[rel >> 5], 1u << (rel & 31u));
         }
     }
-    __syncthreads();
+    ktd::lds_barrier();
 }
 
 // The thread's walk over its 32 window starts [32*tid, 32*tid + 32) of a staged segment: a
@@ -144,7 +144,7 @@ __device__ __forceinline__ void for_each_kmer(const SegArgs &a, uint64_t g, SegS
             w.step();
         }
     }
-    __syncthreads();  // LDS is reused by the next segment
+    ktd::lds_barrier();  // LDS is reused by the next segment
 }
 
 // Same walk, but the thread's 32 canonical k-mers stay in registers: keys[j] = min(fwd, rev) of
@@ -162,7 +162,7 @@ __device__ __forceinline__ void collect_kmers(const SegArgs &a, uint64_t g, SegS
         keys[j] = w.f < w.r ? w.f : w.r;
         w.step();
     }
-    __syncthreads();  // LDS is reused by the next segment
+    ktd::lds_barrier();  // LDS is reused by the next segment
 }
 
 }  // namespace ktseg
