@@ -43,6 +43,9 @@ WORKLOADS = {
     # whole-sequence chaos game walk, 16 bytes of f64 points per base
     "cgr_whole": dict(kind="cgr", k=0, n=10_000_000, L=150, dtype="f64", cfg=6,
                       desc="comp cgr (no -k) whole-sequence walk, vecsize 1, 10M x 150bp per GPU, (x,y) f64 per base"),
+    # window minimisers (w=31, m=7), variable-length (mmer, start, end) lists per read
+    "min_w31_m7": dict(kind="min", k=7, n=10_000_000, L=150, dtype="u64", cfg=7, w=31,
+                       desc="min w=31 m=7, 10M x 150bp per GPU, (minimiser, start, end) triples in read order"),
 }
 
 
@@ -136,6 +139,26 @@ def cpu_baseline_cgr(L, seconds):
                        % (reps, n, L, dt))
 
 
+def cpu_baseline_min(L, w, m, seconds):
+    """CPU oracle (port of kmer/src/minimiser.rs:61-175), one read per call on one host core."""
+    from oracle import kt_oracle as oracle
+    n = 20000
+    hb, _ = oracle.synth_reads(SEED, n, L)
+    raw = hb.tobytes()
+    reads = [raw[r * L:(r + 1) * L] for r in range(n)]
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        for s in reads:
+            oracle.minimisers(s, w, m)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or reps >= 200:
+            break
+    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
+                sample="%d passes over %d x %dbp synthetic reads, w=%d m=%d, one ctypes call per read (python overhead "
+                       "included), 1 thread, %.1f s" % (reps, n, L, w, m, dt))
+
+
 def cpu_baseline_cov(k, L, seconds, genome, bin_size, bin_count):
     """CPU oracle (port of coverage/src/lib.rs:165-184) on one host core per call, table prebuilt."""
     from oracle import kt_oracle as oracle
@@ -220,6 +243,20 @@ def main():
         def step():
             for (bb, oo, cnt) in batch_args:
                 ctx.oligo(bb, oo, cnt, k, out, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+    elif wl["kind"] == "min":
+        w = wl["w"]
+        evo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        one = torch.empty(1, dtype=torch.int64, device="cuda")
+        n_ev = ctx.minimisers(bases, offsets, n, w, k, evo, one, one, one, 0)   # sizing call, untimed
+        mk = torch.empty(n_ev, dtype=torch.int64, device="cuda")
+        ms = torch.empty(n_ev, dtype=torch.int64, device="cuda")
+        me = torch.empty(n_ev, dtype=torch.int64, device="cuda")
+        # bases read by the three passes that touch them + the triples and offsets written
+        alg_bytes_per_launch = n * (L + 8) + n_ev * 24
+        dominant = "min_tile_kernel x2 (count, emit) + finalize; LDS sliding minimum, %d triples" % n_ev
+
+        def step():
+            ctx.minimisers(bases, offsets, n, w, k, evo, mk, ms, me, n_ev)
     elif wl["kind"] == "cgr":
         out = torch.empty((n * L, 2), dtype=torch.float64, device="cuda")
         bad = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -311,7 +348,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "reads_per_gpu": n, "read_len": L, "k": k,
                        "parallelism": "reads sharded by rank, no data-path collective" if wl["kind"] == "oligo"
-                       else "reads sharded by rank, no data-path collective" if wl["kind"] == "cgr"
+                       else "reads sharded by rank, no data-path collective" if wl["kind"] in ("cgr", "min")
                        else "reads sharded by rank, each rank probes the table of its own reads" if wl["kind"] == "cov"
                        else "hash-prefix key ownership, RCCL all-to-all of routed k-mers",
                        "reduced": reduced},
@@ -326,6 +363,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_oligo(k, L, args.cpu_seconds)
             elif wl["kind"] == "cgr":
                 line["cpu_baseline"] = cpu_baseline_cgr(L, args.cpu_seconds)
+            elif wl["kind"] == "min":
+                line["cpu_baseline"] = cpu_baseline_min(L, wl["w"], k, args.cpu_seconds)
             elif wl["kind"] == "cov":
                 line["cpu_baseline"] = cpu_baseline_cov(k, L, args.cpu_seconds, args.genome, wl["bin_size"], wl["bin_count"])
             else:

@@ -155,6 +155,23 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
 int kt_cgr_points(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                   double vecsize, double *xy, uint64_t *bad_pos, int mem);
 
+/* replaces: MinimiserGenerator::new + Iterator::next, kmer/src/minimiser.rs:36-56, :61-175 (and
+ * python MinimiserGenerator, pybindings/src/min.rs:24-47; the per-record loops of
+ * misc/src/minimisers.rs:43-54, :124-135).  For every read, in iterator order, the triples
+ * (minimiser, window start, window end) the reference yields; read i owns entries
+ * [ev_offsets[i], ev_offsets[i+1]) of kmers/starts/ends (starts/ends are read-local, ends
+ * exclusive).  wsize = 0 means "the read's own length" (one minimiser per read,
+ * misc/src/minimisers.rs:44-48); otherwise msize <= wsize and wsize - msize + 1 <= 1024.
+ * 1 <= msize <= 31.  Quirks of the iterator are kept (a change on the last base swallows the
+ * final window; a last run shorter than the window reports UINT64_MAX).  Reads shorter than msize
+ * yield nothing with wsize = 0 (the reference's capacity arithmetic underflows there).
+ * Always synchronises.  *n_events = number of triples.  capacity = room in kmers/starts/ends:
+ * 0 counts only (ev_offsets is then unspecified); if 0 < capacity < *n_events the first
+ * `capacity` triples are written and KT_ERR_ARG is returned. */
+int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                  uint64_t wsize, int msize, uint64_t *ev_offsets, uint64_t *kmers,
+                  uint64_t *starts, uint64_t *ends, uint64_t capacity, uint64_t *n_events, int mem);
+
 /* replaces: CovComputer::vectorise_one, coverage/src/lib.rs:165-184 (and the HashMap
  * re-load of kmers.counts at :82-92: the table is probed where kt_ctr_add_reads left it).
  * For every canonical k-mer of a read (k = the table's k): count = table[kmer] or 0,

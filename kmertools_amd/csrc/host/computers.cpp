@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <charconv>
 #include <chrono>
@@ -166,6 +167,8 @@ static void format_rows(uint64_t n, int threads, size_t bytes_per_row, std::vect
 struct Work {
     Batch b;
     std::vector<double> rows;
+    std::vector<uint64_t> u64[4];  // minimisers: event offsets, m-mers, starts, ends
+    uint64_t n_events = 0;
 };
 
 template <class T>
@@ -203,7 +206,7 @@ class Channel {
 // device(w): fills w.rows from w.b, returns "" or an error message.  emit(w): writes the text.
 static std::string run_pipeline(SeqReader &reader, uint64_t max_bases, uint64_t max_reads, PhaseTimer &pt,
                                 const std::function<std::string(Work &)> &device,
-                                const std::function<void(Work &)> &emit) {
+                                const std::function<void(Work &)> &emit, bool keep_ids = false) {
     constexpr int DEPTH = 3;
     Work items[DEPTH];
     Channel<Work *> free_q, read_q, done_q;
@@ -215,7 +218,7 @@ static std::string run_pipeline(SeqReader &reader, uint64_t max_bases, uint64_t 
         Lap lap;
         while (more && !stop.load() && free_q.pop(w)) {
             lap();
-            more = reader.next_batch(w->b, max_bases, max_reads);
+            more = reader.next_batch(w->b, max_bases, max_reads, keep_ids);
             pt.t[0] += lap();
             if (w->b.n_reads()) read_q.push(w); else free_q.push(w);
         }
@@ -608,6 +611,181 @@ std::string CovComputer::compute_coverages() {
         [&](Work &w) { emit_matrix(out, w, bins, norm_, delim_, threads_, pieces, pt); });  // :112-124
     fclose(out);
     return err;
+}
+
+// ---------------------------------------------------------------------------------------------
+// minimisers: one C-ABI call per batch; the capacity is a guess that is corrected on the first miss
+static std::string minimiser_batch(kt_ctx *ctx, Work &w, uint64_t wsize, int msize) {
+    const uint64_t n = w.b.n_reads();
+    w.u64[0].resize(n + 1);
+    uint64_t cap = w.u64[1].size();
+    if (cap < n + 16) cap = wsize ? w.b.bases.size() / 4 + n + 16 : n + 16;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (int i = 1; i < 4; i++) w.u64[i].resize(cap);
+        const int rc = kt_minimisers(ctx, bases_ptr(w.b), w.b.offsets.data(), n, wsize, msize, w.u64[0].data(),
+                                     w.u64[1].data(), w.u64[2].data(), w.u64[3].data(), cap, &w.n_events, KT_MEM_HOST);
+        if (rc == KT_OK) return "";
+        if (w.n_events <= cap) return kt_last_error();  // a real error, not a capacity miss
+        cap = w.n_events;
+    }
+    return kt_last_error();
+}
+
+static void append_mmer(std::string &s, uint64_t kmer, int msize) {
+    char buf[40];
+    kt_numeric_to_kmer(kmer, msize, buf);  // u64::MAX (no full window) prints as all T, like the reference
+    s += buf;
+}
+
+static void append_u64(std::string &s, uint64_t v) {
+    char buf[24];
+    const auto r = std::to_chars(buf, buf + sizeof buf, v);
+    s.append(buf, (size_t)(r.ptr - buf));
+}
+
+static std::string check_min_args(uint64_t wsize, int msize, const std::string &in_path) {
+    if (msize < 1 || msize > 31) return "minimiser size must be in 1..31";
+    if (wsize != 0 && wsize < (uint64_t)msize) return "window size must not be shorter than the minimiser";
+    if (format_from_path(in_path) == SeqFormat::Unknown && in_path != "-")
+        return "unsupported input extension (expected .fa/.fasta/.fna/.fq/.fastq[.gz]): " + in_path;  // SeqFormat::get().unwrap()
+    return "";
+}
+
+std::string seq_to_min(uint64_t wsize, int msize, const std::string &in_path, const std::string &out_path, int threads,
+                       int device) {
+    if (std::string e = check_min_args(wsize, msize, in_path); !e.empty()) return e;
+    SeqReader reader;
+    if (!reader.open(in_path, false)) return reader.error();
+    FILE *out = fopen(out_path.c_str(), "wb");
+    if (!out) return "Unable to write to file: " + out_path;
+    Device dev;
+    dev.index = device;
+    if (std::string e = dev.ensure(); !e.empty()) {
+        fclose(out);
+        return e;
+    }
+    std::vector<std::string> pieces;
+    PhaseTimer pt("min s2m");
+    const std::string err = run_pipeline(
+        reader, 64ull << 20, 1ull << 19, pt, [&](Work &w) { return minimiser_batch(dev.ctx, w, wsize, msize); },
+        [&](Work &w) {
+            Lap lap;
+            const uint64_t *evo = w.u64[0].data(), *km = w.u64[1].data(), *st = w.u64[2].data(), *en = w.u64[3].data();
+            const uint64_t n = w.b.n_reads();
+            const size_t per_row = n ? (size_t)(w.n_events / n + 1) * (size_t)(msize + 12) + 24 : 1;
+            format_rows(n, threads, per_row, pieces, [&](uint64_t r, std::string &s) {
+                s += w.b.ids[r];  // mins.join("\t") over [id, "MMER:s-e"..., "\n"]  (:131-141)
+                for (uint64_t j = evo[r]; j < evo[r + 1]; j++) {
+                    s += '\t';
+                    append_mmer(s, km[j], msize);
+                    s += ':';
+                    append_u64(s, st[j]);
+                    s += '-';
+                    append_u64(s, en[j]);
+                }
+                s += "\t\n";
+            });
+            pt.t[2] += lap();
+            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+            pt.t[3] += lap();
+        },
+        true);
+    fclose(out);
+    return err;
+}
+
+// Rust's {:?} for a String: quotes, with \" \\ \t \n \r and other control characters escaped
+static void append_debug_str(std::string &s, const std::string &id) {
+    s += '"';
+    for (unsigned char c : id) {
+        switch (c) {
+            case '"': s += "\\\""; break;
+            case '\\': s += "\\\\"; break;
+            case '\t': s += "\\t"; break;
+            case '\n': s += "\\n"; break;
+            case '\r': s += "\\r"; break;
+            case '\'': s += "'"; break;
+            default:
+                if (c < 0x20 || c == 0x7f) {
+                    char buf[16];
+                    snprintf(buf, sizeof buf, "\\u{%x}", c);
+                    s += buf;
+                } else {
+                    s += (char)c;
+                }
+        }
+    }
+    s += '"';
+}
+
+std::string bin_sequences(uint64_t wsize, int msize, const std::string &in_path, const std::string &out_path, int threads,
+                          int device) {
+    if (std::string e = check_min_args(wsize, msize, in_path); !e.empty()) return e;
+    SeqReader reader;
+    if (!reader.open(in_path, false)) return reader.error();
+    FILE *out = fopen(out_path.c_str(), "wb");
+    if (!out) return "Unable to write to file: " + out_path;
+    Device dev;
+    dev.index = device;
+    if (std::string e = dev.ensure(); !e.empty()) {
+        fclose(out);
+        return e;
+    }
+    // the whole file's triples are grouped by minimiser at the end, like the reference's in-memory map
+    struct Hit {
+        uint64_t kmer;
+        uint32_t id, start, end;  // id = index into `ids`
+    };
+    std::vector<Hit> hits;
+    std::vector<std::string> ids;
+    PhaseTimer pt("min m2s");
+    const std::string err = run_pipeline(
+        reader, 64ull << 20, 1ull << 19, pt, [&](Work &w) { return minimiser_batch(dev.ctx, w, wsize, msize); },
+        [&](Work &w) {
+            Lap lap;
+            const uint64_t *evo = w.u64[0].data();
+            const uint32_t id0 = (uint32_t)ids.size();
+            ids.insert(ids.end(), w.b.ids.begin(), w.b.ids.end());
+            for (uint64_t r = 0; r < w.b.n_reads(); r++)
+                for (uint64_t j = evo[r]; j < evo[r + 1]; j++)
+                    hits.push_back(Hit{w.u64[1][j], id0 + (uint32_t)r, (uint32_t)w.u64[2][j], (uint32_t)w.u64[3][j]});
+            pt.t[2] += lap();
+        },
+        true);
+    if (!err.empty()) {
+        fclose(out);
+        return err;
+    }
+    Lap lap;
+    // ascending minimiser text == ascending value of its low 2m bits (A < C < G < T is the 2-bit order)
+    const uint64_t mask = msize >= 32 ? ~0ull : ((1ull << (2 * msize)) - 1ull);
+    std::stable_sort(hits.begin(), hits.end(), [&](const Hit &x, const Hit &y) { return (x.kmer & mask) < (y.kmer & mask); });
+    std::vector<uint64_t> group_start;
+    for (uint64_t i = 0; i < hits.size(); i++)
+        if (i == 0 || (hits[i].kmer & mask) != (hits[i - 1].kmer & mask)) group_start.push_back(i);
+    group_start.push_back(hits.size());
+    std::vector<std::string> pieces;
+    const uint64_t n_groups = group_start.size() - 1;
+    format_rows(n_groups, threads, (size_t)msize + 48, pieces, [&](uint64_t g, std::string &s) {
+        append_mmer(s, hits[group_start[g]].kmer, msize);  // "{k}\t{v:?}\n"  (:81-84)
+        s += "\t[";
+        for (uint64_t i = group_start[g]; i < group_start[g + 1]; i++) {
+            if (i != group_start[g]) s += ", ";
+            s += '(';
+            append_debug_str(s, ids[hits[i].id]);
+            s += ", ";
+            append_u64(s, hits[i].start);
+            s += ", ";
+            append_u64(s, hits[i].end);
+            s += ')';
+        }
+        s += "]\n";
+    });
+    pt.t[2] += lap();
+    for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+    fclose(out);
+    pt.t[3] += lap();
+    return "";
 }
 
 }  // namespace kthost

@@ -4,6 +4,7 @@
 //   CgrComputer        composition/src/cgr.rs:42-144
 //   CountComputer      counter/src/lib.rs:22-90, 172-234
 //   CovComputer        coverage/src/lib.rs:14-184
+//   seq_to_min / bin_sequences   misc/src/minimisers.rs:11-160 (free functions there too)
 // Same constructor arguments, setters and entry points (vectorise / count / merge); the
 // per-read / per-k-mer work goes through the C ABI (include/kmertools_hip.h) to the GPU.
 // The reference's error style is kept: vectorise() returns "" on success or the message that
@@ -109,6 +110,16 @@ class CountComputer {
     Device dev_;
     kt_ctr *ctr_ = nullptr;
 };
+
+// `min -p s2m`: one line per record, "id\tMMER:start-end\t...\t\n" (misc/src/minimisers.rs:93-160).
+// `min -p m2s`: one line per minimiser, "MMER\t[(\"id\", start, end), ...]\n" - Rust's {:?} of the
+// Vec<(String, usize, usize)> (:11-91).  The reference's line order (and, for m2s, the order inside a
+// vector) depends on thread timing; here lines follow the input (s2m) or ascending minimiser text (m2s).
+// wsize 0 = one minimiser per sequence.  Return "" or the error message.
+std::string seq_to_min(uint64_t wsize, int msize, const std::string &in_path, const std::string &out_path, int threads,
+                       int device = 0);
+std::string bin_sequences(uint64_t wsize, int msize, const std::string &in_path, const std::string &out_path, int threads,
+                          int device = 0);
 
 class CovComputer {
   public:

@@ -1,8 +1,7 @@
 // kmertools (GPU drop-in) - command line with the reference's `comp oligo`, `comp cgr -k` and
 // `ctr` flags (kmertools/src/args.rs:70-130, 208-236; dispatcher :239-368) and `cov`
 // (args.rs:132-172, :299-325).  clap conventions are kept: kebab-case long flags, the
-// auto-derived short flags, `--flag=value`, `-k4`.  `min` is outside this build's scope
-//  and says so.
+// auto-derived short flags, `--flag=value`, `-k4`.  `min`: args.rs:172-205, :326-352.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -121,12 +120,12 @@ std::string required_str(const std::map<std::string, std::string> &f, const char
 const char *HELP_MAIN =
     "kmertools: DNA vectorisation\n\n"
     "k-mer based vectorisation for DNA sequences for\nmetagenomics and AI/ML applications\n"
-    "(MI355X build: comp oligo, comp cgr -k, cov and ctr run on the GPU)\n\n"
+    "(MI355X build: every subcommand's per-base work runs on the GPU)\n\n"
     "Usage: kmertools <COMMAND>\n\n"
     "Commands:\n"
     "  comp  Generate sequence composition based features\n"
     "  cov   Generates coverage histogram based on the reads\n"
-    "  min   Bin reads using minimisers (not in this build)\n"
+    "  min   Bin reads using minimisers\n"
     "  ctr   Count k-mers\n"
     "  help  Print this message or the help of the given subcommand(s)\n\n"
     "Options:\n  -h, --help     Print help\n  -V, --version  Print version\n";
@@ -236,6 +235,47 @@ int cmd_cov(int argc, char **argv, int from) {
     if (!e.empty()) {
         fprintf(stderr, "Error: %s\n", e.c_str());
         return 101;  // build_table().unwrap() / unwraps inside compute_coverages
+    }
+    return 0;
+}
+
+const char *HELP_MIN =
+    "Bin reads using minimisers\n\n"
+    "Usage: kmertools min [OPTIONS] --input <INPUT> --output <OUTPUT>\n\n"
+    "Options:\n"
+    "  -i, --input <INPUT>      Input file path\n"
+    "  -o, --output <OUTPUT>    Output vectors path\n"
+    "  -m, --m-size <M_SIZE>    Minimiser size [default: 10]\n"
+    "  -w, --w-size <W_SIZE>    Window size\n"
+    "                           \n"
+    "                           0 - emits one minimiser per sequence (useful for sequencing reads)\n"
+    "                           w_size must be longer than m_size [default: 0]\n"
+    "  -p, --preset <PRESET>    Output type to write [default: s2m] [possible values: s2m, m2s]\n"
+    "  -t, --threads <THREADS>  Thread count for computations 0=auto [default: 0]\n"
+    "      --device <DEVICE>    GPU index [default: 0]\n"
+    "  -h, --help               Print help\n";
+
+int cmd_min(int argc, char **argv, int from) {
+    const std::vector<Spec> specs = {{'i', "input", true},  {'o', "output", true},  {'m', "m-size", true}, {'w', "w-size", true},
+                                     {'p', "preset", true}, {'t', "threads", true}, {0, "device", true}};
+    const auto f = parse_flags(argc, argv, from, specs, HELP_MIN);
+    const std::string in = required_str(f, "input"), out = required_str(f, "output");
+    const int m = (int)ranged(f, "m-size", 7, 28, false, 10);
+    const uint64_t w = ranged(f, "w-size", 0, ~0ull, false, 0);
+    const int threads = (int)ranged(f, "threads", 0, 1 << 20, false, 0);
+    const int device = (int)ranged(f, "device", 0, 63, false, 0);
+    std::string preset = f.count("preset") ? f.at("preset") : "s2m";
+    if (preset != "s2m" && preset != "m2s")
+        usage_error("invalid value '" + preset + "' for '--preset <PRESET>'\n  [possible values: s2m, m2s]");
+    if (w <= (uint64_t)m && w > 0) {  // args.rs:327-330 (returns normally)
+        fprintf(stderr, "Window size must be longer than minimiser size!\n");
+        return 0;
+    }
+    const std::string e = preset == "m2s" ? bin_sequences(w, m, in, out, threads, device)
+                                          : seq_to_min(w, m, in, out, threads, device);
+    if (!e.empty()) {
+        fprintf(stderr, "Error: %s\n", e.c_str());
+        return 101;  // the reference unwraps every failure in these two functions
     }
     return 0;
 }
@@ -436,9 +476,6 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (cmd == "cov") return cmd_cov(argc, argv, 2);
-    if (cmd == "min") {
-        fprintf(stderr, "Error: `kmertools %s` is outside the scope of this GPU build (see DESIGN.md section 7)\n", cmd.c_str());
-        return 2;
-    }
+    if (cmd == "min") return cmd_min(argc, argv, 2);
     usage_error("unrecognized subcommand '" + cmd + "'");
 }

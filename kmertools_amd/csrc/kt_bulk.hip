@@ -60,10 +60,10 @@ struct Meta {           // device arrays carved from ctr->b_meta
 };
 
 __device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) {
-    return (uint32_t)(ktd::mix64(key) >> (64 - p.b1));
+    return (uint32_t)(ktd::khash(key) >> (64 - p.b1));
 }
 __device__ __forceinline__ uint32_t digit2(uint64_t key, const Plan &p) {
-    return (uint32_t)(ktd::mix64(key) >> (64 - p.b1 - p.b2)) & (p.B2 - 1);
+    return (uint32_t)(ktd::khash(key) >> (64 - p.b1 - p.b2)) & (p.B2 - 1);
 }
 
 // exclusive prefix sum of cnt[0..B) into out[0..B) (LDS arrays), B <= MAX_B; returns the total.
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
           for (int u = 0; u < 4; u++) {
             const uint64_t key = kk[u];
             if (key == KT_EMPTY_KEY) continue;
-            uint32_t s = (uint32_t)(ktd::mix64(key) >> shift) & (S - 1);
+            uint32_t s = (uint32_t)(ktd::khash(key) >> shift) & (S - 1);
             bool placed = false;
             for (; s < S; s++) {  // forward only: never wrap inside the range (kt_table.hpp invariant)
                 uint64_t cur = sm.keys[s];

@@ -27,10 +27,25 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-// owner of a canonical k-mer among n owners: LOW 32 bits of the mix, multiply-shift (the
+#ifndef KT_KHASH
+#define KT_KHASH 0
+#endif
+// hash of a canonical k-mer: TOP bits pick the partition digits / home slot, LOW 32 bits the owning GPU
+__host__ __device__ __forceinline__ uint64_t khash(uint64_t key) {
+#if KT_KHASH == 0
+    return mix64(key);
+#elif KT_KHASH == 1
+    uint64_t h = key * 0x9e3779b97f4a7c15ull;
+    return h ^ (h >> 32);
+#else
+    return key << 2;
+#endif
+}
+
+// owner of a canonical k-mer among n owners: LOW 32 bits of the hash, multiply-shift (the
 // table's home slot uses the top bits of the same hash, kt_table.hpp)
 __host__ __device__ __forceinline__ uint32_t owner_of(uint64_t kmer, uint32_t n) {
-    return (uint32_t)(((mix64(kmer) & 0xFFFFFFFFull) * (uint64_t)n) >> 32);
+    return (uint32_t)(((khash(kmer) & 0xFFFFFFFFull) * (uint64_t)n) >> 32);
 }
 
 // reverse complement of a packed k-mer (2 bits/base) without a loop:

@@ -28,7 +28,7 @@ struct TableRef {
 };
 
 __host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, uint32_t shift) {
-    return shift >= 64 ? 0 : (ktd::mix64(key) >> shift);
+    return shift >= 64 ? 0 : (ktd::khash(key) >> shift);
 }
 
 // table[key] += add.  A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe

@@ -144,6 +144,34 @@ class Context:
                  KT_MEM_HOST)
         return xy[:total]
 
+    # -- min: window minimisers ---------------------------------------------------------------------
+    def minimisers(self, bases, offsets, n_reads, wsize, msize, ev_offsets, kmers, starts, ends, capacity,
+                   mem=KT_MEM_DEVICE):
+        """-> number of (minimiser, start, end) triples; capacity 0 only counts (synchronises either way)"""
+        n = C.c_uint64()
+        check(_lib.lib().kt_minimisers(self._h, _ptr(bases), _ptr(offsets), n_reads, int(wsize), int(msize),
+                                       _ptr(ev_offsets), _ptr(kmers), _ptr(starts), _ptr(ends), int(capacity),
+                                       C.byref(n), mem))
+        return n.value
+
+    def minimisers_host(self, bases, offsets, wsize, msize):
+        """-> (ev_offsets u64[n+1], kmers, starts, ends): read i owns [ev_offsets[i], ev_offsets[i+1])"""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        n = len(offsets) - 1
+        evo = np.zeros(n + 1, np.uint64)
+        bb = bases if bases.size else np.zeros(1, np.uint8)
+        empty = np.zeros(1, np.uint64)
+        cnt = self.minimisers(bb, offsets, n, wsize, msize, evo, empty, empty, empty, 0, KT_MEM_HOST) if n else 0
+        k = np.zeros(max(cnt, 1), np.uint64)
+        s = np.zeros(max(cnt, 1), np.uint64)
+        e = np.zeros(max(cnt, 1), np.uint64)
+        if cnt:
+            self.minimisers(bb, offsets, n, wsize, msize, evo, k, s, e, cnt, KT_MEM_HOST)
+        else:
+            evo[:] = 0
+        return evo, k[:cnt], s[:cnt], e[:cnt]
+
     # -- KmerGenerator surface -----------------------------------------------------------
     def kmers(self, bases, offsets, n_reads, k, fwd, rev, valid, mem=KT_MEM_DEVICE):
         check(_lib.lib().kt_kmers(self._h, _ptr(bases), _ptr(offsets), n_reads, k, _ptr(fwd), _ptr(rev),

@@ -7,6 +7,7 @@ Same class names, argument names, defaults and error behaviour:
                         .vectorise_batch(seqs, norm=True, mins=True)   :77
                         .get_header(mins=True)                         :85
     CgrComputer(vecsize).vectorise_one(seq) / .vectorise_batch(seqs)   pybindings/src/cgr.rs:22,38,60
+    MinimiserGenerator(seq, wsize, msize)  iterable of (mmer, start, end), .to_acgt(mmer)   pybindings/src/min.rs:24,36,46
     KmerGenerator(seq, ksize)  iterable of (fwd, rev)                  pybindings/src/kmer.rs:22,39
                  .kmer_pos_maps()                                      :31
     utils.to_acgt(kmer, ksize) / utils.to_numeric(kmer)                :49,:57
@@ -84,6 +85,35 @@ class CgrComputer:
             raise
         pts = list(map(tuple, xy.tolist()))
         return [pts[int(offsets[i]):int(offsets[i + 1])] for i in range(len(offsets) - 1)]
+
+
+class MinimiserGenerator:
+    """An iterator object to iterate minimisers as (kmer, start, end) numeric minimiser tuples"""
+
+    def __init__(self, seq, wsize, msize):
+        self.msize = int(msize)
+        wsize = int(wsize)
+        if not 1 <= self.msize <= 31:
+            raise ValueError("msize must be in 1..31")
+        if wsize < self.msize:
+            # the reference computes `wsize - msize + 1` in usize here (kmer/src/minimiser.rs:53) and panics
+            raise ValueError("wsize must not be smaller than msize")
+        bases, offsets = device.to_csr([seq])
+        evo, k, s, e = _context().minimisers_host(bases, offsets, wsize, self.msize)
+        self._items = list(zip(k.tolist(), s.tolist(), e.tolist()))
+        self._i = 0
+
+    def to_acgt(self, mmer):
+        return device.numeric_to_kmer(int(mmer), self.msize)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._i >= len(self._items):
+            raise StopIteration
+        self._i += 1
+        return self._items[self._i - 1]
 
 
 class KmerGenerator:

@@ -433,6 +433,109 @@ uint64_t kto_cgr_batch(const uint8_t *bases, const uint64_t *offsets, uint64_t n
 }
 
 /* ------------------------------------------------------------------------ */
+/* kmer/src/minimiser.rs:21-175 MinimiserGenerator: state + Iterator::next, statement for statement.
+ * The VecDeque (capacity wsize - msize + 1) is a ring buffer here.  Emits (minimiser, window start,
+ * window end) every time the active minimiser of the sliding window changes, at an ambiguous base
+ * that ends a full window, and once more at the last base.  wsize is used as given (the callers pass
+ * seq.len() for "0", misc/src/minimisers.rs:44-48). */
+typedef struct {
+    const uint8_t *seq;
+    uint64_t len_seq, pos, wsize, msize, m_mask, m_window_start, m_window_end;
+    uint64_t m_val_f, m_val_r, m_val_l, m_active, m_shift;
+    uint64_t *buff;
+    uint64_t cap, head, blen, buff_pos;
+} kto_mingen;
+
+static uint64_t mg_get(const kto_mingen *g, uint64_t j) { return g->buff[(g->head + j) % g->cap]; }
+
+static int kto_mingen_next(kto_mingen *g, uint64_t *kmer, uint64_t *ws, uint64_t *we) {
+    const uint64_t full = g->wsize - g->msize + 1;   /* wraps like usize if wsize < msize - 1: callers exclude it */
+    for (;;) {
+        if (g->pos == g->len_seq) return 0;                                   /* :68-70 */
+        uint64_t fv = NT4[g->seq[g->pos]];
+        uint64_t rv = fv ^ 3;
+        if (fv < 4) {                                                         /* :75-80 */
+            g->m_val_f = ((g->m_val_f << 2) | fv) & g->m_mask;
+            g->m_val_r = (g->m_val_r >> 2) | (rv << g->m_shift);
+            g->m_val_l += 1;
+        } else {                                                              /* :81-101 */
+            int should_return = g->blen == full;
+            uint64_t pm = g->m_active, pws = g->m_window_start, pwe = g->pos;
+            g->buff_pos = 0;
+            g->m_active = ~0ULL;
+            g->m_val_f = g->m_val_r = g->m_val_l = 0;
+            g->m_window_end = 0;
+            g->m_window_start = g->pos + 1;
+            g->blen = 0; g->head = 0;
+            g->pos += 1;
+            if (should_return) { *kmer = pm; *ws = pws; *we = pwe; return 1; }
+            continue;
+        }
+        if (g->m_val_l < g->msize) { g->pos += 1; continue; }                 /* :103-106 */
+        g->m_val_l -= 1;
+        uint64_t mv = g->m_val_f < g->m_val_r ? g->m_val_f : g->m_val_r;      /* :110 */
+        if (g->blen == full) {                                                /* :113 */
+            g->head = (g->head + 1) % g->cap;                                 /* pop_front */
+            g->buff[(g->head + g->blen - 1) % g->cap] = mv;                   /* push_back */
+            if (g->buff_pos == 0) {                                           /* :119-138 */
+                uint64_t new_min = ~0ULL;
+                for (uint64_t j = 0; j < g->blen; j++)
+                    if (mg_get(g, j) < new_min) { g->buff_pos = j; new_min = mg_get(g, j); }
+                if (new_min != g->m_active) {
+                    g->m_window_end = g->pos;
+                    *kmer = g->m_active; *ws = g->m_window_start; *we = g->m_window_end;
+                    g->m_active = new_min;
+                    g->m_window_start = g->pos - g->wsize + 1;
+                    g->pos += 1;
+                    return 1;
+                }
+            } else if (mv < g->m_active) {                                    /* :139-149 */
+                g->m_window_end = g->pos;
+                *kmer = g->m_active; *ws = g->m_window_start; *we = g->m_window_end;
+                g->m_active = mv;
+                g->buff_pos = g->blen - 1;
+                g->m_window_start = g->pos - g->wsize + 1;
+                g->pos += 1;
+                return 1;
+            } else {
+                g->buff_pos -= 1;                                             /* :150-152 */
+            }
+        } else {
+            g->buff[(g->head + g->blen) % g->cap] = mv;                       /* :153-156 */
+            g->blen += 1;
+        }
+        if (g->m_active == ~0ULL && g->blen == full) {                        /* :158-166 */
+            for (uint64_t j = 0; j < g->blen; j++)
+                if (mg_get(g, j) < g->m_active) { g->buff_pos = j; g->m_active = mg_get(g, j); }
+        }
+        if (g->pos == g->len_seq - 1) {                                       /* :168-171 */
+            g->pos += 1;
+            *kmer = g->m_active; *ws = g->m_window_start; *we = g->len_seq;
+            return 1;
+        }
+        g->pos += 1;
+    }
+}
+
+/* all (minimiser, start, end) triples of one sequence; returns the count (<= n + 1) */
+uint64_t kto_minimisers(const uint8_t *seq, uint64_t n, uint64_t wsize, uint64_t msize,
+                        uint64_t *kmers, uint64_t *starts, uint64_t *ends) {
+    pthread_once(&nt4_once, nt4_init);
+    kto_mingen g;
+    memset(&g, 0, sizeof g);
+    g.seq = seq; g.len_seq = n; g.wsize = wsize; g.msize = msize;
+    g.m_active = ~0ULL;
+    g.m_mask = (1ULL << (2 * msize)) - 1;
+    g.m_shift = 2 * (msize - 1);
+    g.cap = wsize - msize + 2;
+    g.buff = (uint64_t *)malloc(g.cap * sizeof(uint64_t));
+    uint64_t c = 0, k, s, e;
+    while (kto_mingen_next(&g, &k, &s, &e)) { kmers[c] = k; starts[c] = s; ends[c] = e; c++; }
+    free(g.buff);
+    return c;
+}
+
+/* ------------------------------------------------------------------------ */
 /* coverage/src/lib.rs:165-184 CovComputer::vectorise_one over a CSR batch:
  * per k-mer: count = table[min(f,r)] or 0 (:171), bin = min(floor(count / bin_size),
  * bin_count - 1) (:172-173), vec[bin] += 1, total += 1; norm: /= max(1, total) (:180-182). */

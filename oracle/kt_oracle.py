@@ -72,6 +72,8 @@ def lib():
         L.kto_counter_export.argtypes = [C.c_void_p, u64p, u32p, C.c_int]
         L.kto_cgr_one.restype = C.c_uint64
         L.kto_cgr_one.argtypes = [u8p, C.c_uint64, C.c_double, f64p]
+        L.kto_minimisers.restype = C.c_uint64
+        L.kto_minimisers.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, u64p]
         L.kto_cgr_batch.restype = C.c_uint64
         L.kto_cgr_batch.argtypes = [u8p, u64p, C.c_uint64, C.c_double, f64p]
         L.kto_cov_batch.restype = C.c_int
@@ -175,6 +177,41 @@ def cgr_coords(k, vecsize):
     xy = np.zeros((c, 2), dtype=np.float64)
     lib().kto_cgr_coords(k, float(vecsize), _p(xy, f64p))
     return xy
+
+
+def minimisers(seq, wsize, msize):
+    """kmer/src/minimiser.rs:61-175: [(minimiser, window_start, window_end)]; wsize 0 = whole sequence
+    (misc/src/minimisers.rs:44-48)"""
+    b = np.frombuffer(seq.encode("latin-1") if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+    n = len(b)
+    if wsize == 0:
+        wsize = n
+    buf = np.zeros(max(n, 1), np.uint8)
+    buf[:n] = b
+    k = np.zeros(n + 2, np.uint64)
+    s = np.zeros(n + 2, np.uint64)
+    e = np.zeros(n + 2, np.uint64)
+    c = lib().kto_minimisers(_p(buf, u8p), n, wsize, msize, _p(k, u64p), _p(s, u64p), _p(e, u64p))
+    return [(int(k[i]), int(s[i]), int(e[i])) for i in range(c)]
+
+
+def seq_to_min_lines(records, wsize, msize):
+    """misc/src/minimisers.rs:131-141: "id\tKMER:s-e\t...\t\n" per record"""
+    out = []
+    for rid, seq in records:
+        parts = [rid] + ["%s:%d-%d" % (numeric_to_kmer(k, msize), s, e) for k, s, e in minimisers(seq, wsize, msize)]
+        parts.append("\n")
+        out.append("\t".join(parts))
+    return out
+
+
+def bin_sequences_lines(records, wsize, msize):
+    """misc/src/minimisers.rs:49-54,81-84: minimiser -> [(id, start, end)] in Rust Debug format"""
+    table = {}
+    for rid, seq in records:
+        for k, s, e in minimisers(seq, wsize, msize):
+            table.setdefault(numeric_to_kmer(k, msize), []).append((rid, s, e))
+    return ["%s\t[%s]\n" % (k, ", ".join('("%s", %d, %d)' % t for t in v)) for k, v in table.items()]
 
 
 def cgr_points(seq, vecsize=1):

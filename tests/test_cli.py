@@ -158,6 +158,20 @@ def test_cli_golden_outputs(cli, golden, tmp_path):
     nfa.write_text(">a\nACGT\n>b\nACNT\n")
     r = run(cli, "comp", "cgr", "-i", nfa, "-o", w)
     assert r.returncode == 101 and "Bad nucleotide, unable to proceed" in r.stderr
+    # min: the two presets against the reference's fixtures, compared like its own tests (trimmed, sorted lines)
+    def trimmed(path):
+        return sorted(ln.strip() for ln in path.read_text().splitlines())
+    mo = tmp_path / "mins"
+    r = run(cli, "min", "-i", golden / "reads.fq", "-o", mo, "-w", "31", "-m", "7")
+    assert r.returncode == 0 and r.stderr == ""
+    assert mo.read_text().endswith("\t\n") and trimmed(mo) == trimmed(golden / "expected_seq_minimisers")
+    r = run(cli, "min", "-i", golden / "reads.fq", "-o", mo, "-p", "m2s")
+    assert r.returncode == 0 and r.stderr == ""
+    assert trimmed(mo) == trimmed(golden / "expected_minimisers")
+    r = run(cli, "min", "-i", golden / "reads.fq", "-o", mo, "-w", "7", "-m", "7")
+    assert r.returncode == 0 and "Window size must be longer than minimiser size!" in r.stderr
+    r = run(cli, "min", "-i", golden / "reads.fq", "-o", mo, "-m", "29")
+    assert r.returncode == 2 and "is not in 7..=28" in r.stderr
     # cov: the reference's test uses k=4 / bin_size 2 / bin_count 3 through the library API, which the
     # CLI's clap ranges (k 7..=31, bins >= 5) cannot express -> check the CLI against the oracle in
     # test_cli_larger_file_matches_oracle and the flag ranges here
@@ -213,3 +227,14 @@ def test_cli_larger_file_matches_oracle(cli, oracle, tmp_path):
     w = tmp_path / "whole.cgr"
     assert run(cli, "comp", "cgr", "-i", fa3, "-o", w, "-v", "16").stderr == ""
     assert w.read_bytes() == oracle.cgr_text([oracle.cgr_points(s, 16) for s in clean])
+    # min on the 5000 ragged reads: s2m lines in input order, m2s grouped by minimiser
+    mo = tmp_path / "mins"
+    recs = [("s%d" % i, s) for i, s in enumerate(seqs)]
+    assert run(cli, "min", "-i", fa, "-o", mo, "-w", "20", "-m", "9").stderr == ""
+    assert mo.read_text() == "".join(oracle.seq_to_min_lines(recs, 20, 9))
+    long_enough = [(i, s) for i, s in recs if len(s) >= 10]
+    fa4 = tmp_path / "r4.fasta"
+    fa4.write_text("".join(">%s\n%s\n" % (i, s) for i, s in long_enough))
+    assert run(cli, "min", "-i", fa4, "-o", mo, "-p", "m2s").stderr == ""
+    assert sorted(mo.read_text().splitlines(keepends=True)) == sorted(oracle.bin_sequences_lines(long_enough, 0, 10))
+    assert mo.read_text().splitlines() == sorted(mo.read_text().splitlines())

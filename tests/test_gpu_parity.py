@@ -693,3 +693,97 @@ def test_cgr_long_sequence(hctx, oracle):
     got = hctx.cgr_host(bases, offsets, 7)
     want = np.concatenate([oracle.cgr_points(s, 7) for s in seqs if len(s)])
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+# ---------------------------------------------------------------------------------------------
+# minimisers (kt_minimisers): kmer/src/minimiser.rs:61-175
+def _min_triples(hctx, seqs, w, m):
+    from kmertools_amd import device
+    bases, offsets = device.to_csr(seqs)
+    evo, k, s, e = hctx.minimisers_host(bases, offsets, w, m)
+    assert len(evo) == len(seqs) + 1 and int(evo[0]) == 0 and int(evo[-1]) == len(k)
+    return [[(int(k[j]), int(s[j]), int(e[j])) for j in range(int(evo[i]), int(evo[i + 1]))] for i in range(len(seqs))]
+
+
+def test_minimisers_reference_cases(hctx, oracle, golden):
+    seq = ("ATGCGATATCGTAGGCGTCGATGGAGAGCTAGATCGATCGATCTAAATCCCGATCGATTCCGAGCGCGATCAAAGCGCGATAGGCTAGCTAAAG"
+           "CTAGCA")
+    assert _min_triples(hctx, [seq], 31, 7)[0] == oracle.minimisers(seq, 31, 7)
+    seq2 = "ATGCGATATCGNTAGGCGTCGATGGA"
+    assert _min_triples(hctx, [seq2], 8, 5)[0] == oracle.minimisers(seq2, 8, 5)
+    recs = [(i, s.decode()) for i, s in oracle.read_records(golden / "reads.fq")]
+    for w, m in ((31, 7), (0, 10)):
+        got = _min_triples(hctx, [s for _, s in recs], w, m)
+        assert got == [oracle.minimisers(s, w, m) for _, s in recs]
+
+
+@pytest.mark.parametrize("w,m", [(31, 7), (8, 5), (5, 5), (12, 3), (40, 28), (200, 15), (1040, 17), (0, 10), (0, 7),
+                                  (64, 31), (33, 1)])
+def test_minimisers_vs_oracle(hctx, oracle, w, m):
+    """ragged reads with N runs, lower case, raw codes, empty reads, reads shorter than m / w, reads that end in
+    N or right after a window filled, and reads longer than several tiles"""
+    rng = np.random.default_rng(1000 * w + m)
+    seqs = [s.decode("latin-1") for s in ragged_reads(300 + w + m, 400, max_len=500)]
+    alpha = np.array(list("ACGT"))
+    for L in (m - 1 if m > 1 else 1, m, m + 1, max(w, m), max(w, m) + 1, 3071, 3072, 3073, 4096, 10000, 25000):
+        seqs.append("".join(rng.choice(alpha, size=L)))
+        if L > 4:
+            s = list(seqs[-1])
+            s[L // 2] = "N"
+            seqs.append("".join(s))
+            seqs.append(seqs[-2] + "N")
+    seqs += ["A" * 5000, "ACGT" * 2000 + "N" + "TTTTT" * 300, "", "N", "NNNN" + "ACGTTGCA" * 100]
+    if w == 0:
+        seqs = [s for s in seqs if len(s) >= m]   # shorter reads: the reference's arithmetic underflows
+    got = _min_triples(hctx, seqs, w, m)
+    for i, s in enumerate(seqs):
+        assert got[i] == oracle.minimisers(s, w, m), (i, len(s), w, m)
+
+
+def test_minimisers_arguments(hctx):
+    from kmertools_amd import device
+    b, o = device.to_csr(["ACGTACGTACGT"])
+    for w, m in ((3, 5), (2000, 7), (10, 0), (10, 32)):
+        with pytest.raises(Exception):
+            hctx.minimisers_host(b, o, w, m)
+    evo, k, s, e = hctx.minimisers_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 31, 7)
+    assert len(k) == 0 and list(evo) == [0]
+
+
+def test_minimisers_full_size(torch_mod, ctx, oracle):
+    """2 M x 150 bp on the device path, w=31 m=7: spot reads against the oracle, and the structural properties
+    of the whole result (offsets monotone, windows inside the read, consecutive windows of a read overlap)"""
+    torch = torch_mod
+    n, L, w, m = 2_000_000, 150, 31, 7
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(33, n, L, bases, offsets, noise=True)
+    evo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    dummy = torch.empty(1, dtype=torch.int64, device="cuda")
+    cnt = ctx.minimisers(bases, offsets, n, w, m, evo, dummy, dummy, dummy, 0)
+    assert cnt > n
+    k = torch.empty(cnt, dtype=torch.int64, device="cuda")
+    s = torch.empty(cnt, dtype=torch.int64, device="cuda")
+    e = torch.empty(cnt, dtype=torch.int64, device="cuda")
+    assert ctx.minimisers(bases, offsets, n, w, m, evo, k, s, e, cnt) == cnt
+    assert int(evo[0]) == 0 and int(evo[-1]) == cnt and bool((evo[1:] >= evo[:-1]).all())
+    assert bool((s >= 0).all()) and bool((e <= L).all()) and bool((s < e).all())
+    hb = bases[: 200 * L].cpu().numpy().tobytes()
+    he, hk, hs, hend = evo[:201].cpu().numpy(), k[: int(evo[200])].cpu().numpy(), s[: int(evo[200])].cpu().numpy(), \
+        e[: int(evo[200])].cpu().numpy()
+    for r in range(200):
+        got = [(int(np.uint64(hk[j])), int(hs[j]), int(hend[j])) for j in range(int(he[r]), int(he[r + 1]))]
+        assert got == oracle.minimisers(hb[r * L:(r + 1) * L], w, m), r
+
+
+def test_minimiser_python_surface(hctx, oracle):
+    from kmertools_amd import pykmertools as kt
+    # tests/test_min.py:7-24
+    seq = ("ATGCGATATCGTAGGCGTCGATGGAGAGCTAGATCGATCGATCTAAATCCCGATCGATTCCGAGCGCGATCAAAGCGCGATAGGCTAGCTAAAG"
+           "CTAGCA")
+    g = kt.MinimiserGenerator(seq, 31, 7)
+    got = list(g)
+    assert [g.to_acgt(k) for k, _, _ in got] == ["ACGATAT", "ACGCCTA", "AGAGCTA", "AAATCCC", "AATCCCG", "AATCGAT", "AAAGCGC"]
+    assert got == oracle.minimisers(seq, 31, 7)
+    with pytest.raises(ValueError):
+        kt.MinimiserGenerator(seq, 3, 7)

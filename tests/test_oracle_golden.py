@@ -188,3 +188,30 @@ def test_whole_sequence_cgr(oracle, golden):
         oracle.cgr_points("ACGNT", 1)
     with pytest.raises(ValueError):
         oracle.cgr_points(b"AC\x01T", 1)   # raw codes are not CGR letters (cgr.rs:19-30)
+
+
+def test_minimisers(oracle, golden):
+    # kmer/src/minimiser.rs:183-280 (w=31, m=7) and :283-305 (an N inside, w=8, m=5)
+    seq = ("ATGCGATATCGTAGGCGTCGATGGAGAGCTAGATCGATCGATCTAAATCCCGATCGATTCCGAGCGCGATCAAAGCGCGATAGGCTAGCTAAAG"
+           "CTAGCA")
+    got = oracle.minimisers(seq, 31, 7)
+    want = [("ACGATAT", "ATGCGATATCGTAGGCGTCGATGGAGAGCTAGATCG"), ("ACGCCTA", "TATCGTAGGCGTCGATGGAGAGCTAGATCGATCGAT"),
+            ("AGAGCTA", "AGGCGTCGATGGAGAGCTAGATCGATCGATCTAAATCC"),
+            ("AAATCCC", "ATGGAGAGCTAGATCGATCGATCTAAATCCCGATCGATTCCGAGCGCGATCAAAG"),
+            ("AATCCCG", "AATCCCGATCGATTCCGAGCGCGATCAAAGC"), ("AATCGAT", "ATCCCGATCGATTCCGAGCGCGATCAAAGCG"),
+            ("AAAGCGC", "TCCCGATCGATTCCGAGCGCGATCAAAGCGCGATAGGCTAGCTAAAGCTAGCA")]
+    assert [(oracle.numeric_to_kmer(k, 7), seq[s:e]) for k, s, e in got] == want
+    seq2 = "ATGCGATATCGNTAGGCGTCGATGGA"
+    got2 = [(seq2[s:e], oracle.numeric_to_kmer(k, 5)) for k, s, e in oracle.minimisers(seq2, 8, 5)]
+    assert got2 == [("ATGCGATA", "ATCGC"), ("TGCGATATCG", "ATATC"), ("TAGGCGTCGA", "ACGCC"), ("GCGTCGATGGA", "ATCGA")]
+    # misc/src/minimisers.rs:166-187: file fixtures (tests sort the lines)
+    # compared like the reference's own test: every line trimmed, then sorted (ktio/src/fops.rs:15-25); the
+    # program itself ends each s2m line with "\t\n" (join of [.., "\n"], misc/src/minimisers.rs:131-141)
+    def trimmed(lines):
+        return sorted(ln.strip() for ln in lines)
+    recs = [(i, s.decode()) for i, s in oracle.read_records(golden / "reads.fq")]
+    s2m = oracle.seq_to_min_lines(recs, 31, 7)
+    assert all(ln.endswith("\t\n") for ln in s2m)
+    assert trimmed(s2m) == trimmed((golden / "expected_seq_minimisers").read_text().splitlines())
+    assert trimmed(oracle.bin_sequences_lines(recs, 0, 10)) == \
+        trimmed((golden / "expected_minimisers").read_text().splitlines())

@@ -5,7 +5,7 @@ cd /root/repo/kmertools_amd/csrc
 name=$1; shift
 mkdir -p ../variants build/v_$name
 objs=""
-for o in kt_host kt_oligo kt_ctr kt_bulk kt_cov kt_cgr kt_synth; do
+for o in kt_host kt_oligo kt_ctr kt_bulk kt_cov kt_cgr kt_min kt_synth; do
   src=$o.hip; [ -f $src ] || src=$o.cpp
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -I. "$@" -x hip -c $src -o build/v_$name/$o.o &
   objs="$objs build/v_$name/$o.o"
