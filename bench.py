@@ -253,7 +253,7 @@ def main():
         me = torch.empty(n_ev, dtype=torch.int64, device="cuda")
         # bases read by the three passes that touch them + the triples and offsets written
         alg_bytes_per_launch = n * (L + 8) + n_ev * 24
-        dominant = "min_tile_kernel x2 (count, emit) + finalize; LDS sliding minimum, %d triples" % n_ev
+        dominant = "min_tile_kernel count + emit passes (LDS sliding minimum), break scan, finalize; %d triples" % n_ev
 
         def step():
             ctx.minimisers(bases, offsets, n, w, k, evo, mk, ms, me, n_ev)

@@ -172,33 +172,38 @@ int device_excl_scan(kt_ctx *ctx, const uint64_t *in, uint64_t n, uint64_t *out,
 
 // ---- the tile kernel ------------------------------------------------------------------------------------
 struct Event {
-    uint64_t val, pos, run;  // minimiser, global position of the event, global start of its run
+    uint64_t val, pos, run, rs;  // minimiser, global position of the event, global start of its run and of its read
 };
 
+// LDS index of local position li: one pad entry per 16, because every thread works on 16 consecutive
+// positions - unpadded, the 64 lanes of a wave would all hit the same bank (measured: 98 us per tile)
+__device__ __forceinline__ uint32_t ph(uint32_t li) { return li + (li >> 4); }
+
+template <class V>
 struct TileShared {
-    uint64_t a[RANGE];           // m-mers -> doubling -> active minimiser; later the event ranks (u32)
-    uint8_t code[RANGE + 32];    // 2-bit codes (4 = ambiguous) of positions range0 - 32 .. range0 + RANGE
+    V a[RANGE + RANGE / 16];     // m-mers -> doubling -> active minimiser (padded, see ph())
+    __attribute__((aligned(16))) uint8_t code[RANGE + 32];  // 2-bit codes (4 = ambiguous) of positions range0 - 32 ..
     uint32_t start_bits[RANGE / 32 + 1];  // bit per position of the range (+1): a read starts here
-    uint64_t scan_tmp[8];
+    uint16_t rank[RANGE];        // EMIT: events of the tile in front of each position
+    int32_t scan_tmp[2][8];
     uint32_t cnt_tmp[8];
 };
 
-// exclusive max-scan of one value per thread over the 256-thread workgroup
-__device__ __forceinline__ uint64_t block_max_excl(uint64_t v, uint64_t *tmp) {
+// exclusive max-scan of one value per thread over the 256-thread workgroup (identity: lowest)
+__device__ __forceinline__ int32_t block_max_excl(int32_t v, int32_t lowest, int32_t *tmp) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint64_t inc = v;
+    int32_t inc = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint64_t o = __shfl_up(inc, off, 64);
+        const int32_t o = __shfl_up(inc, off, 64);
         if (lane >= (uint32_t)off && o > inc) inc = o;
     }
     if (lane == 63) tmp[wave] = inc;
     __syncthreads();
-    uint64_t base = 0;
+    int32_t base = lowest;
     for (uint32_t w = 0; w < wave; w++) base = base > tmp[w] ? base : tmp[w];
-    const uint64_t prev = __shfl_up(inc, 1, 64);
-    const uint64_t ex = lane ? prev : 0;
-    __syncthreads();
+    const int32_t prev = __shfl_up(inc, 1, 64);
+    const int32_t ex = lane ? prev : lowest;
     return base > ex ? base : ex;
 }
 
@@ -222,15 +227,25 @@ __device__ __forceinline__ uint32_t block_sum_excl(uint32_t v, uint32_t *tmp, ui
     return base + inc - v;
 }
 
-template <bool EMIT>
+// V = uint32_t for m <= 16 (an m-mer fits 32 bits; all-ones is never canonical, so it marks "none"),
+// uint64_t otherwise.  Everything inside the tile is in 32-bit local coordinates (index into the range);
+// "break" values are run / read start candidates as local indices, FAR when they lie in front of the range
+// (their exact global values then come from the carries).
+template <class V, bool EMIT>
 __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__restrict__ tile_count,
                                                          const uint64_t *__restrict__ ev_base, Event *__restrict__ ev,
                                                          uint8_t *__restrict__ ev_type, uint64_t *__restrict__ ev_offsets) {
-    __shared__ TileShared sm;
+    __shared__ TileShared<V> sm;
+    constexpr V VNONE = (V)~(V)0;
+    constexpr int32_t FAR = -(1 << 30);
     const uint32_t tid = threadIdx.x;
     const uint64_t t0 = (uint64_t)blockIdx.x * TILE;           // first position owned
     const int64_t range0 = (int64_t)t0 - (int64_t)GRAN;        // position of local index 0 (negative for tile 0)
-    const uint32_t m = a.m, w = a.w, W = a.W;
+    const int32_t m = (int32_t)a.m, w = (int32_t)a.w;
+    const uint32_t W = a.W;
+    // local indices [lo_in, hi_in) are real positions (tile 0 has no halo, the last tile may be short)
+    const int32_t lo_in = range0 < 0 ? (int32_t)GRAN : 0;
+    const int32_t hi_in = a.total - t0 >= TILE ? (int32_t)RANGE : (int32_t)(a.total - t0) + (int32_t)GRAN;
 
     // ---- stage codes (32 bases of context in front of the range) and read-start bits ----
     for (uint32_t i = tid; i < RANGE + 32; i += BLOCK) {
@@ -250,139 +265,129 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         }
     }
     __syncthreads();
-    auto is_start = [&](uint32_t li) { return (sm.start_bits[li >> 5] >> (li & 31u)) & 1u; };
 
-    // ---- run starts: thread-local pass, workgroup max-scan, carry from the granules before the range ----
-    const uint32_t l0 = tid * PER;  // first local index of this thread
-    uint64_t local_break = 0;       // 1 + latest run-start candidate among this thread's positions
-    for (uint32_t j = 0; j < PER; j++) {
-        const uint32_t li = l0 + j;
-        const int64_t p = range0 + (int64_t)li;
-        if (p < 0 || (uint64_t)p >= a.total) continue;
-        if (is_start(li)) local_break = (uint64_t)p + 1;
-        if (sm.code[li + 32] > 3) local_break = (uint64_t)p + 2;
-    }
-    uint64_t brk = block_max_excl(local_break, sm.scan_tmp);
+    // ---- this thread's 16 positions: codes and read-start bits into registers ----
+    const int32_t l0 = (int32_t)(tid * PER);  // first local index of this thread
+    uint32_t cd[PER];
     {
-        const uint64_t c = range0 > 0 ? a.carry[(uint64_t)range0 / GRAN] : 0;
-        if (c > brk) brk = c;
+        const uint4 cw = *reinterpret_cast<const uint4 *>(&sm.code[l0 + 32]);
+        const uint32_t wds[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) cd[j] = (wds[j >> 2] >> (8 * (j & 3u))) & 0xFFu;
     }
-    // brk - 1 = start of the run that position (range0 + l0 - 1) belongs to, had it been unambiguous
+    // bit j: a read starts at position l0 + j (bit 16: at the position after this thread's last)
+    const uint32_t sb = (uint32_t)((((uint64_t)sm.start_bits[(l0 >> 5) + 1] << 32) | sm.start_bits[l0 >> 5]) >> (l0 & 31)) &
+                        0x1FFFFu;
+    uint32_t inside = 0;
+#pragma unroll
+    for (int32_t j = 0; j < (int32_t)PER; j++) inside |= (l0 + j >= lo_in && l0 + j < hi_in ? 1u : 0u) << j;
+
+    // ---- run / read starts: thread-local pass, workgroup max-scans, carries from in front of the range ----
+    int32_t loc_run = FAR, loc_read = FAR;  // latest run-start / read-start candidate among this thread's positions
+#pragma unroll
+    for (int32_t j = 0; j < (int32_t)PER; j++) {
+        if (!((inside >> j) & 1u)) continue;
+        if ((sb >> j) & 1u) loc_run = loc_read = l0 + j;
+        if (cd[j] > 3) loc_run = l0 + j + 1;
+    }
+    const int32_t run0 = block_max_excl(loc_run, FAR, sm.scan_tmp[0]);    // as of the position in front of l0
+    const int32_t read0 = block_max_excl(loc_read, FAR, sm.scan_tmp[1]);
+    // exact global starts for candidates in front of the range (only read when an event needs them)
+    const uint64_t carry_run = range0 > 0 ? a.carry[(uint64_t)range0 / GRAN] - 1 : 0;
+    uint64_t carry_read = 0;
+    if (range0 > 0) {  // the read that holds position range0 - 1
+        const uint64_t g = (uint64_t)range0 / GRAN;
+        uint64_t r = a.gfirst[g];  // first read starting at or after range0
+        carry_read = a.offsets[r - 1];  // r >= 1: read 0 starts at 0 < range0
+    }
+    auto global_of = [&](int32_t loc, uint64_t far_value) {
+        return loc == FAR ? far_value : (uint64_t)(range0 + (int64_t)loc);
+    };
 
     // ---- canonical m-mers of this thread's positions -> sm.a ----
     {
-        uint64_t f = 0, r = 0;
-        const uint64_t mask = m == 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
-        const uint32_t rsh = 2 * (m - 1);
+        V f = 0, r = 0;
+        const V mask = (V)(((uint64_t)1 << (2 * m)) - 1ull);
+        const uint32_t rsh = 2 * (uint32_t)(m - 1);
         // the m - 1 codes in front of the first position (ambiguous ones are harmless: run_len gates the use)
-        for (uint32_t j = 0; j + 1 < m; j++) {
+        for (int32_t j = 0; j + 1 < m; j++) {
             const uint32_t c = sm.code[l0 + 32 - (m - 1) + j] & 3u;
-            f = ((f << 2) | c) & mask;
-            r = (r >> 2) | ((uint64_t)(3u - c) << rsh);
+            f = (V)(((f << 2) | c) & mask);
+            r = (V)((r >> 2) | ((V)(3u - c) << rsh));
         }
-        uint64_t b = brk;
-        for (uint32_t j = 0; j < PER; j++) {
-            const uint32_t li = l0 + j;
-            const int64_t p = range0 + (int64_t)li;
-            const uint32_t cd = sm.code[li + 32];
-            const uint32_t c = cd & 3u;
-            f = ((f << 2) | c) & mask;
-            r = (r >> 2) | ((uint64_t)(3u - c) << rsh);
-            uint64_t v = NONE;
-            if (p >= 0 && (uint64_t)p < a.total) {
-                if (is_start(li)) b = (uint64_t)p + 1;
-                if (cd > 3) b = (uint64_t)p + 2;
-                const uint64_t run_len = (uint64_t)p + 2 > b ? (uint64_t)p + 2 - b : 0;  // p + 1 - (b - 1)
-                if (run_len >= m) v = f < r ? f : r;
+        int32_t b = run0;
+#pragma unroll
+        for (int32_t j = 0; j < (int32_t)PER; j++) {
+            const uint32_t c = cd[j] & 3u;
+            f = (V)(((f << 2) | c) & mask);
+            r = (V)((r >> 2) | ((V)(3u - c) << rsh));
+            V v = VNONE;
+            if ((inside >> j) & 1u) {
+                if ((sb >> j) & 1u) b = l0 + j;
+                if (cd[j] > 3) b = l0 + j + 1;
+                if (l0 + j + 1 - b >= m) v = f < r ? f : r;  // run_len = position + 1 - run start
             }
-            sm.a[li] = v;
+            sm.a[ph((uint32_t)(l0 + j))] = v;
         }
     }
     __syncthreads();
 
     // ---- sliding minimum over W m-mers: doubling, then two overlapping power-of-two windows ----
     {
+        auto combine = [&](uint32_t dist) {
+            V x[PER];
+#pragma unroll
+            for (uint32_t j = 0; j < PER; j++) {
+                const uint32_t li = (uint32_t)l0 + j;
+                const V u = sm.a[ph(li)];
+                const V o = li >= dist ? sm.a[ph(li - dist)] : VNONE;
+                x[j] = u < o ? u : o;
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < PER; j++) sm.a[ph((uint32_t)l0 + j)] = x[j];
+            __syncthreads();
+        };
         uint32_t span = 1;  // sm.a[i] = min of the `span` m-mers ending at i
         while (span * 2 <= W) {
-            uint64_t x[PER];
-#pragma unroll
-            for (uint32_t j = 0; j < PER; j++) {
-                const uint32_t li = l0 + j;
-                const uint64_t u = sm.a[li];
-                const uint64_t o = li >= span ? sm.a[li - span] : NONE;
-                x[j] = u < o ? u : o;
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t j = 0; j < PER; j++) sm.a[l0 + j] = x[j];
-            __syncthreads();
+            combine(span);
             span *= 2;
         }
-        if (span < W) {
-            const uint32_t d = W - span;
-            uint64_t x[PER];
-#pragma unroll
-            for (uint32_t j = 0; j < PER; j++) {
-                const uint32_t li = l0 + j;
-                const uint64_t u = sm.a[li];
-                const uint64_t o = li >= d ? sm.a[li - d] : NONE;
-                x[j] = u < o ? u : o;
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t j = 0; j < PER; j++) sm.a[l0 + j] = x[j];
-            __syncthreads();
-        }
+        if (span < W) combine(W - span);
     }
 
     // ---- events of the positions this workgroup owns (local index >= GRAN) ----
-    uint32_t n_ev = 0;
-    uint32_t ev_kind[PER];
-    uint64_t ev_val[PER], ev_run[PER];
-    {
-        uint64_t b = brk;
-        for (uint32_t j = 0; j < PER; j++) {
-            const uint32_t li = l0 + j;
-            const int64_t p = range0 + (int64_t)li;
-            ev_kind[j] = 0;
-            if (p < 0 || (uint64_t)p >= a.total) continue;
-            const uint64_t b_prev = b;  // run bookkeeping as of position p - 1
-            const uint32_t cd = sm.code[li + 32];
-            const bool st = is_start(li);
-            if (st) b = (uint64_t)p + 1;
-            if (cd > 3) b = (uint64_t)p + 2;
-            if (li < GRAN) continue;  // halo: state only
-            const uint64_t run_len = (uint64_t)p + 2 > b ? (uint64_t)p + 2 - b : 0;
-            // run length of p - 1 (0 at a read start: the previous base belongs to another read)
-            const uint64_t prev_len = (st || p == 0) ? 0 : ((uint64_t)p + 1 > b_prev ? (uint64_t)p + 1 - b_prev : 0);
-            const bool last = ((uint64_t)p + 1 == a.total) || is_start(li + 1);
-            uint32_t kind = 0;
-            uint64_t val = 0, run = 0;
-            if (cd > 3) {
-                if (prev_len >= w) {  // E2: an ambiguous base closes a full window
-                    kind = 2;
-                    val = sm.a[li - 1];
-                    run = b_prev - 1;
-                }
-            } else {
-                if (run_len > w && sm.a[li] != sm.a[li - 1]) {  // E1: the active minimiser changed
-                    kind = 1;
-                    val = sm.a[li - 1];
-                    run = b - 1;
-                } else if (last && run_len >= m) {  // E3: the read's last window
-                    kind = 3;
-                    val = run_len >= w ? sm.a[li] : NONE;
-                    run = b - 1;
-                }
-            }
-            if (kind) {
-                ev_kind[j] = kind;
-                ev_val[j] = val;
-                ev_run[j] = run;
-                n_ev++;
+    // visit(j, kind, val, run start (local)) is called for every event, in position order
+    V act[PER + 1];
+    act[0] = l0 ? sm.a[ph((uint32_t)l0 - 1)] : VNONE;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) act[j + 1] = sm.a[ph((uint32_t)l0 + j)];
+    auto scan_events = [&](auto &&visit) {
+        int32_t b = run0;
+#pragma unroll
+        for (int32_t j = 0; j < (int32_t)PER; j++) {
+            if (!((inside >> j) & 1u)) continue;
+            const int32_t li = l0 + j;
+            const int32_t b_prev = b;  // run bookkeeping as of the previous position
+            const bool st = (sb >> j) & 1u;
+            if (st) b = li;
+            if (cd[j] > 3) b = li + 1;
+            if (li < (int32_t)GRAN) continue;  // halo positions only carry state
+            const int32_t run_len = li + 1 - b;
+            // run length of the previous position (0 at a read start: that base belongs to another read)
+            const int32_t prev_len = st ? 0 : li - b_prev;
+            const bool last = (li + 1 == hi_in && t0 + TILE >= a.total) || ((sb >> (j + 1)) & 1u);
+            if (cd[j] > 3) {
+                if (prev_len >= w) visit(j, 2u, act[j], b_prev);                  // E2: an ambiguous base closes a full window
+            } else if (run_len > w && act[j + 1] != act[j]) {
+                visit(j, 1u, act[j], b);                                          // E1: the active minimiser changed
+            } else if (last && run_len >= m) {
+                visit(j, 3u, run_len >= w ? act[j + 1] : VNONE, b);               // E3: the read's last window
             }
         }
-    }
+    };
+    uint32_t n_ev = 0;
+    scan_events([&](int32_t, uint32_t, V, int32_t) { n_ev++; });
     uint32_t tile_total;
     const uint32_t rank0 = block_sum_excl(n_ev, sm.cnt_tmp, &tile_total);
     if (!EMIT) {
@@ -390,26 +395,35 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         return;
     }
     const uint64_t base = ev_base[blockIdx.x];
-    // event ranks per owned position (exclusive), for the reads that start inside the tile
-    uint32_t *rank = reinterpret_cast<uint32_t *>(sm.a);
-    __syncthreads();  // sm.a is done as the minimiser array
     {
-        uint32_t rk = rank0;
+        // read start of every position of this thread (for the events' read-local coordinates)
+        uint32_t rk = rank0, done = 0;  // done: bit j set once position j's rank is stored
+        int32_t rd = read0;
+        uint32_t next_j = 0;
+        scan_events([&](int32_t j, uint32_t kind, V val, int32_t run) {
+            for (; next_j <= (uint32_t)j; next_j++)
+                if (((inside >> next_j) & 1u) && ((sb >> next_j) & 1u)) rd = l0 + (int32_t)next_j;
+            // an E2 sits on the ambiguous base itself, which belongs to the same read as the window it closes
+            ev[base + rk] = Event{val == VNONE ? NONE : (uint64_t)val, (uint64_t)(range0 + (int64_t)(l0 + j)),
+                                  global_of(run, carry_run), global_of(rd, carry_read)};
+            ev_type[base + rk] = (uint8_t)kind;
+            sm.rank[l0 + j] = (uint16_t)rk;
+            done |= 1u << j;
+            rk++;
+        });
+        // positions without an event: events in front of them = rank0 + events among the earlier positions
+        uint32_t before = rank0;
+#pragma unroll
         for (uint32_t j = 0; j < PER; j++) {
-            const uint32_t li = l0 + j;
-            rank[li] = rk;
-            if (ev_kind[j]) {
-                ev[base + rk] = Event{ev_val[j], (uint64_t)(range0 + (int64_t)li), ev_run[j]};
-                ev_type[base + rk] = (uint8_t)ev_kind[j];
-                rk++;
-            }
+            if ((done >> j) & 1u) before++;
+            else sm.rank[l0 + j] = (uint16_t)before;
         }
     }
     __syncthreads();
     for (uint64_t r = a.gfirst[t0 / GRAN] + tid; r < a.n_reads; r += BLOCK) {
         const uint64_t o = a.offsets[r];
         if (o >= t0 + TILE || o >= a.total) break;
-        ev_offsets[r] = base + rank[(uint32_t)((int64_t)o - range0)];
+        ev_offsets[r] = base + sm.rank[(uint32_t)((int64_t)o - range0)];
     }
 }
 
@@ -420,23 +434,21 @@ __global__ void min_tail_kernel(uint64_t *__restrict__ ev_offsets, uint64_t n_re
     if (r == n_reads || ev_offsets[r] == NONE) ev_offsets[r] = *total;
 }
 
-// one thread per read: window starts (previous change of the same run) and read-local coordinates
-__global__ void min_finalize_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads,
-                                    const uint64_t *__restrict__ ev_offsets, const Event *__restrict__ ev,
-                                    const uint8_t *__restrict__ ev_type, uint32_t w, uint64_t capacity,
-                                    uint64_t *__restrict__ kmers, uint64_t *__restrict__ starts,
-                                    uint64_t *__restrict__ ends) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint64_t e0 = ev_offsets[r], e1 = ev_offsets[r + 1], rs = offsets[r];
-    for (uint64_t j = e0; j < e1 && j < capacity; j++) {
-        const Event e = ev[j];
-        uint64_t ws = e.run;
-        if (j > e0 && ev_type[j - 1] == 1 && ev[j - 1].run == e.run) ws = ev[j - 1].pos + 1 - w;
-        kmers[j] = e.val;
-        starts[j] = ws - rs;
-        ends[j] = (ev_type[j] == 3 ? e.pos + 1 : e.pos) - rs;
+// one thread per event: window start (the previous change of the same run) and read-local coordinates
+__global__ void min_finalize_kernel(const Event *__restrict__ ev, const uint8_t *__restrict__ ev_type, uint64_t n_ev,
+                                    uint32_t w, uint64_t capacity, uint64_t *__restrict__ kmers,
+                                    uint64_t *__restrict__ starts, uint64_t *__restrict__ ends) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_ev || j >= capacity) return;
+    const Event e = ev[j];
+    uint64_t ws = e.run;
+    if (j > 0 && ev_type[j - 1] == 1) {
+        const Event q = ev[j - 1];
+        if (q.run == e.run && q.rs == e.rs) ws = q.pos + 1 - w;
     }
+    kmers[j] = e.val;
+    starts[j] = ws - e.rs;
+    ends[j] = (ev_type[j] == 3 ? e.pos + 1 : e.pos) - e.rs;
 }
 
 // ---- w = 0: one window per read ------------------------------------------------------------------------------
@@ -576,8 +588,15 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
             if (int rc = device_excl_scan<true>(ctx, lastbreak, n_gran, carry, partial, nullptr)) return rc;
             MinArgs a{d_bases, d_offsets, gfirst, carry, n_reads, total, n_gran,
                       (uint32_t)wsize, (uint32_t)msize, (uint32_t)(wsize - (uint64_t)msize + 1)};
-            hipLaunchKernelGGL(min_tile_kernel<false>, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, tcount,
-                               (const uint64_t *)nullptr, (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
+            const bool narrow = msize <= 16;
+            if (narrow)
+                hipLaunchKernelGGL((min_tile_kernel<uint32_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a,
+                                   tcount, (const uint64_t *)nullptr, (Event *)nullptr, (uint8_t *)nullptr,
+                                   (uint64_t *)nullptr);
+            else
+                hipLaunchKernelGGL((min_tile_kernel<uint64_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a,
+                                   tcount, (const uint64_t *)nullptr, (Event *)nullptr, (uint8_t *)nullptr,
+                                   (uint64_t *)nullptr);
             if (int rc = device_excl_scan<false>(ctx, tcount, n_tiles, tbase, partial, d_total)) return rc;
             KT_HIP(hipMemcpyAsync(&n_ev, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
             KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -585,12 +604,16 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
                 if (int rc = ctx->s_aux2.reserve(align256(n_ev * sizeof(Event)) + n_ev + 256)) return rc;
                 Event *ev = (Event *)ctx->s_aux2.p;
                 uint8_t *ev_type = (uint8_t *)ctx->s_aux2.p + align256(n_ev * sizeof(Event));
-                hipLaunchKernelGGL(min_tile_kernel<true>, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a,
-                                   (uint64_t *)nullptr, tbase, ev, ev_type, d_evoff);
+                if (narrow)
+                    hipLaunchKernelGGL((min_tile_kernel<uint32_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0,
+                                       ctx->stream, a, (uint64_t *)nullptr, tbase, ev, ev_type, d_evoff);
+                else
+                    hipLaunchKernelGGL((min_tile_kernel<uint64_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0,
+                                       ctx->stream, a, (uint64_t *)nullptr, tbase, ev, ev_type, d_evoff);
                 hipLaunchKernelGGL(min_tail_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                    d_evoff, n_reads, d_total);
-                hipLaunchKernelGGL(min_finalize_kernel, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   d_offsets, n_reads, d_evoff, ev, ev_type, (uint32_t)wsize, capacity, d_k, d_s, d_e);
+                hipLaunchKernelGGL(min_finalize_kernel, dim3((uint32_t)((n_ev + 255) / 256)), dim3(256), 0, ctx->stream, ev,
+                                   ev_type, n_ev, (uint32_t)wsize, capacity, d_k, d_s, d_e);
                 KT_HIP(hipGetLastError());
             }
         }
