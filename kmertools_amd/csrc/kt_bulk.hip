@@ -103,18 +103,49 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_
     return total;
 }
 
+// ---- where the level-1 passes get their keys ---------------------------------------------------------------
+// A source hands every workgroup "units" of up to 8192 canonical k-mers, 32 per thread in registers
+// (bit j of `ok` = keys[j] is a k-mer).
+struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segment (kt_segment.hpp)
+    SegArgs a;
+    __device__ uint64_t n_units() const { return a.n_seg; }
+    __device__ void collect(uint64_t g, SegShared &sm, uint64_t (&keys)[ktseg::PER_THREAD], uint32_t &ok) const {
+        ktseg::collect_kmers(a, g, sm, keys, ok);
+    }
+};
+struct KeysSource {  // canonical k-mers that are already an array (routed here from other GPUs): unit = 8192 keys
+    const uint64_t *keys;
+    uint64_t n;
+    __device__ uint64_t n_units() const { return (n + ktseg::SEG - 1) / ktseg::SEG; }
+    __device__ void collect(uint64_t g, SegShared &, uint64_t (&out)[ktseg::PER_THREAD], uint32_t &ok) const {
+        ok = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < ktseg::PER_THREAD; j++) {  // consecutive lanes read consecutive keys
+            const uint64_t i = g * ktseg::SEG + (uint64_t)j * BLOCK + threadIdx.x;
+            const uint64_t key = i < n ? keys[i] : KT_EMPTY_KEY;
+            out[j] = key;
+            ok |= (key != KT_EMPTY_KEY ? 1u : 0u) << j;
+        }
+    }
+};
+
 // ---- hist1 --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void hist1_kernel(SegArgs a, Plan p, uint32_t *__restrict__ H) {
+template <class Source>
+__global__ __launch_bounds__(BLOCK) void hist1_kernel(Source src, Plan p, uint32_t *__restrict__ H) {
     __shared__ SegShared sm;
     __shared__ uint32_t cnt[MAX_B];
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) cnt[i] = 0;
     ktd::lds_barrier();
-    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
-        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
-            const uint64_t m = f < r ? f : r;
-            atomicAdd(&cnt[digit1(m, p)], 1u);
-        });
+    const uint64_t n_units = src.n_units();
+    for (uint64_t g = blockIdx.x; g < n_units; g += gridDim.x) {
+        uint64_t keys[ktseg::PER_THREAD];
+        uint32_t ok;
+        src.collect(g, sm, keys, ok);
+#pragma unroll
+        for (uint32_t j = 0; j < ktseg::PER_THREAD; j++)
+            if ((ok >> j) & 1u) atomicAdd(&cnt[digit1(keys[j], p)], 1u);
     }
+    ktd::lds_barrier();
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) H[(uint64_t)blockIdx.x * p.B1 + i] = cnt[i];
 }
 
@@ -161,16 +192,18 @@ struct Scatter1Shared {
     uint32_t tmp[BLOCK];
 };
 
-__global__ __launch_bounds__(BLOCK) void scatter1_kernel(SegArgs a, Plan p, const uint64_t *__restrict__ O,
+template <class Source>
+__global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, const uint64_t *__restrict__ O,
                                                          uint64_t *__restrict__ keys1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Scatter1Shared &sm = *reinterpret_cast<Scatter1Shared *>(smem_raw);
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cursor[i] = O[(uint64_t)blockIdx.x * p.B1 + i];
-    for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
+    const uint64_t n_units = src.n_units();
+    for (uint64_t g = blockIdx.x; g < n_units; g += gridDim.x) {
         // one front-end pass: the thread's 32 canonical k-mers stay in registers
         uint64_t keys[ktseg::PER_THREAD];
         uint32_t ok;
-        ktseg::collect_kmers(a, g, sm.seg, keys, ok);
+        src.collect(g, sm.seg, keys, ok);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cnt[i] = 0;
@@ -385,14 +418,12 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
     return strtoull(s, nullptr, 10);
 }
 
-}  // namespace
-
-int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                  uint64_t total_bases, int *done) {
+// plans the partition, carves the buffers and runs hist1 .. build for `n_units` units of `src` that hold at
+// most `max_keys` k-mers in total
+template <class Source>
+int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t max_keys, int *done) {
     *done = 0;
     kt_ctx *ctx = ctr->ctx;
-    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
-    if (total_bases < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
     Plan p{};
     p.n = ctr->log2cap;
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
@@ -403,14 +434,12 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     if (p.b2 > 11) return KT_OK;
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
-    const uint64_t n_seg = (total_bases + ktseg::SEG - 1) / ktseg::SEG;
     uint64_t G = (uint64_t)ctx->n_cu * 2;
-    if (G > n_seg) G = n_seg;
+    if (G > n_units) G = n_units;
     p.G = (uint32_t)G;
 
-    // buffers: two key arrays (upper bound: one k-mer per base) + metadata; if HBM is short,
-    // fall back to the incremental path
-    const uint64_t spill_cap = total_bases / 64 + (1u << 16);
+    // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
+    const uint64_t spill_cap = max_keys / 64 + (1u << 16);
     size_t meta = 0;
     const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;
@@ -418,7 +447,7 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     const size_t off_fs = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
-    if (ctr->b_keys1.reserve(total_bases * 8) != KT_OK || ctr->b_keys2.reserve(total_bases * 8) != KT_OK ||
+    if (ctr->b_keys1.reserve(max_keys * 8) != KT_OK || ctr->b_keys2.reserve(max_keys * 8) != KT_OK ||
         ctr->b_meta.reserve(meta) != KT_OK) {
         ctr->b_keys1.release();
         ctr->b_keys2.release();
@@ -437,26 +466,13 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     m.spill_cap = spill_cap;
     uint64_t *keys1 = (uint64_t *)ctr->b_keys1.p, *keys2 = (uint64_t *)ctr->b_keys2.p;
 
-    // the segment index (seg_first) lives in ctx scratch; same helper kernel as the other paths
-    const uint64_t n_seg_alloc = n_seg + 2;
-    if (int rc = ctx->s_aux0.reserve(n_seg_alloc * sizeof(uint64_t))) return rc;
-    uint64_t *seg_first = (uint64_t *)ctx->s_aux0.p;
-    hipLaunchKernelGGL(ktseg::seg_index_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       d_offsets, n_reads, seg_first, n_seg);
-    SegArgs a;
-    a.bases = d_bases;
-    a.offsets = d_offsets;
-    a.seg_first = seg_first;
-    a.n_reads = n_reads;
-    a.n_seg = n_seg;
-    a.k = (uint32_t)ctr->k;
-
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(hist1_kernel, dim3(p.G), dim3(BLOCK), 0, ctx->stream, a, p, m.H);
+    hipLaunchKernelGGL(hist1_kernel<Source>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, src, p, m.H);
     hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.H, p, m.O, m.bstart);
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel),
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<Source>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared)));
-    hipLaunchKernelGGL(scatter1_kernel, dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared), ctx->stream, a, p, m.O, keys1);
+    hipLaunchKernelGGL(scatter1_kernel<Source>, dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared), ctx->stream, src, p, m.O,
+                       keys1);
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Part2Shared)));
     hipLaunchKernelGGL(part2_kernel, dim3(p.B1), dim3(BLOCK), sizeof(Part2Shared), ctx->stream, keys1, m.bstart, p, keys2,
@@ -474,4 +490,38 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     KT_HIP(hipGetLastError());
     *done = 1;
     return KT_OK;
+}
+
+}  // namespace
+
+int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                  uint64_t total_bases, int *done) {
+    *done = 0;
+    kt_ctx *ctx = ctr->ctx;
+    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
+    if (total_bases < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
+    const uint64_t n_seg = (total_bases + ktseg::SEG - 1) / ktseg::SEG;
+    // the segment index (seg_first) lives in ctx scratch; same helper kernel as the other paths
+    if (int rc = ctx->s_aux0.reserve((n_seg + 2) * sizeof(uint64_t))) return rc;
+    uint64_t *seg_first = (uint64_t *)ctx->s_aux0.p;
+    hipLaunchKernelGGL(ktseg::seg_index_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_offsets, n_reads, seg_first, n_seg);
+    ReadsSource src;
+    src.a.bases = d_bases;
+    src.a.offsets = d_offsets;
+    src.a.seg_first = seg_first;
+    src.a.n_reads = n_reads;
+    src.a.n_seg = n_seg;
+    src.a.k = (uint32_t)ctr->k;
+    return bulk_build_from(ctr, src, n_seg, total_bases, done);  // at most one k-mer per base
+}
+
+// same construction from canonical k-mers that already are an array (KT_EMPTY_KEY entries are skipped):
+// the k-mers another GPU routed here.  The table must be empty; counts are one per array entry.
+int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int *done) {
+    *done = 0;
+    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
+    if (n_keys < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;
+    KeysSource src{d_keys, n_keys};
+    return bulk_build_from(ctr, src, (n_keys + ktseg::SEG - 1) / ktseg::SEG, n_keys, done);
 }

@@ -376,6 +376,17 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
             d_counts = (const uint32_t *)ctx->s_aux2.p;
         }
     }
+    if (ctr->empty && !d_counts) {
+        // raw k-mers (routed from other GPUs) into an empty table: the bulk build, no global atomics
+        int done = 0;
+        if (int rc = kt_bulk_build_keys(ctr, d_keys, n, &done)) return rc;
+        if (done) {
+            ctr->empty = false;
+            ctr->needs_clear = false;  // every slot was written
+            if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
+            return KT_OK;
+        }
+    }
     ctr->empty = false;
     if (int rc = ensure_cleared(ctr)) return rc;
     TableRef t{(Slot *)ctr->slots, ctr->cap - 1, (uint32_t)(64 - ctr->log2cap), ctr->flags};

@@ -64,3 +64,5 @@ __device__ __forceinline__ bool table_add(const TableRef &t, uint64_t key, uint3
 // the caller must use the incremental path.
 int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                   uint64_t total_bases, int *done);
+// same, from an array of canonical k-mers (one count each; KT_EMPTY_KEY entries are skipped)
+int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int *done);

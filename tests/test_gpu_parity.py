@@ -487,6 +487,31 @@ def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap):
     ctr.close()
 
 
+@pytest.mark.parametrize("k,log2cap", [(31, 18), (15, 19), (9, 18)])
+def test_ctr_bulk_build_from_routed_keys(hctx, oracle, monkeypatch, k, log2cap):
+    """kt_ctr_add_pairs(keys, counts=NULL) into an empty table = what a GPU does with the k-mers routed to it:
+    takes the bulk path too (duplicates, KT_EMPTY_KEY padding and a ragged tail included)"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    seqs = ragged_reads(5000 + k, 600)
+    bases, offsets = device.to_csr(seqs + seqs[:100])
+    f, r, _ = hctx.kmers_host(bases, offsets, k)
+    canon = np.minimum(f, r)
+    keys = np.concatenate([canon, np.full(777, 0xFFFFFFFFFFFFFFFF, np.uint64), canon[:5000]])
+    rng = np.random.default_rng(k)
+    rng.shuffle(keys)
+    wk, wc = np.unique(np.concatenate([canon, canon[:5000]]), return_counts=True)
+    assert len(wk) < 0.6 * (1 << log2cap)
+    ctr = device.Counter(hctx, k, 1 << log2cap)
+    ctr.add_pairs_host(keys, None)                      # bulk (table empty, no counts)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc.astype(np.uint32))
+    ctr.add_pairs_host(keys, None)                      # incremental on top
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, (2 * wc).astype(np.uint32))
+    ctr.close()
+
+
 def test_ctr_bulk_overfull_ranges_spill(hctx, oracle, monkeypatch):
     """load factor ~0.85: many keys run off the end of their 4096-slot range -> spill path"""
     from kmertools_amd import device
