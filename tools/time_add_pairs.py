@@ -25,3 +25,10 @@ for mode in ("1", "0", "1", "0"):
         a.record(s); ctr.add_pairs(keys, None, nk); b.record(s); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     print("KT_BULK=%s add_pairs(keys): %s ms -> %.1f G keys/s, distinct %d" % (mode, ["%.1f" % t for t in ts], nk / min(ts) / 1e6, ctr.size()))
+for G in (1, 2, 8):
+    ts = []
+    for rep in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s); ctx.route(bases, offsets, n, k, G, keys, oc); b.record(s); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    print("route to %d owners: %s ms -> %.1f Gbases/s" % (G, ["%.1f" % t for t in ts], n * L / min(ts) / 1e6))
