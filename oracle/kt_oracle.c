@@ -535,6 +535,25 @@ uint64_t kto_minimisers(const uint8_t *seq, uint64_t n, uint64_t wsize, uint64_t
     return c;
 }
 
+/* the per-record loop of misc/src/minimisers.rs:43-54 over a CSR batch (serial): returns the number of triples;
+ * wsize 0 = each read's own length; reads shorter than msize are skipped in that mode */
+uint64_t kto_minimisers_batch(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, uint64_t wsize,
+                              uint64_t msize, uint64_t *kmers, uint64_t *starts, uint64_t *ends, uint64_t cap) {
+    uint64_t total = 0;
+    uint64_t tk[4096], ts[4096], te[4096];
+    for (uint64_t i = 0; i < n_reads; i++) {
+        const uint64_t n = offsets[i + 1] - offsets[i];
+        const uint64_t w = wsize ? wsize : n;
+        if (w < msize || n + 2 > 4096) continue;
+        const uint64_t c = kto_minimisers(bases + offsets[i], n, w, msize, tk, ts, te);
+        for (uint64_t j = 0; j < c && total + j < cap; j++) {
+            kmers[total + j] = tk[j]; starts[total + j] = ts[j]; ends[total + j] = te[j];
+        }
+        total += c;
+    }
+    return total;
+}
+
 /* ------------------------------------------------------------------------ */
 /* coverage/src/lib.rs:165-184 CovComputer::vectorise_one over a CSR batch:
  * per k-mer: count = table[min(f,r)] or 0 (:171), bin = min(floor(count / bin_size),

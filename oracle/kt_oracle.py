@@ -74,6 +74,8 @@ def lib():
         L.kto_cgr_one.argtypes = [u8p, C.c_uint64, C.c_double, f64p]
         L.kto_minimisers.restype = C.c_uint64
         L.kto_minimisers.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, u64p]
+        L.kto_minimisers_batch.restype = C.c_uint64
+        L.kto_minimisers_batch.argtypes = [u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, u64p, C.c_uint64]
         L.kto_cgr_batch.restype = C.c_uint64
         L.kto_cgr_batch.argtypes = [u8p, u64p, C.c_uint64, C.c_double, f64p]
         L.kto_cov_batch.restype = C.c_int
@@ -193,6 +195,15 @@ def minimisers(seq, wsize, msize):
     e = np.zeros(n + 2, np.uint64)
     c = lib().kto_minimisers(_p(buf, u8p), n, wsize, msize, _p(k, u64p), _p(s, u64p), _p(e, u64p))
     return [(int(k[i]), int(s[i]), int(e[i])) for i in range(c)]
+
+
+def minimisers_batch_count(bases, offsets, wsize, msize, cap=1 << 22):
+    """CPU-baseline helper: runs the iterator over every read (< 4 kb) of a CSR batch, returns the triple count"""
+    k = np.zeros(cap, np.uint64)
+    s = np.zeros(cap, np.uint64)
+    e = np.zeros(cap, np.uint64)
+    return int(lib().kto_minimisers_batch(_p(bases, u8p), _p(offsets, u64p), len(offsets) - 1, wsize, msize,
+                                          _p(k, u64p), _p(s, u64p), _p(e, u64p), cap))
 
 
 def seq_to_min_lines(records, wsize, msize):
