@@ -19,6 +19,24 @@ __device__ __forceinline__ uint32_t nt4(uint32_t c) {
     return (letter || raw) ? code : (code | 4u);
 }
 
+// 4 bases in one dword -> 2-bit codes packed big-endian in 8 bits (first base in bits 7:6)
+// and 4 invalid flags (first base in bit 3).  Letters ACGTU/acgtu only; raw bytes 0..3 are
+// reported through `raw` (nonzero => caller takes the per-byte path).
+__device__ __forceinline__ void swar4(uint32_t x, uint32_t &codes8, uint32_t &inv4, uint32_t &raw) {
+    x = __builtin_bswap32(x);  // first base -> top byte, so right-shift packing is big-endian
+    const uint32_t c = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    const uint32_t y = x & 0xDFDFDFDFu;  // fold case
+    // expected letter for (code, bit0): keys 4..7 -> A C G U (S0 bytes), key 3 -> T (S1 byte 3)
+    const uint32_t key = c | ((x & 0x01010101u) << 2);
+    const uint32_t expect = __builtin_amdgcn_perm(0x55474341u, 0x54FFFFFFu, key);
+    const uint32_t diff = y ^ expect;
+    const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;  // 0x80 per bad byte
+    codes8 = (c | (c >> 6) | (c >> 12) | (c >> 18)) & 0xFFu;
+    inv4 = ((nz >> 7) | (nz >> 14) | (nz >> 21) | (nz >> 28)) & 0xFu;
+    const uint32_t t = x & 0xFCFCFCFCu;
+    raw = (t - 0x01010101u) & ~t & 0x80808080u;  // some byte < 4 (may over-report, never under)
+}
+
 // splitmix64 finaliser: table slot hash, owner hash and the synthetic-read generator
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9e3779b97f4a7c15ull;

@@ -66,18 +66,33 @@ __device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegS
         uint64_t w = 0;
         uint32_t iv = 0xFFFFFFFFu;
         if (b < total) {
-            unsigned char raw[32];
+            uint32_t d[8];
             if (b + 32 <= total) {
-                __builtin_memcpy(raw, a.bases + b, 32);
+                __builtin_memcpy(d, a.bases + b, 32);
             } else {
+                unsigned char raw[32];
                 for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
+                __builtin_memcpy(d, raw, 32);
             }
-            iv = 0;
+            // four bases per swar4 (letters only); an item holding raw bytes 0..3 takes the per-byte path
+            uint32_t msb_first = 0, any_raw = 0;
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const uint32_t e = ktd::nt4(raw[j]);
-                w = (w << 2) | (e & 3u);
-                iv |= (e >> 2) << j;
+            for (int q = 0; q < 8; q++) {
+                uint32_t c8, i4, rw;
+                ktd::swar4(d[q], c8, i4, rw);
+                w = (w << 8) | c8;
+                msb_first = (msb_first << 4) | i4;
+                any_raw |= rw;
+            }
+            iv = __builtin_bitreverse32(msb_first);  // bit j = base j is not a nucleotide
+            if (any_raw) {
+                w = 0;
+                iv = 0;
+                for (int j = 0; j < 32; j++) {
+                    const uint32_t e = ktd::nt4((d[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                    w = (w << 2) | (e & 3u);
+                    iv |= (e >> 2) << j;
+                }
             }
         }
         sm.codes[i] = w;
