@@ -112,6 +112,10 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
     __device__ void collect(uint64_t g, SegShared &sm, uint64_t (&keys)[ktseg::PER_THREAD], uint32_t &ok) const {
         ktseg::collect_kmers(a, g, sm, keys, ok);
     }
+    template <class Sink>
+    __device__ void for_each(uint64_t g, SegShared &sm, Sink &&sink) const {  // rolling walk: few registers
+        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) { sink(f < r ? f : r); });
+    }
 };
 struct KeysSource {  // canonical k-mers that are already an array (routed here from other GPUs): unit = 8192 keys
     const uint64_t *keys;
@@ -127,6 +131,15 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
             ok |= (key != KT_EMPTY_KEY ? 1u : 0u) << j;
         }
     }
+    template <class Sink>
+    __device__ void for_each(uint64_t g, SegShared &, Sink &&sink) const {
+#pragma unroll 8
+        for (uint32_t j = 0; j < ktseg::PER_THREAD; j++) {
+            const uint64_t i = g * ktseg::SEG + (uint64_t)j * BLOCK + threadIdx.x;
+            const uint64_t key = i < n ? keys[i] : KT_EMPTY_KEY;
+            if (key != KT_EMPTY_KEY) sink(key);
+        }
+    }
 };
 
 // ---- hist1 --------------------------------------------------------------------------------------
@@ -138,12 +151,7 @@ __global__ __launch_bounds__(BLOCK) void hist1_kernel(Source src, Plan p, uint32
     ktd::lds_barrier();
     const uint64_t n_units = src.n_units();
     for (uint64_t g = blockIdx.x; g < n_units; g += gridDim.x) {
-        uint64_t keys[ktseg::PER_THREAD];
-        uint32_t ok;
-        src.collect(g, sm, keys, ok);
-#pragma unroll
-        for (uint32_t j = 0; j < ktseg::PER_THREAD; j++)
-            if ((ok >> j) & 1u) atomicAdd(&cnt[digit1(keys[j], p)], 1u);
+        src.for_each(g, sm, [&](uint64_t key) { atomicAdd(&cnt[digit1(key, p)], 1u); });
     }
     ktd::lds_barrier();
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) H[(uint64_t)blockIdx.x * p.B1 + i] = cnt[i];
