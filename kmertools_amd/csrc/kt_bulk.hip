@@ -190,15 +190,19 @@ __global__ __launch_bounds__(1024) void scan1_kernel(const uint32_t *__restrict_
 // ---- scatter1 ----------------------------------------------------------------------------------------
 constexpr uint32_t HALF = ktseg::SEG / 2;  // keys sorted at a time (two rounds per segment)
 
-struct Scatter1Shared {
+constexpr uint32_t MAX_B1 = 1024;  // level 1 never uses more than 10 bits (bulk_build_from)
+
+struct Scatter1Shared {  // 65 KB: two workgroups per CU (an 8 KB larger layout dropped to one and cost 10 %)
     SegShared seg;
     uint64_t sorted[HALF];
-    uint64_t cursor[MAX_B];
-    uint32_t cnt[MAX_B];
-    uint32_t start[MAX_B];
-    uint32_t fill[MAX_B];
+    uint16_t sdig[HALF];  // level-1 digit of sorted[i]: saves hashing the key a third time
+    uint64_t cursor[MAX_B1];
+    uint32_t cnt[MAX_B1];
+    uint32_t start[MAX_B1];
+    uint32_t fill[MAX_B1];
     uint32_t tmp[BLOCK];
 };
+static_assert(sizeof(Scatter1Shared) <= 80 * 1024, "two scatter1 workgroups per CU");
 
 template <class Source>
 __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, const uint64_t *__restrict__ O,
@@ -227,16 +231,17 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, con
             for (int j = 0; j < 16; j++) {
                 if ((ok >> (half * 16 + j)) & 1u) {
                     const uint64_t m = keys[half * 16 + j];
-                    const uint32_t pos = atomicAdd(&sm.fill[digit1(m, p)], 1u);
+                    const uint32_t d = digit1(m, p);
+                    const uint32_t pos = atomicAdd(&sm.fill[d], 1u);
                     sm.sorted[pos] = m;
+                    sm.sdig[pos] = (uint16_t)d;
                 }
             }
             ktd::lds_barrier();
             // runs of equal d1 are contiguous in `sorted`: consecutive lanes -> consecutive addresses
             for (uint32_t i = threadIdx.x; i < nk; i += BLOCK) {
-                const uint64_t key = sm.sorted[i];
-                const uint32_t d = digit1(key, p);
-                keys1[sm.cursor[d] + (i - sm.start[d])] = key;
+                const uint32_t d = sm.sdig[i];
+                keys1[sm.cursor[d] + (i - sm.start[d])] = sm.sorted[i];
             }
             ktd::lds_barrier();
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cursor[i] += sm.cnt[i];
