@@ -195,10 +195,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    # KT_BENCH_SHARE_GPU=1 (tests only): every rank uses GPU 0 and the collectives go over gloo, so the
+    # multi-rank launch path can be exercised on a one-GPU box.  Numbers from such a run mean nothing.
+    share_gpu = os.environ.get("KT_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     def barrier():
         if world > 1:
@@ -206,7 +213,7 @@ def main():
         torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
-    ctx = device.Context(local_rank, stream=stream.cuda_stream)
+    ctx = device.Context(dev_index, stream=stream.cuda_stream)
     n, L, k = wl["n"], wl["L"], wl["k"]
 
     bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
@@ -303,7 +310,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -812,3 +812,22 @@ def test_minimiser_python_surface(hctx, oracle):
     assert got == oracle.minimisers(seq, 31, 7)
     with pytest.raises(ValueError):
         kt.MinimiserGenerator(seq, 3, 7)
+
+
+@pytest.mark.parametrize("workload", ["comp_oligo_k4", "ctr_k31"])
+def test_bench_two_rank_launch(workload):
+    """bench.py through torch.distributed.run with two ranks (both on GPU 0, gloo collectives): the launch
+    contract the driver uses for --gpus N - one JSON line from rank 0, whole-job value, n_gpus = 2"""
+    import json, os, subprocess, sys, pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, KT_BENCH_SHARE_GPU="1", KT_BULK_MIN_BASES="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", workload, "--reads", "200000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j and j["config"]["reduced"] is True
