@@ -831,3 +831,37 @@ def test_bench_two_rank_launch(workload):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
     assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j and j["config"]["reduced"] is True
+
+
+def test_ctr_cfg3_full_size_properties(torch_mod, ctx):
+    """BASELINE cfg3 at full size (50 M x 150 bp, k=15) through the bulk build: every k-mer instance is
+    counted exactly once (sum of counts = n * 136), no key is outside the canonical 15-mer space or stored
+    twice, and re-counting the exported pairs into a second table reproduces the first"""
+    from kmertools_amd import device
+    torch = torch_mod
+    n, L, k = 50_000_000, 150, 15
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(0x6b6d6572 + 2, n, L, bases, offsets)
+    canon_space = (4 ** k) // 2            # odd k: no palindromes
+    ctr = device.Counter(ctx, k, 1 << 31)
+    ctr.add_reads(bases, offsets, n)
+    distinct = ctr.size()
+    assert 0.9 * canon_space < distinct <= canon_space   # 6.8 G draws over 0.54 G canonical 15-mers
+    keys = torch.empty(distinct, dtype=torch.int64, device="cuda")
+    counts = torch.empty(distinct, dtype=torch.int32, device="cuda")
+    assert ctr.export(keys, counts, distinct) == distinct
+    assert int(counts.to(torch.int64).sum()) == n * (L - k + 1)
+    assert int(keys.min()) >= 0 and int(keys.max()) < 4 ** k
+    sk = torch.sort(keys).values
+    assert bool((sk[1:] != sk[:-1]).all())
+    del sk, bases, offsets
+    ctr.clear()
+    ctr.add_pairs(keys, counts, distinct)
+    assert ctr.size() == distinct
+    k2 = torch.empty(distinct, dtype=torch.int64, device="cuda")
+    c2 = torch.empty(distinct, dtype=torch.int32, device="cuda")
+    ctr.export(k2, c2, distinct)
+    assert int((k2.to(torch.float64) * c2.to(torch.float64)).sum()) == int((keys.to(torch.float64) * counts.to(torch.float64)).sum())
+    assert int(c2.to(torch.int64).sum()) == n * (L - k + 1)
+    ctr.close()
