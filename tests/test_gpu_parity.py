@@ -397,6 +397,7 @@ def _two_rank_worker(rank, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["KT_BULK_MIN_BASES"] = "0"   # the first batch of routed k-mers takes the bulk build, the second the atomics
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
         from kmertools_amd import device, dist as ktdist
