@@ -122,56 +122,64 @@ def cpu_baseline_ctr(k, L, seconds, genome):
                        % (n2, L, k, cores * 8, cores, dt))
 
 
+def _threaded_passes(make_slice_fn, n, L, seconds, what):
+    """Runs `fn()` for one slice of the reads per thread (the C oracle releases the GIL inside ctypes calls): the
+    analogue of the reference's rayon par_iter over records.  Returns the cpu_baseline dict."""
+    from concurrent.futures import ThreadPoolExecutor
+    cores = effective_cores()
+    per = (n + cores - 1) // cores
+    fns = [make_slice_fn(i * per, min(n, (i + 1) * per)) for i in range(cores) if i * per < n]
+    with ThreadPoolExecutor(len(fns)) as pool:
+        list(pool.map(lambda f: f(), fns))   # untimed: first touch of the result buffers
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            list(pool.map(lambda f: f(), fns))
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or reps >= 2000:
+                break
+    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=len(fns), kind="port",
+                sample="%d passes over %d x %dbp synthetic reads, %s, %d threads, %.1f s" % (reps, n, L, what, len(fns), dt))
+
+
 def cpu_baseline_cgr(L, seconds):
-    """CPU oracle (port of composition/src/cgr.rs:127-144) over a CSR batch on one host core."""
+    """CPU oracle (port of composition/src/cgr.rs:127-144), reads split over the host cores."""
+    import numpy as np
     from oracle import kt_oracle as oracle
-    n = 1_000_000
+    n = 800_000
     hb, ho = oracle.synth_reads(SEED, n, L)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.cgr_batch(hb, ho, 1)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 200:
-            break
-    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
-                sample="%d passes over %d x %dbp synthetic reads, 1 thread, %.1f s (includes allocating the 2.4 GB result)"
-                       % (reps, n, L, dt))
+
+    def make(lo, hi):
+        b, o = hb[lo * L:hi * L], (ho[lo:hi + 1] - ho[lo]).copy()
+        res = np.zeros(((hi - lo) * L, 2), np.float64)   # written in place by every pass
+        return lambda: oracle.cgr_batch(b, o, 1, out=res)
+    return _threaded_passes(make, n, L, seconds, "vecsize 1, result buffers reused")
 
 
 def cpu_baseline_min(L, w, m, seconds):
-    """CPU oracle (port of kmer/src/minimiser.rs:61-175) over a CSR batch on one host core."""
+    """CPU oracle (port of kmer/src/minimiser.rs:61-175), reads split over the host cores."""
     from oracle import kt_oracle as oracle
-    n = 200_000
+    n = 1_600_000
     hb, ho = oracle.synth_reads(SEED, n, L)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.minimisers_batch_count(hb, ho, w, m)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 500:
-            break
-    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
-                sample="%d passes over %d x %dbp synthetic reads, w=%d m=%d, 1 thread, %.1f s" % (reps, n, L, w, m, dt))
+
+    def make(lo, hi):
+        b, o = hb[lo * L:hi * L], (ho[lo:hi + 1] - ho[lo]).copy()
+        return lambda: oracle.minimisers_batch_count(b, o, w, m)
+    return _threaded_passes(make, n, L, seconds, "w=%d m=%d" % (w, m))
 
 
 def cpu_baseline_cov(k, L, seconds, genome, bin_size, bin_count):
-    """CPU oracle (port of coverage/src/lib.rs:165-184) on one host core per call, table prebuilt."""
+    """CPU oracle (port of coverage/src/lib.rs:165-184), table prebuilt, reads split over the host cores."""
     from oracle import kt_oracle as oracle
-    n = 400_000
+    n = 800_000
     hb, ho = oracle.synth_reads(SEED, n, L, genome_len=genome)
     c = oracle.Counter(1)
     c.add_reads(hb, ho, k)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        c.cov_batch(hb, ho, k, bin_size, bin_count, True)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 200:
-            break
-    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=1, kind="port",
-                sample="%d passes over %d x %dbp synthetic reads, k=%d, lookups in a prebuilt table, 1 thread, %.1f s"
-                       % (reps, n, L, k, dt))
+
+    def make(lo, hi):
+        b, o = hb[lo * L:hi * L], (ho[lo:hi + 1] - ho[lo]).copy()
+        return lambda: c.cov_batch(b, o, k, bin_size, bin_count, True)
+    return _threaded_passes(make, n, L, seconds, "k=%d, lookups in a prebuilt table" % k)
 
 
 def main():

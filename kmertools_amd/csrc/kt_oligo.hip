@@ -175,6 +175,15 @@ __device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile,
     return t;
 }
 
+#ifndef KT_OLIGO_ABLATION
+#define KT_OLIGO_ABLATION 1  // 1: KT_OLIGO_DEBUG bits are honoured at run time; 0: compiled out
+#endif
+#if KT_OLIGO_ABLATION
+#define KT_DBG(a) ((a).debug)
+#else
+#define KT_DBG(a) 0u
+#endif
+
 #ifndef KT_OLIGO_GLOAD
 #define KT_OLIGO_GLOAD 1
 #endif
@@ -226,7 +235,7 @@ __device__ __forceinline__ uint4 load_chunk(const OligoArgs &a, const ProdTile &
                                             uint64_t total_bytes) {
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     uint4 v = make_uint4(0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu);  // "NNNN": lanes outside the tile
-    if (a.debug & 4u) return make_uint4(0x54474341u + lane, 0x41434754u, 0x47474343u, 0x41544154u);  // ablation
+    if (KT_DBG(a) & 4u) return make_uint4(0x54474341u + lane, 0x41434754u, 0x47474343u, 0x41544154u);  // ablation
     if (!t.general) {
         const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + (int32_t)NB * ((int32_t)lane - 1);
         if (q >= 0 && q < (int32_t)(uint32_t)t.flat_end) {
@@ -317,7 +326,7 @@ __device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t 
             const int i = h * 8 + j;
             const uint32_t sel = (gr >> (15 - i)) & 1u;
             const uint32_t val = (ok >> (15 - i)) & 1u;
-            if (!(a.debug & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[j]], val);
+            if (!(KT_DBG(a) & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[j]], val);
             else if (val + bin[j] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
         }
     }
@@ -484,7 +493,7 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
         for (int u = 0; u < U; u++) {
             const vec_t o = convert(c[u], d[u], y[u]);
             const uint32_t v = vb + u * 64 + lane;
-            if (!(a.debug & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
+            if (!(KT_DBG(a) & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
         }
     }
     for (uint32_t v = vb + lane; v < v_hi; v += 64) {
@@ -493,7 +502,7 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
         *hp = cnt_t{};
         const uint32_t r = __umulhi(v, a.vec_magic);
         const vec_t o = convert(c, dnm[r], rcp[r]);
-        if (!(a.debug & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
+        if (!(KT_DBG(a) & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
     }
 }
 
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
     }
     for (uint64_t j = 0; j < nt; j++) {
         // ---- B: positions ------------------------------------------------------------------
-        if (!(a.debug & 1u)) {
+        if (!(KT_DBG(a) & 1u)) {
             if (lane < t_cur.nr) {
                 roff[lane] = o_cur.o;
                 roff[lane + 1] = o_cur.on;
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
         // ---- D: rows out, histogram cleared behind ---------------------------------------------------
         // the store stream is what must never starve: waves in this phase outrank the waves of
         // other workgroups that are still counting (-5 % wall, profiles/r1_oligo_ablation.txt)
-        if (!(a.debug & 16u)) __builtin_amdgcn_s_setprio(3);
+        if (!(KT_DBG(a) & 16u)) __builtin_amdgcn_s_setprio(3);
         consume_tile<DT, NW>(a, tc, wave, lane, hist, tot, dnm, rcp);
         __builtin_amdgcn_s_setprio(0);
         lds_barrier();

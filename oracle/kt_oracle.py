@@ -238,10 +238,11 @@ def cgr_points(seq, vecsize=1):
     return out[:n].copy()
 
 
-def cgr_batch(bases, offsets, vecsize=1):
-    """all reads of a CSR batch -> (total_bases, 2) f64"""
+def cgr_batch(bases, offsets, vecsize=1, out=None):
+    """all reads of a CSR batch -> (total_bases, 2) f64 (`out`: a preallocated result to fill)"""
     total = int(offsets[-1])
-    out = np.zeros((max(total, 1), 2), np.float64)
+    if out is None:
+        out = np.zeros((max(total, 1), 2), np.float64)
     bb = bases if bases.size else np.zeros(1, np.uint8)
     if lib().kto_cgr_batch(_p(bb, u8p), _p(offsets, u64p), len(offsets) - 1, float(vecsize), _p(out, f64p)):
         raise ValueError("Bad nucleotide, unable to proceed")
