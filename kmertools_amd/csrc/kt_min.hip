@@ -29,6 +29,10 @@
 #include "kt_internal.hpp"
 #include "kt_launch.hpp"
 
+#ifndef KT_MIN_DEBUG
+#define KT_MIN_DEBUG 0  // timing experiments only: 1 = no event stores, 2 = no per-read offsets, 4 = no look-back
+#endif
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -62,29 +66,50 @@ __global__ void gran_index_kernel(const uint64_t *__restrict__ offsets, uint64_t
 }
 
 // lastbreak[g] = 1 + the latest run-start candidate inside granule g (a read start q gives q, an ambiguous
-// base q gives q + 1), 0 if the granule has none
+// base q gives q + 1), 0 if the granule has none.  One wave per granule: a lane checks 16 bases (SWAR).
 __global__ __launch_bounds__(BLOCK) void gran_break_kernel(const uint8_t *__restrict__ bases, uint64_t total,
                                                            const uint64_t *__restrict__ offsets,
-                                                           const uint64_t *__restrict__ gfirst,
-                                                           uint64_t n_reads, uint64_t *__restrict__ lastbreak) {
-    __shared__ unsigned long long best;
-    const uint64_t g = blockIdx.x;
-    if (threadIdx.x == 0) best = 0;
-    __syncthreads();
+                                                           const uint64_t *__restrict__ gfirst, uint64_t n_reads,
+                                                           uint64_t n_gran, uint64_t *__restrict__ lastbreak) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t g = (uint64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    if (g >= n_gran) return;
+    const uint64_t p0 = g * GRAN, p = p0 + 16ull * lane;
     unsigned long long mine = 0;
-    const uint64_t p0 = g * GRAN;
-    for (uint32_t i = threadIdx.x; i < GRAN; i += BLOCK) {
-        const uint64_t p = p0 + i;
-        if (p < total && ktd::nt4(bases[p]) > 3) mine = p + 2;
+    if (p < total) {
+        uint32_t d[4];
+        if (p + 16 <= total) {
+            __builtin_memcpy(d, bases + p, 16);
+        } else {
+            unsigned char raw[16];
+            for (int j = 0; j < 16; j++) raw[j] = p + j < total ? bases[p + j] : (unsigned char)'A';
+            __builtin_memcpy(d, raw, 16);
+        }
+        uint32_t inv = 0, any_raw = 0;  // inv: bit 15 - j = byte j is not a nucleotide
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t c8, i4, rw;
+            ktd::swar4(d[q], c8, i4, rw);
+            inv = (inv << 4) | i4;
+            any_raw |= rw;
+        }
+        if (any_raw) {  // raw codes 0..3 are nucleotides too: per-byte check
+            inv = 0;
+            for (int j = 0; j < 16; j++) inv |= (ktd::nt4((d[j >> 2] >> (8 * (j & 3))) & 0xFFu) >> 2) << (15 - j);
+        }
+        if (inv) mine = p + (15u - (uint32_t)__builtin_ctz(inv)) + 2;  // last ambiguous byte q: candidate q + 1, stored + 1
     }
-    for (uint64_t r = gfirst[g] + threadIdx.x; r < n_reads; r += BLOCK) {
+    for (uint64_t r = gfirst[g] + lane; r < n_reads; r += 64) {
         const uint64_t o = offsets[r];
         if (o >= p0 + GRAN) break;
         if (o + 1 > mine) mine = o + 1;
     }
-    if (mine) atomicMax(&best, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) lastbreak[g] = best;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(mine, off, 64);
+        mine = o > mine ? o : mine;
+    }
+    if (lane == 0) lastbreak[g] = mine;
 }
 
 // ---- device-wide exclusive scans over small arrays (sum or max), three launches ------------------------
@@ -182,7 +207,7 @@ __device__ __forceinline__ uint32_t ph(uint32_t li) { return li + (li >> 4); }
 template <class V>
 struct TileShared {
     V a[RANGE + RANGE / 16];     // m-mers -> doubling -> active minimiser (padded, see ph())
-    __attribute__((aligned(16))) uint8_t code[RANGE + 32];  // 2-bit codes (4 = ambiguous) of positions range0 - 32 ..
+    uint32_t packed[BLOCK + 2];  // 16 bases per word (2-bit codes, first base on top); [0], [1] = the 32 bases before the range
     uint32_t start_bits[RANGE / 32 + 1];  // bit per position of the range (+1): a read starts here
     uint16_t rank[RANGE];        // EMIT: events of the tile in front of each position
     int32_t scan_tmp[2][8];
@@ -231,15 +256,35 @@ __device__ __forceinline__ uint32_t block_sum_excl(uint32_t v, uint32_t *tmp, ui
 // uint64_t otherwise.  Everything inside the tile is in 32-bit local coordinates (index into the range);
 // "break" values are run / read start candidates as local indices, FAR when they lie in front of the range
 // (their exact global values then come from the carries).
+// EMIT = false: count pass, tile_count[tile] = events of the tile.
+// EMIT = true:  single pass.  Tiles take their number from a ticket counter (so a tile only ever waits for
+// tiles that are already running), publish their event count, and find their output offset by looking back
+// over the predecessors' published counts / prefixes (decoupled look-back, one wave, 64 tiles per step);
+// no separate count pass or scan is needed when the caller's capacity is known to suffice.
+struct Chain {
+    unsigned long long *status;  // [n_tiles] (count or inclusive prefix) | flag in the top two bits; zeroed
+    unsigned long long *ticket;  // [1] zeroed
+    uint64_t *total;             // [1] receives the number of events
+    uint64_t n_tiles, capacity;
+};
+constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = 3ull << 62;
+
 template <class V, bool EMIT>
-__global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__restrict__ tile_count,
-                                                         const uint64_t *__restrict__ ev_base, Event *__restrict__ ev,
-                                                         uint8_t *__restrict__ ev_type, uint64_t *__restrict__ ev_offsets) {
+__global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__restrict__ tile_count, Chain chain,
+                                                         Event *__restrict__ ev, uint8_t *__restrict__ ev_type,
+                                                         uint64_t *__restrict__ ev_offsets) {
     __shared__ TileShared<V> sm;
+    __shared__ uint64_t sh_u64;
     constexpr V VNONE = (V)~(V)0;
     constexpr int32_t FAR = -(1 << 30);
     const uint32_t tid = threadIdx.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;           // first position owned
+    uint64_t tile = blockIdx.x;
+    if (EMIT) {
+        if (tid == 0) sh_u64 = atomicAdd(chain.ticket, 1ull);
+        __syncthreads();
+        tile = sh_u64;
+    }
+    const uint64_t t0 = tile * TILE;           // first position owned
     const int64_t range0 = (int64_t)t0 - (int64_t)GRAN;        // position of local index 0 (negative for tile 0)
     const int32_t m = (int32_t)a.m, w = (int32_t)a.w;
     const uint32_t W = a.W;
@@ -247,10 +292,46 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
     const int32_t lo_in = range0 < 0 ? (int32_t)GRAN : 0;
     const int32_t hi_in = a.total - t0 >= TILE ? (int32_t)RANGE : (int32_t)(a.total - t0) + (int32_t)GRAN;
 
-    // ---- stage codes (32 bases of context in front of the range) and read-start bits ----
-    for (uint32_t i = tid; i < RANGE + 32; i += BLOCK) {
-        const int64_t p = range0 - 32 + (int64_t)i;
-        sm.code[i] = (p >= 0 && (uint64_t)p < a.total) ? (uint8_t)ktd::nt4(a.bases[p]) : (uint8_t)4;
+    // ---- this thread's 16 bases: one 16-byte load, SWAR-encoded (codes P, ambiguity flags inv) ----
+    const int32_t l0 = (int32_t)(tid * PER);  // first local index of this thread
+    // P: base j at bits 31-2j..30-2j; inv: bit 15-j set = base j is not a nucleotide (or outside the batch)
+    auto encode16 = [&](int64_t p, uint32_t &P, uint32_t &inv) {
+        uint32_t d[4];
+        if (p >= 0 && (uint64_t)p + 16 <= a.total) {
+            __builtin_memcpy(d, a.bases + p, 16);
+        } else {
+            unsigned char raw[16];
+            for (int j = 0; j < 16; j++) raw[j] = (p + j >= 0 && (uint64_t)(p + j) < a.total) ? a.bases[p + j] : (unsigned char)'N';
+            __builtin_memcpy(d, raw, 16);
+        }
+        uint32_t any_raw = 0;
+        P = 0;
+        inv = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t c8, i4, rw;
+            ktd::swar4(d[q], c8, i4, rw);
+            P = (P << 8) | c8;
+            inv = (inv << 4) | i4;
+            any_raw |= rw;
+        }
+        if (any_raw) {  // raw codes 0..3 in the input: per-byte table
+            P = 0;
+            inv = 0;
+            for (int j = 0; j < 16; j++) {
+                const uint32_t e = ktd::nt4((d[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                P |= (e & 3u) << (30 - 2 * j);
+                inv |= (e >> 2) << (15 - j);
+            }
+        }
+    };
+    uint32_t P, inv16;
+    encode16(range0 + (int64_t)l0, P, inv16);
+    sm.packed[tid + 2] = P;
+    if (tid < 2) {
+        uint32_t Pc, ic;
+        encode16(range0 - 32 + 16 * (int64_t)tid, Pc, ic);
+        sm.packed[tid] = Pc;
     }
     for (uint32_t i = tid; i < RANGE / 32 + 1; i += BLOCK) sm.start_bits[i] = 0;
     __syncthreads();
@@ -266,15 +347,9 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
     }
     __syncthreads();
 
-    // ---- this thread's 16 positions: codes and read-start bits into registers ----
-    const int32_t l0 = (int32_t)(tid * PER);  // first local index of this thread
-    uint32_t cd[PER];
-    {
-        const uint4 cw = *reinterpret_cast<const uint4 *>(&sm.code[l0 + 32]);
-        const uint32_t wds[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-        for (uint32_t j = 0; j < PER; j++) cd[j] = (wds[j >> 2] >> (8 * (j & 3u))) & 0xFFu;
-    }
+    // code / ambiguity of the thread's position j (compile-time j: bit-field extracts)
+#define KT_CODE(j) ((P >> (30 - 2 * (j))) & 3u)
+#define KT_AMBIG(j) ((inv16 >> (15 - (j))) & 1u)
     // bit j: a read starts at position l0 + j (bit 16: at the position after this thread's last)
     const uint32_t sb = (uint32_t)((((uint64_t)sm.start_bits[(l0 >> 5) + 1] << 32) | sm.start_bits[l0 >> 5]) >> (l0 & 31)) &
                         0x1FFFFu;
@@ -288,7 +363,7 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
     for (int32_t j = 0; j < (int32_t)PER; j++) {
         if (!((inside >> j) & 1u)) continue;
         if ((sb >> j) & 1u) loc_run = loc_read = l0 + j;
-        if (cd[j] > 3) loc_run = l0 + j + 1;
+        if (KT_AMBIG(j)) loc_run = l0 + j + 1;
     }
     const int32_t run0 = block_max_excl(loc_run, FAR, sm.scan_tmp[0]);    // as of the position in front of l0
     const int32_t read0 = block_max_excl(loc_read, FAR, sm.scan_tmp[1]);
@@ -309,22 +384,24 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         V f = 0, r = 0;
         const V mask = (V)(((uint64_t)1 << (2 * m)) - 1ull);
         const uint32_t rsh = 2 * (uint32_t)(m - 1);
-        // the m - 1 codes in front of the first position (ambiguous ones are harmless: run_len gates the use)
-        for (int32_t j = 0; j + 1 < m; j++) {
-            const uint32_t c = sm.code[l0 + 32 - (m - 1) + j] & 3u;
-            f = (V)(((f << 2) | c) & mask);
-            r = (V)((r >> 2) | ((V)(3u - c) << rsh));
+        // the m - 1 codes in front of the first position = the low bits of the two packed words before this
+        // thread's (ambiguous ones are harmless: run_len gates the use); their reverse complement seeds r
+        if (m > 1) {
+            const uint64_t ctx = ((uint64_t)sm.packed[tid] << 32) | sm.packed[tid + 1];
+            const uint64_t fm = ctx & ((1ull << (2 * (m - 1))) - 1ull);
+            f = (V)fm;
+            r = (V)(ktd::rev_comp(fm, m - 1) << 2);
         }
         int32_t b = run0;
 #pragma unroll
         for (int32_t j = 0; j < (int32_t)PER; j++) {
-            const uint32_t c = cd[j] & 3u;
+            const uint32_t c = KT_CODE(j);
             f = (V)(((f << 2) | c) & mask);
             r = (V)((r >> 2) | ((V)(3u - c) << rsh));
             V v = VNONE;
             if ((inside >> j) & 1u) {
                 if ((sb >> j) & 1u) b = l0 + j;
-                if (cd[j] > 3) b = l0 + j + 1;
+                if (KT_AMBIG(j)) b = l0 + j + 1;
                 if (l0 + j + 1 - b >= m) v = f < r ? f : r;  // run_len = position + 1 - run start
             }
             sm.a[ph((uint32_t)(l0 + j))] = v;
@@ -334,18 +411,25 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
 
     // ---- sliding minimum over W m-mers: doubling, then two overlapping power-of-two windows ----
     {
+        // only windows ending at local index >= GRAN - 1 are ever read; the values they are built from reach
+        // back less than 2 W positions, so the threads further in front (most of the halo wave) just keep step
+        const bool needed = (uint32_t)l0 + PER + 2 * W + 2 > GRAN;
         auto combine = [&](uint32_t dist) {
             V x[PER];
+            if (needed) {
 #pragma unroll
-            for (uint32_t j = 0; j < PER; j++) {
-                const uint32_t li = (uint32_t)l0 + j;
-                const V u = sm.a[ph(li)];
-                const V o = li >= dist ? sm.a[ph(li - dist)] : VNONE;
-                x[j] = u < o ? u : o;
+                for (uint32_t j = 0; j < PER; j++) {
+                    const uint32_t li = (uint32_t)l0 + j;
+                    const V u = sm.a[ph(li)];
+                    const V o = li >= dist ? sm.a[ph(li - dist)] : VNONE;
+                    x[j] = u < o ? u : o;
+                }
             }
             __syncthreads();
+            if (needed) {
 #pragma unroll
-            for (uint32_t j = 0; j < PER; j++) sm.a[ph((uint32_t)l0 + j)] = x[j];
+                for (uint32_t j = 0; j < PER; j++) sm.a[ph((uint32_t)l0 + j)] = x[j];
+            }
             __syncthreads();
         };
         uint32_t span = 1;  // sm.a[i] = min of the `span` m-mers ending at i
@@ -357,69 +441,127 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
     }
 
     // ---- events of the positions this workgroup owns (local index >= GRAN) ----
-    // visit(j, kind, val, run start (local)) is called for every event, in position order
-    V act[PER + 1];
-    act[0] = l0 ? sm.a[ph((uint32_t)l0 - 1)] : VNONE;
-#pragma unroll
-    for (uint32_t j = 0; j < PER; j++) act[j + 1] = sm.a[ph((uint32_t)l0 + j)];
-    auto scan_events = [&](auto &&visit) {
+    // detection only: which of the thread's positions emit (ev_bits), of which kind (2 bits each), and whether an
+    // E3 reports "no full window" (none_bits).  The records are built afterwards, one per set bit.
+    uint32_t ev_bits = 0, kinds = 0, none_bits = 0, inv_bits = 0;
+    {
+        V act_prev = l0 ? sm.a[ph((uint32_t)l0 - 1)] : VNONE;
         int32_t b = run0;
 #pragma unroll
         for (int32_t j = 0; j < (int32_t)PER; j++) {
-            if (!((inside >> j) & 1u)) continue;
-            const int32_t li = l0 + j;
-            const int32_t b_prev = b;  // run bookkeeping as of the previous position
-            const bool st = (sb >> j) & 1u;
-            if (st) b = li;
-            if (cd[j] > 3) b = li + 1;
-            if (li < (int32_t)GRAN) continue;  // halo positions only carry state
-            const int32_t run_len = li + 1 - b;
-            // run length of the previous position (0 at a read start: that base belongs to another read)
-            const int32_t prev_len = st ? 0 : li - b_prev;
-            const bool last = (li + 1 == hi_in && t0 + TILE >= a.total) || ((sb >> (j + 1)) & 1u);
-            if (cd[j] > 3) {
-                if (prev_len >= w) visit(j, 2u, act[j], b_prev);                  // E2: an ambiguous base closes a full window
-            } else if (run_len > w && act[j + 1] != act[j]) {
-                visit(j, 1u, act[j], b);                                          // E1: the active minimiser changed
-            } else if (last && run_len >= m) {
-                visit(j, 3u, run_len >= w ? act[j + 1] : VNONE, b);               // E3: the read's last window
+            const V act = sm.a[ph((uint32_t)(l0 + j))];
+            if ((inside >> j) & 1u) {
+                const int32_t li = l0 + j;
+                const int32_t b_prev = b;  // run bookkeeping as of the previous position
+                const bool st = (sb >> j) & 1u;
+                if (st) b = li;
+                if (KT_AMBIG(j)) {
+                    b = li + 1;
+                    inv_bits |= 1u << j;
+                }
+                if (li >= (int32_t)GRAN) {  // halo positions only carry state
+                    const int32_t run_len = li + 1 - b;
+                    // run length of the previous position (0 at a read start: that base belongs to another read)
+                    const int32_t prev_len = st ? 0 : li - b_prev;
+                    const bool last = (li + 1 == hi_in && t0 + TILE >= a.total) || ((sb >> (j + 1)) & 1u);
+                    uint32_t kind = 0;
+                    if (KT_AMBIG(j)) {
+                        if (prev_len >= w) kind = 2;                    // E2: an ambiguous base closes a full window
+                    } else if (run_len > w && act != act_prev) {
+                        kind = 1;                                       // E1: the active minimiser changed
+                    } else if (last && run_len >= m) {
+                        kind = 3;                                       // E3: the read's last window
+                        if (run_len < w) none_bits |= 1u << j;
+                    }
+                    if (kind) {
+                        ev_bits |= 1u << j;
+                        kinds |= kind << (2 * j);
+                    }
+                }
             }
+            act_prev = act;
         }
-    };
-    uint32_t n_ev = 0;
-    scan_events([&](int32_t, uint32_t, V, int32_t) { n_ev++; });
+    }
+    const uint32_t n_ev = (uint32_t)__builtin_popcount(ev_bits);
     uint32_t tile_total;
     const uint32_t rank0 = block_sum_excl(n_ev, sm.cnt_tmp, &tile_total);
     if (!EMIT) {
-        if (tid == 0) tile_count[blockIdx.x] = tile_total;
+        if (tid == 0) tile_count[tile] = tile_total;
         return;
     }
-    const uint64_t base = ev_base[blockIdx.x];
-    {
-        // read start of every position of this thread (for the events' read-local coordinates)
-        uint32_t rk = rank0, done = 0;  // done: bit j set once position j's rank is stored
-        int32_t rd = read0;
-        uint32_t next_j = 0;
-        scan_events([&](int32_t j, uint32_t kind, V val, int32_t run) {
-            for (; next_j <= (uint32_t)j; next_j++)
-                if (((inside >> next_j) & 1u) && ((sb >> next_j) & 1u)) rd = l0 + (int32_t)next_j;
-            // an E2 sits on the ambiguous base itself, which belongs to the same read as the window it closes
-            ev[base + rk] = Event{val == VNONE ? NONE : (uint64_t)val, (uint64_t)(range0 + (int64_t)(l0 + j)),
-                                  global_of(run, carry_run), global_of(rd, carry_read)};
-            ev_type[base + rk] = (uint8_t)kind;
-            sm.rank[l0 + j] = (uint16_t)rk;
-            done |= 1u << j;
-            rk++;
-        });
-        // positions without an event: events in front of them = rank0 + events among the earlier positions
-        uint32_t before = rank0;
+    // ---- output offset of this tile: publish the count, look back over the predecessors ----
+    if (tid < 64) {
+        if (tid == 0)
+            // the status word carries its own payload, so relaxed device-scope atomics are enough (acquire loads
+            // in the polling loop invalidated the L1 on every probe: 50 ms instead of 15)
+            __hip_atomic_store(&chain.status[tile], (unsigned long long)tile_total | (tile ? ST_AGG : ST_PREFIX),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t sum = 0;
+        int64_t j0 = (KT_MIN_DEBUG & 4) ? -1 : (int64_t)tile - 1;  // lane l looks at tile j0 - l
+        while (j0 >= 0) {
+            const int64_t j = j0 - (int64_t)tid;
+            unsigned long long st = ST_PREFIX;  // tiles in front of tile 0: an empty prefix
+            if (j >= 0) {
+                do {
+                    st = __hip_atomic_load(&chain.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((st & ST_MASK) == 0);
+            }
+            const uint64_t is_prefix = __ballot((st & ST_MASK) == ST_PREFIX);
+            const uint32_t first = is_prefix ? (uint32_t)__builtin_ctzll(is_prefix) : 64u;  // nearest tile with a prefix
+            uint64_t part = tid <= first ? (uint64_t)(st & ~ST_MASK) : 0;
 #pragma unroll
-        for (uint32_t j = 0; j < PER; j++) {
-            if ((done >> j) & 1u) before++;
-            else sm.rank[l0 + j] = (uint16_t)before;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+            sum += __shfl(part, 0, 64);
+            if (is_prefix) break;
+            j0 -= 64;
+        }
+        if (tid == 0) {
+            if (tile)
+                __hip_atomic_store(&chain.status[tile], (unsigned long long)(sum + tile_total) | ST_PREFIX, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (tile + 1 == chain.n_tiles) *chain.total = sum + tile_total;
+            sh_u64 = sum;
         }
     }
     __syncthreads();
+    const uint64_t base = sh_u64;
+    {
+        // one record per set bit of ev_bits.  Everything a record needs is a function of the bit masks: the run
+        // start is the latest break (read start -> its position, ambiguous base -> the position after it) at or,
+        // for an E2, before the event's position; the read start likewise; the minimiser sits in sm.a.
+        const uint32_t starts_in = sb & inside & 0xFFFFu;
+        uint32_t bits = ev_bits, rk = rank0;
+        while (bits) {
+            const uint32_t j = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t kind = (kinds >> (2 * j)) & 3u;
+            const uint32_t li = (uint32_t)l0 + j;
+            V val = sm.a[ph(kind == 3 ? li : li - 1)];
+            if ((none_bits >> j) & 1u) val = VNONE;
+            const uint32_t upto = (2u << j) - 1u;                     // positions <= j
+            const uint32_t before = kind == 2 ? (upto >> 1) : upto;   // an E2 closes the run that ended before it
+            const uint32_t sm_run = starts_in & before, im_run = inv_bits & before, sm_read = starts_in & upto;
+            int32_t run = run0;
+            if (sm_run) run = max(run, l0 + 31 - (int32_t)__builtin_clz(sm_run));
+            if (im_run) run = max(run, l0 + 32 - (int32_t)__builtin_clz(im_run));
+            const int32_t rd = sm_read ? l0 + 31 - (int32_t)__builtin_clz(sm_read) : read0;
+            if (base + rk < chain.capacity && !(KT_MIN_DEBUG & 1)) {
+                ev[base + rk] = Event{val == VNONE ? NONE : (uint64_t)val, (uint64_t)(range0 + (int64_t)li),
+                                      global_of(run, carry_run), global_of(rd, carry_read)};
+                ev_type[base + rk] = (uint8_t)kind;
+            }
+            rk++;
+        }
+        // events in front of every position (for the reads that start inside the tile)
+        uint32_t before_pos = rank0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            sm.rank[l0 + j] = (uint16_t)before_pos;
+            before_pos += (ev_bits >> j) & 1u;
+        }
+    }
+    __syncthreads();
+    if (KT_MIN_DEBUG & 2) return;
     for (uint64_t r = a.gfirst[t0 / GRAN] + tid; r < a.n_reads; r += BLOCK) {
         const uint64_t o = a.offsets[r];
         if (o >= t0 + TILE || o >= a.total) break;
@@ -583,41 +725,51 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
         } else {
             hipLaunchKernelGGL(gran_index_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                d_offsets, n_reads, gfirst, n_gran);
-            hipLaunchKernelGGL(gran_break_kernel, dim3((uint32_t)n_gran), dim3(BLOCK), 0, ctx->stream, d_bases, total,
-                               d_offsets, gfirst, n_reads, lastbreak);
+            hipLaunchKernelGGL(gran_break_kernel, dim3((uint32_t)((n_gran + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0,
+                               ctx->stream, d_bases, total, d_offsets, gfirst, n_reads, n_gran, lastbreak);
             if (int rc = device_excl_scan<true>(ctx, lastbreak, n_gran, carry, partial, nullptr)) return rc;
             MinArgs a{d_bases, d_offsets, gfirst, carry, n_reads, total, n_gran,
                       (uint32_t)wsize, (uint32_t)msize, (uint32_t)(wsize - (uint64_t)msize + 1)};
             const bool narrow = msize <= 16;
-            if (narrow)
-                hipLaunchKernelGGL((min_tile_kernel<uint32_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a,
-                                   tcount, (const uint64_t *)nullptr, (Event *)nullptr, (uint8_t *)nullptr,
-                                   (uint64_t *)nullptr);
-            else
-                hipLaunchKernelGGL((min_tile_kernel<uint64_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a,
-                                   tcount, (const uint64_t *)nullptr, (Event *)nullptr, (uint8_t *)nullptr,
-                                   (uint64_t *)nullptr);
-            if (int rc = device_excl_scan<false>(ctx, tcount, n_tiles, tbase, partial, d_total)) return rc;
-            KT_HIP(hipMemcpyAsync(&n_ev, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-            KT_HIP(hipStreamSynchronize(ctx->stream));
-            if (capacity && n_ev) {
-                if (int rc = ctx->s_aux2.reserve(align256(n_ev * sizeof(Event)) + n_ev + 256)) return rc;
-                Event *ev = (Event *)ctx->s_aux2.p;
-                uint8_t *ev_type = (uint8_t *)ctx->s_aux2.p + align256(n_ev * sizeof(Event));
+            Chain chain{(unsigned long long *)tcount, (unsigned long long *)(d_total + 1), d_total, n_tiles, capacity};
+            if (capacity == 0) {
+                // count only: per-tile counts, then their sum
                 if (narrow)
-                    hipLaunchKernelGGL((min_tile_kernel<uint32_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0,
-                                       ctx->stream, a, (uint64_t *)nullptr, tbase, ev, ev_type, d_evoff);
+                    hipLaunchKernelGGL((min_tile_kernel<uint32_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
+                                       a, tcount, chain, (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
                 else
-                    hipLaunchKernelGGL((min_tile_kernel<uint64_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0,
-                                       ctx->stream, a, (uint64_t *)nullptr, tbase, ev, ev_type, d_evoff);
+                    hipLaunchKernelGGL((min_tile_kernel<uint64_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
+                                       a, tcount, chain, (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
+                if (int rc = device_excl_scan<false>(ctx, tcount, n_tiles, tbase, partial, d_total)) return rc;
+                KT_HIP(hipMemcpyAsync(&n_ev, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KT_HIP(hipStreamSynchronize(ctx->stream));
+            } else {
+                // single pass: the tiles chain their output offsets themselves (decoupled look-back)
+                if (int rc = ctx->s_aux2.reserve(align256(capacity * sizeof(Event)) + capacity + 256)) return rc;
+                Event *ev = (Event *)ctx->s_aux2.p;
+                uint8_t *ev_type = (uint8_t *)ctx->s_aux2.p + align256(capacity * sizeof(Event));
+                KT_HIP(hipMemsetAsync(tcount, 0, n_tiles * 8, ctx->stream));
+                KT_HIP(hipMemsetAsync(d_total, 0, 16, ctx->stream));
+                if (narrow)
+                    hipLaunchKernelGGL((min_tile_kernel<uint32_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
+                                       a, (uint64_t *)nullptr, chain, ev, ev_type, d_evoff);
+                else
+                    hipLaunchKernelGGL((min_tile_kernel<uint64_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
+                                       a, (uint64_t *)nullptr, chain, ev, ev_type, d_evoff);
                 hipLaunchKernelGGL(min_tail_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                    d_evoff, n_reads, d_total);
-                hipLaunchKernelGGL(min_finalize_kernel, dim3((uint32_t)((n_ev + 255) / 256)), dim3(256), 0, ctx->stream, ev,
-                                   ev_type, n_ev, (uint32_t)wsize, capacity, d_k, d_s, d_e);
                 KT_HIP(hipGetLastError());
+                KT_HIP(hipMemcpyAsync(&n_ev, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KT_HIP(hipStreamSynchronize(ctx->stream));
+                const uint64_t n_fin = n_ev < capacity ? n_ev : capacity;
+                if (n_fin) {
+                    hipLaunchKernelGGL(min_finalize_kernel, dim3((uint32_t)((n_fin + 255) / 256)), dim3(256), 0, ctx->stream, ev,
+                                       ev_type, n_fin, (uint32_t)wsize, capacity, d_k, d_s, d_e);
+                    KT_HIP(hipGetLastError());
+                }
             }
         }
-        if (total == 0 || !(capacity && n_ev)) {
+        if (total == 0 || capacity == 0) {
             // no emit pass ran: every read's offset is the (possibly zero) total
             hipLaunchKernelGGL(min_tail_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                d_evoff, n_reads, d_total);
