@@ -20,12 +20,15 @@
 // w = 0 ("one minimiser per sequence", misc/src/minimisers.rs:44-48) makes w the read's own length;
 // it has its own one-thread-per-read kernel.
 //
-// General w: the batch is cut into tiles of 3072 positions (+ a 1024-position halo in front, so
-// W <= 1024).  Run starts are a max-scan ("latest break before p") carried across tiles by a
-// small prefix pass over 1024-position granules; the sliding minimum is log2(W) doubling steps
-// over an LDS array of the tile's m-mers.  Two passes (count, then emit at scanned offsets) keep
-// the output dense and in read order; a last pass resolves ws and read-local coordinates.
-// HBM traffic is a few bytes per base; the work is LDS/VALU bound.  No MFMA.
+// General w: the batch is cut into tiles of 7168 positions (+ a 1024-position halo in front, so
+// W <= 1024), 16 consecutive positions per thread (one 16-byte load, SWAR-encoded).  Run starts
+// are a max-scan ("latest break before p") carried across tiles by a small prefix pass over
+// 1024-position granules; the sliding minimum is log2(W) doubling steps over a padded LDS array
+// of the tile's m-mers.  Output is dense and in read order: with a known capacity one pass does it
+// all - tiles take tickets, publish their event counts and chain their output offsets by
+// decoupled look-back - and a capacity-0 call is the count-only pass.  A last small kernel
+// resolves window starts and read-local coordinates.  HBM traffic is a few bytes per base; the
+// work is LDS/VALU bound.  No MFMA.
 #include "kt_internal.hpp"
 #include "kt_launch.hpp"
 
@@ -35,11 +38,14 @@
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef KT_MIN_BLOCK
+#define KT_MIN_BLOCK 512
+#endif
+constexpr int BLOCK = KT_MIN_BLOCK;
 constexpr uint32_t GRAN = 1024;               // carry granule (positions)
-constexpr uint32_t TILE = 3 * GRAN;           // positions owned by a workgroup
-constexpr uint32_t RANGE = TILE + GRAN;       // with the halo granule in front
-constexpr uint32_t PER = RANGE / BLOCK;       // 16 consecutive positions per thread
+constexpr uint32_t PER = 16;                  // consecutive positions per thread
+constexpr uint32_t RANGE = BLOCK * PER;       // positions a workgroup looks at: one halo granule + its tile
+constexpr uint32_t TILE = RANGE - GRAN;       // positions owned by a workgroup
 constexpr uint64_t NONE = ~0ull;
 static_assert(PER * BLOCK == RANGE, "tiling");
 
