@@ -371,10 +371,17 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         if ((sb >> j) & 1u) loc_run = loc_read = l0 + j;
         if (KT_AMBIG(j)) loc_run = l0 + j + 1;
     }
-    const int32_t run0 = block_max_excl(loc_run, FAR, sm.scan_tmp[0]);    // as of the position in front of l0
+    int32_t run0 = block_max_excl(loc_run, FAR, sm.scan_tmp[0]);          // as of the position in front of l0
     const int32_t read0 = block_max_excl(loc_read, FAR, sm.scan_tmp[1]);
-    // exact global starts for candidates in front of the range (only read when an event needs them)
+    // starts in front of the range come from the carries.  A run start shortly before the range keeps its
+    // (negative) local index: with w > 1024 an owned position can still be inside that run's first w bases,
+    // and the run lengths must be exact there; anything further away collapses to FAR.
     const uint64_t carry_run = range0 > 0 ? a.carry[(uint64_t)range0 / GRAN] - 1 : 0;
+    if (range0 > 0) {
+        const int64_t rel = (int64_t)carry_run - range0;
+        const int32_t carry_local = rel < (int64_t)FAR ? FAR : (int32_t)rel;
+        run0 = run0 > carry_local ? run0 : carry_local;
+    }
     uint64_t carry_read = 0;
     if (range0 > 0) {  // the read that holds position range0 - 1
         const uint64_t g = (uint64_t)range0 / GRAN;

@@ -866,3 +866,23 @@ def test_ctr_cfg3_full_size_properties(torch_mod, ctx):
     assert int((k2.to(torch.float64) * c2.to(torch.float64)).sum()) == int((keys.to(torch.float64) * counts.to(torch.float64)).sum())
     assert int(c2.to(torch.int64).sum()) == n * (L - k + 1)
     ctr.close()
+
+
+def test_minimisers_wide_window_run_start_before_halo(hctx, oracle):
+    """w > 1024 (W <= 1024 still): a run that starts a few bases in front of a tile's halo must keep its exact
+    length for the tile's first positions (found by tools/fuzz_parity.py: w=1050, m=27)"""
+    rng = np.random.default_rng(5)
+    alpha = np.array(list("ACGT"))
+    seqs = []
+    for d in (1, 5, 26, 27, 40, 200):
+        s = rng.choice(alpha, size=40000)
+        for tile in range(1, 5):
+            for unit in (3072, 7168):                 # tile sizes this kernel has used
+                p = tile * unit - 1024 - d
+                if 0 <= p < len(s):
+                    s[p] = "N"
+        seqs.append("".join(s))
+    for w, m in ((1050, 27), (1054, 31), (1030, 7)):
+        got = _min_triples(hctx, seqs, w, m)
+        for i, s in enumerate(seqs):
+            assert got[i] == oracle.minimisers(s, w, m), (i, w, m)
