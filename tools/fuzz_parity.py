@@ -51,6 +51,11 @@ while time.time() < t_end:
     k = int(rng.integers(3, 8)); cm = bool(rng.integers(0, 2)); norm = bool(rng.integers(0, 2))
     got = ctx.oligo_host(bases, offsets, k, count_min=cm, norm=norm)
     assert np.array_equal(got, oracle.oligo_batch(bases, offsets, k, cm, norm)), ("oligo", seed, k, cm, norm)
+    if rng.random() < 0.3:
+        g32 = ctx.oligo_host(bases, offsets, k, count_min=cm, norm=True, dtype="f32")
+        assert np.abs(g32.astype(np.float64) - oracle.oligo_batch(bases, offsets, k, cm, True)).max() <= 1e-6
+        gu = ctx.oligo_host(bases, offsets, k, count_min=cm, norm=False, dtype="u32")
+        assert np.array_equal(gu.astype(np.float64), oracle.oligo_batch(bases, offsets, k, cm, False))
     cases["oligo"] += 1
     # ctr + cov
     k = int(rng.integers(1, 32))
@@ -62,6 +67,19 @@ while time.time() < t_end:
     ctr.add_reads_host(b1, o1); ctr.add_reads_host(b2, o2)
     gk, gc = ctr.export_host()
     assert np.array_equal(gk, wk) and np.array_equal(gc, wc), ("ctr", seed, k)
+    if rng.random() < 0.5 and int(offsets[-1]):
+        # the routed-keys route: canonical k-mers as an array into an empty table (bulk), then once more (atomics)
+        f, r, _ = ctx.kmers_host(bases, offsets, k)
+        keys = np.minimum(f, r)
+        rng.shuffle(keys)
+        ctr.clear()
+        ctr.add_pairs_host(keys, None)
+        ctr.add_pairs_host(keys[: len(keys) // 3], None)
+        uk, uc = np.unique(np.concatenate([keys, keys[: len(keys) // 3]]), return_counts=True)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, uk) and np.array_equal(gc, uc.astype(np.uint32)), ("pairs", seed, k)
+        ctr.clear()
+        ctr.add_reads_host(bases, offsets)
     cases["ctr"] += 1
     q = reads()
     qb, qo = oracle.to_csr(q)
