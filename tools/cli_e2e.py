@@ -28,6 +28,9 @@ cmds = [
     ("comp oligo k=4 counts", ["comp", "oligo", "-i", fa, "-o", tmp / "o4c.kmers", "-k", "4", "-c"]),
     ("ctr k=31", ["ctr", "-i", fa, "-o", tmp / "c31", "-k", "31"]),
     ("cov k=15", ["cov", "-i", fa, "-o", tmp / "v15", "-k", "15"]),
+    ("comp cgr (whole seq)", ["comp", "cgr", "-i", fa, "-o", tmp / "whole.cgr"]),
+    ("min w=31 m=7 s2m", ["min", "-i", fa, "-o", tmp / "mins.s2m", "-w", "31", "-m", "7"]),
+    ("min w=0 m=10 m2s", ["min", "-i", fa, "-o", tmp / "mins.m2s", "-p", "m2s"]),
 ]
 for name, args in cmds:
     t0 = time.perf_counter()
