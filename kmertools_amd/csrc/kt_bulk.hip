@@ -36,7 +36,13 @@ using kttab::Slot;
 using kttab::TableRef;
 
 constexpr int BLOCK = ktseg::BLOCK;       // 256
-constexpr uint32_t LOG2_S = 13;           // slots per fine bucket
+#ifndef KT_LOG2_S
+#define KT_LOG2_S 13
+#endif
+#ifndef KT_BUILD_T
+#define KT_BUILD_T 1024
+#endif
+constexpr uint32_t LOG2_S = KT_LOG2_S;    // slots per fine bucket
 constexpr uint32_t S = 1u << LOG2_S;      // 4096 slots = 64 KB of table per fine bucket
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 constexpr uint32_t CHUNK2 = 4096;         // keys sorted at a time in part2
@@ -350,7 +356,7 @@ struct BuildShared {
     uint32_t counts[S];
 };
 
-constexpr int BUILD_T = 1024;  // 16 waves per fine bucket: short serial probe chains, full occupancy
+constexpr int BUILD_T = KT_BUILD_T;  // 16 waves per fine bucket: short serial probe chains, full occupancy
 
 __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restrict__ keys2,
                                                       const uint64_t *__restrict__ fstart, Plan p,
@@ -369,42 +375,44 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
         }
         ktd::lds_barrier();
         const uint64_t lo = fstart[fb], hi = fstart[fb + 1];
-        for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)BUILD_T * 4) {  // 4 loads in flight per thread
-          uint64_t kk[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-              const uint64_t i = i0 + (uint64_t)u * BUILD_T;
-              kk[u] = i < hi ? keys2[i] : KT_EMPTY_KEY;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint64_t key = kk[u];
-            if (key == KT_EMPTY_KEY) continue;
-            uint32_t s = (uint32_t)(ktd::khash(key) >> shift) & (S - 1);
-            bool placed = false;
-            for (; s < S; s++) {  // forward only: never wrap inside the range (kt_table.hpp invariant)
-                uint64_t cur = sm.keys[s];
-                if (cur == KT_EMPTY_KEY) {
-                    const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&sm.keys[s]),
-                                                    (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key);
-                    if (prev == KT_EMPTY_KEY) {  // claimed: first occurrence, stored count stays 0
-                        placed = true;
-                        break;
-                    }
-                    cur = prev;
-                }
-                if (cur == key) {
+        // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
+        // trip, and a lane that has placed its key moves on to its next one at once.  The obvious "for each key:
+        // probe until placed" makes the wave wait for its longest probe chain on every key (8x more trips at load
+        // factor 0.7).  Four keys are kept prefetched so the loads are never waited for.
+        {
+            uint64_t idx = lo + tid;
+            auto fetch = [&]() {
+                const uint64_t k = idx < hi ? keys2[idx] : KT_EMPTY_KEY;
+                idx += BUILD_T;
+                return k;
+            };
+            uint64_t cur = fetch(), q0 = fetch(), q1 = fetch(), q2 = fetch();
+            uint32_t s = (uint32_t)(ktd::khash(cur) >> shift) & (S - 1);
+            while (cur != KT_EMPTY_KEY) {
+                // one LDS operation per probe: the CAS itself reports what the slot holds (64-bit LDS atomics run at
+                // about a lane per clock, so a separate read before it doubled the cost of the common case)
+                const uint64_t v = atomicCAS(reinterpret_cast<unsigned long long *>(&sm.keys[s]),
+                                             (unsigned long long)KT_EMPTY_KEY, (unsigned long long)cur);
+                bool done = v == KT_EMPTY_KEY;  // claimed: first occurrence, stored count stays 0
+                if (!done && v == cur) {
                     atomicAdd(&sm.counts[s], 1u);
-                    placed = true;
-                    break;
+                    done = true;
+                }
+                if (!done && ++s >= S) {  // forward only: never wrap inside the range (kt_table.hpp invariant);
+                    // ran off the end: goes through the probing path afterwards
+                    const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
+                    if (at < spill_cap) spill_keys[at] = cur;
+                    else atomicOr(flags, 1u);
+                    done = true;
+                }
+                if (done) {
+                    cur = q0;
+                    q0 = q1;
+                    q1 = q2;
+                    q2 = fetch();
+                    s = (uint32_t)(ktd::khash(cur) >> shift) & (S - 1);
                 }
             }
-            if (!placed) {  // ran off the end of the range: goes through the probing path afterwards
-                const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
-                if (at < spill_cap) spill_keys[at] = key;
-                else atomicOr(flags, 1u);
-            }
-          }
         }
         ktd::lds_barrier();
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * S);
@@ -491,7 +499,7 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     hipLaunchKernelGGL(part2_kernel, dim3(p.B1), dim3(BLOCK), sizeof(Part2Shared), ctx->stream, keys1, m.bstart, p, keys2,
                        m.fstart);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
-    uint64_t gb = (uint64_t)ctx->n_cu * 2 * 2;
+    uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
     if (gb > n_fine) gb = n_fine;
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)sizeof(BuildShared)));
