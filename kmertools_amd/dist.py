@@ -21,11 +21,12 @@ import torch.distributed as dist
 from . import device
 
 
-def exchange_keys(keys, send_counts, group=None):
+def exchange_keys(keys, send_counts, group=None, recv_buf=None):
     """All-to-all of owner-grouped k-mers.
 
     keys        1-D int64 tensor; the first sum(send_counts) entries are grouped by owner rank
     send_counts python list / 1-D int64 CPU tensor of length world: group sizes
+    recv_buf    optional 1-D int64 tensor on keys.device to receive into when it is large enough (fabric path)
     returns     (received_keys int64 tensor, recv_counts list)
     Works on CUDA tensors (RCCL) and CPU tensors (gloo).
     """
@@ -40,7 +41,10 @@ def exchange_keys(keys, send_counts, group=None):
     dist.all_to_all_single(r, s, group=group)
     recv = [int(x) for x in r.cpu()]
     src = keys[: sum(send)].contiguous().to(xdev)
-    out = torch.empty(sum(recv), dtype=torch.int64, device=xdev)
+    if recv_buf is not None and on_gpu_fabric and recv_buf.numel() >= sum(recv):
+        out = recv_buf[: sum(recv)]
+    else:
+        out = torch.empty(sum(recv), dtype=torch.int64, device=xdev)
     dist.all_to_all_single(out, src, output_split_sizes=recv, input_split_sizes=send, group=group)
     return out.to(keys.device), recv
 
@@ -57,6 +61,7 @@ class ShardedCounter:
         self.table = device.Counter(ctx, k, capacity_slots)
         self._route_buf = None
         self._owner_counts = None
+        self._recv_buf = None   # grow-only receive buffer: one 8 B/k-mer array alive instead of two
 
     def clear(self):
         self.table.clear()
@@ -71,13 +76,17 @@ class ShardedCounter:
             self._route_buf = torch.empty(total, dtype=torch.int64, device=bases.device)
             self._owner_counts = torch.empty(64, dtype=torch.int64, device=bases.device)
         self.ctx.route(bases, offsets, n_reads, self.k, self.world, self._route_buf, self._owner_counts)
-        # the routing kernels run on ctx's stream = torch's current stream, so .cpu() orders after them
+        # wait for the routing kernels (and for the previous batch's table build, which reads the receive
+        # buffer) whatever stream the context runs on, before torch reads the counts / refills the buffer
+        self.ctx.sync()
         send = self._owner_counts[: self.world].cpu().tolist()
-        recv_keys, _ = exchange_keys(self._route_buf, send, self.group)
+        recv_keys, _ = exchange_keys(self._route_buf, send, self.group, self._recv_buf)
+        if self._recv_buf is None or recv_keys.numel() > self._recv_buf.numel():
+            self._recv_buf = recv_keys
         if recv_keys.numel():
+            if dist.get_backend(self.group) == "nccl":
+                torch.cuda.current_stream().synchronize()   # the collective's output is complete
             self.table.add_pairs(recv_keys, None, recv_keys.numel())
-            # recv_keys must outlive the enqueued kernel
-            self._last_recv = recv_keys
 
     def size_local(self):
         return self.table.size()
