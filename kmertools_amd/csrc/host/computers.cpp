@@ -203,6 +203,46 @@ class Channel {
     }
 };
 
+// Writes formatted batches on its own thread, so formatting batch i + 1 overlaps the write of batch i.
+// write() swaps the caller's pieces with a drained spare (capacities survive, nothing is reallocated)
+// and blocks only when two batches are already waiting.
+class AsyncWriter {
+    using Pieces = std::vector<std::string>;
+    FILE *out_;
+    PhaseTimer &pt_;
+    Pieces bufs_[3];
+    Channel<Pieces *> todo_, spare_;
+    std::thread th_;
+    bool finished_ = false;
+
+  public:
+    AsyncWriter(FILE *out, PhaseTimer &pt) : out_(out), pt_(pt) {
+        for (auto &b : bufs_) spare_.push(&b);
+        th_ = std::thread([this] {
+            Pieces *p = nullptr;
+            while (todo_.pop(p)) {
+                Lap lap;
+                for (const auto &s : *p) fwrite(s.data(), 1, s.size(), out_);
+                pt_.t[3] += lap();
+                spare_.push(p);
+            }
+        });
+    }
+    void write(Pieces &pieces) {
+        Pieces *p = nullptr;
+        spare_.pop(p);
+        p->swap(pieces);
+        todo_.push(p);
+    }
+    void finish() {  // call before fclose(out)
+        if (finished_) return;
+        finished_ = true;
+        todo_.close();
+        th_.join();
+    }
+    ~AsyncWriter() { finish(); }
+};
+
 // device(w): fills w.rows from w.b, returns "" or an error message.  emit(w): writes the text.
 static std::string run_pipeline(SeqReader &reader, uint64_t max_bases, uint64_t max_reads, PhaseTimer &pt,
                                 const std::function<std::string(Work &)> &device,
@@ -261,7 +301,7 @@ static uint64_t batch_bases(uint64_t memory) {
 static const uint8_t *bases_ptr(const Batch &b) { return b.bases.empty() ? (const uint8_t *)"" : b.bases.data(); }
 
 // writes `rows` (n x bins) as delimited text: {:.6} when normalised, Display otherwise
-static void emit_matrix(FILE *out, const Work &w, uint64_t bins, bool norm, const std::string &delim, int threads,
+static void emit_matrix(AsyncWriter &writer, const Work &w, uint64_t bins, bool norm, const std::string &delim, int threads,
                         std::vector<std::string> &pieces, PhaseTimer &pt) {
     Lap lap;
     const double *rows = w.rows.data();
@@ -275,8 +315,7 @@ static void emit_matrix(FILE *out, const Work &w, uint64_t bins, bool norm, cons
         s += '\n';
     });
     pt.t[2] += lap();
-    for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
-    pt.t[3] += lap();
+    writer.write(pieces);
 }
 
 // hidden `kmertools debug-emit`: times the text stage alone on fabricated count-ratio rows
@@ -295,7 +334,10 @@ double debug_emit_bench(uint64_t n_rows, uint64_t bins, bool norm, int threads, 
     double best = 1e30;
     for (int i = 0; i < reps; i++) {
         Lap lap;
-        emit_matrix(out, w, bins, norm, " ", threads, pieces, pt);
+        {
+            AsyncWriter writer(out, pt);
+            emit_matrix(writer, w, bins, norm, " ", threads, pieces, pt);
+        }
         const double d = lap();
         if (d < best) best = d;
     }
@@ -355,6 +397,7 @@ std::string OligoComputer::vectorise() {
     }
     std::vector<std::string> pieces;
     PhaseTimer pt("comp oligo");
+    AsyncWriter writer(out, pt);
     const std::string err = run_pipeline(
         reader, batch_bases(memory_), 1ull << 19, pt,
         [&](Work &w) -> std::string {
@@ -365,7 +408,8 @@ std::string OligoComputer::vectorise() {
                 return kt_last_error();
             return "";
         },
-        [&](Work &w) { emit_matrix(out, w, bins, norm_, delim_, threads_, pieces, pt); });
+        [&](Work &w) { emit_matrix(writer, w, bins, norm_, delim_, threads_, pieces, pt); });
+    writer.finish();
     fclose(out);
     return err;
 }
@@ -399,6 +443,7 @@ std::string OligoCgrComputer::vectorise() {
     }
     std::vector<std::string> pieces;
     PhaseTimer pt("comp cgr -k");
+    AsyncWriter writer(out, pt);
     // rows are 8 * bins bytes each: bound the batch by reads as well
     const uint64_t max_reads = bins >= 2048 ? 8192 : 262144;
     const std::string err = run_pipeline(
@@ -425,9 +470,9 @@ std::string OligoCgrComputer::vectorise() {
                 s += '\n';
             });
             pt.t[2] += lap();
-            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
-            pt.t[3] += lap();
+            writer.write(pieces);
         });
+    writer.finish();
     fclose(out);
     return err;
 }
@@ -447,6 +492,7 @@ std::string CgrComputer::vectorise() {
     }
     std::vector<std::string> pieces;
     PhaseTimer pt("comp cgr (whole sequence)");
+    AsyncWriter writer(out, pt);
     // 16 bytes of points and ~40 bytes of text per base: keep the batches small
     const std::string err = run_pipeline(
         reader, 16ull << 20, 1ull << 18, pt,
@@ -476,9 +522,9 @@ std::string CgrComputer::vectorise() {
                 s += '\n';
             });
             pt.t[2] += lap();
-            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
-            pt.t[3] += lap();
+            writer.write(pieces);
         });
+    writer.finish();
     fclose(out);
     return err;
 }
@@ -598,6 +644,7 @@ std::string CovComputer::compute_coverages() {
     std::vector<std::string> pieces;
     const uint64_t bins = bin_count_;
     PhaseTimer pt("cov");
+    AsyncWriter writer(out, pt);
     const std::string err = run_pipeline(
         reader, batch_bases(256ull << 20), bins >= 2048 ? 8192 : 1ull << 19, pt,
         [&](Work &w) -> std::string {
@@ -608,7 +655,8 @@ std::string CovComputer::compute_coverages() {
                 return kt_last_error();
             return "";
         },
-        [&](Work &w) { emit_matrix(out, w, bins, norm_, delim_, threads_, pieces, pt); });  // :112-124
+        [&](Work &w) { emit_matrix(writer, w, bins, norm_, delim_, threads_, pieces, pt); });  // :112-124
+    writer.finish();
     fclose(out);
     return err;
 }
@@ -666,6 +714,7 @@ std::string seq_to_min(uint64_t wsize, int msize, const std::string &in_path, co
     }
     std::vector<std::string> pieces;
     PhaseTimer pt("min s2m");
+    AsyncWriter writer(out, pt);
     const std::string err = run_pipeline(
         reader, 64ull << 20, 1ull << 19, pt, [&](Work &w) { return minimiser_batch(dev.ctx, w, wsize, msize); },
         [&](Work &w) {
@@ -686,10 +735,10 @@ std::string seq_to_min(uint64_t wsize, int msize, const std::string &in_path, co
                 s += "\t\n";
             });
             pt.t[2] += lap();
-            for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
-            pt.t[3] += lap();
+            writer.write(pieces);
         },
         true);
+    writer.finish();
     fclose(out);
     return err;
 }
