@@ -64,6 +64,13 @@ int kt_ctx_create(int device, void *stream, int own_stream, kt_ctx **out);
 int kt_ctx_destroy(kt_ctx *ctx);
 int kt_ctx_sync(kt_ctx *ctx);
 
+/* Page-locks / releases a host buffer of the caller (hipHostRegister) so that KT_MEM_HOST calls move it
+ * by DMA at full PCIe rate instead of through the driver's pageable staging.  Optional: every entry point
+ * accepts ordinary pageable memory.  Worth it for buffers that are reused over many batches (the
+ * reference's batch loops, composition/src/oligo.rs:147-164, reuse theirs the same way). */
+int kt_host_register(kt_ctx *ctx, void *ptr, size_t bytes);
+int kt_host_unregister(kt_ctx *ctx, void *ptr);
+
 /* ---- host-side helpers (no GPU work) ------------------------------------------ */
 
 /* number of output bins: canonical count (count_min != 0) or 4^k.

@@ -169,6 +169,34 @@ struct Work {
     std::vector<double> rows;
     std::vector<uint64_t> u64[4];  // minimisers: event offsets, m-mers, starts, ends
     uint64_t n_events = 0;
+
+    // From its second batch on (i.e. for files of many batches, where the cost of locking is repaid) the row
+    // buffer of a work item is page-locked, so the device-to-host copy of the rows - by far the largest
+    // transfer - runs by DMA instead of through the driver's pageable staging.
+    void pin_rows(kt_ctx *ctx) {
+        if (++uses_ < 2) return;
+        void *p = rows.data();
+        const size_t bytes = rows.capacity() * sizeof(double);
+        if (p == pin_ptr_ && bytes == pin_bytes_) return;
+        unpin();
+        if (bytes && kt_host_register(ctx, p, bytes) == KT_OK) {
+            pin_ctx_ = ctx;
+            pin_ptr_ = p;
+            pin_bytes_ = bytes;
+        }
+    }
+    void unpin() {
+        if (pin_ptr_) kt_host_unregister(pin_ctx_, pin_ptr_);
+        pin_ptr_ = nullptr;
+        pin_bytes_ = 0;
+    }
+    ~Work() { unpin(); }
+
+  private:
+    uint64_t uses_ = 0;
+    kt_ctx *pin_ctx_ = nullptr;
+    void *pin_ptr_ = nullptr;
+    size_t pin_bytes_ = 0;
 };
 
 template <class T>
@@ -403,6 +431,7 @@ std::string OligoComputer::vectorise() {
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
             w.rows.resize(n * bins);
+            w.pin_rows(dev_.ctx);
             if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, count_min_, norm_, 1, KT_F64,
                                w.rows.data(), KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
@@ -451,6 +480,7 @@ std::string OligoCgrComputer::vectorise() {
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
             w.rows.resize(n * bins);
+            w.pin_rows(dev_.ctx);
             if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, 1, norm_, 1, KT_F64, w.rows.data(),
                                KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
@@ -499,6 +529,7 @@ std::string CgrComputer::vectorise() {
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
             w.rows.resize(2 * w.b.bases.size() + 2);
+            w.pin_rows(dev_.ctx);
             if (kt_cgr_points(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, (double)vecsize_, w.rows.data(), nullptr,
                               KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
@@ -650,6 +681,7 @@ std::string CovComputer::compute_coverages() {
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
             w.rows.resize(n * bins);
+            w.pin_rows(ctr_->context());
             if (kt_cov_batch(ctr_->table(), bases_ptr(w.b), w.b.offsets.data(), n, bin_size_, bin_count_, norm_, KT_F64,
                              w.rows.data(), KT_MEM_HOST) != KT_OK)
                 return kt_last_error();

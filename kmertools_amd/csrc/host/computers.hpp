@@ -100,6 +100,7 @@ class CountComputer {
     std::string merge(bool del);     // counter/src/lib.rs:172-234: writes {out_dir}/kmers.counts
     uint64_t seq_count() const { return seq_count_; }
     kt_ctr *table() const { return ctr_; }  // the resident table (valid after count())
+    kt_ctx *context() const { return dev_.ctx; }
 
   private:
     std::string in_path_, out_dir_;

@@ -163,6 +163,20 @@ int kt_ctx_sync(kt_ctx *ctx) {
     return KT_OK;
 }
 
+int kt_host_register(kt_ctx *ctx, void *ptr, size_t bytes) {
+    if (!ctx || !ptr || !bytes) return kt::fail(KT_ERR_ARG, "kt_host_register: null");
+    if (int rc = ctx->use()) return rc;
+    KT_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return KT_OK;
+}
+
+int kt_host_unregister(kt_ctx *ctx, void *ptr) {
+    if (!ctx || !ptr) return kt::fail(KT_ERR_ARG, "kt_host_unregister: null");
+    if (int rc = ctx->use()) return rc;
+    KT_HIP(hipHostUnregister(ptr));
+    return KT_OK;
+}
+
 int kt_bins(int k, int count_min, uint64_t *bins) {
     if (!bins) return kt::fail(KT_ERR_ARG, "kt_bins: null");
     if (k < 1 || k > 15) return kt::fail(KT_ERR_ARG, "kt_bins: k must be in 1..15");

@@ -32,7 +32,10 @@ cmds = [
     ("min w=31 m=7 s2m", ["min", "-i", fa, "-o", tmp / "mins.s2m", "-w", "31", "-m", "7"]),
     ("min w=0 m=10 m2s", ["min", "-i", fa, "-o", tmp / "mins.m2s", "-p", "m2s"]),
 ]
+only = os.environ.get("ONLY")
 for name, args in cmds:
+    if only and only not in name:
+        continue
     t0 = time.perf_counter()
     r = subprocess.run([str(cli)] + [str(a) for a in args], env=env, capture_output=True, text=True)
     dt = time.perf_counter() - t0
