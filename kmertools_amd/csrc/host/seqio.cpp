@@ -92,6 +92,30 @@ bool SeqReader::read_line(std::string &line) {
     }
 }
 
+bool SeqReader::read_line_view(const char *&p, size_t &n) {
+    if (pos_ == end_ && !fill()) return false;
+    const unsigned char *b = buf_.data() + pos_;
+    const unsigned char *nl = (const unsigned char *)memchr(b, '\n', end_ - pos_);
+    if (nl) {  // the common case: the line ends inside the buffer
+        p = (const char *)b;
+        n = (size_t)(nl - b);
+        pos_ += n + 1;
+        return true;
+    }
+    if (!read_line(line_)) return false;  // spans a refill (or is the unterminated last line): assemble a copy
+    p = line_.data();
+    n = line_.size();
+    return true;
+}
+
+static void trim_end_view(const char *p, size_t &n) {
+    while (n) {
+        const unsigned char c = (unsigned char)p[n - 1];
+        if (c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f') n--;
+        else break;
+    }
+}
+
 static void trim_end(std::string &s) {
     while (!s.empty()) {
         const unsigned char c = (unsigned char)s.back();
@@ -130,14 +154,16 @@ bool SeqReader::next_batch(Batch &b, uint64_t max_bases, uint64_t max_reads, boo
             }
             if (keep_ids) b.ids.push_back(first_token(pending_));
             have_pending_ = false;
-            while (read_line(line_)) {
-                if (!line_.empty() && line_[0] == '>') {
-                    pending_.swap(line_);
+            const char *lp;
+            size_t ln;
+            while (read_line_view(lp, ln)) {
+                if (ln && lp[0] == '>') {
+                    pending_.assign(lp, ln);
                     have_pending_ = true;
                     break;
                 }
-                trim_end(line_);
-                b.bases.insert(b.bases.end(), line_.begin(), line_.end());
+                trim_end_view(lp, ln);
+                b.bases.insert(b.bases.end(), lp, lp + ln);
             }
         } else {
             if (pending_[0] != '@') {
@@ -149,13 +175,15 @@ bool SeqReader::next_batch(Batch &b, uint64_t max_bases, uint64_t max_reads, boo
             uint64_t seq_lines = 0;
             const size_t start = b.bases.size();
             bool plus = false;
-            while (read_line(line_)) {
-                if (!line_.empty() && line_[0] == '+') {
+            const char *lp;
+            size_t ln;
+            while (read_line_view(lp, ln)) {
+                if (ln && lp[0] == '+') {
                     plus = true;
                     break;
                 }
-                trim_end(line_);
-                b.bases.insert(b.bases.end(), line_.begin(), line_.end());
+                trim_end_view(lp, ln);
+                b.bases.insert(b.bases.end(), lp, lp + ln);
                 seq_lines++;
             }
             if (!plus) {
@@ -164,9 +192,9 @@ bool SeqReader::next_batch(Batch &b, uint64_t max_bases, uint64_t max_reads, boo
             }
             uint64_t qual = 0;
             for (uint64_t i = 0; i < seq_lines; i++) {
-                if (!read_line(line_)) break;
-                trim_end(line_);
-                qual += line_.size();
+                if (!read_line_view(lp, ln)) break;
+                trim_end_view(lp, ln);
+                qual += ln;
             }
             if (qual != b.bases.size() - start) {
                 err_ = "Unequal length of sequence an qualities.";

@@ -62,6 +62,8 @@ class SeqReader {
   private:
     bool fill();
     bool read_line(std::string &line);  // without the trailing '\n'; false at EOF
+    // same, without a copy when the whole line sits in the read buffer: [p, p + n) stays valid until the next call
+    bool read_line_view(const char *&p, size_t &n);
     bool peek(int &c);
     gzFile gz_ = nullptr;  // zlib reads plain files transparently
     std::vector<unsigned char> buf_;
