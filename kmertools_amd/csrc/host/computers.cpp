@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <atomic>
@@ -573,7 +574,17 @@ std::string CountComputer::count() {
     // sizes the HBM table instead of the reference's partition count
     std::string err;
     Lap setup;
-    if (!SeqReader::seq_stats(in_path_, seq_count_, total_length_, err)) return err;
+    // An upper bound of the number of bases is all the sizing needs.  A plain file gives one without being read:
+    // its size (FASTA), or half of it (FASTQ: as many quality bytes as bases).  Compressed input keeps the pre-pass.
+    struct stat st;
+    const bool plain = in_path_ != "-" && !(in_path_.size() > 3 && in_path_.compare(in_path_.size() - 3, 3, ".gz") == 0) &&
+                       stat(in_path_.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+    if (plain) {
+        seq_count_ = 0;
+        total_length_ = format_from_path(in_path_) == SeqFormat::Fastq ? (uint64_t)st.st_size / 2 : (uint64_t)st.st_size;
+    } else if (!SeqReader::seq_stats(in_path_, seq_count_, total_length_, err)) {
+        return err;
+    }
     const double t_stats = setup();
     if (std::string e = dev_.ensure(); !e.empty()) return e;
     const double t_dev = setup();
@@ -587,7 +598,7 @@ std::string CountComputer::count() {
     while (cap < 2 * max_distinct) cap <<= 1;
     if (kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_) != KT_OK) return kt_last_error();
     if (getenv("KT_CLI_TIMING"))
-        fprintf(stderr, "[timing] ctr setup: seq_stats pre-pass %.3f s, device init %.3f s, table of %llu slots %.3f s\n", t_stats,
+        fprintf(stderr, "[timing] ctr setup: sizing (pre-pass only for compressed input) %.3f s, device init %.3f s, table of %llu slots %.3f s\n", t_stats,
                 t_dev, (unsigned long long)cap, setup());
     SeqReader reader;
     if (!reader.open(in_path_, false)) return reader.error();

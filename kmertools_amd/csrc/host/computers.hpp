@@ -98,7 +98,7 @@ class CountComputer {
     void set_device(int d) { dev_.index = d; }
     std::string count();             // counter/src/lib.rs:69-90 (no temp files: one resident table)
     std::string merge(bool del);     // counter/src/lib.rs:172-234: writes {out_dir}/kmers.counts
-    uint64_t seq_count() const { return seq_count_; }
+    uint64_t seq_count() const { return seq_count_; }  // 0 when the sizing pre-pass was skipped (plain files)
     kt_ctr *table() const { return ctr_; }  // the resident table (valid after count())
     kt_ctx *context() const { return dev_.ctx; }
 
