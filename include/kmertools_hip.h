@@ -63,6 +63,8 @@ int kt_device_count(int *count);
 int kt_ctx_create(int device, void *stream, int own_stream, kt_ctx **out);
 int kt_ctx_destroy(kt_ctx *ctx);
 int kt_ctx_sync(kt_ctx *ctx);
+/* free / total HBM of the context's device in bytes (hipMemGetInfo): lets a caller size a table to what fits */
+int kt_device_memory(kt_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* Page-locks / releases a host buffer of the caller (hipHostRegister) so that KT_MEM_HOST calls move it
  * by DMA at full PCIe rate instead of through the driver's pageable staging.  Optional: every entry point

@@ -25,6 +25,7 @@ SYMBOLS = {
     "kt_device_count": (_i, [C.POINTER(_i)]),
     "kt_ctx_create": (_i, [_i, _vp, _i, C.POINTER(_vp)]),
     "kt_ctx_destroy": (_i, [_vp]),
+    "kt_device_memory": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "kt_host_register": (_i, [_vp, _vp, C.c_size_t]),
     "kt_host_unregister": (_i, [_vp, _vp]),
     "kt_ctx_sync": (_i, [_vp]),

@@ -596,6 +596,11 @@ std::string CountComputer::count() {
     }
     uint64_t cap = 1024;
     while (cap < 2 * max_distinct) cap <<= 1;
+    // the reference spills to disk when memory is short; here the table is capped at what HBM holds next to the
+    // bulk-build buffers, and running out of slots is reported (KT_ERR_FULL) rather than silently mis-counted
+    uint64_t free_b = 0, total_b = 0;
+    if (kt_device_memory(dev_.ctx, &free_b, &total_b) == KT_OK)
+        while (cap > 1024 && cap * 16 > free_b / 2) cap >>= 1;
     if (kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_) != KT_OK) return kt_last_error();
     if (getenv("KT_CLI_TIMING"))
         fprintf(stderr, "[timing] ctr setup: sizing (pre-pass only for compressed input) %.3f s, device init %.3f s, table of %llu slots %.3f s\n", t_stats,

@@ -163,6 +163,16 @@ int kt_ctx_sync(kt_ctx *ctx) {
     return KT_OK;
 }
 
+int kt_device_memory(kt_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return kt::fail(KT_ERR_ARG, "kt_device_memory: null");
+    if (int rc = ctx->use()) return rc;
+    size_t f = 0, t = 0;
+    KT_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+    return KT_OK;
+}
+
 int kt_host_register(kt_ctx *ctx, void *ptr, size_t bytes) {
     if (!ctx || !ptr || !bytes) return kt::fail(KT_ERR_ARG, "kt_host_register: null");
     if (int rc = ctx->use()) return rc;
