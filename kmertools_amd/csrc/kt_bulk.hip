@@ -7,7 +7,7 @@
 // can instead be built by streaming passes:
 //
 //   hist1     persistent workgroups run the segment front end over their reads and count
-//             k-mers per level-1 bucket d1 = top b1 bits of mix64(key)   (LDS counters)
+//             k-mers per level-1 bucket d1 = top b1 bits of khash(key)   (LDS counters)
 //   scan1     exact output offset of every (workgroup, d1) pair - no reservation atomics
 //   scatter1  same front end again; each segment's <= 8192 keys are counting-sorted by d1 in
 //             LDS and every d1 run is copied to its bucket with coalesced stores
@@ -17,7 +17,7 @@
 //   build     one workgroup per fine bucket (d1,d2): its keys are counted in an LDS
 //             open-addressing table that *is* the image of the global slot range
 //             [(d1,d2) * S, +S) (home slot = top log2(cap) hash bits, kt_table.hpp), and the
-//             4096 slots are written out with 16-byte coalesced stores - including the empty
+//             8192 slots are written out with 16-byte coalesced stores - including the empty
 //             ones, so the bulk build needs no cleared table.  Keys that would probe past the
 //             end of their range go to a small spill list and are inserted afterwards through
 //             the ordinary (probing, atomic) path.
@@ -43,7 +43,7 @@ constexpr int BLOCK = ktseg::BLOCK;       // 256
 #define KT_BUILD_T 1024
 #endif
 constexpr uint32_t LOG2_S = KT_LOG2_S;    // slots per fine bucket
-constexpr uint32_t S = 1u << LOG2_S;      // 4096 slots = 64 KB of table per fine bucket
+constexpr uint32_t S = 1u << LOG2_S;      // 8192 slots = 128 KB of table per fine bucket
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 constexpr uint32_t CHUNK2 = 4096;         // keys sorted at a time in part2
 

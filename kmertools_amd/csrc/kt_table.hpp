@@ -2,7 +2,7 @@
 // path in kt_ctr.hip and the bulk (partition + LDS build) path in kt_bulk.hip.
 //
 // Layout: cap = 2^n slots of 16 bytes {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks
-// a free slot.  Home slot = TOP n bits of mix64(key), linear probing forward (wrapping at
+// a free slot.  Home slot = TOP n bits of khash(key), linear probing forward (wrapping at
 // cap).  Using the top bits makes "all keys of hash prefix p" one contiguous slot range, which
 // is what lets the bulk path build the table range by range in LDS.  GPU ownership
 // (ktd::owner_of) uses the LOW 32 bits of the same hash, so a shard's keys still spread over
