@@ -74,6 +74,7 @@ int kt_ctx::canon_lut(int k, const uint16_t **out) {
         const size_t n = (size_t)1 << (2 * k);
         std::vector<uint16_t> h(n);
         kt::build_canon_lut(k, h.data());
+        for (auto &x : h) x = (uint16_t)(x * 4u);  // the device copy holds byte offsets of the u32 counters (k <= 7: < 2^15)
         uint16_t *d = nullptr;
         KT_HIP(hipMalloc((void **)&d, n * sizeof(uint16_t)));
         hipError_t e = hipMemcpy(d, h.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice);

@@ -36,7 +36,8 @@ struct kt_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cu = 256;
-    // device copies of the canonical-bin LUT (u16[4^k], lut[f] = rank(min(f, rc f))), k = 1..7
+    // device copies of the canonical-bin LUT (u16[4^k], lut[f] = 4 * rank(min(f, rc f)): the byte offset of the
+    // bin's u32 counter inside a row), k = 1..7
     uint16_t *lut_dev[kt::KT_MAX_OLIGO_K + 1] = {};
     kt::Scratch s_bases, s_offsets, s_out, s_aux0, s_aux1, s_aux2;
     int use();  // hipSetDevice

@@ -309,9 +309,12 @@ __device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t 
     uint32_t ok = g1 & ~(B | grl | (gr & ~grk)) & 0xFFFFu;
     ok = lane != 0 ? ok : 0u;
     const uint32_t rsafe = rid0 < R ? rid0 : R - 1;  // dead lanes add 0 to a real row
-    const uint32_t row0 = rsafe * bins;
     const uint32_t has_next = rsafe + 1 < R ? 1u : 0u;
-    const uint32_t rowstep = has_next ? bins : 0u;
+    // byte addressing throughout: the LUT already holds 4 * bin, so one k-mer costs compare + select + add3 + the
+    // validity bit (it was seven VALU instructions with element indices)
+    char *const hist_b = reinterpret_cast<char *>(hist);
+    const uint32_t row0_b = rsafe * bins * 4u;
+    const uint32_t rowstep_b = has_next ? bins * 4u : 0u;
 #pragma unroll
     for (int h = 0; h < 2; h++) {  // two batches of 8: LUT reads first, then the adds
         uint32_t bin[8];
@@ -319,14 +322,14 @@ __device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t 
         for (int j = 0; j < 8; j++) {
             const int i = h * 8 + j;
             const uint32_t f = __builtin_amdgcn_alignbit(Whi, P, 2 * (15 - i)) & KMASK;
-            bin[j] = CANON ? (uint32_t)lut[f] : f;
+            bin[j] = CANON ? (uint32_t)lut[f] : f * 4u;  // byte offset of the bin inside its row
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int i = h * 8 + j;
-            const uint32_t sel = (gr >> (15 - i)) & 1u;
+            const uint32_t step_b = ((gr >> (15 - i)) & 1u) ? rowstep_b : 0u;
             const uint32_t val = (ok >> (15 - i)) & 1u;
-            if (!(KT_DBG(a) & 8u)) atomicAdd(&hist[row0 + sel * rowstep + bin[j]], val);
+            if (!(KT_DBG(a) & 8u)) atomicAdd(reinterpret_cast<uint32_t *>(hist_b + row0_b + step_b + bin[j]), val);
             else if (val + bin[j] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
         }
     }
@@ -414,8 +417,8 @@ __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile
         const uint32_t bad = (VV >> (15 - i)) & ((1u << K) - 1u);
         if (p64 >= (uint64_t)(K - 1) && bad == 0) {
             const uint32_t f = (uint32_t)((((uint64_t)Whi << 32) | P) >> (2 * (15 - i))) & KMASK;
-            const uint32_t bin = CANON ? (uint32_t)lut[f] : f;
-            atomicAdd(&hist[rid * bins + bin], 1u);
+            const uint32_t bin_b = CANON ? (uint32_t)lut[f] : f * 4u;  // byte offset inside the row
+            atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(hist) + rid * bins * 4u + bin_b), 1u);
             atomicAdd(&tot[rid], 1u);
         }
     }
