@@ -184,6 +184,14 @@ __device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile,
 #define KT_DBG(a) 0u
 #endif
 
+// six waves per SIMD (77 VGPRs instead of 82) and tiles small enough for six workgroups per CU: the kernel is
+// a three-way balance of VALU (60 % busy), LDS (50 %) and the store stream, with waves parked half of the time
+// (profiles/r1_oligo_final_pmc.txt) - one more resident workgroup measured -2.5 %, two more (spills) +8 %
+#ifndef KT_OLIGO_WPE
+#define KT_OLIGO_WPE 6
+#endif
+#define KT_OLIGO_WPE_ATTR __attribute__((amdgpu_waves_per_eu(KT_OLIGO_WPE, KT_OLIGO_WPE)))
+
 #ifndef KT_OLIGO_GLOAD
 #define KT_OLIGO_GLOAD 1
 #endif
@@ -514,7 +522,7 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
 // kernel, so twice the resident workgroups; loads for the next tile are issued between the
 // phases so they are in flight while the rows are being stored.
 template <int K, bool CANON, int DT, int NW>
-__global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
+__device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // k <= 5: the canonical-rank LUT (<= 2 KB) lives in LDS; k >= 6 (8 / 32 KB) it is read through
     // L2 instead, because there the LDS is better spent on resident tiles (rows are 8-64 KB)
@@ -611,22 +619,34 @@ __global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
     }
 }
 
+// small rows (k <= 4): six waves per SIMD; larger rows keep the compiler's own register budget (the cap cost 2 %)
+template <int K, bool CANON, int DT, int NW>
+__global__ __launch_bounds__(NW * 64) void oligo_sb_kernel(OligoArgs a) {
+    oligo_sb_body<K, CANON, DT, NW>(a);
+}
+template <int K, bool CANON, int DT, int NW>
+__global__ __launch_bounds__(NW * 64) KT_OLIGO_WPE_ATTR void oligo_sb_kernel_dense(OligoArgs a) {
+    oligo_sb_body<K, CANON, DT, NW>(a);
+}
+
 using kern_t = void (*)(OligoArgs);
 
 template <int K, int NW>
 kern_t pick_sb(int count_min, int dt) {
+#define KT_PICK(CANON, DT) (K <= 4 ? (kern_t)oligo_sb_kernel_dense<K, CANON, DT, NW> : (kern_t)oligo_sb_kernel<K, CANON, DT, NW>)
     if (count_min) {
         switch (dt) {
-            case KT_F64: return oligo_sb_kernel<K, true, KT_F64, NW>;
-            case KT_F32: return oligo_sb_kernel<K, true, KT_F32, NW>;
-            default: return oligo_sb_kernel<K, true, KT_U32, NW>;
+            case KT_F64: return KT_PICK(true, KT_F64);
+            case KT_F32: return KT_PICK(true, KT_F32);
+            default: return KT_PICK(true, KT_U32);
         }
     }
     switch (dt) {
-        case KT_F64: return oligo_sb_kernel<K, false, KT_F64, NW>;
-        case KT_F32: return oligo_sb_kernel<K, false, KT_F32, NW>;
-        default: return oligo_sb_kernel<K, false, KT_U32, NW>;
+        case KT_F64: return KT_PICK(false, KT_F64);
+        case KT_F32: return KT_PICK(false, KT_F32);
+        default: return KT_PICK(false, KT_U32);
     }
+#undef KT_PICK
 }
 
 template <int NW>
@@ -681,8 +701,10 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     const uint32_t nbuf = 1;
     // small rows: ~22 KB of LDS rows (6 workgroups per CU); big rows (k >= 6, 8-64 KB each) are
     // pure store streams and measured best with one large tile per CU (cfg5: R=4, 0.56 of peak)
-    uint32_t R = (bins <= 1024 ? 28672u : 131072u) / (bins * 4u);
-    if (R >= 8) R &= ~3u;  // k=4: 52 reads = 8 wave-chunks (1008 B) of 150-bp reads, 5 workgroups per CU
+    // small rows: what is left of a sixth of the LDS after the LUT and the per-read arrays
+    const uint32_t small_budget = k <= 4 ? 26624u - 2560u - (count_min ? (2u << (2 * k)) : 0u) : 28672u;
+    uint32_t R = (bins <= 1024 ? small_budget : 131072u) / (bins * 4u);
+    if (R >= 8) R &= ~3u;  // k=4: 40 reads = 6 wave-chunks (1008 B) of 150-bp reads, 6 workgroups per CU
     if (R < 1) R = 1;
     if (R > MAX_R) R = MAX_R;
     R = env_u32("KT_OLIGO_R", R);
