@@ -45,7 +45,11 @@ constexpr int BLOCK = ktseg::BLOCK;       // 256
 constexpr uint32_t LOG2_S = KT_LOG2_S;    // slots per fine bucket
 constexpr uint32_t S = 1u << LOG2_S;      // 8192 slots = 128 KB of table per fine bucket
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
-constexpr uint32_t CHUNK2 = 4096;         // keys sorted at a time in part2
+#ifndef KT_P2T
+#define KT_P2T 512
+#endif
+constexpr int P2T = KT_P2T;               // threads of a part2 workgroup
+constexpr uint32_t CHUNK2 = 16 * P2T;     // keys sorted at a time in part2 (16 per thread)
 
 struct Plan {
     uint32_t n;       // log2(cap)
@@ -75,9 +79,10 @@ __device__ __forceinline__ uint32_t digit2(uint64_t key, const Plan &p) {
 // exclusive prefix sum of cnt[0..B) into out[0..B) (LDS arrays), B <= MAX_B; returns the total.
 // All 256 threads must call; tmp is a 256-entry LDS scratch.  Thread sums are scanned inside
 // each wave with shuffles and across the 4 waves through tmp: 2 barriers.
+template <int NT = BLOCK>
 __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_t *out, uint32_t B, uint32_t *tmp) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per = (B + BLOCK - 1) / BLOCK;  // <= 8
+    const uint32_t per = (B + NT - 1) / NT;  // <= 8
     const uint32_t lo = tid * per;
     uint32_t sum = 0;
     for (uint32_t i = 0; i < per; i++)
@@ -92,7 +97,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_
     ktd::lds_barrier();
     uint32_t wbase = 0, total = 0;
 #pragma unroll
-    for (uint32_t w = 0; w < BLOCK / 64; w++) {
+    for (uint32_t w = 0; w < NT / 64; w++) {
         const uint32_t t = tmp[w];
         if (w < wave) wbase += t;
         total += t;
@@ -264,10 +269,10 @@ struct Part2Shared {
     uint32_t cnt[MAX_B];
     uint32_t start[MAX_B];
     uint32_t fill[MAX_B];
-    uint32_t tmp[BLOCK];
+    uint32_t tmp[P2T];
 };
 
-__global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict__ keys1,
+__global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__ keys1,
                                                       const uint64_t *__restrict__ bstart, Plan p,
                                                       uint64_t *__restrict__ keys2, uint64_t *__restrict__ fstart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -276,13 +281,13 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
     for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
         const uint64_t lo = bstart[j], hi = bstart[j + 1];
         // whole-bucket histogram of d2 -> fine bucket boundaries
-        for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cnt[i] = 0;
+        for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
         ktd::lds_barrier();
-        for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)BLOCK * 8) {  // 8 loads in flight per thread
+        for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)P2T * 8) {  // 8 loads in flight per thread
             uint64_t kk[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const uint64_t i = i0 + (uint64_t)u * BLOCK;
+                const uint64_t i = i0 + (uint64_t)u * P2T;
                 kk[u] = i < hi ? keys1[i] : KT_EMPTY_KEY;
             }
 #pragma unroll
@@ -291,8 +296,8 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
         }
         ktd::lds_barrier();
         // bucket sizes can exceed 32 bits only for > 4 G keys in one level-1 bucket: not supported
-        block_excl_scan(sm.cnt, sm.start, p.B2, sm.tmp);
-        for (uint32_t i = tid; i < p.B2; i += BLOCK) {
+        block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);
+        for (uint32_t i = tid; i < p.B2; i += P2T) {
             const uint64_t pos = lo + sm.start[i];
             sm.cursor[i] = pos;
             fstart[(uint64_t)j * p.B2 + i] = pos;
@@ -301,12 +306,12 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
         ktd::lds_barrier();
         // chunks of CHUNK2 keys: counting sort in LDS, runs appended to the fine buckets.  The next
         // chunk's keys are loaded while the current one is sorted; digits are hashed once.
-        constexpr int PER = CHUNK2 / BLOCK;  // 16 keys per thread, held in registers
+        constexpr int PER = CHUNK2 / P2T;  // 16 keys per thread, held in registers
         uint64_t kcur[PER], knxt[PER];
         auto load_chunk = [&](uint64_t c0, uint64_t (&dst)[PER]) {
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                const uint64_t i = c0 + (uint64_t)u * BLOCK + tid;
+                const uint64_t i = c0 + (uint64_t)u * P2T + tid;
                 dst[u] = i < hi ? keys1[i] : KT_EMPTY_KEY;
             }
         };
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
             const uint64_t n64 = hi - c0;
             const uint32_t nc = n64 < CHUNK2 ? (uint32_t)n64 : CHUNK2;
             if (c0 + CHUNK2 < hi) load_chunk(c0 + CHUNK2, knxt);
-            for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cnt[i] = 0;
+            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
             ktd::lds_barrier();
             uint16_t dg[PER];
 #pragma unroll
@@ -324,8 +329,8 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
                 if (kcur[u] != KT_EMPTY_KEY) atomicAdd(&sm.cnt[dg[u]], 1u);
             }
             ktd::lds_barrier();
-            block_excl_scan(sm.cnt, sm.start, p.B2, sm.tmp);
-            for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.fill[i] = sm.start[i];
+            block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);
+            for (uint32_t i = tid; i < p.B2; i += P2T) sm.fill[i] = sm.start[i];
             ktd::lds_barrier();
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -336,12 +341,12 @@ __global__ __launch_bounds__(BLOCK) void part2_kernel(const uint64_t *__restrict
                 }
             }
             ktd::lds_barrier();
-            for (uint32_t i = tid; i < nc; i += BLOCK) {
+            for (uint32_t i = tid; i < nc; i += P2T) {
                 const uint32_t d = sm.sdig[i];
                 keys2[sm.cursor[d] + (i - sm.start[d])] = sm.sorted[i];
             }
             ktd::lds_barrier();
-            for (uint32_t i = tid; i < p.B2; i += BLOCK) sm.cursor[i] += sm.cnt[i];
+            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cursor[i] += sm.cnt[i];
 #pragma unroll
             for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
             // (the next iteration's first barrier orders the cursor update before its use)
@@ -496,7 +501,7 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
                        keys1);
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Part2Shared)));
-    hipLaunchKernelGGL(part2_kernel, dim3(p.B1), dim3(BLOCK), sizeof(Part2Shared), ctx->stream, keys1, m.bstart, p, keys2,
+    hipLaunchKernelGGL(part2_kernel, dim3(p.B1), dim3(P2T), sizeof(Part2Shared), ctx->stream, keys1, m.bstart, p, keys2,
                        m.fstart);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
