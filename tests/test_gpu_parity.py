@@ -456,6 +456,31 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle):
 # bulk table construction (kt_bulk.hip): partition + LDS build must give exactly the table the
 # incremental (atomic) path gives, and incremental adds must keep working on top of it
 
+@pytest.mark.parametrize("k,cap_request", [(31, 3 << 16), (21, 190_000), (15, 390_000), (9, 190_000), (31, 3 << 19)])
+def test_ctr_odd_capacity_requests(hctx, oracle, monkeypatch, k, cap_request):
+    """capacity requests that are not powers of two (the library rounds them up): bulk build, incremental adds on
+    top, look-ups (cov) and the incremental path alone"""
+    from kmertools_amd import device
+    seqs = ragged_reads(7000 + k, 450)
+    seqs += seqs[10:60] + [b"A" * 2000, b"ACGT" * 500]
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    assert len(wk) < 0.55 * cap_request
+    oc = oracle.Counter(1)
+    oc.add_reads(bases, offsets, k)
+    for bulk in ("0", str(1 << 40)):          # bulk build, then atomics only
+        monkeypatch.setenv("KT_BULK_MIN_BASES", bulk)
+        ctr = device.Counter(hctx, k, cap_request)
+        ctr.add_reads_host(bases, offsets)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        assert np.array_equal(ctr.cov_host(bases, offsets, 1, 12, False), oc.cov_batch(bases, offsets, k, 1, 12, False))
+        ctr.add_reads_host(bases, offsets)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+        ctr.close()
+
+
 @pytest.mark.parametrize("k,log2cap", [(31, 17), (21, 18), (15, 19), (4, 14), (31, 20)])
 def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap):
     from kmertools_amd import device

@@ -56,7 +56,7 @@ while time.time() < t_end:
     os.environ["KT_BULK_MIN_BASES"] = "0" if rounds % 2 == 0 else str(1 << 40)
     k = int(rng.choice([9, 15, 21, 31]))
     wk, wc = oracle.count_reads(hb, ho, k, n_parts=8, threads=8)
-    ctr = device.Counter(ctx, k, 1 << max(14, int(np.ceil(np.log2(len(wk) * 2.2 + 16)))))
+    ctr = device.Counter(ctx, k, max(1 << 14, int(len(wk) * rng.choice([2.1, 2.7, 3.4]))))   # rounded up inside the library
     ctr.add_reads(db, do, n)
     d = ctr.size()
     assert d == len(wk), ("ctr size", seed, rounds, k)

@@ -60,7 +60,7 @@ while time.time() < t_end:
     # ctr + cov
     k = int(rng.integers(1, 32))
     wk, wc = oracle.count_reads(bases, offsets, k)
-    cap = 1 << max(12, int(np.ceil(np.log2(max(len(wk), 1) * 2.5))))
+    cap = max(4096, int(len(wk) * rng.choice([2.1, 2.6, 3.3])))   # rounded up inside the library
     ctr = device.Counter(ctx, k, cap)
     half = len(seqs) // 2
     b1, o1 = oracle.to_csr(seqs[:half]); b2, o2 = oracle.to_csr(seqs[half:])
