@@ -912,3 +912,25 @@ def test_minimisers_wide_window_run_start_before_halo(hctx, oracle):
         got = _min_triples(hctx, seqs, w, m)
         for i, s in enumerate(seqs):
             assert got[i] == oracle.minimisers(s, w, m), (i, w, m)
+
+
+def test_all_empty_reads_everywhere(hctx, oracle):
+    """a batch that holds reads but no bases (every read empty): every entry point returns the empty answer"""
+    from kmertools_amd import device
+    seqs = ["", "", ""]
+    bases, offsets = device.to_csr(seqs)
+    assert not hctx.oligo_host(bases, offsets, 4).any() and hctx.oligo_host(bases, offsets, 4).shape == (3, 136)
+    ctr = device.Counter(hctx, 21, 4096)
+    ctr.add_reads_host(bases, offsets)
+    assert ctr.size() == 0
+    cov = ctr.cov_host(bases, offsets, 2, 5, True)
+    assert cov.shape == (3, 5) and not cov.any()
+    ctr.close()
+    assert hctx.cgr_host(bases, offsets, 1).shape == (0, 2)
+    for w in (0, 31):
+        evo, k, s, e = hctx.minimisers_host(bases, offsets, w, 7)
+        assert list(evo) == [0, 0, 0, 0] and len(k) == 0
+    f, r, idx = hctx.kmers_host(bases, offsets, 5)
+    assert len(f) == 0
+    keys, counts = hctx.route_host(bases, offsets, 21, 4)
+    assert len(keys) == 0 and not counts.any()
