@@ -292,10 +292,10 @@ def main():
     else:
         from kmertools_amd import dist as ktdist
         kmers_per_read = L - k + 1
-        # slots: a power of two above the most distinct keys this rank can see
+        # slots: twice the most distinct keys this rank can see (short probe chains in the LDS build; measured
+        # faster than 1.3x despite the bigger table); the library rounds up to 2^n or 3 * 2^(n-2)
         max_distinct = min(n * kmers_per_read, (4 ** k + 2 ** k) // 2)
-        # (2x: short probe chains in the LDS build; measured faster than 1.3x despite the bigger table)
-        cap = 1 << max(20, (2 * max_distinct - 1).bit_length())
+        cap = max(1 << 20, 2 * max_distinct)
         if args.cap_log2:
             cap = 1 << args.cap_log2
         counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)

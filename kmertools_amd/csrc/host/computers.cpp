@@ -594,8 +594,8 @@ std::string CountComputer::count() {
         const uint64_t canon = (ksize_ & 1) ? n4k / 2 : (n4k + (1ull << ksize_)) / 2;
         if (canon < max_distinct) max_distinct = canon;
     }
-    uint64_t cap = 1024;
-    while (cap < 2 * max_distinct) cap <<= 1;
+    uint64_t cap = 2 * max_distinct;  // the library rounds this up to 2^n or 3 * 2^(n-2) slots
+    if (cap < 1024) cap = 1024;
     // the reference spills to disk when memory is short; here the table is capped at what HBM holds next to the
     // bulk-build buffers, and running out of slots is reported (KT_ERR_FULL) rather than silently mis-counted
     uint64_t free_b = 0, total_b = 0;

@@ -52,7 +52,8 @@ constexpr int P2T = KT_P2T;               // threads of a part2 workgroup
 constexpr uint32_t CHUNK2 = 16 * P2T;     // keys sorted at a time in part2 (16 per thread)
 
 struct Plan {
-    uint32_t n;       // log2(cap)
+    uint32_t n;       // hash bits that address the table: cap = 2^n, or 3 * 2^(n-2) when `three`
+    uint32_t three;
     uint32_t b1, b2;  // hash bits per level; b1 + b2 + LOG2_S == n
     uint32_t B1, B2;
     uint32_t G;       // persistent workgroups of hist1 / scatter1
@@ -356,10 +357,8 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__
 }
 
 // ---- build: one workgroup per fine bucket ------------------------------------------------------------------
-struct BuildShared {
-    uint64_t keys[S];
-    uint32_t counts[S];
-};
+// LDS image of the range: SE keys then SE counts, SE = 8192 or 6144 (the table's shape, kt_table.hpp)
+static_assert(LOG2_S == kttab::LOG2_RANGE, "the 3/4 table shape shrinks 8192-slot ranges");
 
 constexpr int BUILD_T = KT_BUILD_T;  // 16 waves per fine bucket: short serial probe chains, full occupancy
 
@@ -369,14 +368,20 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
                                                       uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
                                                       uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    BuildShared &sm = *reinterpret_cast<BuildShared *>(smem_raw);
+    const uint32_t SE = p.three ? kttab::RANGE_3Q : S;
+    uint64_t *const skeys = reinterpret_cast<uint64_t *>(smem_raw);
+    uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)SE * 8);
     const uint32_t tid = threadIdx.x;
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     const uint32_t shift = 64 - p.n;
+    auto slot_in_range = [&](uint64_t key) {
+        const uint32_t y = (uint32_t)(ktd::khash(key) >> shift) & (S - 1);
+        return p.three ? (y * 3u) >> 2 : y;
+    };
     for (uint64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
-        for (uint32_t i = tid; i < S; i += BUILD_T) {
-            sm.keys[i] = KT_EMPTY_KEY;
-            sm.counts[i] = 0;
+        for (uint32_t i = tid; i < SE; i += BUILD_T) {
+            skeys[i] = KT_EMPTY_KEY;
+            scounts[i] = 0;
         }
         ktd::lds_barrier();
         const uint64_t lo = fstart[fb], hi = fstart[fb + 1];
@@ -392,18 +397,18 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
                 return k;
             };
             uint64_t cur = fetch(), q0 = fetch(), q1 = fetch(), q2 = fetch();
-            uint32_t s = (uint32_t)(ktd::khash(cur) >> shift) & (S - 1);
+            uint32_t s = slot_in_range(cur);
             while (cur != KT_EMPTY_KEY) {
                 // one LDS operation per probe: the CAS itself reports what the slot holds (64-bit LDS atomics run at
                 // about a lane per clock, so a separate read before it doubled the cost of the common case)
-                const uint64_t v = atomicCAS(reinterpret_cast<unsigned long long *>(&sm.keys[s]),
+                const uint64_t v = atomicCAS(reinterpret_cast<unsigned long long *>(&skeys[s]),
                                              (unsigned long long)KT_EMPTY_KEY, (unsigned long long)cur);
                 bool done = v == KT_EMPTY_KEY;  // claimed: first occurrence, stored count stays 0
                 if (!done && v == cur) {
-                    atomicAdd(&sm.counts[s], 1u);
+                    atomicAdd(&scounts[s], 1u);
                     done = true;
                 }
-                if (!done && ++s >= S) {  // forward only: never wrap inside the range (kt_table.hpp invariant);
+                if (!done && ++s >= SE) {  // forward only: never wrap inside the range (kt_table.hpp invariant);
                     // ran off the end: goes through the probing path afterwards
                     const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
                     if (at < spill_cap) spill_keys[at] = cur;
@@ -415,15 +420,15 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
                     q0 = q1;
                     q1 = q2;
                     q2 = fetch();
-                    s = (uint32_t)(ktd::khash(cur) >> shift) & (S - 1);
+                    s = slot_in_range(cur);
                 }
             }
         }
         ktd::lds_barrier();
-        uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * S);
-        for (uint32_t i = tid; i < S; i += BUILD_T) {
-            const uint64_t key = sm.keys[i];
-            dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), sm.counts[i], 0u);
+        uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * SE);
+        for (uint32_t i = tid; i < SE; i += BUILD_T) {
+            const uint64_t key = skeys[i];
+            dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u);
         }
         ktd::lds_barrier();
     }
@@ -451,7 +456,8 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     *done = 0;
     kt_ctx *ctx = ctr->ctx;
     Plan p{};
-    p.n = ctr->log2cap;
+    p.n = 64 - ctr->shift;
+    p.three = ctr->three;
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
@@ -506,11 +512,12 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
     if (gb > n_fine) gb = n_fine;
+    const size_t build_lds = (size_t)(p.three ? kttab::RANGE_3Q : S) * 12;
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)sizeof(BuildShared)));
-    hipLaunchKernelGGL(build_kernel, dim3((uint32_t)gb), dim3(BUILD_T), sizeof(BuildShared), ctx->stream, keys2, m.fstart, p,
+                               (int)build_lds));
+    hipLaunchKernelGGL(build_kernel, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, keys2, m.fstart, p,
                        (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, ctr->flags);
-    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, 64 - ctr->log2cap, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->three}, ctr->flags};
     hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
                        m.spill_cap, t);
     KT_HIP(hipGetLastError());

@@ -33,8 +33,7 @@ constexpr uint32_t ROWS_LDS = 6144;  // u32 cells of bin rows staged per segment
 
 struct CovArgs {
     const Slot *slots;
-    uint64_t mask;       // cap - 1
-    uint32_t shift;      // 64 - log2(cap)
+    kttab::Geom g;       // capacity and hash -> home slot mapping
     uint32_t bin_size;   // 0 = wider than any u32 count: every k-mer falls in bin 0
     uint32_t bin_count;
     uint32_t *counts;    // n_reads x bin_count, zeroed
@@ -46,11 +45,11 @@ __device__ __forceinline__ uint4 load_slot(const Slot *slots, uint64_t slot) {
 
 // occurrences of `key` given the already-loaded home slot `v`; walks on only on a collision
 __device__ __forceinline__ uint32_t resolve_count(const CovArgs &c, uint4 v, uint64_t slot, uint64_t key) {
-    for (uint64_t probe = 0; probe <= c.mask; probe++) {
+    for (uint64_t probe = 0; probe < c.g.cap; probe++) {
         const uint64_t kk = ((uint64_t)v.y << 32) | v.x;
         if (kk == key) return v.z + 1u;  // stored value is occurrences - 1
         if (kk == KT_EMPTY_KEY) return 0u;
-        slot = (slot + 1) & c.mask;
+        slot = kttab::next_slot(slot, c.g);
         v = load_slot(c.slots, slot);
     }
     return 0u;
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
                 for (uint32_t u = 0; u < GROUP; u++) {
                     key[u] = w.f < w.r ? w.f : w.r;
                     w.step();
-                    sl[u] = kttab::home_slot(key[u], c.shift);
+                    sl[u] = kttab::home_slot(key[u], c.g);
                     v[u] = load_slot(c.slots, sl[u]);
                 }
 #pragma unroll
@@ -195,7 +194,7 @@ extern "C" int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t 
     if (total) {
         SegArgs a;
         if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, table->k, &a)) return rc;
-        CovArgs c{(const Slot *)table->slots, table->cap - 1, (uint32_t)(64 - table->log2cap),
+        CovArgs c{(const Slot *)table->slots, kttab::Geom{table->cap, table->shift, table->three},
                   bin_size > 0xFFFFFFFFull ? 0u : (uint32_t)bin_size, (uint32_t)bin_count, d_counts};
         hipLaunchKernelGGL(cov_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, c);
         KT_HIP(hipGetLastError());

@@ -259,15 +259,15 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     *out = nullptr;
     if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_ctr_create: k must be in 1..31");
     if (int rc = ctx->use()) return rc;
-    uint64_t cap = 1024;
-    while (cap < capacity_slots) cap <<= 1;
+    const kttab::Geom geom = kttab::make_geom(capacity_slots);
+    const uint64_t cap = geom.cap;
     kt_ctr *c = new (std::nothrow) kt_ctr();
     if (!c) return kt::fail(KT_ERR_NOMEM, "kt_ctr_create: host alloc");
     c->ctx = ctx;
     c->k = k;
     c->cap = cap;
-    c->log2cap = 0;
-    while ((1ull << c->log2cap) < cap) c->log2cap++;
+    c->shift = geom.shift;
+    c->three = geom.three;
     hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
@@ -351,7 +351,7 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
     if (int rc = ensure_cleared(ctr)) return rc;
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
-    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, (uint32_t)(64 - ctr->log2cap), ctr->flags};
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->three}, ctr->flags};
     hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t);
     KT_HIP(hipGetLastError());
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -389,7 +389,7 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
     }
     ctr->empty = false;
     if (int rc = ensure_cleared(ctr)) return rc;
-    TableRef t{(Slot *)ctr->slots, ctr->cap - 1, (uint32_t)(64 - ctr->log2cap), ctr->flags};
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->three}, ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctx->stream, d_keys, d_counts, n, t);
     KT_HIP(hipGetLastError());

@@ -1,7 +1,7 @@
 // kt_table.hpp - the HBM-resident canonical k-mer table shared by the incremental (atomic)
 // path in kt_ctr.hip and the bulk (partition + LDS build) path in kt_bulk.hip.
 //
-// Layout: cap = 2^n slots of 16 bytes {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks
+// Layout: cap = 2^n or 3 * 2^(n-2) slots of 16 bytes {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks
 // a free slot.  Home slot = TOP n bits of khash(key), linear probing forward (wrapping at
 // cap).  Using the top bits makes "all keys of hash prefix p" one contiguous slot range, which
 // is what lets the bulk path build the table range by range in LDS.  GPU ownership
@@ -20,15 +20,46 @@ struct Slot {
 };
 static_assert(sizeof(Slot) == 16, "slot layout");
 
+// Capacities come in two shapes, so that a table is at most 1.5x (not 2x) what was asked for.  With x = the top
+// n bits of the hash:
+//   cap = 2^n            home = x
+//   cap = 3 * 2^(n - 2)  home = (x >> 13) * 6144 + ((x & 8191) * 3 >> 2): every 8192-slot range of the 2^n layout
+//                        shrinks to 6144 slots in place
+// Either way the home slot is monotone in the hash and the top n - 13 bits of the hash select one contiguous range
+// of slots (RANGE_FULL or RANGE_3Q of them) - which is all the bulk build needs, so its partition passes are the
+// same for both shapes.
+constexpr uint32_t LOG2_RANGE = 13, RANGE_FULL = 1u << LOG2_RANGE, RANGE_3Q = RANGE_FULL / 4 * 3;
+
+struct Geom {
+    uint64_t cap;
+    uint32_t shift;  // 64 - n
+    uint32_t three;  // cap = 3 * 2^(n - 2)
+};
+
+inline Geom make_geom(uint64_t cap_request) {
+    uint64_t p = 1024;
+    uint32_t n = 10;
+    while (p < cap_request) {
+        p <<= 1;
+        n++;
+    }
+    const bool three = n >= LOG2_RANGE + 2 && p / 4 * 3 >= cap_request;
+    return Geom{three ? p / 4 * 3 : p, 64 - n, three ? 1u : 0u};
+}
+
 struct TableRef {
     Slot *slots;
-    uint64_t mask;   // cap - 1
-    uint32_t shift;  // 64 - log2(cap)
+    Geom g;
     uint32_t *flags; // [0] = overflow flag
 };
 
-__host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, uint32_t shift) {
-    return shift >= 64 ? 0 : (ktd::khash(key) >> shift);
+__host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, const Geom &g) {
+    const uint64_t x = ktd::khash(key) >> g.shift;  // n <= 54 bits
+    if (!g.three) return x;
+    return (x >> LOG2_RANGE) * RANGE_3Q + ((((uint32_t)x & (RANGE_FULL - 1)) * 3u) >> 2);
+}
+__host__ __device__ __forceinline__ uint64_t next_slot(uint64_t slot, const Geom &g) {
+    return slot + 1 == g.cap ? 0 : slot + 1;
 }
 
 // table[key] += add.  A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe
@@ -36,8 +67,8 @@ __host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, uint32_t sh
 // XCDs) settles that case.  A k-mer seen once costs one probing load + one CAS (claiming the
 // slot is its first count); a repeat costs one load + one 32-bit atomic add.
 __device__ __forceinline__ bool table_add(const TableRef &t, uint64_t key, uint32_t add) {
-    uint64_t slot = home_slot(key, t.shift);
-    for (uint64_t probe = 0; probe <= t.mask; probe++) {
+    uint64_t slot = home_slot(key, t.g);
+    for (uint64_t probe = 0; probe < t.g.cap; probe++) {
         uint64_t cur = __hip_atomic_load(&t.slots[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == KT_EMPTY_KEY) {
             const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.slots[slot].key),
@@ -52,7 +83,7 @@ __device__ __forceinline__ bool table_add(const TableRef &t, uint64_t key, uint3
             atomicAdd(&t.slots[slot].count, add);
             return true;
         }
-        slot = (slot + 1) & t.mask;
+        slot = next_slot(slot, t.g);
     }
     return false;
 }
