@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--genome", type=int, default=0, help="ctr: sample reads from a random genome of this length")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cap-log2", type=int, default=0, help="ctr: override log2 of the table capacity (experiments)")
+    ap.add_argument("--cap-slots", type=float, default=0, help="ctr: override the requested table capacity (experiments)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -298,6 +299,8 @@ def main():
         cap = max(1 << 20, 2 * max_distinct)
         if args.cap_log2:
             cap = 1 << args.cap_log2
+        if args.cap_slots:
+            cap = int(args.cap_slots)
         counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
         dominant = "ctr k=%d step: bulk table build (hist1 + scatter1 + part2 + build kernels)" % k

@@ -128,7 +128,7 @@ int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, u
 /* replaces: CountComputer::new / count_chunk's table, counter/src/lib.rs:37-55, :100.
  * One HBM-resident open-addressing table (u64 keys, u32 counts - the reference's
  * types) takes the place of the reference's n_parts scc maps and chunk files.
- * capacity_slots is rounded up to the next 2^n or 3 * 2^(n-2) (at most 1.5x the request; at least 1024);
+ * capacity_slots is rounded up to the next m * 2^j with m in 5..8 (at most 1.25x the request; at least 1024);
  * keep distinct keys <= ~70 % of it. */
 int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out);
 int kt_ctr_destroy(kt_ctr *ctr);

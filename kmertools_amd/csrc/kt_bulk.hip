@@ -52,8 +52,8 @@ constexpr int P2T = KT_P2T;               // threads of a part2 workgroup
 constexpr uint32_t CHUNK2 = 16 * P2T;     // keys sorted at a time in part2 (16 per thread)
 
 struct Plan {
-    uint32_t n;       // hash bits that address the table: cap = 2^n, or 3 * 2^(n-2) when `three`
-    uint32_t three;
+    uint32_t n;       // hash bits that address the table: cap = m8 * 2^(n-3) (kttab::Geom)
+    uint32_t m8;
     uint32_t b1, b2;  // hash bits per level; b1 + b2 + LOG2_S == n
     uint32_t B1, B2;
     uint32_t G;       // persistent workgroups of hist1 / scatter1
@@ -357,8 +357,8 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__
 }
 
 // ---- build: one workgroup per fine bucket ------------------------------------------------------------------
-// LDS image of the range: SE keys then SE counts, SE = 8192 or 6144 (the table's shape, kt_table.hpp)
-static_assert(LOG2_S == kttab::LOG2_RANGE, "the 3/4 table shape shrinks 8192-slot ranges");
+// LDS image of the range: SE keys then SE counts, SE = 5120 .. 8192 (the table's shape, kt_table.hpp)
+static_assert(LOG2_S == kttab::LOG2_RANGE, "the m/8 table shapes shrink 8192-slot ranges");
 
 constexpr int BUILD_T = KT_BUILD_T;  // 16 waves per fine bucket: short serial probe chains, full occupancy
 
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
                                                       uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
                                                       uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t SE = p.three ? kttab::RANGE_3Q : S;
+    const uint32_t SE = p.m8 << (LOG2_S - 3);
     uint64_t *const skeys = reinterpret_cast<uint64_t *>(smem_raw);
     uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)SE * 8);
     const uint32_t tid = threadIdx.x;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
     const uint32_t shift = 64 - p.n;
     auto slot_in_range = [&](uint64_t key) {
         const uint32_t y = (uint32_t)(ktd::khash(key) >> shift) & (S - 1);
-        return p.three ? (y * 3u) >> 2 : y;
+        return (y * p.m8) >> 3;
     };
     for (uint64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
         for (uint32_t i = tid; i < SE; i += BUILD_T) {
@@ -457,7 +457,7 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     kt_ctx *ctx = ctr->ctx;
     Plan p{};
     p.n = 64 - ctr->shift;
-    p.three = ctr->three;
+    p.m8 = ctr->m8;
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
@@ -512,12 +512,12 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
     if (gb > n_fine) gb = n_fine;
-    const size_t build_lds = (size_t)(p.three ? kttab::RANGE_3Q : S) * 12;
+    const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * 12;
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)build_lds));
     hipLaunchKernelGGL(build_kernel, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, keys2, m.fstart, p,
                        (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, ctr->flags);
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->three}, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
                        m.spill_cap, t);
     KT_HIP(hipGetLastError());

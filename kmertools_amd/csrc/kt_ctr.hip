@@ -267,7 +267,7 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     c->k = k;
     c->cap = cap;
     c->shift = geom.shift;
-    c->three = geom.three;
+    c->m8 = geom.m8;
     hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
@@ -351,7 +351,7 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
     if (int rc = ensure_cleared(ctr)) return rc;
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->three}, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t);
     KT_HIP(hipGetLastError());
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -389,7 +389,7 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
     }
     ctr->empty = false;
     if (int rc = ensure_cleared(ctr)) return rc;
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->three}, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctx->stream, d_keys, d_counts, n, t);
     KT_HIP(hipGetLastError());

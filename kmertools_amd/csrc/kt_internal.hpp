@@ -47,9 +47,9 @@ struct kt_ctx {
 struct kt_ctr {
     kt_ctx *ctx = nullptr;
     int k = 0;
-    uint64_t cap = 0;          // 2^n or 3 * 2^(n-2) slots (kttab::Geom)
+    uint64_t cap = 0;          // m8 * 2^(n-3) slots (kttab::Geom)
     uint32_t shift = 0;        // 64 - n
-    uint32_t three = 0;        // the 3/4 shape
+    uint32_t m8 = 8;           // eighths of 2^n
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls

@@ -1,7 +1,7 @@
 // kt_table.hpp - the HBM-resident canonical k-mer table shared by the incremental (atomic)
 // path in kt_ctr.hip and the bulk (partition + LDS build) path in kt_bulk.hip.
 //
-// Layout: cap = 2^n or 3 * 2^(n-2) slots of 16 bytes {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks
+// Layout: cap = 2^n or m * 2^(n-3) slots (m = 5, 6, 7) of 16 bytes {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks
 // a free slot.  Home slot = TOP n bits of khash(key), linear probing forward (wrapping at
 // cap).  Using the top bits makes "all keys of hash prefix p" one contiguous slot range, which
 // is what lets the bulk path build the table range by range in LDS.  GPU ownership
@@ -20,20 +20,19 @@ struct Slot {
 };
 static_assert(sizeof(Slot) == 16, "slot layout");
 
-// Capacities come in two shapes, so that a table is at most 1.5x (not 2x) what was asked for.  With x = the top
-// n bits of the hash:
-//   cap = 2^n            home = x
-//   cap = 3 * 2^(n - 2)  home = (x >> 13) * 6144 + ((x & 8191) * 3 >> 2): every 8192-slot range of the 2^n layout
-//                        shrinks to 6144 slots in place
-// Either way the home slot is monotone in the hash and the top n - 13 bits of the hash select one contiguous range
-// of slots (RANGE_FULL or RANGE_3Q of them) - which is all the bulk build needs, so its partition passes are the
-// same for both shapes.
-constexpr uint32_t LOG2_RANGE = 13, RANGE_FULL = 1u << LOG2_RANGE, RANGE_3Q = RANGE_FULL / 4 * 3;
+// Capacities come in eighths of a power of two, so that a table is at most 1.25x (not 2x) what was asked for.
+// With x = the top n bits of the hash and m8 in 5..8:
+//   cap = m8 * 2^(n-3)   home = (x >> 13) * (1024 * m8) + ((x & 8191) * m8 >> 3)
+// i.e. every 8192-slot range of the 2^n layout shrinks to 1024 * m8 slots in place (m8 = 8: home = x).  The home
+// slot is monotone in the hash and the top n - 13 bits of the hash select one contiguous range of slots - which is
+// all the bulk build needs, so its partition passes are the same for every shape.
+constexpr uint32_t LOG2_RANGE = 13, RANGE_FULL = 1u << LOG2_RANGE;
 
 struct Geom {
     uint64_t cap;
     uint32_t shift;  // 64 - n
-    uint32_t three;  // cap = 3 * 2^(n - 2)
+    uint32_t m8;     // slots per range / 1024
+    __host__ __device__ uint32_t range_slots() const { return m8 << (LOG2_RANGE - 3); }
 };
 
 inline Geom make_geom(uint64_t cap_request) {
@@ -43,8 +42,10 @@ inline Geom make_geom(uint64_t cap_request) {
         p <<= 1;
         n++;
     }
-    const bool three = n >= LOG2_RANGE + 2 && p / 4 * 3 >= cap_request;
-    return Geom{three ? p / 4 * 3 : p, 64 - n, three ? 1u : 0u};
+    uint32_t m8 = 8;
+    if (n >= LOG2_RANGE + 2)
+        while (m8 > 5 && p / 8 * (m8 - 1) >= cap_request) m8--;
+    return Geom{p / 8 * m8, 64 - n, m8};
 }
 
 struct TableRef {
@@ -55,8 +56,8 @@ struct TableRef {
 
 __host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, const Geom &g) {
     const uint64_t x = ktd::khash(key) >> g.shift;  // n <= 54 bits
-    if (!g.three) return x;
-    return (x >> LOG2_RANGE) * RANGE_3Q + ((((uint32_t)x & (RANGE_FULL - 1)) * 3u) >> 2);
+    if (g.m8 == 8) return x;
+    return (x >> LOG2_RANGE) * g.range_slots() + ((((uint32_t)x & (RANGE_FULL - 1)) * g.m8) >> 3);
 }
 __host__ __device__ __forceinline__ uint64_t next_slot(uint64_t slot, const Geom &g) {
     return slot + 1 == g.cap ? 0 : slot + 1;

@@ -456,9 +456,9 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle):
 # bulk table construction (kt_bulk.hip): partition + LDS build must give exactly the table the
 # incremental (atomic) path gives, and incremental adds must keep working on top of it
 
-@pytest.mark.parametrize("k,cap_request", [(31, 3 << 16), (21, 190_000), (15, 390_000), (9, 190_000), (31, 3 << 19)])
+@pytest.mark.parametrize("k,cap_request", [(31, 3 << 16), (21, 190_000), (15, 390_000), (9, 190_000), (31, 3 << 19), (31, 320_000), (21, 450_000)])
 def test_ctr_odd_capacity_requests(hctx, oracle, monkeypatch, k, cap_request):
-    """capacity requests that are not powers of two (the library rounds them up): bulk build, incremental adds on
+    """capacity requests that are not powers of two (the library rounds them up to 5..8 eighths of one): bulk build, incremental adds on
     top, look-ups (cov) and the incremental path alone"""
     from kmertools_amd import device
     seqs = ragged_reads(7000 + k, 450)
