@@ -22,7 +22,9 @@
 //             end of their range go to a small spill list and are inserted afterwards through
 //             the ordinary (probing, atomic) path.
 //
-// Traffic ~ 1 B/base x 2 + 8 B/k-mer x 5 + 16 B/slot, all streaming.
+// Traffic ~ 1 B/base x 2 + 8 B/k-mer x 5 + 16 B/slot, all streaming.  The intermediate key arrays and the LDS
+// sort / insert arrays hold 32-bit keys when k <= 16 (template parameter K): half the partition traffic, whole
+// units sorted at once in scatter1, and 32-bit LDS atomics in build (64-bit ones run at about a lane per clock).
 #include <stdlib.h>
 
 #include "kt_segment.hpp"
@@ -58,6 +60,9 @@ struct Plan {
     uint32_t B1, B2;
     uint32_t G;       // persistent workgroups of hist1 / scatter1
 };
+
+template <class K>
+constexpr K empty_of() { return (K) ~(K)0; }  // K = uint64_t: KT_EMPTY_KEY; canonical k-mers of k <= 16 are never all ones
 
 struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *H;        // [G][B1] k-mers of workgroup g in bucket d1
@@ -200,27 +205,32 @@ __global__ __launch_bounds__(1024) void scan1_kernel(const uint32_t *__restrict_
 }
 
 // ---- scatter1 ----------------------------------------------------------------------------------------
-constexpr uint32_t HALF = ktseg::SEG / 2;  // keys sorted at a time (two rounds per segment)
+// keys sorted at a time: half a unit of 64-bit keys (two rounds), a whole unit of 32-bit keys
+template <class K>
+constexpr uint32_t round_keys() { return sizeof(K) == 8 ? ktseg::SEG / 2 : ktseg::SEG; }
 
 constexpr uint32_t MAX_B1 = 1024;  // level 1 never uses more than 10 bits (bulk_build_from)
 
-struct Scatter1Shared {  // 65 KB: two workgroups per CU (an 8 KB larger layout dropped to one and cost 10 %)
+template <class K>
+struct Scatter1Shared {  // 65 / 73 KB: two workgroups per CU (an 85 KB layout dropped to one and cost 10 %)
     SegShared seg;
-    uint64_t sorted[HALF];
-    uint16_t sdig[HALF];  // level-1 digit of sorted[i]: saves hashing the key a third time
+    K sorted[round_keys<K>()];
+    uint16_t sdig[round_keys<K>()];  // level-1 digit of sorted[i]: saves hashing the key a third time
     uint64_t cursor[MAX_B1];
     uint32_t cnt[MAX_B1];
     uint32_t start[MAX_B1];
     uint32_t fill[MAX_B1];
     uint32_t tmp[BLOCK];
 };
-static_assert(sizeof(Scatter1Shared) <= 80 * 1024, "two scatter1 workgroups per CU");
+static_assert(sizeof(Scatter1Shared<uint64_t>) <= 80 * 1024 && sizeof(Scatter1Shared<uint32_t>) <= 80 * 1024,
+              "two scatter1 workgroups per CU");
 
-template <class Source>
+template <class Source, class K>
 __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, const uint64_t *__restrict__ O,
-                                                         uint64_t *__restrict__ keys1) {
+                                                         K *__restrict__ keys1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Scatter1Shared &sm = *reinterpret_cast<Scatter1Shared *>(smem_raw);
+    Scatter1Shared<K> &sm = *reinterpret_cast<Scatter1Shared<K> *>(smem_raw);
+    constexpr int ROUNDS = ktseg::SEG / round_keys<K>(), PERR = ktseg::PER_THREAD / ROUNDS;
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cursor[i] = O[(uint64_t)blockIdx.x * p.B1 + i];
     const uint64_t n_units = src.n_units();
     for (uint64_t g = blockIdx.x; g < n_units; g += gridDim.x) {
@@ -229,23 +239,23 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, con
         uint32_t ok;
         src.collect(g, sm.seg, keys, ok);
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
+        for (int half = 0; half < ROUNDS; half++) {
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cnt[i] = 0;
             ktd::lds_barrier();
 #pragma unroll
-            for (int j = 0; j < 16; j++)
-                if ((ok >> (half * 16 + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * 16 + j], p)], 1u);
+            for (int j = 0; j < PERR; j++)
+                if ((ok >> (half * PERR + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * PERR + j], p)], 1u);
             ktd::lds_barrier();
             const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.fill[i] = sm.start[i];
             ktd::lds_barrier();
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                if ((ok >> (half * 16 + j)) & 1u) {
-                    const uint64_t m = keys[half * 16 + j];
+            for (int j = 0; j < PERR; j++) {
+                if ((ok >> (half * PERR + j)) & 1u) {
+                    const uint64_t m = keys[half * PERR + j];
                     const uint32_t d = digit1(m, p);
                     const uint32_t pos = atomicAdd(&sm.fill[d], 1u);
-                    sm.sorted[pos] = m;
+                    sm.sorted[pos] = (K)m;
                     sm.sdig[pos] = (uint16_t)d;
                 }
             }
@@ -263,8 +273,9 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, con
 }
 
 // ---- part2: one workgroup per level-1 bucket -----------------------------------------------------------
+template <class K>
 struct Part2Shared {
-    uint64_t sorted[CHUNK2];
+    K sorted[CHUNK2];
     uint16_t sdig[CHUNK2];
     uint64_t cursor[MAX_B];
     uint32_t cnt[MAX_B];
@@ -273,11 +284,13 @@ struct Part2Shared {
     uint32_t tmp[P2T];
 };
 
-__global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__ keys1,
+template <class K>
+__global__ __launch_bounds__(P2T) void part2_kernel(const K *__restrict__ keys1,
                                                       const uint64_t *__restrict__ bstart, Plan p,
-                                                      uint64_t *__restrict__ keys2, uint64_t *__restrict__ fstart) {
+                                                      K *__restrict__ keys2, uint64_t *__restrict__ fstart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Part2Shared &sm = *reinterpret_cast<Part2Shared *>(smem_raw);
+    Part2Shared<K> &sm = *reinterpret_cast<Part2Shared<K> *>(smem_raw);
+    constexpr K EMPTY = empty_of<K>();
     const uint32_t tid = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
         const uint64_t lo = bstart[j], hi = bstart[j + 1];
@@ -285,15 +298,15 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__
         for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
         ktd::lds_barrier();
         for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)P2T * 8) {  // 8 loads in flight per thread
-            uint64_t kk[8];
+            K kk[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint64_t i = i0 + (uint64_t)u * P2T;
-                kk[u] = i < hi ? keys1[i] : KT_EMPTY_KEY;
+                kk[u] = i < hi ? keys1[i] : EMPTY;
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                if (kk[u] != KT_EMPTY_KEY) atomicAdd(&sm.cnt[digit2(kk[u], p)], 1u);
+                if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2(kk[u], p)], 1u);
         }
         ktd::lds_barrier();
         // bucket sizes can exceed 32 bits only for > 4 G keys in one level-1 bucket: not supported
@@ -308,12 +321,12 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__
         // chunks of CHUNK2 keys: counting sort in LDS, runs appended to the fine buckets.  The next
         // chunk's keys are loaded while the current one is sorted; digits are hashed once.
         constexpr int PER = CHUNK2 / P2T;  // 16 keys per thread, held in registers
-        uint64_t kcur[PER], knxt[PER];
-        auto load_chunk = [&](uint64_t c0, uint64_t (&dst)[PER]) {
+        K kcur[PER], knxt[PER];
+        auto load_chunk = [&](uint64_t c0, K (&dst)[PER]) {
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint64_t i = c0 + (uint64_t)u * P2T + tid;
-                dst[u] = i < hi ? keys1[i] : KT_EMPTY_KEY;
+                dst[u] = i < hi ? keys1[i] : EMPTY;
             }
         };
         if (lo < hi) load_chunk(lo, kcur);
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 dg[u] = (uint16_t)digit2(kcur[u], p);
-                if (kcur[u] != KT_EMPTY_KEY) atomicAdd(&sm.cnt[dg[u]], 1u);
+                if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[dg[u]], 1u);
             }
             ktd::lds_barrier();
             block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const uint64_t *__restrict__
             ktd::lds_barrier();
 #pragma unroll
             for (int u = 0; u < PER; u++) {
-                if (kcur[u] != KT_EMPTY_KEY) {
+                if (kcur[u] != EMPTY) {
                     const uint32_t pos = atomicAdd(&sm.fill[dg[u]], 1u);
                     sm.sorted[pos] = kcur[u];
                     sm.sdig[pos] = dg[u];
@@ -362,15 +375,25 @@ static_assert(LOG2_S == kttab::LOG2_RANGE, "the m/8 table shapes shrink 8192-slo
 
 constexpr int BUILD_T = KT_BUILD_T;  // 16 waves per fine bucket: short serial probe chains, full occupancy
 
-__global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restrict__ keys2,
+template <class K>
+struct lds_word;
+template <>
+struct lds_word<uint64_t> { using type = unsigned long long; };
+template <>
+struct lds_word<uint32_t> { using type = unsigned int; };
+
+template <class K>
+__global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ keys2,
                                                       const uint64_t *__restrict__ fstart, Plan p,
                                                       Slot *__restrict__ slots, uint64_t *__restrict__ spill_n,
                                                       uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
                                                       uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t SE = p.m8 << (LOG2_S - 3);
-    uint64_t *const skeys = reinterpret_cast<uint64_t *>(smem_raw);
-    uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)SE * 8);
+    using W = typename lds_word<K>::type;
+    constexpr K EMPTY = empty_of<K>();
+    K *const skeys = reinterpret_cast<K *>(smem_raw);
+    uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)SE * sizeof(K));
     const uint32_t tid = threadIdx.x;
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     const uint32_t shift = 64 - p.n;
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
     };
     for (uint64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
         for (uint32_t i = tid; i < SE; i += BUILD_T) {
-            skeys[i] = KT_EMPTY_KEY;
+            skeys[i] = EMPTY;
             scounts[i] = 0;
         }
         ktd::lds_barrier();
@@ -392,18 +415,17 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
         {
             uint64_t idx = lo + tid;
             auto fetch = [&]() {
-                const uint64_t k = idx < hi ? keys2[idx] : KT_EMPTY_KEY;
+                const K k = idx < hi ? keys2[idx] : EMPTY;
                 idx += BUILD_T;
                 return k;
             };
-            uint64_t cur = fetch(), q0 = fetch(), q1 = fetch(), q2 = fetch();
+            K cur = fetch(), q0 = fetch(), q1 = fetch(), q2 = fetch();
             uint32_t s = slot_in_range(cur);
-            while (cur != KT_EMPTY_KEY) {
+            while (cur != EMPTY) {
                 // one LDS operation per probe: the CAS itself reports what the slot holds (64-bit LDS atomics run at
                 // about a lane per clock, so a separate read before it doubled the cost of the common case)
-                const uint64_t v = atomicCAS(reinterpret_cast<unsigned long long *>(&skeys[s]),
-                                             (unsigned long long)KT_EMPTY_KEY, (unsigned long long)cur);
-                bool done = v == KT_EMPTY_KEY;  // claimed: first occurrence, stored count stays 0
+                const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
+                bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
                 if (!done && v == cur) {
                     atomicAdd(&scounts[s], 1u);
                     done = true;
@@ -427,7 +449,8 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const uint64_t *__restri
         ktd::lds_barrier();
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * SE);
         for (uint32_t i = tid; i < SE; i += BUILD_T) {
-            const uint64_t key = skeys[i];
+            const K kk = skeys[i];
+            const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : (uint64_t)kk;
             dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u);
         }
         ktd::lds_barrier();
@@ -451,8 +474,8 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
 
 // plans the partition, carves the buffers and runs hist1 .. build for `n_units` units of `src` that hold at
 // most `max_keys` k-mers in total
-template <class Source>
-int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t max_keys, int *done) {
+template <class Source, class K>
+int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t max_keys, int *done) {
     *done = 0;
     kt_ctx *ctx = ctr->ctx;
     Plan p{};
@@ -479,7 +502,7 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     const size_t off_fs = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
-    if (ctr->b_keys1.reserve(max_keys * 8) != KT_OK || ctr->b_keys2.reserve(max_keys * 8) != KT_OK ||
+    if (ctr->b_keys1.reserve(max_keys * sizeof(K)) != KT_OK || ctr->b_keys2.reserve(max_keys * sizeof(K)) != KT_OK ||
         ctr->b_meta.reserve(meta) != KT_OK) {
         ctr->b_keys1.release();
         ctr->b_keys2.release();
@@ -496,26 +519,26 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     m.spill_n = (uint64_t *)(mb + off_sn);
     m.spill_keys = (uint64_t *)(mb + off_sk);
     m.spill_cap = spill_cap;
-    uint64_t *keys1 = (uint64_t *)ctr->b_keys1.p, *keys2 = (uint64_t *)ctr->b_keys2.p;
+    K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
 
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
     hipLaunchKernelGGL(hist1_kernel<Source>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, src, p, m.H);
     hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.H, p, m.O, m.bstart);
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<Source>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared)));
-    hipLaunchKernelGGL(scatter1_kernel<Source>, dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared), ctx->stream, src, p, m.O,
-                       keys1);
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Part2Shared)));
-    hipLaunchKernelGGL(part2_kernel, dim3(p.B1), dim3(P2T), sizeof(Part2Shared), ctx->stream, keys1, m.bstart, p, keys2,
-                       m.fstart);
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<Source, K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
+    hipLaunchKernelGGL((scatter1_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>), ctx->stream, src,
+                       p, m.O, keys1);
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Part2Shared<K>)));
+    hipLaunchKernelGGL(part2_kernel<K>, dim3(p.B1), dim3(P2T), sizeof(Part2Shared<K>), ctx->stream, (const K *)keys1,
+                       m.bstart, p, keys2, m.fstart);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
     if (gb > n_fine) gb = n_fine;
-    const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * 12;
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)build_lds));
-    hipLaunchKernelGGL(build_kernel, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, keys2, m.fstart, p,
+    const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel<K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_lds));
+    hipLaunchKernelGGL(build_kernel<K>, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, p,
                        (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, ctr->flags);
     TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
@@ -523,6 +546,13 @@ int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t m
     KT_HIP(hipGetLastError());
     *done = 1;
     return KT_OK;
+}
+
+template <class Source>
+int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t max_keys, int *done) {
+    if (ctr->k <= 16 && env_u64("KT_BULK_NARROW", 1))
+        return bulk_build_typed<Source, uint32_t>(ctr, src, n_units, max_keys, done);
+    return bulk_build_typed<Source, uint64_t>(ctr, src, n_units, max_keys, done);
 }
 
 }  // namespace

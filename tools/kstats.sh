@@ -2,8 +2,9 @@
 # usage (GPU box): tools/kstats.sh <tag> <python script + args...>   -> per-kernel average times
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 tag=$1; shift
+[ $# -ge 1 ] || { echo "usage: tools/kstats.sh <tag> <script> [args]"; exit 2; }
 out=gpurun_out/ks_$tag; mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out -o kt --output-format csv -- python3 "$@" > $out/stdout.txt 2> $out/stderr.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d $out -o kt --output-format csv -- python3 "$@" > $out/stdout.txt 2> $out/stderr.txt
 python3 - $out <<'PY'
 import csv, sys
 out = sys.argv[1]
