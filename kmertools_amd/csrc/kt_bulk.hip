@@ -51,7 +51,15 @@ constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 #define KT_P2T 512
 #endif
 constexpr int P2T = KT_P2T;               // threads of a part2 workgroup
-constexpr uint32_t CHUNK2 = 16 * P2T;     // keys sorted at a time in part2 (16 per thread)
+#ifndef KT_P2_WPE
+#define KT_P2_WPE 2                       // waves per SIMD part2 is compiled for (4 = two workgroups per CU: spills, slower)
+#endif
+#ifndef KT_P2_PER32
+#define KT_P2_PER32 32
+#endif
+// keys sorted at a time in part2: 16 per thread (KT_P2_PER32 for 32-bit keys)
+template <class K>
+constexpr uint32_t chunk2() { return (sizeof(K) == 8 ? 16 : KT_P2_PER32) * P2T; }
 
 struct Plan {
     uint32_t n;       // hash bits that address the table: cap = m8 * 2^(n-3) (kttab::Geom)
@@ -273,23 +281,37 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, con
 }
 
 // ---- part2: one workgroup per level-1 bucket -----------------------------------------------------------
+// LDS of part2, carved at run time so that the per-digit arrays take B2 entries, not MAX_B: with 32-bit keys and
+// B2 <= 1024 two workgroups fit a CU
 template <class K>
 struct Part2Shared {
-    K sorted[CHUNK2];
-    uint16_t sdig[CHUNK2];
-    uint64_t cursor[MAX_B];
-    uint32_t cnt[MAX_B];
-    uint32_t start[MAX_B];
-    uint32_t fill[MAX_B];
-    uint32_t tmp[P2T];
+    K *sorted;         // [chunk2<K>()]
+    uint64_t *cursor;  // [B2]
+    uint32_t *cnt, *start, *fill;  // [B2] each
+    uint32_t *tmp;     // [P2T]
+    uint16_t *sdig;    // [chunk2<K>()]
+    static size_t bytes(uint32_t B2) {
+        return (size_t)chunk2<K>() * sizeof(K) + (size_t)B2 * (8 + 3 * 4) + (size_t)P2T * 4 + (size_t)chunk2<K>() * 2;
+    }
+    __device__ Part2Shared(unsigned char *raw, uint32_t B2) {
+        sorted = reinterpret_cast<K *>(raw);
+        raw += (size_t)chunk2<K>() * sizeof(K);
+        cursor = reinterpret_cast<uint64_t *>(raw);
+        raw += (size_t)B2 * 8;
+        cnt = reinterpret_cast<uint32_t *>(raw);
+        start = cnt + B2;
+        fill = start + B2;
+        tmp = fill + B2;
+        sdig = reinterpret_cast<uint16_t *>(tmp + P2T);
+    }
 };
 
 template <class K>
-__global__ __launch_bounds__(P2T) void part2_kernel(const K *__restrict__ keys1,
+__global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restrict__ keys1,
                                                       const uint64_t *__restrict__ bstart, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Part2Shared<K> &sm = *reinterpret_cast<Part2Shared<K> *>(smem_raw);
+    const Part2Shared<K> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
     const uint32_t tid = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
@@ -318,9 +340,9 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const K *__restrict__ keys1,
         }
         if (j == p.B1 - 1 && tid == 0) fstart[(uint64_t)p.B1 * p.B2] = hi;
         ktd::lds_barrier();
-        // chunks of CHUNK2 keys: counting sort in LDS, runs appended to the fine buckets.  The next
+        // chunks of chunk2<K>() keys: counting sort in LDS, runs appended to the fine buckets.  The next
         // chunk's keys are loaded while the current one is sorted; digits are hashed once.
-        constexpr int PER = CHUNK2 / P2T;  // 16 keys per thread, held in registers
+        constexpr int PER = chunk2<K>() / P2T;  // 16 keys per thread, held in registers
         K kcur[PER], knxt[PER];
         auto load_chunk = [&](uint64_t c0, K (&dst)[PER]) {
 #pragma unroll
@@ -330,10 +352,10 @@ __global__ __launch_bounds__(P2T) void part2_kernel(const K *__restrict__ keys1,
             }
         };
         if (lo < hi) load_chunk(lo, kcur);
-        for (uint64_t c0 = lo; c0 < hi; c0 += CHUNK2) {
+        for (uint64_t c0 = lo; c0 < hi; c0 += chunk2<K>()) {
             const uint64_t n64 = hi - c0;
-            const uint32_t nc = n64 < CHUNK2 ? (uint32_t)n64 : CHUNK2;
-            if (c0 + CHUNK2 < hi) load_chunk(c0 + CHUNK2, knxt);
+            const uint32_t nc = n64 < chunk2<K>() ? (uint32_t)n64 : chunk2<K>();
+            if (c0 + chunk2<K>() < hi) load_chunk(c0 + chunk2<K>(), knxt);
             for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
             ktd::lds_barrier();
             uint16_t dg[PER];
@@ -528,9 +550,10 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
     hipLaunchKernelGGL((scatter1_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>), ctx->stream, src,
                        p, m.O, keys1);
+    const size_t part2_lds = Part2Shared<K>::bytes(p.B2);
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Part2Shared<K>)));
-    hipLaunchKernelGGL(part2_kernel<K>, dim3(p.B1), dim3(P2T), sizeof(Part2Shared<K>), ctx->stream, (const K *)keys1,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds));
+    hipLaunchKernelGGL(part2_kernel<K>, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1,
                        m.bstart, p, keys2, m.fstart);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
