@@ -133,6 +133,8 @@ int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, u
 int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out);
 int kt_ctr_destroy(kt_ctr *ctr);
 int kt_ctr_clear(kt_ctr *ctr);
+/* the slots the table really has (capacity_slots after rounding) */
+int kt_ctr_capacity(kt_ctr *ctr, uint64_t *slots);
 
 /* replaces: the hot loop of count_chunk, counter/src/lib.rs:119-131:
  * for every k-mer of every read: table[min(fwd,rev)] += 1.  Repeatable (= chunks). */

@@ -397,6 +397,12 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
     return KT_OK;
 }
 
+int kt_ctr_capacity(kt_ctr *ctr, uint64_t *slots) {
+    if (!ctr || !slots) return kt::fail(KT_ERR_ARG, "kt_ctr_capacity: null");
+    *slots = ctr->cap;
+    return KT_OK;
+}
+
 int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct) {
     if (!ctr || !distinct) return kt::fail(KT_ERR_ARG, "kt_ctr_size: null");
     kt_ctx *ctx = ctr->ctx;

@@ -258,6 +258,12 @@ class Counter:
         check(_lib.lib().kt_ctr_size(self._h, C.byref(n)))
         return n.value
 
+    def capacity(self):
+        """slots the table really has (the request rounded up to 5..8 eighths of a power of two)"""
+        n = C.c_uint64()
+        check(_lib.lib().kt_ctr_capacity(self._h, C.byref(n)))
+        return n.value
+
     def export(self, keys, counts, max_out, mem=KT_MEM_DEVICE):
         n = C.c_uint64()
         check(_lib.lib().kt_ctr_export(self._h, _ptr(keys), _ptr(counts), max_out, C.byref(n), mem))

@@ -471,6 +471,8 @@ def test_ctr_odd_capacity_requests(hctx, oracle, monkeypatch, k, cap_request):
     for bulk in ("0", str(1 << 40)):          # bulk build, then atomics only
         monkeypatch.setenv("KT_BULK_MIN_BASES", bulk)
         ctr = device.Counter(hctx, k, cap_request)
+        cap = ctr.capacity()
+        assert cap_request <= cap <= 1.25 * cap_request and (cap & (cap - 1) == 0 or (cap >> (cap.bit_length() - 3)) in (5, 6, 7))
         ctr.add_reads_host(bases, offsets)
         gk, gc = ctr.export_host()
         assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
