@@ -67,6 +67,7 @@ struct Plan {
     uint32_t b1, b2;  // hash bits per level; b1 + b2 + LOG2_S == n
     uint32_t B1, B2;
     uint32_t G;       // persistent workgroups of hist1 / scatter1
+    uint64_t cap1;    // paged level 1: keys of room per level-1 bucket in keys1 / keys2
 };
 
 template <class K>
@@ -76,7 +77,10 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *H;        // [G][B1] k-mers of workgroup g in bucket d1
     uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
-    uint64_t *fstart;   // [B1 * B2 + 1] fine bucket boundaries in keys2
+    uint64_t *gcur;     // [B1] paged level 1: keys of bucket room handed out so far (page allocator)
+    uint32_t *ovf;      // [1]  paged level 1: a bucket ran out of room
+    uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
+    uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
     uint64_t *spill_keys;
     uint32_t *spill_counts;
@@ -280,6 +284,134 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, con
     }
 }
 
+// ---- scatter1, paged: no hist1 --------------------------------------------------------------------------
+// hist1 is a whole front-end pass whose only purpose is to make scatter1's output offsets exact.  The paged
+// variant drops it: every level-1 bucket owns a fixed region of cap1 keys, and a workgroup appends to a bucket
+// through a private 512-byte page that it replaces from the bucket's allocator (one global atomic per page, not
+// per run).  Pages are aligned and filled front to back; what is left of a workgroup's last pages is filled
+// with the empty key, which part2 skips.  A bucket that runs out of room (a batch dominated by a few k-mers)
+// raises *ovf and the build is redone through hist1 / scan1 / scatter1.
+#ifndef KT_PAGE_BYTES
+#define KT_PAGE_BYTES 512
+#endif
+template <class K>
+constexpr uint32_t page_keys() { return KT_PAGE_BYTES / sizeof(K); }
+
+template <class K>
+struct Scatter1PShared {
+    SegShared seg;
+    K sorted[round_keys<K>()];
+    uint16_t sdig[round_keys<K>()];
+    uint32_t pbase[MAX_B1];  // the workgroup's current page of the bucket (key offset inside the bucket's region)
+    uint32_t nbase[MAX_B1];  // pages allocated this round
+    uint32_t fill[MAX_B1];   // keys in the current page (page_keys: no page yet, or page full)
+    uint32_t cnt[MAX_B1];
+    uint32_t start[MAX_B1];
+    uint32_t tmp[BLOCK];
+    uint32_t ovf;
+};
+static_assert(sizeof(Scatter1PShared<uint64_t>) <= 80 * 1024 && sizeof(Scatter1PShared<uint32_t>) <= 80 * 1024,
+              "two scatter1 workgroups per CU");
+
+template <class Source, class K>
+__global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, uint64_t *__restrict__ gcur,
+                                                          uint32_t *__restrict__ ovf, K *__restrict__ keys1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Scatter1PShared<K> &sm = *reinterpret_cast<Scatter1PShared<K> *>(smem_raw);
+    constexpr int ROUNDS = ktseg::SEG / round_keys<K>(), PERR = ktseg::PER_THREAD / ROUNDS;
+    constexpr uint32_t PAGE = page_keys<K>();
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) {
+        sm.pbase[i] = 0;
+        sm.fill[i] = PAGE;
+    }
+    if (threadIdx.x == 0) sm.ovf = 0;
+    const uint64_t n_units = src.n_units();
+    bool stop = false;
+    for (uint64_t g = blockIdx.x; g < n_units && !stop; g += gridDim.x) {
+        uint64_t keys[ktseg::PER_THREAD];
+        uint32_t ok;
+        src.collect(g, sm.seg, keys, ok);
+#pragma unroll
+        for (int half = 0; half < ROUNDS; half++) {  // (no early exit in here: the loop must stay unrolled)
+            for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cnt[i] = 0;
+            ktd::lds_barrier();
+#pragma unroll
+            for (int j = 0; j < PERR; j++)
+                if ((ok >> (half * PERR + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * PERR + j], p)], 1u);
+            ktd::lds_barrier();
+            const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
+            // buckets whose run does not fit the current page get the pages for the rest; the allocator's answers
+            // are only looked at after the placement pass, so their round trip is hidden behind it
+            constexpr int ALLOC_IT = MAX_B1 / BLOCK;
+            uint64_t got[ALLOC_IT];
+            uint32_t room[ALLOC_IT];
+#pragma unroll
+            for (int it = 0; it < ALLOC_IT; it++) {
+                const uint32_t d = threadIdx.x + it * BLOCK;
+                room[it] = 0;
+                got[it] = 0;
+                if (d < p.B1) {
+                    const uint32_t t = sm.fill[d] + sm.cnt[d];
+                    if (t > PAGE) {
+                        room[it] = ((t - 1) / PAGE) * PAGE;  // whole pages; the last one may stay partly used
+                        got[it] = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[d]), (unsigned long long)room[it]);
+                    }
+                }
+            }
+            // placement: start[d] itself is the cursor, so afterwards start[d] = run start + cnt[d]
+#pragma unroll
+            for (int j = 0; j < PERR; j++) {
+                if ((ok >> (half * PERR + j)) & 1u) {
+                    const uint64_t m = keys[half * PERR + j];
+                    const uint32_t d = digit1(m, p);
+                    const uint32_t pos = atomicAdd(&sm.start[d], 1u);
+                    sm.sorted[pos] = (K)m;
+                    sm.sdig[pos] = (uint16_t)d;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ALLOC_IT; it++) {
+                if (room[it]) {
+                    if (got[it] + room[it] > p.cap1) {
+                        sm.ovf = 1;
+                        atomicOr(ovf, 1u);
+                    }
+                    sm.nbase[threadIdx.x + it * BLOCK] = (uint32_t)got[it];
+                }
+            }
+            ktd::lds_barrier();
+            stop = sm.ovf != 0;  // the same for every thread
+            if (!stop) {
+                for (uint32_t i = threadIdx.x; i < nk; i += BLOCK) {
+                    const uint32_t d = sm.sdig[i];
+                    const uint32_t q = sm.fill[d] + (i - (sm.start[d] - sm.cnt[d]));
+                    const uint32_t at = q < PAGE ? sm.pbase[d] + q : sm.nbase[d] + (q - PAGE);
+                    keys1[(uint64_t)d * p.cap1 + at] = sm.sorted[i];
+                }
+            }
+            ktd::lds_barrier();
+            // (same thread -> same buckets as the loop that zeroes cnt at the top of the next round)
+            for (uint32_t d = threadIdx.x; d < p.B1; d += BLOCK) {
+                const uint32_t t = sm.fill[d] + sm.cnt[d];
+                if (t > PAGE) {
+                    const uint32_t room = ((t - 1) / PAGE) * PAGE;
+                    sm.pbase[d] = sm.nbase[d] + room - PAGE;
+                    sm.fill[d] = t - room;
+                } else {
+                    sm.fill[d] = t;
+                }
+            }
+        }
+    }
+    ktd::lds_barrier();
+    if (sm.ovf) return;
+    // the unused tail of every bucket's last page
+    for (uint32_t idx = threadIdx.x; idx < p.B1 * PAGE; idx += BLOCK) {
+        const uint32_t d = idx / PAGE, q = idx % PAGE;
+        if (q >= sm.fill[d]) keys1[(uint64_t)d * p.cap1 + sm.pbase[d] + q] = empty_of<K>();
+    }
+}
+
 // ---- part2: one workgroup per level-1 bucket -----------------------------------------------------------
 // LDS of part2, carved at run time so that the per-digit arrays take B2 entries, not MAX_B: with 32-bit keys and
 // B2 <= 1024 two workgroups fit a CU
@@ -308,14 +440,18 @@ struct Part2Shared {
 
 template <class K>
 __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restrict__ keys1,
-                                                      const uint64_t *__restrict__ bstart, Plan p,
-                                                      K *__restrict__ keys2, uint64_t *__restrict__ fstart) {
+                                                      const uint64_t *__restrict__ bstart,
+                                                      const uint64_t *__restrict__ gcur, Plan p,
+                                                      K *__restrict__ keys2, uint64_t *__restrict__ fstart,
+                                                      uint64_t *__restrict__ fend) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Part2Shared<K> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
     const uint32_t tid = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
-        const uint64_t lo = bstart[j], hi = bstart[j + 1];
+        // exact level 1: keys1 is dense; paged level 1 (cap1 != 0): the bucket's region, empty keys in the gaps
+        const uint64_t lo = p.cap1 ? (uint64_t)j * p.cap1 : bstart[j];
+        const uint64_t hi = p.cap1 ? lo + gcur[j] : bstart[j + 1];
         // whole-bucket histogram of d2 -> fine bucket boundaries
         for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
         ktd::lds_barrier();
@@ -337,8 +473,8 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
             const uint64_t pos = lo + sm.start[i];
             sm.cursor[i] = pos;
             fstart[(uint64_t)j * p.B2 + i] = pos;
+            fend[(uint64_t)j * p.B2 + i] = pos + sm.cnt[i];
         }
-        if (j == p.B1 - 1 && tid == 0) fstart[(uint64_t)p.B1 * p.B2] = hi;
         ktd::lds_barrier();
         // chunks of chunk2<K>() keys: counting sort in LDS, runs appended to the fine buckets.  The next
         // chunk's keys are loaded while the current one is sorted; digits are hashed once.
@@ -353,8 +489,6 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
         };
         if (lo < hi) load_chunk(lo, kcur);
         for (uint64_t c0 = lo; c0 < hi; c0 += chunk2<K>()) {
-            const uint64_t n64 = hi - c0;
-            const uint32_t nc = n64 < chunk2<K>() ? (uint32_t)n64 : chunk2<K>();
             if (c0 + chunk2<K>() < hi) load_chunk(c0 + chunk2<K>(), knxt);
             for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
             ktd::lds_barrier();
@@ -365,7 +499,7 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
                 if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[dg[u]], 1u);
             }
             ktd::lds_barrier();
-            block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);
+            const uint32_t nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
             for (uint32_t i = tid; i < p.B2; i += P2T) sm.fill[i] = sm.start[i];
             ktd::lds_barrier();
 #pragma unroll
@@ -406,7 +540,8 @@ struct lds_word<uint32_t> { using type = unsigned int; };
 
 template <class K>
 __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ keys2,
-                                                      const uint64_t *__restrict__ fstart, Plan p,
+                                                      const uint64_t *__restrict__ fstart,
+                                                      const uint64_t *__restrict__ fend, Plan p,
                                                       Slot *__restrict__ slots, uint64_t *__restrict__ spill_n,
                                                       uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
                                                       uint32_t *__restrict__ flags) {
@@ -429,7 +564,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             scounts[i] = 0;
         }
         ktd::lds_barrier();
-        const uint64_t lo = fstart[fb], hi = fstart[fb + 1];
+        const uint64_t lo = fstart[fb], hi = fend[fb];
         // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
         // trip, and a lane that has placed its key moves on to its next one at once.  The obvious "for each key:
         // probe until placed" makes the wave wait for its longest probe chain on every key (8x more trips at load
@@ -514,6 +649,13 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     uint64_t G = (uint64_t)ctx->n_cu * 2;
     if (G > n_units) G = n_units;
     p.G = (uint32_t)G;
+    // paged level 1 (no hist1): room per bucket = its share of the most keys there can be + 1/8 + a page per
+    // workgroup (every workgroup leaves at most one partly used page per bucket)
+    bool paged = env_u64("KT_BULK_PAGED", 1) != 0 && !ctr->paged_failed;
+    const uint64_t PAGE = page_keys<K>();
+    uint64_t cap1 = (max_keys / p.B1 + max_keys / p.B1 / 8 + (G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
+    if (cap1 >= (1ull << 32)) paged = false;
+    const uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
     const uint64_t spill_cap = max_keys / 64 + (1u << 16);
@@ -522,9 +664,12 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;
     const size_t off_bs = meta;      meta += ((size_t)(p.B1 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fs = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
+    const size_t off_fe = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
+    const size_t off_gc = meta;      meta += ((size_t)p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_ov = meta;      meta += 256;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
-    if (ctr->b_keys1.reserve(max_keys * sizeof(K)) != KT_OK || ctr->b_keys2.reserve(max_keys * sizeof(K)) != KT_OK ||
+    if (ctr->b_keys1.reserve(key_room * sizeof(K)) != KT_OK || ctr->b_keys2.reserve(key_room * sizeof(K)) != KT_OK ||
         ctr->b_meta.reserve(meta) != KT_OK) {
         ctr->b_keys1.release();
         ctr->b_keys2.release();
@@ -538,30 +683,54 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     m.O = (uint64_t *)(mb + off_O);
     m.bstart = (uint64_t *)(mb + off_bs);
     m.fstart = (uint64_t *)(mb + off_fs);
+    m.fend = (uint64_t *)(mb + off_fe);
+    m.gcur = (uint64_t *)(mb + off_gc);
+    m.ovf = (uint32_t *)(mb + off_ov);
     m.spill_n = (uint64_t *)(mb + off_sn);
     m.spill_keys = (uint64_t *)(mb + off_sk);
     m.spill_cap = spill_cap;
     K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
 
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(hist1_kernel<Source>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, src, p, m.H);
-    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.H, p, m.O, m.bstart);
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<Source, K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
-    hipLaunchKernelGGL((scatter1_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>), ctx->stream, src,
-                       p, m.O, keys1);
+    if (paged) {
+        p.cap1 = cap1;
+        KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)p.B1 * 8, ctx->stream));
+        KT_HIP(hipMemsetAsync(m.ovf, 0, 4, ctx->stream));
+        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<Source, K>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
+        hipLaunchKernelGGL((scatter1p_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>), ctx->stream,
+                           src, p, m.gcur, m.ovf, keys1);
+        KT_HIP(hipGetLastError());
+        // the one host round trip of the build: did every bucket fit its region?
+        uint32_t ovf = 0;
+        KT_HIP(hipMemcpyAsync(&ovf, m.ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        if (ovf) {  // skewed batch: exact offsets after all, and no more paged attempts on this table
+            paged = false;
+            ctr->paged_failed = true;
+            p.cap1 = 0;
+        }
+    }
+    if (!paged) {
+        hipLaunchKernelGGL(hist1_kernel<Source>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, src, p, m.H);
+        hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.H, p, m.O, m.bstart);
+        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<Source, K>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
+        hipLaunchKernelGGL((scatter1_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>), ctx->stream,
+                           src, p, m.O, keys1);
+    }
     const size_t part2_lds = Part2Shared<K>::bytes(p.B2);
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<K>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds));
     hipLaunchKernelGGL(part2_kernel<K>, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1,
-                       m.bstart, p, keys2, m.fstart);
+                       m.bstart, m.gcur, p, keys2, m.fstart, m.fend);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel<K>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_lds));
-    hipLaunchKernelGGL(build_kernel<K>, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, p,
+    hipLaunchKernelGGL(build_kernel<K>, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend, p,
                        (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, ctr->flags);
     TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,

@@ -50,6 +50,7 @@ struct kt_ctr {
     uint64_t cap = 0;          // m8 * 2^(n-3) slots (kttab::Geom)
     uint32_t shift = 0;        // 64 - n
     uint32_t m8 = 8;           // eighths of 2^n
+    bool paged_failed = false; // a bulk build overflowed a paged level-1 bucket: exact offsets from now on
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls

@@ -483,10 +483,12 @@ def test_ctr_odd_capacity_requests(hctx, oracle, monkeypatch, k, cap_request):
         ctr.close()
 
 
+@pytest.mark.parametrize("paged", ["1", "0"])
 @pytest.mark.parametrize("k,log2cap", [(31, 17), (21, 18), (15, 19), (4, 14), (31, 20)])
-def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap):
+def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap, paged):
     from kmertools_amd import device
     monkeypatch.setenv("KT_BULK_MIN_BASES", "0")       # force the bulk path on a small batch
+    monkeypatch.setenv("KT_BULK_PAGED", paged)         # level 1 through pages (default) / through exact offsets
     seqs = ragged_reads(4000 + k + log2cap, 500)
     comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
     seqs += seqs[10:80] + [s.translate(comp)[::-1] for s in seqs[20:60]] + [b"A" * 3000, b"ACGT" * 700]
@@ -512,6 +514,25 @@ def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap):
     ctr.add_reads_host(b2, o2)                          # incremental
     gk, gc = ctr.export_host()
     assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    ctr.close()
+
+
+@pytest.mark.parametrize("k", [31, 15])
+def test_ctr_bulk_build_skewed_batch_falls_back(hctx, oracle, monkeypatch, k):
+    """a batch dominated by one k-mer overflows its paged level-1 bucket: the build must notice and redo level 1
+    with exact offsets; the table keeps working (and stops trying pages) afterwards"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    seqs = [b"A" * 6000] * 60 + ragged_reads(99 + k, 300) + [b"ACGT" * 2000] * 20
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    assert wc.max() > 300_000
+    ctr = device.Counter(hctx, k, 1 << 19)
+    for _ in range(2):
+        ctr.add_reads_host(bases, offsets)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        ctr.clear()
     ctr.close()
 
 
