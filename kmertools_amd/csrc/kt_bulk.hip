@@ -302,9 +302,11 @@ struct Scatter1PShared {
     SegShared seg;
     K sorted[round_keys<K>()];
     uint16_t sdig[round_keys<K>()];
-    uint32_t pbase[MAX_B1];  // the workgroup's current page of the bucket (key offset inside the bucket's region)
-    uint32_t nbase[MAX_B1];  // pages allocated this round
-    uint32_t fill[MAX_B1];   // keys in the current page (page_keys: no page yet, or page full)
+    uint16_t split[MAX_B1];  // this round: sorted[i] of bucket d goes to the current page iff i < split[d]
+    uint32_t cur[MAX_B1];    // where the workgroup's next key of the bucket goes (key offset inside the bucket's
+                             // region); on a page boundary = no room left, a new page is needed
+    uint32_t to_cur[MAX_B1]; // this round: position of sorted[i] = to_cur[d] + i (current page) ...
+    uint32_t to_new[MAX_B1]; //             ... or to_new[d] + i (the pages allocated this round)
     uint32_t cnt[MAX_B1];
     uint32_t start[MAX_B1];
     uint32_t tmp[BLOCK];
@@ -320,10 +322,8 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
     Scatter1PShared<K> &sm = *reinterpret_cast<Scatter1PShared<K> *>(smem_raw);
     constexpr int ROUNDS = ktseg::SEG / round_keys<K>(), PERR = ktseg::PER_THREAD / ROUNDS;
     constexpr uint32_t PAGE = page_keys<K>();
-    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) {
-        sm.pbase[i] = 0;
-        sm.fill[i] = PAGE;
-    }
+    constexpr int OWN = MAX_B1 / BLOCK;  // buckets a thread looks after: d = tid + it * BLOCK
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cur[i] = 0;
     if (threadIdx.x == 0) sm.ovf = 0;
     const uint64_t n_units = src.n_units();
     bool stop = false;
@@ -340,25 +340,34 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
                 if ((ok >> (half * PERR + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * PERR + j], p)], 1u);
             ktd::lds_barrier();
             const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
-            // buckets whose run does not fit the current page get the pages for the rest; the allocator's answers
-            // are only looked at after the placement pass, so their round trip is hidden behind it
-            constexpr int ALLOC_IT = MAX_B1 / BLOCK;
-            uint64_t got[ALLOC_IT];
-            uint32_t room[ALLOC_IT];
+            // every bucket's run is laid out: what fits goes to the current page, the rest to new pages.  The
+            // allocator's answers are only looked at after the placement pass, which hides their round trip.
+            uint64_t got[OWN];
+            uint32_t room[OWN], spl[OWN], nxt[OWN];
 #pragma unroll
-            for (int it = 0; it < ALLOC_IT; it++) {
+            for (int it = 0; it < OWN; it++) {
                 const uint32_t d = threadIdx.x + it * BLOCK;
                 room[it] = 0;
                 got[it] = 0;
+                spl[it] = 0;
+                nxt[it] = 0;
                 if (d < p.B1) {
-                    const uint32_t t = sm.fill[d] + sm.cnt[d];
-                    if (t > PAGE) {
-                        room[it] = ((t - 1) / PAGE) * PAGE;  // whole pages; the last one may stay partly used
+                    const uint32_t c = sm.cnt[d], rs = sm.start[d], cur = sm.cur[d];
+                    const uint32_t left = (0u - cur) & (PAGE - 1u);
+                    sm.to_cur[d] = cur - rs;
+                    spl[it] = rs + (c < left ? c : left);
+                    sm.split[d] = (uint16_t)spl[it];
+                    if (c > left) {
+                        const uint32_t need = c - left;
+                        room[it] = (need + PAGE - 1u) / PAGE * PAGE;  // whole pages; the last one may stay partly used
                         got[it] = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[d]), (unsigned long long)room[it]);
+                        nxt[it] = need;
+                    } else {
+                        sm.cur[d] = cur + c;
                     }
                 }
             }
-            // placement: start[d] itself is the cursor, so afterwards start[d] = run start + cnt[d]
+            ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
 #pragma unroll
             for (int j = 0; j < PERR; j++) {
                 if ((ok >> (half * PERR + j)) & 1u) {
@@ -370,13 +379,15 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
                 }
             }
 #pragma unroll
-            for (int it = 0; it < ALLOC_IT; it++) {
+            for (int it = 0; it < OWN; it++) {
                 if (room[it]) {
+                    const uint32_t d = threadIdx.x + it * BLOCK;
                     if (got[it] + room[it] > p.cap1) {
                         sm.ovf = 1;
                         atomicOr(ovf, 1u);
                     }
-                    sm.nbase[threadIdx.x + it * BLOCK] = (uint32_t)got[it];
+                    sm.to_new[d] = (uint32_t)got[it] - spl[it];
+                    sm.cur[d] = (uint32_t)got[it] + nxt[it];
                 }
             }
             ktd::lds_barrier();
@@ -384,23 +395,11 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
             if (!stop) {
                 for (uint32_t i = threadIdx.x; i < nk; i += BLOCK) {
                     const uint32_t d = sm.sdig[i];
-                    const uint32_t q = sm.fill[d] + (i - (sm.start[d] - sm.cnt[d]));
-                    const uint32_t at = q < PAGE ? sm.pbase[d] + q : sm.nbase[d] + (q - PAGE);
+                    const uint32_t at = (i < sm.split[d] ? sm.to_cur[d] : sm.to_new[d]) + i;
                     keys1[(uint64_t)d * p.cap1 + at] = sm.sorted[i];
                 }
             }
             ktd::lds_barrier();
-            // (same thread -> same buckets as the loop that zeroes cnt at the top of the next round)
-            for (uint32_t d = threadIdx.x; d < p.B1; d += BLOCK) {
-                const uint32_t t = sm.fill[d] + sm.cnt[d];
-                if (t > PAGE) {
-                    const uint32_t room = ((t - 1) / PAGE) * PAGE;
-                    sm.pbase[d] = sm.nbase[d] + room - PAGE;
-                    sm.fill[d] = t - room;
-                } else {
-                    sm.fill[d] = t;
-                }
-            }
         }
     }
     ktd::lds_barrier();
@@ -408,7 +407,8 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
     // the unused tail of every bucket's last page
     for (uint32_t idx = threadIdx.x; idx < p.B1 * PAGE; idx += BLOCK) {
         const uint32_t d = idx / PAGE, q = idx % PAGE;
-        if (q >= sm.fill[d]) keys1[(uint64_t)d * p.cap1 + sm.pbase[d] + q] = empty_of<K>();
+        const uint32_t cur = sm.cur[d];
+        if (q < ((0u - cur) & (PAGE - 1u))) keys1[(uint64_t)d * p.cap1 + cur + q] = empty_of<K>();
     }
 }
 
