@@ -303,7 +303,7 @@ def main():
             cap = int(args.cap_slots)
         counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
-        dominant = "ctr k=%d step: bulk table build (hist1 + scatter1 + part2 + build kernels)" % k
+        dominant = "ctr k=%d step: bulk table build (scatter1p + part2 + build kernels)" % k
 
         def step():
             counter.clear()

@@ -6,6 +6,8 @@
 // (one CAS or atomic add per k-mer, kt_ctr.hip) cannot exceed ~20 G k-mers/s.  An EMPTY table
 // can instead be built by streaming passes:
 //
+//   (level 1 is normally done by scatter1p below - fixed bucket regions filled through pages, no counting pass;
+//    hist1 / scan1 / scatter1 are the exact-offset fallback for batches that overflow a region)
 //   hist1     persistent workgroups run the segment front end over their reads and count
 //             k-mers per level-1 bucket d1 = top b1 bits of khash(key)   (LDS counters)
 //   scan1     exact output offset of every (workgroup, d1) pair - no reservation atomics
