@@ -27,6 +27,7 @@
 // Traffic ~ 1 B/base x 2 + 8 B/k-mer x 5 + 16 B/slot, all streaming.  The intermediate key arrays and the LDS
 // sort / insert arrays hold 32-bit keys when k <= 16 (template parameter K): half the partition traffic, whole
 // units sorted at once in scatter1, and 32-bit LDS atomics in build (64-bit ones run at about a lane per clock).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "kt_segment.hpp"
@@ -70,6 +71,7 @@ struct Plan {
     uint32_t B1, B2;
     uint32_t G;       // persistent workgroups of hist1 / scatter1
     uint64_t cap1;    // paged level 1: keys of room per level-1 bucket in keys1 / keys2
+    uint64_t cap2;    // ... and per fine bucket in keys2 (cap1 / B2)
 };
 
 template <class K>
@@ -80,7 +82,7 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
     uint64_t *gcur;     // [B1] paged level 1: keys of bucket room handed out so far (page allocator)
-    uint32_t *ovf;      // [1]  paged level 1: a bucket ran out of room
+    uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room; [1] fixed fine regions: the spill list did
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -440,12 +442,18 @@ struct Part2Shared {
     }
 };
 
-template <class K>
+// FIXED (with paged level 1): every fine bucket owns cap2 keys of room in keys2, so the whole-bucket histogram
+// pass (a second read of keys1) is not needed; the keys of a fine bucket that outgrows its room go to the spill
+// list, i.e. through the probing path after the build (heavy hitters of real data), and if that list overflows the
+// build is redone with exact offsets.
+template <class K, bool FIXED>
 __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restrict__ keys1,
                                                       const uint64_t *__restrict__ bstart,
                                                       const uint64_t *__restrict__ gcur, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart,
-                                                      uint64_t *__restrict__ fend) {
+                                                      uint64_t *__restrict__ fend, uint64_t *__restrict__ spill_n,
+                                                      uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
+                                                      uint32_t *__restrict__ ovf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Part2Shared<K> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
@@ -454,6 +462,14 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
         // exact level 1: keys1 is dense; paged level 1 (cap1 != 0): the bucket's region, empty keys in the gaps
         const uint64_t lo = p.cap1 ? (uint64_t)j * p.cap1 : bstart[j];
         const uint64_t hi = p.cap1 ? lo + gcur[j] : bstart[j + 1];
+        if constexpr (FIXED) {
+            for (uint32_t i = tid; i < p.B2; i += P2T) {
+                const uint64_t pos = lo + (uint64_t)i * p.cap2;
+                sm.cursor[i] = pos;
+                fstart[(uint64_t)j * p.B2 + i] = pos;
+            }
+            ktd::lds_barrier();
+        } else {
         // whole-bucket histogram of d2 -> fine bucket boundaries
         for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
         ktd::lds_barrier();
@@ -478,6 +494,7 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
             fend[(uint64_t)j * p.B2 + i] = pos + sm.cnt[i];
         }
         ktd::lds_barrier();
+        }
         // chunks of chunk2<K>() keys: counting sort in LDS, runs appended to the fine buckets.  The next
         // chunk's keys are loaded while the current one is sorted; digits are hashed once.
         constexpr int PER = chunk2<K>() / P2T;  // 16 keys per thread, held in registers
@@ -515,13 +532,26 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
             ktd::lds_barrier();
             for (uint32_t i = tid; i < nc; i += P2T) {
                 const uint32_t d = sm.sdig[i];
-                keys2[sm.cursor[d] + (i - sm.start[d])] = sm.sorted[i];
+                const uint64_t pos = sm.cursor[d] + (i - sm.start[d]);
+                if (!FIXED || pos < lo + (uint64_t)(d + 1) * p.cap2) {
+                    keys2[pos] = sm.sorted[i];
+                } else {
+                    const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
+                    if (at < spill_cap) spill_keys[at] = (uint64_t)sm.sorted[i];
+                    else atomicOr(ovf + 1, 1u);
+                }
             }
             ktd::lds_barrier();
             for (uint32_t i = tid; i < p.B2; i += P2T) sm.cursor[i] += sm.cnt[i];
 #pragma unroll
             for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
             // (the next iteration's first barrier orders the cursor update before its use)
+        }
+        if constexpr (FIXED) {  // (same thread -> same fine buckets as the cursor update above)
+            for (uint32_t i = tid; i < p.B2; i += P2T) {
+                const uint64_t c = sm.cursor[i], lim = lo + (uint64_t)(i + 1) * p.cap2;
+                fend[(uint64_t)j * p.B2 + i] = c < lim ? c : lim;
+            }
         }
         ktd::lds_barrier();
     }
@@ -696,8 +726,9 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
     if (paged) {
         p.cap1 = cap1;
+        p.cap2 = env_u64("KT_BULK_FIXED2", 1) ? cap1 / p.B2 : 0;
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)p.B1 * 8, ctx->stream));
-        KT_HIP(hipMemsetAsync(m.ovf, 0, 4, ctx->stream));
+        KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
         KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<Source, K>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
         hipLaunchKernelGGL((scatter1p_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>), ctx->stream,
@@ -711,6 +742,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
             paged = false;
             ctr->paged_failed = true;
             p.cap1 = 0;
+            p.cap2 = 0;
         }
     }
     if (!paged) {
@@ -722,10 +754,11 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
                            src, p, m.O, keys1);
     }
     const size_t part2_lds = Part2Shared<K>::bytes(p.B2);
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2_kernel<K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)part2_lds));
-    hipLaunchKernelGGL(part2_kernel<K>, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1,
-                       m.bstart, m.gcur, p, keys2, m.fstart, m.fend);
+    auto part2 = p.cap2 ? part2_kernel<K, true> : part2_kernel<K, false>;
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)part2_lds));
+    hipLaunchKernelGGL(part2, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur, p,
+                       keys2, m.fstart, m.fend, m.spill_n, m.spill_keys, m.spill_cap, m.ovf);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
     if (gb > n_fine) gb = n_fine;
@@ -733,11 +766,28 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel<K>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_lds));
     hipLaunchKernelGGL(build_kernel<K>, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend, p,
-                       (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, ctr->flags);
+                       (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, p.cap2 ? m.ovf + 1 : ctr->flags);
     TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
                        m.spill_cap, t);
     KT_HIP(hipGetLastError());
+    if (env_u64("KT_BULK_VERBOSE", 0)) {
+        uint64_t spilled = 0;
+        KT_HIP(hipMemcpyAsync(&spilled, m.spill_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s spilled=%llu\n", ctr->k, (unsigned long long)max_keys,
+                paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact", (unsigned long long)spilled);
+    }
+    if (p.cap2) {  // did the spill list hold what the fixed fine regions could not?
+        uint32_t ovf2 = 0;
+        KT_HIP(hipMemcpyAsync(&ovf2, m.ovf + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        if (ovf2) {  // no: once more with exact offsets at both levels (the build rewrites every slot)
+            ctr->paged_failed = true;
+            KT_HIP(hipMemsetAsync(ctr->flags, 0, 4, ctx->stream));
+            return bulk_build_typed<Source, K>(ctr, src, n_units, max_keys, done);
+        }
+    }
     *done = 1;
     return KT_OK;
 }

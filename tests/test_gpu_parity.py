@@ -536,6 +536,32 @@ def test_ctr_bulk_build_skewed_batch_falls_back(hctx, oracle, monkeypatch, k):
     ctr.close()
 
 
+@pytest.mark.parametrize("k,repeat,want", [(31, 600, "spill"), (15, 600, "spill"), (31, 20000, "redo")])
+def test_ctr_bulk_build_heavy_hitters_in_fixed_regions(hctx, oracle, monkeypatch, capfd, k, repeat, want):
+    """k-mers that occur far more often than a fine bucket's fixed room: the excess goes through the spill list
+    (probing path); when even that overflows, the build is redone with exact offsets"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    monkeypatch.setenv("KT_BULK_VERBOSE", "1")
+    rng = np.random.default_rng(5 + k)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=1000)) for _ in range(400)]
+    seqs += [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=40)) * repeat for _ in range(4)]
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    ctr = device.Counter(hctx, k, 1 << 21)
+    capfd.readouterr()
+    ctr.add_reads_host(bases, offsets)
+    lines = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[bulk]")]
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    if want == "spill":
+        assert len(lines) == 1 and "level1=paged level2=fixed" in lines[0]
+        assert int(lines[0].split("spilled=")[1]) > 1000
+    else:  # (a level-1 region may give up first: then the first attempt already reports exact offsets)
+        assert "level1=exact level2=exact" in lines[-1]
+    ctr.close()
+
+
 @pytest.mark.parametrize("k,log2cap", [(31, 18), (15, 19), (9, 18)])
 def test_ctr_bulk_build_from_routed_keys(hctx, oracle, monkeypatch, k, log2cap):
     """kt_ctr_add_pairs(keys, counts=NULL) into an empty table = what a GPU does with the k-mers routed to it:
