@@ -687,7 +687,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     const uint64_t PAGE = page_keys<K>();
     uint64_t cap1 = (max_keys / p.B1 + max_keys / p.B1 / 8 + (G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
     if (cap1 >= (1ull << 32)) paged = false;
-    const uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
+    uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
     const uint64_t spill_cap = max_keys / 64 + (1u << 16);
@@ -701,8 +701,18 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     const size_t off_ov = meta;      meta += 256;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
-    if (ctr->b_keys1.reserve(key_room * sizeof(K)) != KT_OK || ctr->b_keys2.reserve(key_room * sizeof(K)) != KT_OK ||
-        ctr->b_meta.reserve(meta) != KT_OK) {
+    auto reserve_all = [&]() {
+        return ctr->b_keys1.reserve(key_room * sizeof(K)) == KT_OK && ctr->b_keys2.reserve(key_room * sizeof(K)) == KT_OK &&
+               ctr->b_meta.reserve(meta) == KT_OK;
+    };
+    bool have = reserve_all();
+    if (!have && paged) {  // the paged layout wants 1/8 more room than the keys: try the exact one before giving up
+        paged = false;
+        key_room = max_keys;
+        have = reserve_all();
+        if (have) kt::set_error("");
+    }
+    if (!have) {
         ctr->b_keys1.release();
         ctr->b_keys2.release();
         ctr->b_meta.release();
