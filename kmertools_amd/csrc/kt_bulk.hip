@@ -6,27 +6,30 @@
 // (one CAS or atomic add per k-mer, kt_ctr.hip) cannot exceed ~20 G k-mers/s.  An EMPTY table
 // can instead be built by streaming passes:
 //
-//   (level 1 is normally done by scatter1p below - fixed bucket regions filled through pages, no counting pass;
-//    hist1 / scan1 / scatter1 are the exact-offset fallback for batches that overflow a region)
-//   hist1     persistent workgroups run the segment front end over their reads and count
-//             k-mers per level-1 bucket d1 = top b1 bits of khash(key)   (LDS counters)
-//   scan1     exact output offset of every (workgroup, d1) pair - no reservation atomics
-//   scatter1  same front end again; each segment's <= 8192 keys are counting-sorted by d1 in
-//             LDS and every d1 run is copied to its bucket with coalesced stores
-//   part2     one workgroup per level-1 bucket: histogram of d2 (next b2 hash bits), then the
-//             bucket is re-read in 4096-key chunks, each chunk counting-sorted in LDS and its
-//             runs appended to the fine buckets
+//   scatter1p persistent workgroups run the segment front end over their reads; each unit's <= 8192 keys are
+//             counting-sorted in LDS by d1 = top b1 bits of khash(key) and every d1 run is appended to the
+//             bucket's fixed region of the key array through the workgroup's private aligned pages (one global
+//             atomic per page, no counting pass)
+//   part2     one workgroup per level-1 bucket: the bucket is read in 8192 / 16384-key chunks, each chunk
+//             counting-sorted in LDS by d2 (next b2 hash bits) and its runs appended to the fine buckets, which
+//             own fixed shares of the bucket's region; what outgrows a share goes to the spill list
 //   build     one workgroup per fine bucket (d1,d2): its keys are counted in an LDS
-//             open-addressing table that *is* the image of the global slot range
-//             [(d1,d2) * S, +S) (home slot = top log2(cap) hash bits, kt_table.hpp), and the
-//             8192 slots are written out with 16-byte coalesced stores - including the empty
-//             ones, so the bulk build needs no cleared table.  Keys that would probe past the
-//             end of their range go to a small spill list and are inserted afterwards through
+//             open-addressing table that *is* the image of the global slot range of that hash prefix
+//             (kt_table.hpp), and the range is written out with 16-byte coalesced stores - including the
+//             empty slots, so the bulk build needs no cleared table.  Keys that would probe past the
+//             end of their range go to the spill list too, which is inserted afterwards through
 //             the ordinary (probing, atomic) path.
 //
-// Traffic ~ 1 B/base x 2 + 8 B/k-mer x 5 + 16 B/slot, all streaming.  The intermediate key arrays and the LDS
+// Fixed regions assume the hash spreads the batch; a batch dominated by a few k-mers overflows a level-1 region or
+// the spill list, is noticed (two 4-byte reads by the host), and is redone with exact offsets:
+//   hist1     a front-end pass that counts k-mers per (workgroup, d1)          (LDS counters)
+//   scan1     exact output offset of every (workgroup, d1) pair
+//   scatter1  as scatter1p, every run copied to its exact place
+//   part2     first histograms the whole bucket by d2 (a second read) to get the fine boundaries
+//
+// Traffic ~ 1 B/base + 8 B/k-mer x 4 + 16 B/slot, all streaming.  The intermediate key arrays and the LDS
 // sort / insert arrays hold 32-bit keys when k <= 16 (template parameter K): half the partition traffic, whole
-// units sorted at once in scatter1, and 32-bit LDS atomics in build (64-bit ones run at about a lane per clock).
+// units sorted at once in level 1, and 32-bit LDS atomics in build (64-bit ones run at about a lane per clock).
 #include <stdio.h>
 #include <stdlib.h>
 
