@@ -20,8 +20,8 @@
 // w = 0 ("one minimiser per sequence", misc/src/minimisers.rs:44-48) makes w the read's own length;
 // it has its own one-thread-per-read kernel.
 //
-// General w: the batch is cut into tiles of 7168 positions (+ a 1024-position halo in front, so
-// W <= 1024), 16 consecutive positions per thread (one 16-byte load, SWAR-encoded).  Run starts
+// General w: the batch is cut into tiles of 7168 positions + a 1024-position halo in front (W <= 1024; tiles of
+// 4096 + a 4096-position halo for W <= 4096), 16 consecutive positions per thread (one 16-byte load, SWAR-encoded).  Run starts
 // are a max-scan ("latest break before p") carried across tiles by a small prefix pass over
 // 1024-position granules; the sliding minimum is log2(W) doubling steps over a padded LDS array
 // of the tile's m-mers.  Output is dense and in read order: with a known capacity one pass does it
@@ -45,7 +45,7 @@ constexpr int BLOCK = KT_MIN_BLOCK;
 constexpr uint32_t GRAN = 1024;               // carry granule (positions)
 constexpr uint32_t PER = 16;                  // consecutive positions per thread
 constexpr uint32_t RANGE = BLOCK * PER;       // positions a workgroup looks at: one halo granule + its tile
-constexpr uint32_t TILE = RANGE - GRAN;       // positions owned by a workgroup
+constexpr uint32_t MAX_HG = 4;                // widest halo: windows of up to 4096 m-mers
 constexpr uint64_t NONE = ~0ull;
 static_assert(PER * BLOCK == RANGE, "tiling");
 
@@ -275,7 +275,9 @@ struct Chain {
 };
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = 3ull << 62;
 
-template <class V, bool EMIT>
+// HG = granules of halo in front of the tile: windows of up to HG * 1024 m-mers (1: tiles of 7168 positions;
+// 4: tiles of 4096, for the rare wide windows)
+template <class V, bool EMIT, int HG>
 __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__restrict__ tile_count, Chain chain,
                                                          Event *__restrict__ ev, uint8_t *__restrict__ ev_type,
                                                          uint64_t *__restrict__ ev_offsets) {
@@ -290,13 +292,15 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         __syncthreads();
         tile = sh_u64;
     }
+    constexpr uint32_t HALO = HG * GRAN, TILE = RANGE - HALO;
+    static_assert(HALO <= TILE, "only tile 0 may start in front of the batch");
     const uint64_t t0 = tile * TILE;           // first position owned
-    const int64_t range0 = (int64_t)t0 - (int64_t)GRAN;        // position of local index 0 (negative for tile 0)
+    const int64_t range0 = (int64_t)t0 - (int64_t)HALO;        // position of local index 0 (negative for tile 0)
     const int32_t m = (int32_t)a.m, w = (int32_t)a.w;
     const uint32_t W = a.W;
     // local indices [lo_in, hi_in) are real positions (tile 0 has no halo, the last tile may be short)
-    const int32_t lo_in = range0 < 0 ? (int32_t)GRAN : 0;
-    const int32_t hi_in = a.total - t0 >= TILE ? (int32_t)RANGE : (int32_t)(a.total - t0) + (int32_t)GRAN;
+    const int32_t lo_in = range0 < 0 ? (int32_t)HALO : 0;
+    const int32_t hi_in = a.total - t0 >= TILE ? (int32_t)RANGE : (int32_t)(a.total - t0) + (int32_t)HALO;
 
     // ---- this thread's 16 bases: one 16-byte load, SWAR-encoded (codes P, ambiguity flags inv) ----
     const int32_t l0 = (int32_t)(tid * PER);  // first local index of this thread
@@ -424,9 +428,9 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
 
     // ---- sliding minimum over W m-mers: doubling, then two overlapping power-of-two windows ----
     {
-        // only windows ending at local index >= GRAN - 1 are ever read; the values they are built from reach
+        // only windows ending at local index >= HALO - 1 are ever read; the values they are built from reach
         // back less than 2 W positions, so the threads further in front (most of the halo wave) just keep step
-        const bool needed = (uint32_t)l0 + PER + 2 * W + 2 > GRAN;
+        const bool needed = (uint32_t)l0 + PER + 2 * W + 2 > HALO;
         auto combine = [&](uint32_t dist) {
             V x[PER];
             if (needed) {
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         if (span < W) combine(W - span);
     }
 
-    // ---- events of the positions this workgroup owns (local index >= GRAN) ----
+    // ---- events of the positions this workgroup owns (local index >= HALO) ----
     // detection only: which of the thread's positions emit (ev_bits), of which kind (2 bits each), and whether an
     // E3 reports "no full window" (none_bits).  The records are built afterwards, one per set bit.
     uint32_t ev_bits = 0, kinds = 0, none_bits = 0, inv_bits = 0;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
                     b = li + 1;
                     inv_bits |= 1u << j;
                 }
-                if (li >= (int32_t)GRAN) {  // halo positions only carry state
+                if (li >= (int32_t)HALO) {  // halo positions only carry state
                     const int32_t run_len = li + 1 - b;
                     // run length of the previous position (0 at a read start: that base belongs to another read)
                     const int32_t prev_len = st ? 0 : li - b_prev;
@@ -672,8 +676,8 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     if (msize < 1 || msize > 31) return kt::fail(KT_ERR_ARG, "kt_minimisers: msize must be in 1..31");
     if (wsize != 0 && wsize < (uint64_t)msize)
         return kt::fail(KT_ERR_ARG, "kt_minimisers: wsize must be 0 or >= msize");
-    if (wsize != 0 && wsize - (uint64_t)msize + 1 > GRAN)
-        return kt::fail(KT_ERR_ARG, "kt_minimisers: windows of more than 1024 m-mers are not supported by this build");
+    if (wsize != 0 && wsize - (uint64_t)msize + 1 > MAX_HG * GRAN)
+        return kt::fail(KT_ERR_ARG, "kt_minimisers: windows of more than 4096 m-mers are not supported by this build");
     if (n_reads == 0) return KT_OK;
     if (!offsets || !ev_offsets) return kt::fail(KT_ERR_ARG, "kt_minimisers: null offsets");
     if (capacity && (!kmers || !starts || !ends)) return kt::fail(KT_ERR_ARG, "kt_minimisers: null output");
@@ -698,7 +702,10 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
 
     // internal buffers (one scratch allocation): granule index/carries, per-tile counts/bases, scan partials
     const uint64_t n_gran = (total + GRAN - 1) / GRAN;
-    const uint64_t n_tiles = (total + TILE - 1) / TILE;
+    // halo granules in front of every tile: one for windows of up to 1024 m-mers, four for wider ones
+    const int hg = (wsize == 0 || wsize - (uint64_t)msize + 1 <= GRAN) ? 1 : (int)MAX_HG;
+    const uint64_t tile_len = RANGE - (uint64_t)hg * GRAN;
+    const uint64_t n_tiles = (total + tile_len - 1) / tile_len;
     const uint64_t n_scan = (n_reads > n_gran ? n_reads : n_gran) + 1;
     size_t off = 0;
     const size_t o_gfirst = off;  off += align256((n_gran + 2) * 8);
@@ -747,12 +754,10 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
             Chain chain{(unsigned long long *)tcount, (unsigned long long *)(d_total + 1), d_total, n_tiles, capacity};
             if (capacity == 0) {
                 // count only: per-tile counts, then their sum
-                if (narrow)
-                    hipLaunchKernelGGL((min_tile_kernel<uint32_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
-                                       a, tcount, chain, (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
-                else
-                    hipLaunchKernelGGL((min_tile_kernel<uint64_t, false>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
-                                       a, tcount, chain, (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
+                auto kern = narrow ? (hg == 1 ? min_tile_kernel<uint32_t, false, 1> : min_tile_kernel<uint32_t, false, MAX_HG>)
+                                   : (hg == 1 ? min_tile_kernel<uint64_t, false, 1> : min_tile_kernel<uint64_t, false, MAX_HG>);
+                hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, tcount, chain,
+                                   (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
                 if (int rc = device_excl_scan<false>(ctx, tcount, n_tiles, tbase, partial, d_total)) return rc;
                 KT_HIP(hipMemcpyAsync(&n_ev, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
                 KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -763,12 +768,10 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
                 uint8_t *ev_type = (uint8_t *)ctx->s_aux2.p + align256(capacity * sizeof(Event));
                 KT_HIP(hipMemsetAsync(tcount, 0, n_tiles * 8, ctx->stream));
                 KT_HIP(hipMemsetAsync(d_total, 0, 16, ctx->stream));
-                if (narrow)
-                    hipLaunchKernelGGL((min_tile_kernel<uint32_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
-                                       a, (uint64_t *)nullptr, chain, ev, ev_type, d_evoff);
-                else
-                    hipLaunchKernelGGL((min_tile_kernel<uint64_t, true>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream,
-                                       a, (uint64_t *)nullptr, chain, ev, ev_type, d_evoff);
+                auto kern = narrow ? (hg == 1 ? min_tile_kernel<uint32_t, true, 1> : min_tile_kernel<uint32_t, true, MAX_HG>)
+                                   : (hg == 1 ? min_tile_kernel<uint64_t, true, 1> : min_tile_kernel<uint64_t, true, MAX_HG>);
+                hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, (uint64_t *)nullptr, chain,
+                                   ev, ev_type, d_evoff);
                 hipLaunchKernelGGL(min_tail_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                    d_evoff, n_reads, d_total);
                 KT_HIP(hipGetLastError());

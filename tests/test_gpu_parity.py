@@ -843,7 +843,7 @@ def test_minimisers_vs_oracle(hctx, oracle, w, m):
 def test_minimisers_arguments(hctx):
     from kmertools_amd import device
     b, o = device.to_csr(["ACGTACGTACGT"])
-    for w, m in ((3, 5), (2000, 7), (10, 0), (10, 32)):
+    for w, m in ((3, 5), (5000, 7), (10, 0), (10, 32)):
         with pytest.raises(Exception):
             hctx.minimisers_host(b, o, w, m)
     evo, k, s, e = hctx.minimisers_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 31, 7)
@@ -961,6 +961,28 @@ def test_minimisers_wide_window_run_start_before_halo(hctx, oracle):
         got = _min_triples(hctx, seqs, w, m)
         for i, s in enumerate(seqs):
             assert got[i] == oracle.minimisers(s, w, m), (i, w, m)
+
+
+def test_minimisers_windows_wider_than_a_granule(hctx, oracle):
+    """1024 < W <= 4096 runs on tiles with a four-granule halo: reads that span several tiles, breaks near the tile
+    and halo boundaries, windows right up to the limit; one m-mer more is refused"""
+    rng = np.random.default_rng(11)
+    alpha = np.array(list("ACGT"))
+    seqs = []
+    for d in (0, 1, 30, 500):
+        s = rng.choice(alpha, size=30000)
+        for p in (4096 - d, 8192 - d, 8192 + d, 12288 - 17 - d):
+            s[p] = "N"
+        seqs.append("".join(s))
+    seqs += ["".join(rng.choice(alpha, size=n)) for n in (5000, 4126, 4127, 100, 0, 9000)]
+    for w, m in ((1040, 15), (2000, 31), (3000, 9), (4100, 5), (4126, 31), (4111, 16)):
+        got = _min_triples(hctx, seqs, w, m)
+        for i, s in enumerate(seqs):
+            assert got[i] == oracle.minimisers(s, w, m), (i, w, m)
+    from kmertools_amd import device, _lib
+    bases, offsets = device.to_csr(seqs)
+    with pytest.raises(_lib.KmertoolsError):
+        hctx.minimisers_host(bases, offsets, 4127, 31)
 
 
 def test_all_empty_reads_everywhere(hctx, oracle):

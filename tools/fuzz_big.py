@@ -73,7 +73,7 @@ while time.time() < t_end:
     assert np.array_equal(cov.cpu().numpy(), oc.cov_batch(hb, ho, k, bs, bc, True)), ("cov", seed, rounds, k)
     ctr.close()
     # min
-    m = int(rng.integers(3, 32)); w = m + int(rng.choice([0, 1, 24, 200, 1000]))
+    m = int(rng.integers(3, 32)); w = m + int(rng.choice([0, 1, 24, 200, 1000, 1500, 4000]))
     evo = torch.empty(n + 1, dtype=torch.int64, device="cuda"); one = torch.empty(1, dtype=torch.int64, device="cuda")
     ne = ctx.minimisers(db, do, n, w, m, evo, one, one, one, 0)
     mk = torch.empty(max(ne, 1), dtype=torch.int64, device="cuda"); ms = torch.empty_like(mk); me = torch.empty_like(mk)

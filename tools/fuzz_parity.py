@@ -97,7 +97,7 @@ while time.time() < t_end:
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), ("cgr", seed, v)
     cases["cgr"] += 1
     # min
-    m = int(rng.integers(1, 32)); w = int(rng.choice([0, m, m + 1, m + int(rng.integers(0, 60)), m + 1023]))
+    m = int(rng.integers(1, 32)); w = int(rng.choice([0, m, m + 1, m + int(rng.integers(0, 60)), m + 1023, m + 1024, m + 4095]))
     ms = [s for s in seqs if w != 0 or len(s) >= m]
     mb, mo = oracle.to_csr(ms)
     evo, kk, ss, ee = ctx.minimisers_host(mb, mo, w, m)
