@@ -693,7 +693,9 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
-    const uint64_t spill_cap = max_keys / 64 + (1u << 16);
+    // spill list: keys beyond a range's end in build, and what outgrows the fixed fine regions in part2 (heavy
+    // hitters of real data; they go through the probing path at ~27 G/s, so a few per cent are cheap)
+    const uint64_t spill_cap = max_keys / 16 + (1u << 16);
     size_t meta = 0;
     const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;

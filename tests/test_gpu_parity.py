@@ -536,7 +536,7 @@ def test_ctr_bulk_build_skewed_batch_falls_back(hctx, oracle, monkeypatch, k):
     ctr.close()
 
 
-@pytest.mark.parametrize("k,repeat,want", [(31, 600, "spill"), (15, 600, "spill"), (31, 20000, "redo")])
+@pytest.mark.parametrize("k,repeat,want", [(31, 600, "spill"), (15, 600, "spill"), (31, 60000, "redo")])
 def test_ctr_bulk_build_heavy_hitters_in_fixed_regions(hctx, oracle, monkeypatch, capfd, k, repeat, want):
     """k-mers that occur far more often than a fine bucket's fixed room: the excess goes through the spill list
     (probing path); when even that overflows, the build is redone with exact offsets"""

@@ -27,6 +27,11 @@ def batch(clean=False):
     offsets[1:] = np.cumsum(lens)
     n = int(offsets[-1])
     b = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=n)].copy()
+    if rng.random() < 0.3:   # heavy hitters: a tandem repeat over part of the batch (spill list / exact-offset redo)
+        period = int(rng.integers(1, 60))
+        span = int(n * rng.choice([0.02, 0.2, 0.9]))
+        at = int(rng.integers(0, n - span + 1))
+        b[at:at + span] = np.resize(b[at:at + period].copy(), span)
     m = rng.random(n)
     b[(m > 0.3) & (m < 0.35)] |= 0x20
     if not clean:
