@@ -428,9 +428,10 @@ struct Part2Shared {
     uint64_t *cursor;  // [B2]
     uint32_t *cnt, *start, *fill;  // [B2] each
     uint32_t *tmp;     // [P2T]
+    uint32_t *flag;    // [1] (+1 pad) fixed fine regions: a fine bucket is outgrowing its room
     uint16_t *sdig;    // [chunk2<K>()]
     static size_t bytes(uint32_t B2) {
-        return (size_t)chunk2<K>() * sizeof(K) + (size_t)B2 * (8 + 3 * 4) + (size_t)P2T * 4 + (size_t)chunk2<K>() * 2;
+        return (size_t)chunk2<K>() * sizeof(K) + (size_t)B2 * (8 + 3 * 4) + (size_t)P2T * 4 + 8 + (size_t)chunk2<K>() * 2;
     }
     __device__ Part2Shared(unsigned char *raw, uint32_t B2) {
         sorted = reinterpret_cast<K *>(raw);
@@ -441,67 +442,33 @@ struct Part2Shared {
         start = cnt + B2;
         fill = start + B2;
         tmp = fill + B2;
-        sdig = reinterpret_cast<uint16_t *>(tmp + P2T);
+        flag = tmp + P2T;
+        sdig = reinterpret_cast<uint16_t *>(flag + 2);
     }
 };
 
 // FIXED (with paged level 1): every fine bucket owns cap2 keys of room in keys2, so the whole-bucket histogram
-// pass (a second read of keys1) is not needed; the keys of a fine bucket that outgrows its room go to the spill
-// list, i.e. through the probing path after the build (heavy hitters of real data), and if that list overflows the
-// build is redone with exact offsets.
+// pass (a second read of keys1) is not needed - as long as the bucket's keys spread over its fine buckets the way
+// a hash spreads distinct keys.  They do not when few distinct k-mers make up the batch (deep coverage of a small
+// genome, repeats): the attempt watches every fine bucket's fill against the fraction of the level-1 bucket
+// processed so far, and as soon as one is heading past its room it stops placing keys, finishes the pass counting
+// only (which is exactly the histogram), and the bucket is redone with the exact boundaries - the price of a
+// wrong guess is the part of the pass done before it was noticed.
 template <class K, bool FIXED>
 __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restrict__ keys1,
                                                       const uint64_t *__restrict__ bstart,
                                                       const uint64_t *__restrict__ gcur, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart,
-                                                      uint64_t *__restrict__ fend, uint64_t *__restrict__ spill_n,
-                                                      uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
-                                                      uint32_t *__restrict__ ovf) {
+                                                      uint64_t *__restrict__ fend) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Part2Shared<K> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
+    constexpr int PER = chunk2<K>() / P2T;  // 16 (32) keys per thread, held in registers
     const uint32_t tid = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
         // exact level 1: keys1 is dense; paged level 1 (cap1 != 0): the bucket's region, empty keys in the gaps
         const uint64_t lo = p.cap1 ? (uint64_t)j * p.cap1 : bstart[j];
         const uint64_t hi = p.cap1 ? lo + gcur[j] : bstart[j + 1];
-        if constexpr (FIXED) {
-            for (uint32_t i = tid; i < p.B2; i += P2T) {
-                const uint64_t pos = lo + (uint64_t)i * p.cap2;
-                sm.cursor[i] = pos;
-                fstart[(uint64_t)j * p.B2 + i] = pos;
-            }
-            ktd::lds_barrier();
-        } else {
-        // whole-bucket histogram of d2 -> fine bucket boundaries
-        for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
-        ktd::lds_barrier();
-        for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)P2T * 8) {  // 8 loads in flight per thread
-            K kk[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint64_t i = i0 + (uint64_t)u * P2T;
-                kk[u] = i < hi ? keys1[i] : EMPTY;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2(kk[u], p)], 1u);
-        }
-        ktd::lds_barrier();
-        // bucket sizes can exceed 32 bits only for > 4 G keys in one level-1 bucket: not supported
-        block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);
-        for (uint32_t i = tid; i < p.B2; i += P2T) {
-            const uint64_t pos = lo + sm.start[i];
-            sm.cursor[i] = pos;
-            fstart[(uint64_t)j * p.B2 + i] = pos;
-            fend[(uint64_t)j * p.B2 + i] = pos + sm.cnt[i];
-        }
-        ktd::lds_barrier();
-        }
-        // chunks of chunk2<K>() keys: counting sort in LDS, runs appended to the fine buckets.  The next
-        // chunk's keys are loaded while the current one is sorted; digits are hashed once.
-        constexpr int PER = chunk2<K>() / P2T;  // 16 keys per thread, held in registers
-        K kcur[PER], knxt[PER];
         auto load_chunk = [&](uint64_t c0, K (&dst)[PER]) {
 #pragma unroll
             for (int u = 0; u < PER; u++) {
@@ -509,54 +476,116 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
                 dst[u] = i < hi ? keys1[i] : EMPTY;
             }
         };
-        if (lo < hi) load_chunk(lo, kcur);
-        for (uint64_t c0 = lo; c0 < hi; c0 += chunk2<K>()) {
-            if (c0 + chunk2<K>() < hi) load_chunk(c0 + chunk2<K>(), knxt);
+        // one pass over the bucket in chunks of chunk2<K>() keys: counting sort in LDS, runs appended at the fine
+        // buckets' cursors.  The next chunk's keys are loaded while the current one is sorted; digits are hashed once.
+        // attempt = fixed fine regions (cursors may run past their room: then nothing is stored any more)
+        auto run_pass = [&](const bool attempt) {
+            K kcur[PER], knxt[PER];
+            bool counting_only = false;
+            if (lo < hi) load_chunk(lo, kcur);
+            for (uint64_t c0 = lo; c0 < hi; c0 += chunk2<K>()) {
+                if (c0 + chunk2<K>() < hi) load_chunk(c0 + chunk2<K>(), knxt);
+                for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
+                ktd::lds_barrier();
+                if (attempt) counting_only = *sm.flag != 0;  // (written before the barrier above; same for every thread)
+                uint32_t dgp[PER / 2];  // digits, two per register
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t d = digit2(kcur[u], p);
+                    dgp[u / 2] = (u & 1) ? dgp[u / 2] | (d << 16) : d;
+                    if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[d], 1u);
+                }
+                ktd::lds_barrier();
+                if (!counting_only) {
+                    const uint32_t nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
+                    for (uint32_t i = tid; i < p.B2; i += P2T) sm.fill[i] = sm.start[i];
+                    ktd::lds_barrier();
+#pragma unroll
+                    for (int u = 0; u < PER; u++) {
+                        if (kcur[u] != EMPTY) {
+                            const uint32_t d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
+                            const uint32_t pos = atomicAdd(&sm.fill[d], 1u);
+                            sm.sorted[pos] = kcur[u];
+                            sm.sdig[pos] = (uint16_t)d;
+                        }
+                    }
+                    ktd::lds_barrier();
+                    for (uint32_t i = tid; i < nc; i += P2T) {
+                        const uint32_t d = sm.sdig[i];
+                        const uint64_t pos = sm.cursor[d] + (i - sm.start[d]);
+                        if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = sm.sorted[i];
+                    }
+                    ktd::lds_barrier();
+                }
+                // cursors move on; during an attempt every fine bucket's fill is held against its room scaled to
+                // the part of the level-1 bucket seen so far (+ 6 sigma): hashed distinct keys never get there
+                float allowed = 0.f;
+                if (attempt) {
+                    const float seen = (float)(c0 + chunk2<K>() - lo) / (float)(hi - lo);
+                    const float room = (float)p.cap2 * (seen < 1.f ? seen : 1.f);
+                    allowed = 0.93f * room + 6.f * sqrtf(room) + 32.f;
+                }
+                for (uint32_t i = tid; i < p.B2; i += P2T) {
+                    const uint64_t c = sm.cursor[i] + sm.cnt[i];
+                    sm.cursor[i] = c;
+                    if (attempt && !counting_only && (float)(c - (lo + (uint64_t)i * p.cap2)) > allowed) *sm.flag = 1;
+                }
+#pragma unroll
+                for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
+                // (the next iteration's first barrier orders the cursor / flag updates before their use)
+            }
+            ktd::lds_barrier();
+        };
+
+        bool exact = !FIXED;
+        if constexpr (FIXED) {
+            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cursor[i] = lo + (uint64_t)i * p.cap2;
+            if (tid == 0) *sm.flag = 0;
+            ktd::lds_barrier();
+            run_pass(true);
+            // did every fine bucket stay inside its room?  (the running check is a prediction; this is the fact)
+            for (uint32_t i = tid; i < p.B2; i += P2T)
+                if (sm.cursor[i] - (lo + (uint64_t)i * p.cap2) > p.cap2) *sm.flag = 1;
+            ktd::lds_barrier();
+            if (*sm.flag == 0) {
+                for (uint32_t i = tid; i < p.B2; i += P2T) {
+                    fstart[(uint64_t)j * p.B2 + i] = lo + (uint64_t)i * p.cap2;
+                    fend[(uint64_t)j * p.B2 + i] = sm.cursor[i];
+                }
+            } else {  // no: the cursors hold the exact sizes now
+                for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = (uint32_t)(sm.cursor[i] - (lo + (uint64_t)i * p.cap2));
+                exact = true;
+            }
+            ktd::lds_barrier();
+        } else {
+            // whole-bucket histogram of d2
             for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
             ktd::lds_barrier();
-            uint16_t dg[PER];
+            for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)P2T * 8) {  // 8 loads in flight per thread
+                K kk[8];
 #pragma unroll
-            for (int u = 0; u < PER; u++) {
-                dg[u] = (uint16_t)digit2(kcur[u], p);
-                if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[dg[u]], 1u);
-            }
-            ktd::lds_barrier();
-            const uint32_t nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
-            for (uint32_t i = tid; i < p.B2; i += P2T) sm.fill[i] = sm.start[i];
-            ktd::lds_barrier();
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                if (kcur[u] != EMPTY) {
-                    const uint32_t pos = atomicAdd(&sm.fill[dg[u]], 1u);
-                    sm.sorted[pos] = kcur[u];
-                    sm.sdig[pos] = dg[u];
+                for (int u = 0; u < 8; u++) {
+                    const uint64_t i = i0 + (uint64_t)u * P2T;
+                    kk[u] = i < hi ? keys1[i] : EMPTY;
                 }
-            }
-            ktd::lds_barrier();
-            for (uint32_t i = tid; i < nc; i += P2T) {
-                const uint32_t d = sm.sdig[i];
-                const uint64_t pos = sm.cursor[d] + (i - sm.start[d]);
-                if (!FIXED || pos < lo + (uint64_t)(d + 1) * p.cap2) {
-                    keys2[pos] = sm.sorted[i];
-                } else {
-                    const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
-                    if (at < spill_cap) spill_keys[at] = (uint64_t)sm.sorted[i];
-                    else atomicOr(ovf + 1, 1u);
-                }
-            }
-            ktd::lds_barrier();
-            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cursor[i] += sm.cnt[i];
 #pragma unroll
-            for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
-            // (the next iteration's first barrier orders the cursor update before its use)
+                for (int u = 0; u < 8; u++)
+                    if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2(kk[u], p)], 1u);
+            }
+            ktd::lds_barrier();
         }
-        if constexpr (FIXED) {  // (same thread -> same fine buckets as the cursor update above)
+        if (exact) {
+            // fine bucket boundaries from the sizes (a level-1 bucket of > 4 G keys is not supported)
+            block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);
             for (uint32_t i = tid; i < p.B2; i += P2T) {
-                const uint64_t c = sm.cursor[i], lim = lo + (uint64_t)(i + 1) * p.cap2;
-                fend[(uint64_t)j * p.B2 + i] = c < lim ? c : lim;
+                const uint64_t pos = lo + sm.start[i];
+                sm.cursor[i] = pos;
+                fstart[(uint64_t)j * p.B2 + i] = pos;
+                fend[(uint64_t)j * p.B2 + i] = pos + sm.cnt[i];
             }
+            ktd::lds_barrier();
+            run_pass(false);
         }
-        ktd::lds_barrier();
     }
 }
 
@@ -773,7 +802,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)part2_lds));
     hipLaunchKernelGGL(part2, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur, p,
-                       keys2, m.fstart, m.fend, m.spill_n, m.spill_keys, m.spill_cap, m.ovf);
+                       keys2, m.fstart, m.fend);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
     if (gb > n_fine) gb = n_fine;

@@ -536,10 +536,10 @@ def test_ctr_bulk_build_skewed_batch_falls_back(hctx, oracle, monkeypatch, k):
     ctr.close()
 
 
-@pytest.mark.parametrize("k,repeat,want", [(31, 600, "spill"), (15, 600, "spill"), (31, 60000, "redo")])
-def test_ctr_bulk_build_heavy_hitters_in_fixed_regions(hctx, oracle, monkeypatch, capfd, k, repeat, want):
-    """k-mers that occur far more often than a fine bucket's fixed room: the excess goes through the spill list
-    (probing path); when even that overflows, the build is redone with exact offsets"""
+@pytest.mark.parametrize("k,repeat", [(31, 600), (15, 600), (31, 60000)])
+def test_ctr_bulk_build_heavy_hitters_in_fixed_regions(hctx, oracle, monkeypatch, capfd, k, repeat):
+    """k-mers that occur far more often than a fine bucket's fixed room: level 2 notices that a fine bucket outgrows
+    its room and redoes that level-1 bucket with exact boundaries; a level-1 region that overflows redoes level 1"""
     from kmertools_amd import device
     monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
     monkeypatch.setenv("KT_BULK_VERBOSE", "1")
@@ -554,11 +554,33 @@ def test_ctr_bulk_build_heavy_hitters_in_fixed_regions(hctx, oracle, monkeypatch
     lines = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[bulk]")]
     gk, gc = ctr.export_host()
     assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
-    if want == "spill":
-        assert len(lines) == 1 and "level1=paged level2=fixed" in lines[0]
-        assert int(lines[0].split("spilled=")[1]) > 1000
-    else:  # (a level-1 region may give up first: then the first attempt already reports exact offsets)
-        assert "level1=exact level2=exact" in lines[-1]
+    assert len(lines) == 1
+    if repeat == 600:
+        assert "level1=paged level2=fixed" in lines[0]
+    ctr.close()
+
+
+@pytest.mark.parametrize("k", [31, 15])
+def test_ctr_bulk_build_deep_coverage(hctx, oracle, monkeypatch, capfd, k):
+    """few distinct k-mers, each seen hundreds of times (deep coverage of a small genome): fine buckets are far from
+    evenly filled, so the fixed-room attempt of level 2 gives way to exact boundaries bucket by bucket"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    monkeypatch.setenv("KT_BULK_VERBOSE", "1")
+    rng = np.random.default_rng(70 + k)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=3000)
+    at = rng.integers(0, len(genome) - 100, size=30000)
+    seqs = [bytes(genome[a:a + 100]) for a in at]
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    assert len(wk) < 6100 and np.median(wc) > 100
+    ctr = device.Counter(hctx, k, 1 << 20)
+    capfd.readouterr()
+    ctr.add_reads_host(bases, offsets)
+    lines = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[bulk]")]
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    assert len(lines) == 1      # (level 1 may or may not have fitted its regions; level 2 never needs a second build)
     ctr.close()
 
 
