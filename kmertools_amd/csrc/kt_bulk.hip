@@ -12,12 +12,13 @@
 //             atomic per page, no counting pass)
 //   part2     one workgroup per level-1 bucket: the bucket is read in 8192 / 16384-key chunks, each chunk
 //             counting-sorted in LDS by d2 (next b2 hash bits) and its runs appended to the fine buckets, which
-//             own fixed shares of the bucket's region; what outgrows a share goes to the spill list
+//             own fixed shares of the bucket's region; a bucket whose keys do not spread that evenly is noticed
+//             during the pass and redone with exact fine boundaries (see part2_kernel)
 //   build     one workgroup per fine bucket (d1,d2): its keys are counted in an LDS
 //             open-addressing table that *is* the image of the global slot range of that hash prefix
 //             (kt_table.hpp), and the range is written out with 16-byte coalesced stores - including the
 //             empty slots, so the bulk build needs no cleared table.  Keys that would probe past the
-//             end of their range go to the spill list too, which is inserted afterwards through
+//             end of their range go to a spill list, which is inserted afterwards through
 //             the ordinary (probing, atomic) path.
 //
 // Fixed regions assume the hash spreads the batch; a batch dominated by a few k-mers overflows a level-1 region or
@@ -85,7 +86,7 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
     uint64_t *gcur;     // [B1] paged level 1: keys of bucket room handed out so far (page allocator)
-    uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room; [1] fixed fine regions: the spill list did
+    uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room; [1] paged build: the spill list did
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -722,8 +723,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
-    // spill list: keys beyond a range's end in build, and what outgrows the fixed fine regions in part2 (heavy
-    // hitters of real data; they go through the probing path at ~27 G/s, so a few per cent are cheap)
+    // spill list: keys beyond a range's end in build (they go through the probing path afterwards)
     const uint64_t spill_cap = max_keys / 16 + (1u << 16);
     size_t meta = 0;
     const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
@@ -822,7 +822,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
         fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s spilled=%llu\n", ctr->k, (unsigned long long)max_keys,
                 paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact", (unsigned long long)spilled);
     }
-    if (p.cap2) {  // did the spill list hold what the fixed fine regions could not?
+    if (p.cap2) {  // did the spill list hold what build could not place?
         uint32_t ovf2 = 0;
         KT_HIP(hipMemcpyAsync(&ovf2, m.ovf + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));
