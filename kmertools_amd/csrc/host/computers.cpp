@@ -602,9 +602,12 @@ std::string CountComputer::count() {
     if (kt_device_memory(dev_.ctx, &free_b, &total_b) == KT_OK)
         while (cap > 1024 && cap * 16 > free_b / 2) cap >>= 1;
     if (kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_) != KT_OK) return kt_last_error();
-    if (getenv("KT_CLI_TIMING"))
+    if (getenv("KT_CLI_TIMING")) {
+        uint64_t slots = cap;
+        (void)kt_ctr_capacity(ctr_, &slots);
         fprintf(stderr, "[timing] ctr setup: sizing (pre-pass only for compressed input) %.3f s, device init %.3f s, table of %llu slots %.3f s\n", t_stats,
-                t_dev, (unsigned long long)cap, setup());
+                t_dev, (unsigned long long)slots, setup());
+    }
     SeqReader reader;
     if (!reader.open(in_path_, false)) return reader.error();
     Batch b;
