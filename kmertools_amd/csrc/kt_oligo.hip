@@ -432,6 +432,17 @@ __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile
     }
 }
 
+// 16 bytes of an output row: written once and never read back by this kernel, so the store is marked
+// non-temporal (-2 % on the k=4 benchmark against a plain store, same box)
+template <class V>
+__device__ __forceinline__ void store_row16(char *dst, const V &o) {
+    static_assert(sizeof(V) == 16, "one 16-byte vector per lane");
+    typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+    raw4 raw;
+    __builtin_memcpy(&raw, &o, 16);
+    __builtin_nontemporal_store(raw, reinterpret_cast<raw4 *>(dst));
+}
+
 // ---- consumer: finished histogram rows -> output matrix ------------------------------------------
 // Executed by NC consumer waves; wave `cw` streams the rows [cw*nr/NC, (cw+1)*nr/NC) out,
 // clears them and their totals.  dnm/rcp slots are per read, so consumer waves never share.
@@ -504,7 +515,7 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
         for (int u = 0; u < U; u++) {
             const vec_t o = convert(c[u], d[u], y[u]);
             const uint32_t v = vb + u * 64 + lane;
-            if (!(KT_DBG(a) & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
+            if (!(KT_DBG(a) & 2u)) store_row16(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t)), o);
         }
     }
     for (uint32_t v = vb + lane; v < v_hi; v += 64) {
@@ -513,7 +524,7 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
         *hp = cnt_t{};
         const uint32_t r = __umulhi(v, a.vec_magic);
         const vec_t o = convert(c, dnm[r], rcp[r]);
-        if (!(KT_DBG(a) & 2u)) *reinterpret_cast<vec_t *>(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t))) = o;
+        if (!(KT_DBG(a) & 2u)) store_row16(dstb + (uint32_t)(v * (uint32_t)sizeof(vec_t)), o);
     }
 }
 
