@@ -299,6 +299,9 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, con
 // per run).  Pages are aligned and filled front to back; what is left of a workgroup's last pages is filled
 // with the empty key, which part2 skips.  A bucket that runs out of room (a batch dominated by a few k-mers)
 // raises *ovf and the build is redone through hist1 / scan1 / scatter1.
+#ifndef KT_BUILD_NT
+#define KT_BUILD_NT 1  // the table image is written once, whole lines at a time: non-temporal stores (k=31 -5 %).  The
+#endif                 // partition passes' short key runs need the L2 to merge them: there the same hint costs 50 %.
 #ifndef KT_PAGE_BYTES
 #define KT_PAGE_BYTES 512
 #endif
@@ -673,7 +676,15 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         for (uint32_t i = tid; i < SE; i += BUILD_T) {
             const K kk = skeys[i];
             const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : (uint64_t)kk;
+#if KT_BUILD_NT
+            {
+                typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+                const raw4 raw = {(uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u};
+                __builtin_nontemporal_store(raw, reinterpret_cast<raw4 *>(dst + i));
+            }
+#else
             dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u);
+#endif
         }
         ktd::lds_barrier();
     }
