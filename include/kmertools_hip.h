@@ -16,7 +16,9 @@
  *    `offsets` = uint64[n_reads + 1], read i = bases[offsets[i] .. offsets[i+1]).
  *  - `mem` says where `bases`, `offsets` and the output buffers live:
  *    KT_MEM_DEVICE = all are device (HBM) pointers, work is enqueued on the ctx
- *    stream and the call returns without synchronising;
+ *    stream and the call returns without waiting for it to finish (a few calls
+ *    say that they synchronise; a large batch into an empty k-mer table waits
+ *    once or twice for a 4-byte flag in the middle of its kernels);
  *    KT_MEM_HOST   = all are host pointers, the library stages them through its
  *    own device scratch and returns after the results are back on the host.
  *  - k-mers are uint64 (`type Kmer = u64`, kmer/src/lib.rs:4), 2 bits per base,
