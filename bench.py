@@ -293,10 +293,11 @@ def main():
     else:
         from kmertools_amd import dist as ktdist
         kmers_per_read = L - k + 1
-        # slots: twice the most distinct keys this rank can see (short probe chains in the LDS build; measured
-        # faster than 1.3x despite the bigger table); the library rounds up to 2^n or 3 * 2^(n-2)
+        # slots: about twice the most distinct keys this rank can see (short probe chains in the LDS build;
+        # measured faster than 1.3x despite the bigger table); the library rounds up to m * 2^j, m in 5..8.
+        # (1.9x, not 2x: the canonical 15-mers are 2^29 + 2^14, and 2x of that is just past a power of two)
         max_distinct = min(n * kmers_per_read, (4 ** k + 2 ** k) // 2)
-        cap = max(1 << 20, 2 * max_distinct)
+        cap = max(1 << 20, int(1.9 * max_distinct))
         if args.cap_log2:
             cap = 1 << args.cap_log2
         if args.cap_slots:
