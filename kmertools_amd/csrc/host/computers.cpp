@@ -594,7 +594,9 @@ std::string CountComputer::count() {
         const uint64_t canon = (ksize_ & 1) ? n4k / 2 : (n4k + (1ull << ksize_)) / 2;
         if (canon < max_distinct) max_distinct = canon;
     }
-    uint64_t cap = 2 * max_distinct;  // the library rounds this up to 2^n or 3 * 2^(n-2) slots
+    // ~1.9 slots per possible key (the library rounds up to m * 2^j, m in 5..8; 2x of the canonical 15-mers would
+    // land just past a power of two)
+    uint64_t cap = max_distinct + max_distinct / 10 * 9;
     if (cap < 1024) cap = 1024;
     // the reference spills to disk when memory is short; here the table is capped at what HBM holds next to the
     // bulk-build buffers, and running out of slots is reported (KT_ERR_FULL) rather than silently mis-counted
