@@ -5,20 +5,30 @@
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
 A "step" is one pass of the hot path over one batch of synthetic reads that is already
-resident in HBM.  Default workload = BASELINE.json configs[1]: `comp oligo k=4`,
-10 M x 150 bp reads, f64 rows (the reference's element type) on each GPU (weak scaling).
+resident in HBM.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel: algorithmic bytes
-per launch (DESIGN.md "Measurement") / average launch duration measured with HIP events
-on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle (a C
-restatement of the reference's algorithm - the Rust reference cannot be built here)
-timed on this box's host cores on a bounded sample, rank 0, N = 1 only.
+Default (no --workload) = BASELINE.json's whole headline metric, one after the other:
+  * `comp oligo k=4`, 10 M x 150 bp reads per GPU, f64 rows (configs[1]) - the line's top-level
+    `value` / `roofline` / `cpu_baseline`;
+  * `ctr k=31`, 25 M x 150 bp reads per GPU (at --gpus 8 that is configs[3]) - the `ctr_k31` object with
+    its own `value`, `ms_per_step`, `roofline`, `cpu_baseline` and the genome-sampled read distribution.
+Both run W warm-up and exactly K timed steps between barrier + synchronize brackets (max over ranks).
+
+ctr's step is what SURVEY.md 8d puts inside it: clear + insert (+ the key exchange at N > 1) +
+kt_ctr_size + kt_ctr_export into device arrays; algorithmic bytes = L + kmers*16 per read + distinct*12.
+
+`roofline` is for the step's kernels: algorithmic bytes per launch (DESIGN.md "Measurement") / the
+average launch duration measured with HIP events on the launch stream inside the timed region.
+`cpu_baseline` is the CPU oracle (a C restatement of the reference's algorithm - the Rust reference
+cannot be built here) timed on this box's host cores on a bounded sample, rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
 import pathlib
+import statistics
 import sys
+import tempfile
 import time
 
 ROOT = pathlib.Path(__file__).resolve().parent
@@ -26,6 +36,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 SEED = 0x6b6d6572
+METRIC = "Gbases/s on comp-oligo k=4 and ctr k=31, 150bp synthetic reads, 1/2/4/8 GPU"
 
 WORKLOADS = {
     # name: kind, k, reads per GPU, read length, dtype, batch (reads per launch)
@@ -34,9 +45,10 @@ WORKLOADS = {
     "comp_cgr_k7": dict(kind="oligo", k=7, n=10_000_000, L=150, dtype="f32", batch=1_000_000, cfg=4,
                         desc="comp cgr k=7 (8192 canonical bins), 10M x 150bp per GPU, f32 rows, 1M-read output ring"),
     "ctr_k15": dict(kind="ctr", k=15, n=50_000_000, L=150, cfg=2,
-                    desc="ctr k=15 canonical counts, 50M x 150bp per GPU, hash table in HBM"),
+                    desc="ctr k=15 canonical counts, 50M x 150bp per GPU, hash table in HBM, exported to device arrays"),
     "ctr_k31": dict(kind="ctr", k=31, n=25_000_000, L=150, cfg=3,
-                    desc="ctr k=31 canonical counts, 25M x 150bp per GPU (200M over 8), hash-prefix sharded"),
+                    desc="ctr k=31 canonical counts, 25M x 150bp per GPU (200M over 8), hash-prefix sharded, "
+                         "exported to device arrays"),
     # next row of SURVEY.md 8f: per-read coverage histograms against the resident table (table build untimed)
     "cov_k15": dict(kind="cov", k=15, n=10_000_000, L=150, dtype="f64", cfg=5, bin_size=16, bin_count=16,
                     desc="cov k=15 bin_size 16 x 16 bins, 10M x 150bp per GPU against the table of the same reads, f64 rows"),
@@ -47,6 +59,8 @@ WORKLOADS = {
     "min_w31_m7": dict(kind="min", k=7, n=10_000_000, L=150, dtype="u64", cfg=7, w=31,
                        desc="min w=31 m=7, 10M x 150bp per GPU, (minimiser, start, end) triples in read order"),
 }
+HEADLINE = ("comp_oligo_k4", "ctr_k31")
+GENOME_LEN = 1_000_000_000   # second ctr distribution, reads sampled from a random 1 Gbp genome
 
 
 def parse():
@@ -54,13 +68,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="comp_oligo_k4", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="headline", choices=["headline"] + sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (debug; marks the line as reduced)")
     ap.add_argument("--genome", type=int, default=0, help="ctr: sample reads from a random genome of this length")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-genome", action="store_true", help="headline: skip ctr's genome-sampled distribution")
+    ap.add_argument("--no-export", action="store_true", help="ctr: time clear + insert only (round-1 region; experiments)")
     ap.add_argument("--cap-log2", type=int, default=0, help="ctr: override log2 of the table capacity (experiments)")
     ap.add_argument("--cap-slots", type=float, default=0, help="ctr: override the requested table capacity (experiments)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
 
@@ -80,17 +96,16 @@ def effective_cores():
     return n
 
 
+# ---- cpu_baseline legs (the only place bench.py touches oracle/) ------------------------------------------
+
 def cpu_baseline_oligo(k, L, seconds):
-    """CPU oracle (port of composition/src/oligo.rs:231-259 + rayon par_iter analogue) on host cores."""
+    """CPU oracle (restatement of composition/src/oligo.rs:231-259 + the rayon par_iter of
+    pybindings/src/oligo.rs:77-81) on the host cores, and on one core."""
     from oracle import kt_oracle as oracle
     cores = effective_cores()
-    n = 100_000
-    hb, ho = oracle.synth_reads(SEED, n, L)
-    t0 = time.perf_counter()
-    oracle.oligo_batch(hb, ho, k, True, True, 1.0, threads=cores)
-    dt = max(time.perf_counter() - t0, 1e-4)
     n2 = 2_000_000
     hb, ho = oracle.synth_reads(SEED, n2, L)
+    oracle.oligo_batch(hb[:100_000 * L], ho[:100_001], k, True, True, 1.0, threads=cores)   # warm
     reps, t0 = 0, time.perf_counter()
     while True:   # bounded sample: repeat the 2 M-read batch until ~`seconds` of CPU work
         oracle.oligo_batch(hb, ho, k, True, True, 1.0, threads=cores)
@@ -98,29 +113,63 @@ def cpu_baseline_oligo(k, L, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds or reps >= 200:
             break
-    return dict(value=reps * n2 * L / dt / 1e9, unit="Gbases/s", cores=cores, kind="port",
-                sample="%d passes over %d x %dbp synthetic reads, k=%d canonical f64 rows, %d threads, %.1f s"
-                       % (reps, n2, L, k, cores, dt))
+    n1 = 400_000
+    t1 = time.perf_counter()
+    oracle.oligo_batch(hb[:n1 * L], ho[:n1 + 1], k, True, True, 1.0, threads=1)
+    dt1 = time.perf_counter() - t1
+    return dict(value=reps * n2 * L / dt / 1e9, unit="Gbases/s", cores=cores, kind="port", label="restatement",
+                value_1_thread=n1 * L / dt1 / 1e9,
+                sample="%d passes over %d x %dbp synthetic reads, k=%d canonical f64 rows, %d threads, %.1f s; "
+                       "1 thread: %d reads, %.1f s" % (reps, n2, L, k, cores, dt, n1, dt1))
 
 
 def cpu_baseline_ctr(k, L, seconds, genome):
-    """CPU oracle (port of counter/src/lib.rs:100-131 sharded maps, in memory) on host cores."""
+    """CPU oracle (restatement of counter/src/lib.rs:100-131 sharded maps; :151-167 text spill; :188-231 merge)
+    on the host cores: in memory (T = cores and T = 1) and with the temp-file round trip the real CLI pays."""
     from oracle import kt_oracle as oracle
     cores = effective_cores()
+    # counter/src/lib.rs:243-247 has n_parts = max(threads, ...) maps, each an scc map with a lock per bucket; the
+    # restatement has one mutex per map, so it gets 8x the maps to stand in for the finer locks
+    parts = max(cores, 1) * 8
     n = 50_000
     hb, ho = oracle.synth_reads(SEED, n, L, genome_len=genome)
     t0 = time.perf_counter()
-    oracle.count_reads(hb, ho, k, n_parts=max(cores, 1) * 8, threads=cores)
+    oracle.count_reads(hb, ho, k, n_parts=parts, threads=cores)
     dt = max(time.perf_counter() - t0, 1e-4)
-    n2 = int(min(max(n * seconds / dt, n), 2_000_000))
+    n2 = int(min(max(n * (seconds * 0.4) / dt, n), 2_000_000))
     hb, ho = oracle.synth_reads(SEED, n2, L, genome_len=genome)
-    c = oracle.Counter(max(cores, 1) * 8)
+    c = oracle.Counter(parts)
     t0 = time.perf_counter()
     c.add_reads(hb, ho, k, threads=cores)
-    dt = time.perf_counter() - t0
-    return dict(value=n2 * L / dt / 1e9, unit="Gbases/s", cores=cores, kind="port",
-                sample="%d x %dbp synthetic reads, k=%d, %d sharded maps, %d threads, %.1f s, in-memory count only"
-                       % (n2, L, k, cores * 8, cores, dt))
+    dt_mem = time.perf_counter() - t0
+    del c
+    # a smaller chunk through count_chunk's spill and merge's re-parse as well (what `kmertools ctr` does with
+    # every chunk: counter/src/lib.rs:151-167, :195-216); the reference's own n_parts here, it names the files
+    n3 = max(n2 // 8, 10_000)
+    c = oracle.Counter(max(cores, 1))
+    with tempfile.TemporaryDirectory(prefix="kt_cpu_ctr_") as d:
+        t0 = time.perf_counter()
+        c.add_reads(hb[:n3 * L], ho[:n3 + 1], k, threads=cores)
+        c.spill(d, 0, threads=cores)
+        lines = oracle.merge_files(d, max(cores, 1), 1, threads=cores)
+        dt_disk = time.perf_counter() - t0
+    del c
+    n1 = max(n2 // max(cores, 1), 10_000)
+    c1 = oracle.Counter(parts)
+    t0 = time.perf_counter()
+    c1.add_reads(hb[:n1 * L], ho[:n1 + 1], k, threads=1)
+    dt1 = time.perf_counter() - t0
+    del c1
+    return dict(value=n2 * L / dt_mem / 1e9, unit="Gbases/s", cores=cores, kind="port", label="restatement",
+                value_with_text_spill_and_merge=n3 * L / dt_disk / 1e9,
+                value_1_thread=n1 * L / dt1 / 1e9,
+                sample="%d x %dbp synthetic reads%s, k=%d, %d sharded maps, %d threads, in-memory count %.1f s; "
+                       "count + text spill + merge: %d reads, %d lines, %.1f s; 1 thread: %d reads, %.1f s"
+                       % (n2, L, " (genome-sampled)" if genome else "", k, parts, cores, dt_mem, n3, lines, dt_disk,
+                          n1, dt1),
+                weakness="one mutex per sharded map where scc locks per bucket (8 maps per thread stand in for "
+                         "that), so the threaded figure may under-state the Rust reference; the 1-thread figure "
+                         "has no lock contention")
 
 
 def _threaded_passes(make_slice_fn, n, L, seconds, what):
@@ -139,12 +188,12 @@ def _threaded_passes(make_slice_fn, n, L, seconds, what):
             dt = time.perf_counter() - t0
             if dt >= seconds or reps >= 2000:
                 break
-    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=len(fns), kind="port",
+    return dict(value=reps * n * L / dt / 1e9, unit="Gbases/s", cores=len(fns), kind="port", label="restatement",
                 sample="%d passes over %d x %dbp synthetic reads, %s, %d threads, %.1f s" % (reps, n, L, what, len(fns), dt))
 
 
 def cpu_baseline_cgr(L, seconds):
-    """CPU oracle (port of composition/src/cgr.rs:127-144), reads split over the host cores."""
+    """CPU oracle (restatement of composition/src/cgr.rs:127-144), reads split over the host cores."""
     import numpy as np
     from oracle import kt_oracle as oracle
     n = 800_000
@@ -158,7 +207,7 @@ def cpu_baseline_cgr(L, seconds):
 
 
 def cpu_baseline_min(L, w, m, seconds):
-    """CPU oracle (port of kmer/src/minimiser.rs:61-175), reads split over the host cores."""
+    """CPU oracle (restatement of kmer/src/minimiser.rs:61-175), reads split over the host cores."""
     from oracle import kt_oracle as oracle
     n = 1_600_000
     hb, ho = oracle.synth_reads(SEED, n, L)
@@ -170,7 +219,7 @@ def cpu_baseline_min(L, w, m, seconds):
 
 
 def cpu_baseline_cov(k, L, seconds, genome, bin_size, bin_count):
-    """CPU oracle (port of coverage/src/lib.rs:165-184), table prebuilt, reads split over the host cores."""
+    """CPU oracle (restatement of coverage/src/lib.rs:165-184), table prebuilt, reads split over the host cores."""
     from oracle import kt_oracle as oracle
     n = 800_000
     hb, ho = oracle.synth_reads(SEED, n, L, genome_len=genome)
@@ -183,54 +232,91 @@ def cpu_baseline_cov(k, L, seconds, genome, bin_size, bin_count):
     return _threaded_passes(make, n, L, seconds, "k=%d, lookups in a prebuilt table" % k)
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+def cpu_baseline_for(wl, args, genome):
+    k, L = wl["k"], wl["L"]
+    if wl["kind"] == "oligo":
+        return cpu_baseline_oligo(k, L, args.cpu_seconds)
+    if wl["kind"] == "cgr":
+        return cpu_baseline_cgr(L, args.cpu_seconds)
+    if wl["kind"] == "min":
+        return cpu_baseline_min(L, wl["w"], k, args.cpu_seconds)
+    if wl["kind"] == "cov":
+        return cpu_baseline_cov(k, L, args.cpu_seconds, genome, wl["bin_size"], wl["bin_count"])
+    return cpu_baseline_ctr(k, L, args.cpu_seconds, genome)
 
-    from kmertools_amd import device
 
-    wl = dict(WORKLOADS[args.workload])
+# ---- one workload: setup, W warm-up steps, exactly K timed steps -------------------------------------------
+
+class Env:
+    """what every workload run shares: torch, the process group, the library context"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from kmertools_amd import device
+        self.torch, self.dist, self.device = torch, dist, device
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
+            args.gpus = self.world
+        # KT_BENCH_SHARE_GPU=1 (tests only): every rank uses GPU 0 and the collectives go over gloo, so the
+        # multi-rank launch path can be exercised on a one-GPU box.  Numbers from such a run mean nothing.
+        self.share_gpu = os.environ.get("KT_BENCH_SHARE_GPU") == "1"
+        self.dev_index = 0 if self.share_gpu else local_rank
+        torch.cuda.set_device(self.dev_index)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.share_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+        self.stream = torch.cuda.current_stream()
+        self.ctx = device.Context(self.dev_index, stream=self.stream.cuda_stream)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.share_gpu else "cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.ctx.close()
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def run_workload(env, name, args, genome=0, steps=None, warmup=None):
+    """-> dict(value, ms_per_step, ms_median, ms_min, roofline, config, dtype, extra...) for one workload"""
+    torch, device, ctx = env.torch, env.device, env.ctx
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    wl = dict(WORKLOADS[name])
     reduced = False
     if args.reads:
         wl["n"] = args.reads
         wl["batch"] = min(wl.get("batch", args.reads), args.reads)
         reduced = True
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
-        args.gpus = world
-    # KT_BENCH_SHARE_GPU=1 (tests only): every rank uses GPU 0 and the collectives go over gloo, so the
-    # multi-rank launch path can be exercised on a one-GPU box.  Numbers from such a run mean nothing.
-    share_gpu = os.environ.get("KT_BENCH_SHARE_GPU") == "1"
-    dev_index = 0 if share_gpu else local_rank
-    torch.cuda.set_device(dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    stream = torch.cuda.current_stream()
-    ctx = device.Context(dev_index, stream=stream.cuda_stream)
     n, L, k = wl["n"], wl["L"], wl["k"]
+    world, rank = env.world, env.rank
 
     bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
     offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    ctx.synth_reads(SEED + wl["cfg"], n, L, bases, offsets, genome_len=args.genome, first_read=rank * n)
+    ctx.synth_reads(SEED + wl["cfg"], n, L, bases, offsets, genome_len=genome, first_read=rank * n)
     torch.cuda.synchronize()
 
     launches_per_step = 1
+    extra = {}
+    finish = lambda: None
+    alg_extra = lambda: 0
     if wl["kind"] == "oligo":
         B = wl["batch"]
         bins = device.bins(k, True)
@@ -251,6 +337,7 @@ def main():
                 batch_args.append((bases[r0 * L:], o, r1 - r0))
         alg_bytes_per_launch = min(B, n) * (L + bins * esz)
         dominant = "oligo_sb_kernel<k=%d,canonical,%s,4 waves>" % (k, wl["dtype"])
+        parallelism = "reads sharded by rank, no data-path collective"
 
         def step():
             for (bb, oo, cnt) in batch_args:
@@ -266,6 +353,7 @@ def main():
         # bases read by the three passes that touch them + the triples and offsets written
         alg_bytes_per_launch = n * (L + 8) + n_ev * 24
         dominant = "min_tile_kernel count + emit passes (LDS sliding minimum), break scan, finalize; %d triples" % n_ev
+        parallelism = "reads sharded by rank, no data-path collective"
 
         def step():
             ctx.minimisers(bases, offsets, n, w, k, evo, mk, ms, me, n_ev)
@@ -274,6 +362,7 @@ def main():
         bad = torch.zeros(1, dtype=torch.int64, device="cuda")
         alg_bytes_per_launch = n * (L * 17 + 8)
         dominant = "cgr_kernel (128-base chunks per lane, bracketing start, LDS-transposed stores)"
+        parallelism = "reads sharded by rank, no data-path collective"
 
         def step():
             ctx.cgr(bases, offsets, n, 1, out, bad)
@@ -287,107 +376,131 @@ def main():
         out = torch.empty((n, bc), dtype=torch.float64, device="cuda")
         alg_bytes_per_launch = n * (L + kmers_per_read * 16 + bc * 8)
         dominant = "cov_kernel k=%d (one 16-byte table probe per k-mer)" % k
+        parallelism = "reads sharded by rank, each rank probes the table of its own reads"
+        extra["distinct_rank0"] = table.size()
+        finish = table.close
 
         def step():
             table.cov(bases, offsets, n, wl["bin_size"], bc, out, norm=True, dtype="f64")
     else:
         from kmertools_amd import dist as ktdist
         kmers_per_read = L - k + 1
-        # slots: about twice the most distinct keys this rank can see (short probe chains in the LDS build;
-        # measured faster than 1.3x despite the bigger table); the library rounds up to m * 2^j, m in 5..8.
-        # (1.9x, not 2x: the canonical 15-mers are 2^29 + 2^14, and 2x of that is just past a power of two)
-        max_distinct = min(n * kmers_per_read, (4 ** k + 2 ** k) // 2)
-        cap = max(1 << 20, int(1.9 * max_distinct))
+        # the most distinct keys this rank can end up owning (its share of the hash space; 3 % head room for the
+        # imbalance between owners)
+        max_distinct = min(int(n * kmers_per_read * (1.03 if world > 1 else 1.0)), (4 ** k + 2 ** k) // 2)
+        cap = max(1 << 20, int(float(os.environ.get("KT_BENCH_CAP_FACTOR", "1.9")) * max_distinct))
         if args.cap_log2:
             cap = 1 << args.cap_log2
         if args.cap_slots:
             cap = int(args.cap_slots)
-        counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else dist.group.WORLD)
+        counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else env.dist.group.WORLD)
+        with_export = not args.no_export
+        xk = torch.empty(max_distinct if with_export else 1, dtype=torch.int64, device="cuda")
+        xc = torch.empty(max_distinct if with_export else 1, dtype=torch.int32, device="cuda")
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
-        dominant = "ctr k=%d step: bulk table build (scatter1p + part2 + build kernels)" % k
+        state = {"distinct": 0}
+        dominant = ("ctr k=%d step: clear + bulk table build (scatter1p, part2, build kernels)%s"
+                    % (k, " + size + export (table_export_kernel)" if with_export else ""))
+        parallelism = "hash-prefix key ownership, RCCL all-to-all of routed k-mers"
+        finish = counter.close
+        if with_export:
+            alg_extra = lambda: state["distinct"] * 12
 
         def step():
             counter.clear()
             counter.add_reads(bases, offsets, n)
+            if with_export:
+                d = counter.size_local()
+                got = counter.table.export(xk, xc, max_distinct)
+                assert got == d
+                state["distinct"] = d
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    env.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record(stream)
+    for i in range(steps):
+        ev[i][0].record(env.stream)
         step()
-        ev[i][1].record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        ev[i][1].record(env.stream)
+    env.barrier()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * n * L * args.steps / elapsed / 1e9
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / (args.steps * launches_per_step)
+    ms_per_step = elapsed / steps * 1e3
+    value = world * n * L * steps / elapsed / 1e9
+    per_step_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = sum(per_step_ms) / (steps * launches_per_step)
+    alg_bytes_per_launch += alg_extra()
     achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9
 
     # HBM bytes per launch from PMC counters (collected in separate rocprofv3 --pmc passes and
     # committed under profiles/; see profiles/traffic.json) - null when not collected
     traffic = None
     try:
-        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(args.workload)
-        if tj and not reduced and not args.genome:
+        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(name + ("_genome" if genome else ""))
+        if tj and not reduced and not (wl["kind"] == "ctr" and args.no_export):
             traffic = int((tj["fetch_kib"] * tj.get("fetch_correction", 1) + tj["write_kib"]) * 1024)
     except (OSError, ValueError, KeyError):
         traffic = None
 
-    extra = {}
-    if wl["kind"] == "cov":
-        extra["distinct_rank0"] = table.size()
     if wl["kind"] == "ctr":
-        extra["distinct_rank0"] = counter.size_local()
+        extra["distinct_rank0"] = state["distinct"] if not args.no_export else counter.size_local()
+        extra["table_slots_rank0"] = counter.table.capacity()
+    res = {
+        "value": round(value, 3),
+        "unit": "Gbases/s",
+        "ms_per_step": round(ms_per_step, 4),
+        "ms_median": round(statistics.median(per_step_ms), 4),
+        "ms_min": round(min(per_step_ms), 4),
+        "dtype": wl.get("dtype", "u64 keys / u32 counts"),
+        "config": {"workload": wl["desc"] + (", reads sampled from a random %d bp genome (1 %% substitutions)" % genome
+                                             if genome else ""),
+                   "reads_per_gpu": n, "read_len": L, "k": k, "parallelism": parallelism, "reduced": reduced},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": dominant, "kernel_ms": round(kern_ms, 4),
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+    }
+    res.update(extra)
+    finish()
+    del bases, offsets
+    torch.cuda.empty_cache()
+    return res, wl
 
-    if rank == 0:
-        line = {
-            "metric": "Gbases/s on comp-oligo k=4 and ctr k=31, 150bp synthetic reads, 1/2/4/8 GPU",
-            "value": round(value, 3),
-            "unit": "Gbases/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": wl.get("dtype", "u64 keys / u32 counts"),
-            "data": "synthetic",
-            "config": {"workload": wl["desc"], "reads_per_gpu": n, "read_len": L, "k": k,
-                       "parallelism": "reads sharded by rank, no data-path collective" if wl["kind"] == "oligo"
-                       else "reads sharded by rank, no data-path collective" if wl["kind"] in ("cgr", "min")
-                       else "reads sharded by rank, each rank probes the table of its own reads" if wl["kind"] == "cov"
-                       else "hash-prefix key ownership, RCCL all-to-all of routed k-mers",
-                       "reduced": reduced},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": dominant, "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
-        }
-        line.update(extra)
-        if world == 1 and not args.no_cpu:
-            if wl["kind"] == "oligo":
-                line["cpu_baseline"] = cpu_baseline_oligo(k, L, args.cpu_seconds)
-            elif wl["kind"] == "cgr":
-                line["cpu_baseline"] = cpu_baseline_cgr(L, args.cpu_seconds)
-            elif wl["kind"] == "min":
-                line["cpu_baseline"] = cpu_baseline_min(L, wl["w"], k, args.cpu_seconds)
-            elif wl["kind"] == "cov":
-                line["cpu_baseline"] = cpu_baseline_cov(k, L, args.cpu_seconds, args.genome, wl["bin_size"], wl["bin_count"])
-            else:
-                line["cpu_baseline"] = cpu_baseline_ctr(k, L, args.cpu_seconds, args.genome)
+
+def main():
+    args = parse()
+    env = Env(args)
+    names = HEADLINE if args.workload == "headline" else (args.workload,)
+    results = []
+    for name in names:
+        res, wl = run_workload(env, name, args, genome=args.genome if WORKLOADS[name]["kind"] in ("ctr", "cov") else 0)
+        if (args.workload == "headline" and name == "ctr_k31" and not args.no_genome and not args.genome):
+            # the second read distribution for ctr (uniform reads make nearly every 31-mer unique)
+            g, _ = run_workload(env, name, args, genome=GENOME_LEN, steps=min(args.steps, 5), warmup=min(args.warmup, 2))
+            res["genome_sampled"] = {key: g[key] for key in ("value", "ms_per_step", "ms_median", "ms_min", "roofline",
+                                                             "distinct_rank0")}
+            res["genome_sampled"]["genome_len"] = GENOME_LEN
+            res["genome_sampled"]["steps"] = min(args.steps, 5)
+        results.append((name, res, wl))
+
+    if env.rank == 0:
+        name, top, wl = results[0]
+        line = {"metric": METRIC, "value": top["value"], "unit": "Gbases/s", "n_gpus": env.world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": top["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": top["dtype"], "data": "synthetic"}
+        line.update({key: v for key, v in top.items() if key not in line})
+        if env.world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline_for(wl, args, args.genome)
+        for name, res, wl in results[1:]:
+            obj = dict(res)
+            obj.update({"n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak"})
+            if env.world == 1 and not args.no_cpu:
+                obj["cpu_baseline"] = cpu_baseline_for(wl, args, 0)
+            line[name] = obj
         print(json.dumps(line), flush=True)
-
-    if world > 1:
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

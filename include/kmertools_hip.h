@@ -127,6 +127,14 @@ int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, u
                    int k, int count_min, int norm, int total_step, int out_dtype, void *out,
                    int mem);
 
+/* Self-test of the f64 normalisation: the kernels compute `vec[i] /= max(1, total)` (composition/src/oligo.rs:255-257)
+ * as a reciprocal + two fused multiply-adds per bin instead of a division.  For every divisor d in [d_lo, d_hi]
+ * and every count c in 0..d this runs that exact device code and the IEEE division side by side:
+ * *n_checked pairs, *n_mismatch of them with different bits (must be 0), *checksum = sum of the division's
+ * bit patterns mod 2^64 (lets a host check the device's division itself).  Synchronises. */
+int kt_selftest_quotient(kt_ctx *ctx, uint32_t d_lo, uint32_t d_hi, uint64_t *n_checked, uint64_t *n_mismatch,
+                         uint64_t *checksum);
+
 /* replaces: CountComputer::new / count_chunk's table, counter/src/lib.rs:37-55, :100.
  * One HBM-resident open-addressing table (u64 keys, u32 counts - the reference's
  * types) takes the place of the reference's n_parts scc maps and chunk files.

@@ -476,9 +476,8 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
         vec_t o;
         if constexpr (DT == KT_F64) {
             const double cx = (double)c.x, cy = (double)c.y;
-            const double qx = __dmul_rn(cx, y), qy = __dmul_rn(cy, y);
-            o.x = __fma_rn(__fma_rn(-qx, d, cx), y, qx);
-            o.y = __fma_rn(__fma_rn(-qy, d, cy), y, qy);
+            o.x = ktd::quot_f64(cx, d, y);
+            o.y = ktd::quot_f64(cy, d, y);
         } else if constexpr (DT == KT_F32) {
             const float df = (float)d, yf = (float)y;
             const float cx = (float)c.x, cy = (float)c.y, cz = (float)c.z, cw4 = (float)c.w;
@@ -751,6 +750,53 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     if (grid == 0) return KT_OK;
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(nthreads), lds, ctx->stream, a);
     KT_HIP(hipGetLastError());
+    return KT_OK;
+}
+
+// ---- self-test of the normalisation quotient -------------------------------------------------------------
+// one workgroup per divisor d (grid-stride), lanes over c = 0..d: quot_f64 against the IEEE division
+__global__ __launch_bounds__(256) void quotient_check_kernel(uint32_t d_lo, uint32_t d_hi, uint64_t *__restrict__ out) {
+    uint64_t bad = 0, sum = 0, n = 0;
+    for (uint32_t dd = d_lo + blockIdx.x; dd <= d_hi; dd += gridDim.x) {
+        const double d = (double)dd, y = 1.0 / d;   // as consume_tile computes them
+        for (uint32_t c = threadIdx.x; c <= dd; c += 256) {
+            const double q = ktd::quot_f64((double)c, d, y);
+            const double t = __ddiv_rn((double)c, d);
+            bad += __double_as_longlong(q) != __double_as_longlong(t);
+            sum += (uint64_t)__double_as_longlong(t);
+            n++;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        bad += __shfl_down(bad, o, 64);
+        sum += __shfl_down(sum, o, 64);
+        n += __shfl_down(n, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(out), (unsigned long long)n);
+        atomicAdd(reinterpret_cast<unsigned long long *>(out + 1), (unsigned long long)bad);
+        atomicAdd(reinterpret_cast<unsigned long long *>(out + 2), (unsigned long long)sum);
+    }
+}
+
+extern "C" int kt_selftest_quotient(kt_ctx *ctx, uint32_t d_lo, uint32_t d_hi, uint64_t *n_checked,
+                                    uint64_t *n_mismatch, uint64_t *checksum) {
+    if (!ctx || !n_checked || !n_mismatch || !checksum) return kt::fail(KT_ERR_ARG, "kt_selftest_quotient: null");
+    if (d_lo < 1 || d_hi < d_lo) return kt::fail(KT_ERR_ARG, "kt_selftest_quotient: need 1 <= d_lo <= d_hi");
+    if (int rc = ctx->use()) return rc;
+    if (int rc = ctx->s_aux2.reserve(64)) return rc;
+    uint64_t *d_out = (uint64_t *)ctx->s_aux2.p;
+    KT_HIP(hipMemsetAsync(d_out, 0, 24, ctx->stream));
+    uint32_t grid = d_hi - d_lo + 1;
+    if (grid > (uint32_t)ctx->n_cu * 16) grid = (uint32_t)ctx->n_cu * 16;
+    hipLaunchKernelGGL(quotient_check_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lo, d_hi, d_out);
+    KT_HIP(hipGetLastError());
+    uint64_t h[3] = {0, 0, 0};
+    KT_HIP(hipMemcpyAsync(h, d_out, 24, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
+    *n_checked = h[0];
+    *n_mismatch = h[1];
+    *checksum = h[2];
     return KT_OK;
 }
 

@@ -127,6 +127,12 @@ class Context:
                        total_step, dtype, KT_MEM_HOST)
         return out
 
+    def selftest_quotient(self, d_lo, d_hi):
+        """-> (pairs checked, mismatches, checksum of the IEEE quotients' bits) for all 0 <= c <= d, d_lo <= d <= d_hi"""
+        n, bad, chk = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(_lib.lib().kt_selftest_quotient(self._h, int(d_lo), int(d_hi), C.byref(n), C.byref(bad), C.byref(chk)))
+        return n.value, bad.value, chk.value
+
     # -- comp cgr (whole sequence) ---------------------------------------------------------------
     def cgr(self, bases, offsets, n_reads, vecsize, xy, bad_pos=None, mem=KT_MEM_DEVICE):
         """xy: 2 f64 per base; bad_pos: u64 scalar (device pointer in device mode) or None"""

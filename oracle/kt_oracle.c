@@ -21,6 +21,7 @@
 #include <pthread.h>
 #include <stdatomic.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -396,6 +397,116 @@ uint64_t kto_counter_export(const kto_counter *c, uint64_t *keys, uint32_t *coun
     for (uint64_t i = 0; i < n; i++) { keys[i] = kv[i].k; counts[i] = kv[i].v; }
     free(kv);
     return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* The on-disk half of the reference's counter, restated so that the CPU baseline can pay
+ * what the real CLI pays: count_chunk's spill (counter/src/lib.rs:151-167: one text file
+ * "temp_kmers.part_P_chunk_C" per partition, lines "{kmer}\t{count}\n", partitions written
+ * in parallel) and merge (:188-231: partitions one after the other; the chunk files of a
+ * partition parsed by parallel tasks into one shared map with `*entry(kmer).or_insert(0) +=
+ * count`; the map scanned into "kmers.counts", numeric or ACGT keys; temp files deleted). */
+typedef struct { const kto_counter *c; const char *dir; uint64_t chunk; _Atomic uint64_t *next; int err; } spill_job;
+
+static void *spill_worker(void *p) {
+    spill_job *j = (spill_job *)p;
+    char path[4096];
+    for (;;) {
+        uint64_t part = atomic_fetch_add(j->next, 1);            /* counts_table.par_iter().enumerate() :152-155 */
+        if (part >= j->c->n_parts) break;
+        snprintf(path, sizeof path, "%s/temp_kmers.part_%llu_chunk_%llu", j->dir,
+                 (unsigned long long)part, (unsigned long long)j->chunk);   /* :156-159 */
+        FILE *f = fopen(path, "w");
+        if (!f) { j->err = 1; continue; }
+        const kto_map *m = &j->c->parts[part];
+        for (uint64_t i = 0; i < m->cap; i++)                     /* map.scan :162-165 */
+            if (m->keys[i] != KTO_EMPTY)
+                fprintf(f, "%llu\t%u\n", (unsigned long long)m->keys[i], m->vals[i]);
+        fclose(f);
+    }
+    return NULL;
+}
+
+/* writes the counter's partitions as chunk `chunk` of `dir`; 0 on success */
+int kto_counter_spill(const kto_counter *c, const char *dir, uint64_t chunk, int threads) {
+    _Atomic uint64_t next = 0;
+    spill_job job = {c, dir, chunk, &next, 0};
+    if (threads <= 1) {
+        spill_worker(&job);
+    } else {
+        pthread_t *t = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+        for (int i = 0; i < threads; i++) pthread_create(&t[i], NULL, spill_worker, &job);
+        for (int i = 0; i < threads; i++) pthread_join(t[i], NULL);
+        free(t);
+    }
+    return job.err;
+}
+
+typedef struct { kto_map *map; const char *dir; uint64_t part, chunks; _Atomic uint64_t *next; int del, err; } merge_job;
+
+static void *merge_worker(void *p) {
+    merge_job *j = (merge_job *)p;
+    char path[4096], line[128];
+    for (;;) {
+        uint64_t chunk = atomic_fetch_add(j->next, 1);           /* for chunk in 0..chunks: scope.spawn :194-199 */
+        if (chunk >= j->chunks) break;
+        snprintf(path, sizeof path, "%s/temp_kmers.part_%llu_chunk_%llu", j->dir,
+                 (unsigned long long)j->part, (unsigned long long)chunk);
+        FILE *f = fopen(path, "r");
+        if (!f) { j->err = 1; continue; }
+        while (fgets(line, sizeof line, f)) {                     /* buff.lines() :203 */
+            char *tab = NULL;
+            unsigned long long kmer = strtoull(line, &tab, 10);   /* parts.next().parse::<Kmer>() :205 */
+            if (tab == line || *tab != '\t') continue;
+            uint32_t count = (uint32_t)strtoul(tab + 1, NULL, 10);/* :206 */
+            pthread_mutex_lock(&j->map->mu);
+            map_add_nolock(j->map, kmer, count);                  /* *entry(kmer).or_insert(0) += count :207 */
+            pthread_mutex_unlock(&j->map->mu);
+        }
+        fclose(f);
+        if (j->del) remove(path);                                 /* :208-210 */
+    }
+    return NULL;
+}
+
+/* merge(delete): `dir`/kmers.counts from the chunk files of n_parts partitions; returns the
+ * number of lines written, or (uint64_t)-1 on an I/O error.  k is only used with acgt != 0. */
+uint64_t kto_merge(const char *dir, uint64_t n_parts, uint64_t chunks, int threads, int acgt, uint64_t k, int del) {
+    char path[4096], mer[40];
+    snprintf(path, sizeof path, "%s/kmers.counts", dir);          /* :178 */
+    FILE *out = fopen(path, "w");
+    if (!out) return (uint64_t)-1;
+    uint64_t lines = 0;
+    int err = 0;
+    for (uint64_t part = 0; part < n_parts; part++) {             /* for part in 0..n_parts :188 (serial) */
+        kto_map map; map_init(&map, 1024);                        /* SccMap::new() :190 */
+        _Atomic uint64_t next = 0;
+        merge_job job = {&map, dir, part, chunks, &next, del, 0};
+        int T = threads < 1 ? 1 : threads;
+        if ((uint64_t)T > chunks) T = (int)chunks;
+        if (T <= 1) {
+            merge_worker(&job);
+        } else {
+            pthread_t *t = (pthread_t *)malloc(sizeof(pthread_t) * T);
+            for (int i = 0; i < T; i++) pthread_create(&t[i], NULL, merge_worker, &job);
+            for (int i = 0; i < T; i++) pthread_join(t[i], NULL);
+            free(t);
+        }
+        err |= job.err;
+        for (uint64_t i = 0; i < map.cap; i++) {                  /* map_arc.scan :220-230 */
+            if (map.keys[i] == KTO_EMPTY) continue;
+            if (acgt) {
+                kto_numeric_to_kmer(map.keys[i], k, mer);
+                fprintf(out, "%s\t%u\n", mer, map.vals[i]);
+            } else {
+                fprintf(out, "%llu\t%u\n", (unsigned long long)map.keys[i], map.vals[i]);
+            }
+            lines++;
+        }
+        map_free(&map);
+    }
+    fclose(out);
+    return err ? (uint64_t)-1 : lines;
 }
 
 /* ------------------------------------------------------------------------ */

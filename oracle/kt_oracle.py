@@ -70,6 +70,10 @@ def lib():
         L.kto_counter_size.argtypes = [C.c_void_p]
         L.kto_counter_export.restype = C.c_uint64
         L.kto_counter_export.argtypes = [C.c_void_p, u64p, u32p, C.c_int]
+        L.kto_counter_spill.restype = C.c_int
+        L.kto_counter_spill.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int]
+        L.kto_merge.restype = C.c_uint64
+        L.kto_merge.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int]
         L.kto_cgr_one.restype = C.c_uint64
         L.kto_cgr_one.argtypes = [u8p, C.c_uint64, C.c_double, f64p]
         L.kto_minimisers.restype = C.c_uint64
@@ -276,6 +280,11 @@ class Counter:
     def size(self):
         return int(lib().kto_counter_size(self.h))
 
+    def spill(self, out_dir, chunk, threads=1):
+        """count_chunk's text spill (counter/src/lib.rs:151-167): temp_kmers.part_P_chunk_<chunk> per partition"""
+        if lib().kto_counter_spill(self.h, str(out_dir).encode(), chunk, threads):
+            raise OSError("spill to %s failed" % out_dir)
+
     def cov_batch(self, bases, offsets, k, bin_size, bin_count, norm=True):
         """coverage/src/lib.rs:165-184 over a CSR batch -> (n_reads, bin_count) f64"""
         n = len(offsets) - 1
@@ -295,6 +304,14 @@ class Counter:
         if getattr(self, "h", None) and _LIB is not None:
             _LIB.kto_counter_free(self.h)
             self.h = None
+
+
+def merge_files(out_dir, n_parts, chunks, threads=1, acgt=False, k=0, delete=True):
+    """CountComputer::merge (counter/src/lib.rs:172-234) over the chunk files in out_dir -> lines of kmers.counts"""
+    n = lib().kto_merge(str(out_dir).encode(), n_parts, chunks, threads, int(acgt), k, int(delete))
+    if n == 2 ** 64 - 1:
+        raise OSError("merge in %s failed" % out_dir)
+    return int(n)
 
 
 def count_reads(bases, offsets, k, n_parts=1, threads=1):

@@ -918,8 +918,13 @@ def test_bench_two_rank_launch(workload):
     import json, os, subprocess, sys, pathlib
     root = pathlib.Path(__file__).resolve().parents[1]
     env = dict(os.environ, KT_BENCH_SHARE_GPU="1", KT_BULK_MIN_BASES="0")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--workload", workload, "--reads", "200000"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -1027,3 +1032,109 @@ def test_all_empty_reads_everywhere(hctx, oracle):
     assert len(f) == 0
     keys, counts = hctx.route_host(bases, offsets, 21, 4)
     assert len(keys) == 0 and not counts.any()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs at full size that round 1 only exercised through bench.py
+
+def test_cfg5_device_ring_sampled_rows(torch_mod, ctx, oracle):
+    """comp cgr k=7 (cfg5) the way bench.py runs it: 10 M x 150 bp through the device-pointer path in 1 M-read
+    batches that reuse one f32 output ring; every row sums to 1, three 4096-row slices match the oracle <= 1e-6"""
+    torch = torch_mod
+    n, L, k, B, seed = 10_000_000, 150, 7, 1_000_000, 0x6b6d6572 + 4
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(seed, n, L, bases, offsets)
+    ring = torch.empty((B, 8192), dtype=torch.float32, device="cuda")
+    samples = {0: 0, 4: 4_567_890, 9: n - 4096}     # batch -> first read of the sampled slice
+    for b in range(n // B):
+        r0 = b * B
+        o = (offsets[r0:r0 + B + 1] - offsets[r0]).contiguous()
+        ring.fill_(-1.0)                              # a row the kernel skipped would show
+        ctx.oligo(bases[r0 * L:], o, B, k, ring, dtype="f32")
+        torch.cuda.synchronize()
+        s = ring.sum(dim=1, dtype=torch.float64)
+        assert float((s - 1.0).abs().max()) < 1e-5
+        assert float(ring.min()) >= 0.0
+        if b in samples:
+            first = samples[b]
+            hb, ho = oracle.synth_reads(seed, 4096, L, first_read=first)
+            want = oracle.oligo_batch(hb, ho, k, True, True, 1.0, threads=4)
+            got = ring[first - r0:first - r0 + 4096].cpu().numpy()
+            assert np.abs(got.astype(np.float64) - want).max() <= 1e-6     # north_star tolerance for f32 rows
+            assert np.array_equal(got != 0, want != 0)
+
+
+def test_ctr_cfg4_per_gpu_shard_properties(torch_mod, ctx, oracle):
+    """BASELINE cfg4's per-GPU shard (25 M x 150 bp, k=31, about 3 G distinct keys): every k-mer instance counted
+    once, no key stored twice, export -> re-import idempotent, and three 1 M-read sub-batches against the oracle
+    (their own tables bit-exact; every one of their keys present in the big table with at least that count)"""
+    from kmertools_amd import device
+    torch = torch_mod
+    n, L, k, seed = 25_000_000, 150, 31, 0x6b6d6572 + 3
+    kpr = L - k + 1
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(seed, n, L, bases, offsets)
+    ctr = device.Counter(ctx, k, int(1.9 * n * kpr))
+    ctr.add_reads(bases, offsets, n)
+    distinct = ctr.size()
+    assert 0.99 * n * kpr < distinct <= n * kpr          # uniform reads: nearly every 31-mer is unique
+    keys = torch.empty(distinct, dtype=torch.int64, device="cuda")
+    counts = torch.empty(distinct, dtype=torch.int32, device="cuda")
+    assert ctr.export(keys, counts, distinct) == distinct
+    ctr.close()                                            # the table and the build scratch: ~160 GB back
+    assert int(counts.to(torch.int64).sum()) == n * kpr
+    assert int(keys.min()) >= 0 and int(keys.max()) < 4 ** k
+    sk, order = torch.sort(keys)
+    assert bool((sk[1:] != sk[:-1]).all())
+    sc = counts[order]
+    del order
+    # sampled sub-batches
+    sub = 1_000_000
+    small = device.Counter(ctx, k, 1 << 28)
+    for first in (0, 11_000_000, n - sub):
+        hb, ho = oracle.synth_reads(seed, sub, L, first_read=first)
+        wk, wc = oracle.count_reads(hb, ho, k, n_parts=64, threads=8)
+        small.clear()
+        small.add_reads(bases[first * L:(first + sub) * L], offsets[:sub + 1], sub)
+        d = small.size()
+        gk = torch.empty(d, dtype=torch.int64, device="cuda")
+        gc = torch.empty(d, dtype=torch.int32, device="cuda")
+        small.export(gk, gc, d)
+        gk, o2 = torch.sort(gk)
+        assert np.array_equal(gk.cpu().numpy().view(np.uint64), wk)
+        assert np.array_equal(gc[o2].cpu().numpy().view(np.uint32), wc)
+        pos = torch.searchsorted(sk, gk)
+        assert bool((pos < distinct).all()) and bool((sk[pos.clamp(max=distinct - 1)] == gk).all())
+        assert bool((sc[pos] >= gc[o2]).all())
+        del gk, gc, o2, pos
+    small.close()
+    del sk, sc, bases, offsets
+    torch.cuda.empty_cache()
+    # merge idempotence at full size: the exported pairs into an empty table
+    ctr2 = device.Counter(ctx, k, int(1.9 * n * kpr))
+    ctr2.add_pairs(keys, counts, distinct)
+    assert ctr2.size() == distinct
+    k2 = torch.empty(distinct, dtype=torch.int64, device="cuda")
+    c2 = torch.empty(distinct, dtype=torch.int32, device="cuda")
+    assert ctr2.export(k2, c2, distinct) == distinct
+    ctr2.close()
+    assert int(c2.to(torch.int64).sum()) == n * kpr
+    # order-independent exact checksums (int64 arithmetic wraps mod 2^64 on both sides)
+    assert int((k2 * c2.to(torch.int64)).sum()) == int((keys * counts.to(torch.int64)).sum())
+    assert int((k2 ^ (k2 >> 29)).sum()) == int((keys ^ (keys >> 29)).sum())
+
+
+def test_quotient_exhaustive(hctx):
+    """the reciprocal + fma normalisation against the IEEE division for every count / divisor pair a read of up to
+    32 768 k-mers can produce (total_step 1 and 2: d = total_step * kmers, c <= kmers), and the device division
+    itself against numpy on the pairs with d <= 2048"""
+    n, bad, _ = hctx.selftest_quotient(1, 32768)
+    assert n == sum(d + 1 for d in range(1, 32769)) and bad == 0
+    n, bad, chk = hctx.selftest_quotient(1, 2048)
+    want = 0
+    for d in range(1, 2049):
+        q = np.arange(d + 1, dtype=np.float64) / np.float64(d)
+        want = (want + int(q.view(np.uint64).sum(dtype=np.uint64))) % (1 << 64)
+    assert bad == 0 and chk == want

@@ -140,6 +140,36 @@ def test_counter_merge_fixtures(oracle, golden):
         sorted((golden / "expected_counts_acgt_test.counts").read_text().splitlines())
 
 
+def test_counter_merge_through_files(oracle, golden, tmp_path):
+    """the on-disk restatement (kto_merge) over the reference's own chunk files, and a spill -> merge round trip"""
+    import shutil
+    for acgt, want in [(False, "expected_counts_test.counts"), (True, "expected_counts_acgt_test.counts")]:
+        d = tmp_path / ("m%d" % acgt)
+        shutil.copytree(golden / "computed_counts_test", d)
+        n = oracle.merge_files(d, 2, 2, threads=2, acgt=acgt, k=15, delete=True)   # counter/src/lib.rs:279-311
+        got = sorted((d / "kmers.counts").read_text().splitlines())
+        assert got == sorted((golden / want).read_text().splitlines()) and n == len(got)
+        assert [f.name for f in d.iterdir()] == ["kmers.counts"]                     # temp files removed (:208-210)
+    bases, offsets = oracle.to_csr([r[1] for r in oracle.read_records(golden / "reads.fq")])
+    d = tmp_path / "rt"
+    d.mkdir()
+    for chunk in range(2):                                                            # the same reads as two chunks
+        c = oracle.Counter(3)
+        c.add_reads(bases, offsets, 15, threads=2)
+        c.spill(d, chunk, threads=2)
+    # chunk 0 of a 1-partition spill of reads.fq is the reference's own fixture (counter/src/lib.rs:260-276)
+    c1 = oracle.Counter(1)
+    c1.add_reads(bases, offsets, 15)
+    d1 = tmp_path / "one"
+    d1.mkdir()
+    c1.spill(d1, 0)
+    assert sorted((d1 / "temp_kmers.part_0_chunk_0").read_text().splitlines()) == \
+        sorted((golden / "expected_counts.part_0_chunk_0").read_text().splitlines())
+    oracle.merge_files(d, 3, 2, threads=2)
+    keys, counts = oracle.count_reads(bases, offsets, 15)
+    assert sorted((d / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(keys, counts * 2)
+
+
 def test_reader_fixtures(oracle, kat, golden):
     e = kat["reader"]
     for name, ids in [("reads.fq", e["fq_ids"]), ("reads.fa", e["fa_ids"]), ("reads.fq.gz", e["fq_ids"])]:
