@@ -66,36 +66,58 @@ __global__ __launch_bounds__(BLOCK) void table_size_kernel(const Slot *__restric
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(reinterpret_cast<unsigned long long *>(out), (unsigned long long)n);
 }
 
-// stream the table, compact occupied slots: ballot + one cursor atomic per wave
+// stream the table, compact occupied slots.  A workgroup takes tiles of 4096 slots (16 coalesced 16-byte loads per
+// thread, all in flight at once), ballots every load, scans the 64 (wave, load) popcounts and reserves the tile's
+// output range with ONE cursor atomic; every store instruction then writes one contiguous run.  (The first version
+// took one atomic per wave and 64 slots: 100 M atomics on one address for a 6.4 G-slot table = 1.2 s.)
+constexpr uint32_t XPT = 16, XTILE = BLOCK * XPT;
 __global__ __launch_bounds__(BLOCK) void table_export_kernel(const Slot *__restrict__ slots, uint64_t cap,
                                                              uint64_t *__restrict__ out_keys,
                                                              uint32_t *__restrict__ out_counts, uint64_t max_out,
                                                              uint64_t *__restrict__ cursor) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
-    const uint64_t rounds = (cap + stride - 1) / stride;
-    for (uint64_t it = 0; it < rounds; it++) {
-        const uint64_t i = it * stride + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-        uint64_t key = KT_EMPTY_KEY;
-        uint32_t cnt = 0;
-        if (i < cap) {
-            const uint4 v = reinterpret_cast<const uint4 *>(slots)[i];
-            key = ((uint64_t)v.y << 32) | v.x;
-            cnt = v.z + 1u;  // stored value is occurrences - 1
+    __shared__ uint32_t runs[BLOCK / 64 * XPT];  // occupied slots per (wave, load), then their exclusive prefix
+    __shared__ uint64_t tile_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t n_tiles = (cap + XTILE - 1) / XTILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint4 v[XPT];
+#pragma unroll
+        for (uint32_t j = 0; j < XPT; j++) {
+            const uint64_t i = tile * XTILE + (uint64_t)j * BLOCK + tid;
+            v[j] = i < cap ? reinterpret_cast<const uint4 *>(slots)[i] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
         }
-        const bool occ = key != KT_EMPTY_KEY;
-        const uint64_t bal = __ballot(occ);
-        if (bal == 0) continue;
-        uint64_t base = 0;
-        if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(cursor), (unsigned long long)__popcll(bal));
-        base = ktd::uniform64(base);
-        if (occ) {
-            const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < max_out) {
-                out_keys[pos] = key;
-                out_counts[pos] = cnt;
+        uint64_t bal[XPT];
+#pragma unroll
+        for (uint32_t j = 0; j < XPT; j++) {
+            bal[j] = __ballot((v[j].x & v[j].y) != 0xFFFFFFFFu);  // key != KT_EMPTY_KEY
+            if (lane == 0) runs[wave * XPT + j] = (uint32_t)__popcll(bal[j]);
+        }
+        ktd::lds_barrier();
+        if (wave == 0) {  // 64 runs: one wave scans them and reserves the tile's output range
+            const uint32_t c = runs[lane];
+            uint32_t inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(inc, off, 64);
+                if (lane >= (uint32_t)off) inc += u;
+            }
+            runs[lane] = inc - c;
+            if (lane == 63)
+                tile_base = inc ? atomicAdd(reinterpret_cast<unsigned long long *>(cursor), (unsigned long long)inc) : 0;
+        }
+        ktd::lds_barrier();
+        const uint64_t base = tile_base;
+#pragma unroll
+        for (uint32_t j = 0; j < XPT; j++) {
+            if ((bal[j] >> lane) & 1ull) {
+                const uint64_t pos = base + runs[wave * XPT + j] + __popcll(bal[j] & ((1ull << lane) - 1ull));
+                if (pos < max_out) {
+                    out_keys[pos] = ((uint64_t)v[j].y << 32) | v[j].x;
+                    out_counts[pos] = v[j].z + 1u;  // stored value is occurrences - 1
+                }
             }
         }
+        ktd::lds_barrier();  // runs[] / tile_base are rewritten by the next tile
     }
 }
 
@@ -433,7 +455,7 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
         d_counts = (uint32_t *)ctx->s_aux2.p;
     }
     KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(ctx, (ctr->cap + XTILE - 1) / XTILE, 8)), dim3(BLOCK), 0,
                        ctx->stream, (const Slot *)ctr->slots, ctr->cap, d_keys, d_counts, max_out, ctr->cursor);
     KT_HIP(hipGetLastError());
     uint64_t n = 0;

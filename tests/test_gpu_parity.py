@@ -1073,6 +1073,7 @@ def test_ctr_cfg4_per_gpu_shard_properties(torch_mod, ctx, oracle):
     torch = torch_mod
     n, L, k, seed = 25_000_000, 150, 31, 0x6b6d6572 + 3
     kpr = L - k + 1
+    torch.cuda.empty_cache()      # the table, its build scratch and the export arrays need ~200 GB
     bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
     offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     ctx.synth_reads(seed, n, L, bases, offsets)
@@ -1086,10 +1087,14 @@ def test_ctr_cfg4_per_gpu_shard_properties(torch_mod, ctx, oracle):
     ctr.close()                                            # the table and the build scratch: ~160 GB back
     assert int(counts.to(torch.int64).sum()) == n * kpr
     assert int(keys.min()) >= 0 and int(keys.max()) < 4 ** k
-    sk, order = torch.sort(keys)
-    assert bool((sk[1:] != sk[:-1]).all())
-    sc = counts[order]
-    del order
+    # torch.sort takes at most 2^31 - 1 elements: sort the export in pieces of 2^30 (a key stored twice would show
+    # inside a piece here, or across pieces as a smaller table after the re-import below)
+    pieces = []
+    for s0 in range(0, distinct, 1 << 30):
+        sk, order = torch.sort(keys[s0:s0 + (1 << 30)])
+        assert bool((sk[1:] != sk[:-1]).all())
+        pieces.append((sk, counts[s0:s0 + (1 << 30)][order]))
+        del order
     # sampled sub-batches
     sub = 1_000_000
     small = device.Counter(ctx, k, 1 << 28)
@@ -1103,14 +1108,20 @@ def test_ctr_cfg4_per_gpu_shard_properties(torch_mod, ctx, oracle):
         gc = torch.empty(d, dtype=torch.int32, device="cuda")
         small.export(gk, gc, d)
         gk, o2 = torch.sort(gk)
+        gc = gc[o2]
         assert np.array_equal(gk.cpu().numpy().view(np.uint64), wk)
-        assert np.array_equal(gc[o2].cpu().numpy().view(np.uint32), wc)
-        pos = torch.searchsorted(sk, gk)
-        assert bool((pos < distinct).all()) and bool((sk[pos.clamp(max=distinct - 1)] == gk).all())
-        assert bool((sc[pos] >= gc[o2]).all())
-        del gk, gc, o2, pos
+        assert np.array_equal(gc.cpu().numpy().view(np.uint32), wc)
+        hits = torch.zeros(d, dtype=torch.int32, device="cuda")
+        big = torch.zeros(d, dtype=torch.int32, device="cuda")
+        for sk, sc in pieces:
+            pos = torch.searchsorted(sk, gk).clamp(max=sk.numel() - 1)
+            hit = sk[pos] == gk
+            hits += hit.to(torch.int32)
+            big += torch.where(hit, sc[pos], torch.zeros_like(gc))
+        assert bool((hits == 1).all()) and bool((big >= gc).all())
+        del gk, gc, o2, hits, big
     small.close()
-    del sk, sc, bases, offsets
+    del pieces, sk, sc, bases, offsets
     torch.cuda.empty_cache()
     # merge idempotence at full size: the exported pairs into an empty table
     ctr2 = device.Counter(ctx, k, int(1.9 * n * kpr))
