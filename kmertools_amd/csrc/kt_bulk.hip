@@ -45,14 +45,11 @@ using kttab::Slot;
 using kttab::TableRef;
 
 constexpr int BLOCK = ktseg::BLOCK;       // 256
-#ifndef KT_LOG2_S
-#define KT_LOG2_S 13
-#endif
 #ifndef KT_BUILD_T
-#define KT_BUILD_T 1024
+#define KT_BUILD_T 512
 #endif
-constexpr uint32_t LOG2_S = KT_LOG2_S;    // slots per fine bucket
-constexpr uint32_t S = 1u << LOG2_S;      // 8192 slots = 128 KB of table per fine bucket
+constexpr uint32_t LOG2_S = kttab::LOG2_RANGE;  // hash positions per fine bucket = per range of the table
+constexpr uint32_t S = 1u << LOG2_S;            // 4096 positions: 512 * m8 slots, 40 - 64 KB of table
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 #ifndef KT_P2T
 #define KT_P2T 512
@@ -76,6 +73,7 @@ struct Plan {
     uint32_t G;       // persistent workgroups of hist1 / scatter1
     uint64_t cap1;    // paged level 1: keys of room per level-1 bucket in keys1 / keys2
     uint64_t cap2;    // ... and per fine bucket in keys2 (cap1 / B2)
+    uint32_t dbg;     // KT_BUILD_DBG: ablation switches of build_kernel (profiling only)
 };
 
 template <class K>
@@ -86,7 +84,7 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
     uint64_t *gcur;     // [B1] paged level 1: keys of bucket room handed out so far (page allocator)
-    uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room; [1] paged build: the spill list did
+    uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -593,11 +591,29 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
     }
 }
 
-// ---- build: one workgroup per fine bucket ------------------------------------------------------------------
-// LDS image of the range: SE keys then SE counts, SE = 5120 .. 8192 (the table's shape, kt_table.hpp)
-static_assert(LOG2_S == kttab::LOG2_RANGE, "the m/8 table shapes shrink 8192-slot ranges");
+// ---- build: one workgroup per fine bucket = one range of the table ---------------------------------------
+// A range (kt_table.hpp) is a closed, circular linear-probing table of RS = 512 * m8 slots, so its image fits LDS
+// (48 KB of keys + counts): the bucket's keys - and, when the table already holds data, the range's current entries
+// with their counts - are inserted into that image with LDS atomics and the image is written out with coalesced
+// non-temporal 16-byte stores (empty slots included, so an empty table needs no clear).  Nothing ever leaves its
+// range, so nothing goes through the global atomic path afterwards, and an existing range can be rebuilt in place.
+// The insert is latency bound, not throughput bound (tools/ubench/lds_atomics.hip: 2.9 random 64-bit CAS per clock
+// and CU, 4.9 32-bit ones; one probe at a time per wave reached a sixth of that), so every lane runs KT_BUILD_U
+// independent insert state machines: their CAS are issued back to back and only then looked at (one CAS per probe:
+// it reports what the slot holds; a machine that has placed its key takes its next one at once; next keys are
+// prefetched).  That also makes the table's load factor nearly free: 0.8 instead of round 1's 0.47, whose
+// one-probe-at-a-time insert slowed down 1.5x at 0.7.
+// A first version of this round deduplicated in a sparser LDS table and computed the probing layout with a counting
+// sort + prefix maximum instead of probing (git history: 57 ms; dedupe 20, placement 10, image 6 - all of it
+// barrier and latency, none of it overlapping): the direct insert needs three barriers per range.
+// More distinct keys than slots in a range (a table that is too small) go to the spill list and fail there, loudly.
+static_assert(LOG2_S == kttab::LOG2_RANGE, "a fine bucket is a range of the table");
 
-constexpr int BUILD_T = KT_BUILD_T;  // 16 waves per fine bucket: short serial probe chains, full occupancy
+constexpr int BUILD_T = KT_BUILD_T;
+#ifndef KT_BUILD_COOP
+#define KT_BUILD_COOP 16
+#endif
+constexpr uint32_t COOP = KT_BUILD_COOP;  // single-lane probes before a key's walk gets the whole wave
 
 template <class K>
 struct lds_word;
@@ -606,97 +622,195 @@ struct lds_word<uint64_t> { using type = unsigned long long; };
 template <>
 struct lds_word<uint32_t> { using type = unsigned int; };
 
-template <class K>
+template <class K, bool MERGE>
 __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ keys2,
-                                                      const uint64_t *__restrict__ fstart,
-                                                      const uint64_t *__restrict__ fend, Plan p,
-                                                      Slot *__restrict__ slots, uint64_t *__restrict__ spill_n,
-                                                      uint64_t *__restrict__ spill_keys, uint64_t spill_cap,
-                                                      uint32_t *__restrict__ flags) {
+                                                        const uint64_t *__restrict__ fstart,
+                                                        const uint64_t *__restrict__ fend, Plan p,
+                                                        Slot *__restrict__ slots, uint64_t *__restrict__ spill_n,
+                                                        uint64_t *__restrict__ spill_keys,
+                                                        uint32_t *__restrict__ spill_counts, uint64_t spill_cap,
+                                                        uint32_t *__restrict__ spill_ovf,
+                                                        uint64_t *__restrict__ distinct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const uint32_t SE = p.m8 << (LOG2_S - 3);
     using W = typename lds_word<K>::type;
     constexpr K EMPTY = empty_of<K>();
+    const uint32_t RS = p.m8 << (LOG2_S - 3);
     K *const skeys = reinterpret_cast<K *>(smem_raw);
-    uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)SE * sizeof(K));
-    const uint32_t tid = threadIdx.x;
+    uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)RS * sizeof(K));
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     const uint32_t shift = 64 - p.n;
-    auto slot_in_range = [&](uint64_t key) {
-        const uint32_t y = (uint32_t)(ktd::khash(key) >> shift) & (S - 1);
-        return (y * p.m8) >> 3;
+    auto home = [&](uint64_t key) {  // home position inside the range (kttab::probe_of)
+        return (((uint32_t)(ktd::khash(key) >> shift) & (S - 1)) * p.m8) >> 3;
     };
+    auto spill = [&](uint64_t key, uint32_t occurrences) {
+        const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
+        if (at < spill_cap) {
+            spill_keys[at] = key;
+            spill_counts[at] = occurrences;
+        } else {
+            atomicOr(spill_ovf, 1u);
+        }
+    };
+    long long placed = 0;  // per thread: occupied slots written - occupied slots found (MERGE)
     for (uint64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
-        for (uint32_t i = tid; i < SE; i += BUILD_T) {
-            skeys[i] = EMPTY;
-            scounts[i] = 0;
+        const uint64_t lo = fstart[fb], hi = fend[fb];
+        if (MERGE && lo == hi) continue;  // nothing new for this range: it stays as it is
+        if (MERGE) {
+            // what the range holds already goes back where it is: the old image is a valid probing layout
+            for (uint32_t i = tid; i < RS; i += BUILD_T) {
+                const uint4 v = reinterpret_cast<const uint4 *>(slots + fb * RS)[i];
+                const bool occ = (v.x & v.y) != 0xFFFFFFFFu;
+                skeys[i] = occ ? (K)(((uint64_t)v.y << 32) | v.x) : EMPTY;
+                scounts[i] = v.z;
+                placed -= occ;
+            }
+        } else {
+            for (uint32_t i = tid; i < RS; i += BUILD_T) {
+                skeys[i] = EMPTY;
+                scounts[i] = 0;
+            }
         }
         ktd::lds_barrier();
-        const uint64_t lo = fstart[fb], hi = fend[fb];
-        // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
-        // trip, and a lane that has placed its key moves on to its next one at once.  The obvious "for each key:
-        // probe until placed" makes the wave wait for its longest probe chain on every key (8x more trips at load
-        // factor 0.7).  Four keys are kept prefetched so the loads are never waited for.
         {
-            uint64_t idx = lo + tid;
-            auto fetch = [&]() {
-                const K k = idx < hi ? keys2[idx] : EMPTY;
-                idx += BUILD_T;
+            // Every wave owns a contiguous share [wlo, whi) of the bucket's keys and reads it in 64-key chunks (one
+            // coalesced load, the next chunk prefetched).  A lane is an insert state machine: one probe per trip (a
+            // plain LDS read; the CAS only when the slot looks free), and the lanes that have placed their key are
+            // handed the next keys of the chunk at once (ballot + rank + ds_bpermute), so no lane idles while the wave
+            // has keys left - with a fixed key list per lane the wave waited for the lane whose keys drew the longest
+            // probe chains (2x the mean at load 0.5, 5x at 0.8).
+            constexpr uint32_t NW = BUILD_T / 64;
+            const uint32_t wave = tid >> 6;
+            const uint64_t per = ((hi - lo + NW - 1) / NW + 63) & ~63ull;
+            const uint64_t wlo = lo + wave * per < hi ? lo + wave * per : hi;
+            const uint64_t whi = wlo + per < hi ? wlo + per : hi;
+            uint64_t cpos = wlo;
+            auto load_chunk = [&]() {
+                const K k = cpos + lane < whi ? keys2[cpos + lane] : EMPTY;
+                cpos += 64;
                 return k;
             };
-            K cur = fetch(), q0 = fetch(), q1 = fetch(), q2 = fetch();
-            uint32_t s = slot_in_range(cur);
-            while (cur != EMPTY) {
-                // one LDS operation per probe: the CAS itself reports what the slot holds (64-bit LDS atomics run at
-                // about a lane per clock, so a separate read before it doubled the cost of the common case)
-                const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
-                bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
-                if (!done && v == cur) {
-                    atomicAdd(&scounts[s], 1u);
-                    done = true;
+            K chunk = load_chunk(), ahead = load_chunk();
+            uint32_t taken = 0;  // keys of `chunk` handed out so far (wave uniform)
+            bool more = wlo < whi && !(p.dbg & 1u);  // `chunk` may still hold keys
+            K cur = EMPTY;
+            uint32_t s = 0, probes = 0;
+            bool stuck = false;
+            for (;;) {
+                if (more) {
+                    const uint64_t idle = __ballot(cur == EMPTY);
+                    if (idle) {
+                        const uint32_t want = taken + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                        const K k = (K)__shfl(chunk, (int)(want & 63u), 64);
+                        if (cur == EMPTY && want < 64u) {
+                            cur = k;
+                            s = home((uint64_t)k);
+                            probes = 0;
+                        }
+                        taken += (uint32_t)__popcll(idle);
+                        if (taken >= 64u) {  // chunk used up (lanes that got nothing are served next trip)
+                            chunk = ahead;
+                            ahead = load_chunk();
+                            taken = 0;
+                            more = cpos - 128 < whi;  // the new chunk starts inside the share
+                        }
+                    }
                 }
-                if (!done && ++s >= SE) {  // forward only: never wrap inside the range (kt_table.hpp invariant);
-                    // ran off the end: goes through the probing path afterwards
-                    const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
-                    if (at < spill_cap) spill_keys[at] = cur;
-                    else atomicOr(flags, 1u);
-                    done = true;
+                if (__ballot(cur != EMPTY) == 0) {
+                    if (!more) break;
+                    continue;
                 }
-                if (done) {
-                    cur = q0;
-                    q0 = q1;
-                    q1 = q2;
-                    q2 = fetch();
-                    s = slot_in_range(cur);
+                // a lane whose key has walked KT_BUILD_COOP slots is in one of the long clusters of a well filled range
+                // (load 0.8: the longest run of taken slots in a range is a few hundred).  One such lane per trip gets
+                // the whole wave: 64 consecutive slots read at once, the lane jumps to the first that is free or
+                // holds its key.  Without this the workgroup waits for its longest walk, one LDS round trip per slot.
+                const uint64_t stuck_mask = __ballot(stuck);
+                if (stuck_mask) {
+                    const int L = __ffsll((unsigned long long)stuck_mask) - 1;
+                    const K lk = (K)__shfl(cur, L, 64);
+                    const uint32_t ls = (uint32_t)__shfl((int)s, L, 64);
+                    uint32_t at = ls + lane;
+                    at = at >= RS ? at - RS : at;
+                    const K v = skeys[at];
+                    const uint64_t hit = __ballot(v == EMPTY || v == lk);
+                    if ((int)lane == L) {
+                        const uint32_t adv = hit ? (uint32_t)(__ffsll((unsigned long long)hit) - 1) : 64u;
+                        s = ls + adv;
+                        s = s >= RS ? s - RS : s;
+                        probes += adv;
+                        stuck = hit == 0;
+                        if (probes >= RS) {  // once round the range: it is full, the table is too small
+                            spill((uint64_t)cur, 1u);
+                            cur = EMPTY;
+                            stuck = false;
+                        }
+                    }
+                }
+                if (cur != EMPTY && !stuck) {
+                    K v = skeys[s];
+                    if (v == EMPTY) v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
+                    bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
+                    if (!done && v == cur) {
+                        atomicAdd(&scounts[s], 1u);
+                        done = true;
+                    }
+                    if (!done) {
+                        s = s + 1 == RS ? 0 : s + 1;  // round the range (kttab::Probe)
+                        probes++;
+                        stuck = probes >= COOP && RS >= 64u;
+                        if (probes >= RS) {
+                            spill((uint64_t)cur, 1u);
+                            done = true;
+                        }
+                    }
+                    if (done) {
+                        cur = EMPTY;
+                        stuck = false;
+                    }
                 }
             }
         }
         ktd::lds_barrier();
-        uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * SE);
-        for (uint32_t i = tid; i < SE; i += BUILD_T) {
-            const K kk = skeys[i];
-            const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : (uint64_t)kk;
+        uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * RS);
+        if (!(p.dbg & 8u)) {
+            for (uint32_t i = tid; i < RS; i += BUILD_T) {
+                const K kk = skeys[i];
+                const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : (uint64_t)kk;
+                placed += kk != EMPTY;
 #if KT_BUILD_NT
-            {
                 typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
                 const raw4 raw = {(uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u};
                 __builtin_nontemporal_store(raw, reinterpret_cast<raw4 *>(dst + i));
-            }
 #else
-            dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u);
+                dst[i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u);
 #endif
+            }
         }
         ktd::lds_barrier();
     }
+    // the table's distinct counter: one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) placed += __shfl_down(placed, o, 64);
+    if (lane == 0 && placed) atomicAdd(reinterpret_cast<unsigned long long *>(distinct), (unsigned long long)placed);
 }
 
+// what build could not place (a range with more distinct keys than slots): through the probing path, which reports
+// the full table
 __global__ __launch_bounds__(BLOCK) void spill_insert_kernel(const uint64_t *__restrict__ spill_n,
                                                              const uint64_t *__restrict__ spill_keys,
-                                                             uint64_t spill_cap, TableRef t) {
+                                                             const uint32_t *__restrict__ spill_counts,
+                                                             uint64_t spill_cap, TableRef t,
+                                                             uint64_t *__restrict__ distinct) {
     uint64_t n = *spill_n;
     if (n > spill_cap) n = spill_cap;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK)
-        if (!kttab::table_add(t, spill_keys[i], 1u)) atomicOr(t.flags, 1u);
+    uint32_t fresh = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t st = kttab::table_add(t, spill_keys[i], spill_counts[i]);
+        if (st == 0u) atomicOr(t.flags, 1u);
+        fresh += st == 2u;
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_down(fresh, o, 64);
+    if ((threadIdx.x & 63) == 0 && fresh)
+        atomicAdd(reinterpret_cast<unsigned long long *>(distinct), (unsigned long long)fresh);
 }
 
 uint64_t env_u64(const char *name, uint64_t dflt) {
@@ -711,10 +825,13 @@ template <class Source, class K>
 int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t max_keys, int *done) {
     *done = 0;
     kt_ctx *ctx = ctr->ctx;
+    const bool merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
     Plan p{};
     p.n = 64 - ctr->shift;
     p.m8 = ctr->m8;
+    p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
+    if (merge && max_keys < ctr->cap / env_u64("KT_BULK_MERGE_DIV", 8)) return KT_OK;  // a rebuild moves the whole table: small batches are cheaper through the atomics
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
     if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
@@ -734,8 +851,8 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
-    // spill list: keys beyond a range's end in build (they go through the probing path afterwards)
-    const uint64_t spill_cap = max_keys / 16 + (1u << 16);
+    // spill list: keys of ranges that hold more distinct keys than slots (they fail in the probing path: table full)
+    const uint64_t spill_cap = 1u << 20;
     size_t meta = 0;
     const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;
@@ -746,6 +863,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     const size_t off_ov = meta;      meta += 256;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
+    const size_t off_sc = meta;      meta += (spill_cap * 4 + 255) & ~(size_t)255;
     auto reserve_all = [&]() {
         return ctr->b_keys1.reserve(key_room * sizeof(K)) == KT_OK && ctr->b_keys2.reserve(key_room * sizeof(K)) == KT_OK &&
                ctr->b_meta.reserve(meta) == KT_OK;
@@ -775,6 +893,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     m.ovf = (uint32_t *)(mb + off_ov);
     m.spill_n = (uint64_t *)(mb + off_sn);
     m.spill_keys = (uint64_t *)(mb + off_sk);
+    m.spill_counts = (uint32_t *)(mb + off_sc);
     m.spill_cap = spill_cap;
     K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
 
@@ -815,33 +934,26 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     hipLaunchKernelGGL(part2, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur, p,
                        keys2, m.fstart, m.fend);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
-    uint64_t gb = (uint64_t)ctx->n_cu * 8;  // persistent workgroups; up to three are resident per CU
+    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 12);  // persistent workgroups; three are resident per CU
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build_kernel<K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_lds));
-    hipLaunchKernelGGL(build_kernel<K>, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend, p,
-                       (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_cap, p.cap2 ? m.ovf + 1 : ctr->flags);
+    auto build = merge ? build_kernel<K, true> : build_kernel<K, false>;
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)build_lds));
+    hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend,
+                       p, (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_counts, m.spill_cap, ctr->flags,
+                       ctr->distinct);
     TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
-                       m.spill_cap, t);
+                       m.spill_counts, m.spill_cap, t, ctr->distinct);
     KT_HIP(hipGetLastError());
     if (env_u64("KT_BULK_VERBOSE", 0)) {
         uint64_t spilled = 0;
         KT_HIP(hipMemcpyAsync(&spilled, m.spill_n, 8, hipMemcpyDeviceToHost, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s spilled=%llu\n", ctr->k, (unsigned long long)max_keys,
-                paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact", (unsigned long long)spilled);
-    }
-    if (p.cap2) {  // did the spill list hold what build could not place?
-        uint32_t ovf2 = 0;
-        KT_HIP(hipMemcpyAsync(&ovf2, m.ovf + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-        KT_HIP(hipStreamSynchronize(ctx->stream));
-        if (ovf2) {  // no: once more with exact offsets at both levels (the build rewrites every slot)
-            ctr->paged_failed = true;
-            KT_HIP(hipMemsetAsync(ctr->flags, 0, 4, ctx->stream));
-            return bulk_build_typed<Source, K>(ctr, src, n_units, max_keys, done);
-        }
+        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s %s spilled=%llu\n", ctr->k, (unsigned long long)max_keys,
+                paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact", merge ? "merge" : "build",
+                (unsigned long long)spilled);
     }
     *done = 1;
     return KT_OK;

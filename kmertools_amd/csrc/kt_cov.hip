@@ -43,14 +43,19 @@ __device__ __forceinline__ uint4 load_slot(const Slot *slots, uint64_t slot) {
     return *reinterpret_cast<const uint4 *>(slots + slot);
 }
 
-// occurrences of `key` given the already-loaded home slot `v`; walks on only on a collision
-__device__ __forceinline__ uint32_t resolve_count(const CovArgs &c, uint4 v, uint64_t slot, uint64_t key) {
-    for (uint64_t probe = 0; probe < c.g.cap; probe++) {
-        const uint64_t kk = ((uint64_t)v.y << 32) | v.x;
-        if (kk == key) return v.z + 1u;  // stored value is occurrences - 1
+// occurrences of `key` given the already-loaded home slot `v`; walks on (round the key's range, kt_table.hpp)
+// only on a collision - the probe sequence is recomputed then, so that the common case carries no state for it
+__device__ __forceinline__ uint32_t resolve_count(const CovArgs &c, uint4 v, uint64_t key) {
+    uint64_t kk = ((uint64_t)v.y << 32) | v.x;
+    if (kk == key) return v.z + 1u;  // stored value is occurrences - 1
+    if (kk == KT_EMPTY_KEY) return 0u;
+    kttab::Probe p = kttab::probe_of(key, c.g);
+    for (uint32_t probe = 1; probe < p.rs; probe++) {
+        p.next();
+        v = load_slot(c.slots, p.slot());
+        kk = ((uint64_t)v.y << 32) | v.x;
+        if (kk == key) return v.z + 1u;
         if (kk == KT_EMPTY_KEY) return 0u;
-        slot = kttab::next_slot(slot, c.g);
-        v = load_slot(c.slots, slot);
     }
     return 0u;
 }
@@ -92,19 +97,18 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
             // GROUP probes in flight per thread; rolled so the k-mers never sit in registers all at once
 #pragma unroll 1
             for (uint32_t jj = 0; jj < ktseg::PER_THREAD; jj += GROUP) {
-                uint64_t key[GROUP], sl[GROUP];
+                uint64_t key[GROUP];
                 uint4 v[GROUP];
 #pragma unroll
                 for (uint32_t u = 0; u < GROUP; u++) {
                     key[u] = w.f < w.r ? w.f : w.r;
                     w.step();
-                    sl[u] = kttab::home_slot(key[u], c.g);
-                    v[u] = load_slot(c.slots, sl[u]);
+                    v[u] = load_slot(c.slots, kttab::probe_of(key[u], c.g).slot());
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < GROUP; u++) {
                     if (!((ok >> (jj + u)) & 1u)) continue;
-                    const uint32_t cnt = resolve_count(c, v[u], sl[u], key[u]);
+                    const uint32_t cnt = resolve_count(c, v[u], key[u]);
                     uint32_t bin = c.bin_size ? cnt / c.bin_size : 0u;  // coverage/src/lib.rs:172
                     bin = bin < last_bin ? bin : last_bin;              // :173
                     const uint64_t s = s0 + jj + u;

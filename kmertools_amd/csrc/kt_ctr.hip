@@ -29,41 +29,46 @@ using kttab::Slot;
 using kttab::TableRef;
 using kttab::table_add;
 
-__global__ __launch_bounds__(BLOCK) void count_reads_kernel(SegArgs a, TableRef t) {
+// new keys claimed by the thread -> the table's distinct counter: one atomic per wave, at the end of the kernel
+__device__ __forceinline__ void publish_fresh(uint32_t fresh, uint64_t *distinct) {
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_down(fresh, o, 64);
+    if ((threadIdx.x & 63) == 0 && fresh)
+        atomicAdd(reinterpret_cast<unsigned long long *>(distinct), (unsigned long long)fresh);
+}
+
+__global__ __launch_bounds__(BLOCK) void count_reads_kernel(SegArgs a, TableRef t, uint64_t *__restrict__ distinct) {
     __shared__ SegShared sm;
+    uint32_t fresh = 0;
     for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
         ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
             const uint64_t m = f < r ? f : r;  // counter/src/lib.rs:124
-            if (!table_add(t, m, 1u)) atomicOr(t.flags, 1u);
+            const uint32_t st = table_add(t, m, 1u);
+            if (st == 0u) atomicOr(t.flags, 1u);
+            fresh += st == 2u;
         });
     }
+    publish_fresh(fresh, distinct);
 }
 
 __global__ __launch_bounds__(BLOCK) void add_pairs_kernel(const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ counts, uint64_t n,
-                                                          TableRef t) {
+                                                          TableRef t, uint64_t *__restrict__ distinct) {
+    uint32_t fresh = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         const uint64_t key = keys[i];
         const uint32_t c = counts ? counts[i] : 1u;
         if (key == KT_EMPTY_KEY) continue;
-        if (!table_add(t, key, c)) atomicOr(t.flags, 1u);
+        const uint32_t st = table_add(t, key, c);
+        if (st == 0u) atomicOr(t.flags, 1u);
+        fresh += st == 2u;
     }
+    publish_fresh(fresh, distinct);
 }
 
 __global__ __launch_bounds__(BLOCK) void table_clear_kernel(Slot *__restrict__ slots, uint64_t cap) {
     const uint4 empty = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK)
         reinterpret_cast<uint4 *>(slots)[i] = empty;
-}
-
-__global__ __launch_bounds__(BLOCK) void table_size_kernel(const Slot *__restrict__ slots, uint64_t cap,
-                                                           uint64_t *__restrict__ out) {
-    uint64_t n = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK)
-        n += slots[i].key != KT_EMPTY_KEY;
-    // wave reduction, one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(reinterpret_cast<unsigned long long *>(out), (unsigned long long)n);
 }
 
 // stream the table, compact occupied slots.  A workgroup takes tiles of 4096 slots (16 coalesced 16-byte loads per
@@ -293,6 +298,7 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->distinct, 64);
     if (e != hipSuccess) {
         kt_ctr_destroy(c);
         return kt::fail(KT_ERR_NOMEM, std::string("kt_ctr_create: hipMalloc: ") + hipGetErrorString(e));
@@ -310,6 +316,7 @@ int kt_ctr_destroy(kt_ctr *ctr) {
     if (ctr->slots) (void)hipFree(ctr->slots);
     if (ctr->flags) (void)hipFree(ctr->flags);
     if (ctr->cursor) (void)hipFree(ctr->cursor);
+    if (ctr->distinct) (void)hipFree(ctr->distinct);
     ctr->b_keys1.release();
     ctr->b_keys2.release();
     ctr->b_meta.release();
@@ -338,6 +345,7 @@ int kt_ctr_clear(kt_ctr *ctr) {
     if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_clear: null");
     if (int rc = ctr->ctx->use()) return rc;
     KT_HIP(hipMemsetAsync(ctr->flags, 0, 64, ctr->ctx->stream));
+    KT_HIP(hipMemsetAsync(ctr->distinct, 0, 8, ctr->ctx->stream));
     ctr->needs_clear = true;
     ctr->empty = true;
     return KT_OK;
@@ -358,8 +366,9 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
     if (mem == KT_MEM_HOST) {
         if (int rc = stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) return rc;
     }
-    if (ctr->empty) {
-        // a whole batch into an empty table: partition + LDS build, no global atomics
+    {
+        // a whole batch: partition by hash prefix + one LDS build per range of the table, no global atomics.  Into a
+        // table that holds data the ranges are rebuilt from what they have + the batch (worth it for large batches)
         int done = 0;
         if (int rc = kt_bulk_build(ctr, d_bases, d_offsets, n_reads, total, &done)) return rc;
         if (done) {
@@ -374,7 +383,8 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
     TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
-    hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t);
+    hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t,
+                       ctr->distinct);
     KT_HIP(hipGetLastError());
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
     return KT_OK;
@@ -398,8 +408,8 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
             d_counts = (const uint32_t *)ctx->s_aux2.p;
         }
     }
-    if (ctr->empty && !d_counts) {
-        // raw k-mers (routed from other GPUs) into an empty table: the bulk build, no global atomics
+    if (!d_counts) {
+        // raw k-mers (routed from other GPUs): the bulk build, no global atomics
         int done = 0;
         if (int rc = kt_bulk_build_keys(ctr, d_keys, n, &done)) return rc;
         if (done) {
@@ -413,7 +423,7 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
     if (int rc = ensure_cleared(ctr)) return rc;
     TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
-                       ctx->stream, d_keys, d_counts, n, t);
+                       ctx->stream, d_keys, d_counts, n, t, ctr->distinct);
     KT_HIP(hipGetLastError());
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
     return KT_OK;
@@ -429,12 +439,9 @@ int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct) {
     if (!ctr || !distinct) return kt::fail(KT_ERR_ARG, "kt_ctr_size: null");
     kt_ctx *ctx = ctr->ctx;
     if (int rc = ctx->use()) return rc;
-    if (int rc = ensure_cleared(ctr)) return rc;
-    KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(table_size_kernel, dim3(grid_for(ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
-                       ctx->stream, (const Slot *)ctr->slots, ctr->cap, ctr->cursor);
-    KT_HIP(hipGetLastError());
-    KT_HIP(hipMemcpyAsync(distinct, ctr->cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    // every insert path keeps the count of occupied slots (claims in the probing kernels, placed keys in the range
+    // builds), so the size is one 8-byte read - not a scan of the table
+    KT_HIP(hipMemcpyAsync(distinct, ctr->distinct, 8, hipMemcpyDeviceToHost, ctx->stream));
     KT_HIP(hipStreamSynchronize(ctx->stream));
     return check_overflow(ctr);
 }

@@ -49,14 +49,15 @@ struct kt_ctr {
     int k = 0;
     uint64_t cap = 0;          // m8 * 2^(n-3) slots (kttab::Geom)
     uint32_t shift = 0;        // 64 - n
-    uint32_t m8 = 8;           // eighths of 2^n
+    uint32_t m8 = 8;           // eighths of 2^n (slots per 4096-position range / 512)
     bool paged_failed = false; // a bulk build overflowed a paged level-1 bucket: exact offsets from now on
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls
     void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}
     uint32_t *flags = nullptr; // [0] = overflow flag, device
-    uint64_t *cursor = nullptr; // device scalar for export / size
+    uint64_t *cursor = nullptr; // device scalar for export
+    uint64_t *distinct = nullptr; // device scalar: occupied slots (kept by every insert path, so kt_ctr_size is one 8-byte read)
 };
 
 namespace kt {

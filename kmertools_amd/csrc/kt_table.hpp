@@ -1,11 +1,18 @@
 // kt_table.hpp - the HBM-resident canonical k-mer table shared by the incremental (atomic)
-// path in kt_ctr.hip and the bulk (partition + LDS build) path in kt_bulk.hip.
+// path in kt_ctr.hip, the lookups of kt_cov.hip and the bulk (partition + LDS build) path in kt_bulk.hip.
 //
-// Layout: cap = 2^n or m * 2^(n-3) slots (m = 5, 6, 7) of 16 bytes {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks
-// a free slot.  Home slot = TOP n bits of khash(key), linear probing forward (wrapping at
-// cap).  Using the top bits makes "all keys of hash prefix p" one contiguous slot range, which
-// is what lets the bulk path build the table range by range in LDS.  GPU ownership
-// (ktd::owner_of) uses the LOW 32 bits of the same hash, so a shard's keys still spread over
+// Layout: 16-byte slots {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks a free slot.  The table is a
+// row of independent RANGES: with x = the top n bits of khash(key), the top n - 12 bits of x select the range
+// and the low 12 bits the home position inside it; a range has 512 * m8 slots (m8 = 5..8 eighths of 4096, so that
+// a table is at most 1.25x - not 2x - what was asked for) and is a closed linear-probing table of its own: probing
+// runs forward from the home slot and wraps at the END OF THE RANGE, never into the next range.
+//   cap = m8 * 2^(n-3) slots     home = (x >> 12) * (512 * m8) + ((x & 4095) * m8 >> 3)
+// Why ranges: "all keys of hash prefix p" is one contiguous, self-contained piece of the table, so the bulk path can
+// build (or rebuild: merge a new batch into) every range in LDS on its own and write it with streaming stores - no
+// key of one range ever lives in another, no clean-up pass through the atomic path, a load factor of 0.8 instead
+// of 0.5 (round 1's ranges spilled into their successors, which kept them half empty).  The price is one compare
+// per probe step.  Tables of fewer than 4096 slots are a single range of `cap` slots.
+// GPU ownership (ktd::owner_of) uses the LOW 32 bits of the same hash, so a shard's keys still spread over
 // its whole table.
 #pragma once
 #include "kt_device.hpp"
@@ -20,19 +27,19 @@ struct Slot {
 };
 static_assert(sizeof(Slot) == 16, "slot layout");
 
-// Capacities come in eighths of a power of two, so that a table is at most 1.25x (not 2x) what was asked for.
-// With x = the top n bits of the hash and m8 in 5..8:
-//   cap = m8 * 2^(n-3)   home = (x >> 13) * (1024 * m8) + ((x & 8191) * m8 >> 3)
-// i.e. every 8192-slot range of the 2^n layout shrinks to 1024 * m8 slots in place (m8 = 8: home = x).  The home
-// slot is monotone in the hash and the top n - 13 bits of the hash select one contiguous range of slots - which is
-// all the bulk build needs, so its partition passes are the same for every shape.
-constexpr uint32_t LOG2_RANGE = 13, RANGE_FULL = 1u << LOG2_RANGE;
+#ifndef KT_LOG2_RANGE
+#define KT_LOG2_RANGE 12
+#endif
+constexpr uint32_t LOG2_RANGE = KT_LOG2_RANGE, RANGE_FULL = 1u << LOG2_RANGE;
 
 struct Geom {
     uint64_t cap;
     uint32_t shift;  // 64 - n
-    uint32_t m8;     // slots per range / 1024
-    __host__ __device__ uint32_t range_slots() const { return m8 << (LOG2_RANGE - 3); }
+    uint32_t m8;     // slots per range / 512
+    // slots of one range (the whole table when it is smaller than a range)
+    __host__ __device__ uint32_t range_slots() const {
+        return shift > 64 - LOG2_RANGE ? (uint32_t)cap : m8 << (LOG2_RANGE - 3);
+    }
 };
 
 inline Geom make_geom(uint64_t cap_request) {
@@ -54,44 +61,53 @@ struct TableRef {
     uint32_t *flags; // [0] = overflow flag
 };
 
-__host__ __device__ __forceinline__ uint64_t home_slot(uint64_t key, const Geom &g) {
+// a probe sequence: slot = base + rel, rel walks [0, rs) circularly from the key's home position
+struct Probe {
+    uint64_t base;
+    uint32_t rel, rs;
+    __host__ __device__ __forceinline__ uint64_t slot() const { return base + rel; }
+    __host__ __device__ __forceinline__ void next() { rel = rel + 1 == rs ? 0 : rel + 1; }
+};
+
+__host__ __device__ __forceinline__ Probe probe_of(uint64_t key, const Geom &g) {
     const uint64_t x = ktd::khash(key) >> g.shift;  // n <= 54 bits
-    if (g.m8 == 8) return x;
-    return (x >> LOG2_RANGE) * g.range_slots() + ((((uint32_t)x & (RANGE_FULL - 1)) * g.m8) >> 3);
-}
-__host__ __device__ __forceinline__ uint64_t next_slot(uint64_t slot, const Geom &g) {
-    return slot + 1 == g.cap ? 0 : slot + 1;
+    if (g.shift > 64 - LOG2_RANGE) return Probe{0, (uint32_t)x, (uint32_t)g.cap};  // one small range, home = x
+    const uint32_t rs = g.m8 << (LOG2_RANGE - 3);
+    return Probe{(x >> LOG2_RANGE) * rs, (((uint32_t)x & (RANGE_FULL - 1)) * g.m8) >> 3, rs};
 }
 
-// table[key] += add.  A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe
-// can only show EMPTY for a slot that is now taken, and the CAS (device scope, coherent across
-// XCDs) settles that case.  A k-mer seen once costs one probing load + one CAS (claiming the
-// slot is its first count); a repeat costs one load + one 32-bit atomic add.
-__device__ __forceinline__ bool table_add(const TableRef &t, uint64_t key, uint32_t add) {
-    uint64_t slot = home_slot(key, t.g);
-    for (uint64_t probe = 0; probe < t.g.cap; probe++) {
-        uint64_t cur = __hip_atomic_load(&t.slots[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// table[key] += add; returns 0 = the key's range is full, 1 = the key was there, 2 = the key is new.
+// A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe can only show EMPTY for a slot that is now
+// taken, and the CAS (device scope, coherent across XCDs) settles that case.  A k-mer seen once costs one probing load
+// + one CAS (claiming the slot is its first count); a repeat costs one load + one 32-bit atomic add.  At most one
+// trip round the key's range (<= 4096 probes), so a full table fails fast instead of being scanned end to end.
+__device__ __forceinline__ uint32_t table_add(const TableRef &t, uint64_t key, uint32_t add) {
+    Probe p = probe_of(key, t.g);
+    for (uint32_t probe = 0; probe < p.rs; probe++) {
+        Slot *s = t.slots + p.slot();
+        uint64_t cur = __hip_atomic_load(&s->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == KT_EMPTY_KEY) {
-            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&t.slots[slot].key),
+            const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(&s->key),
                                             (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key);
             if (prev == KT_EMPTY_KEY) {
-                if (add > 1u) atomicAdd(&t.slots[slot].count, add - 1u);
-                return true;
+                if (add > 1u) atomicAdd(&s->count, add - 1u);
+                return 2u;
             }
             cur = prev;
         }
         if (cur == key) {
-            atomicAdd(&t.slots[slot].count, add);
-            return true;
+            atomicAdd(&s->count, add);
+            return 1u;
         }
-        slot = next_slot(slot, t.g);
+        p.next();
     }
-    return false;
+    return 0u;
 }
 
 }  // namespace kttab
 
-// kt_bulk.hip: builds an EMPTY table from a whole read batch without global atomics.
+// kt_bulk.hip: adds a whole read batch to the table without global atomics (partition by hash prefix, then every
+// range is built - or rebuilt with what it already holds - in LDS).
 // Returns KT_OK, or an error; `*done` = 0 when the batch / table shape is not eligible and
 // the caller must use the incremental path.
 int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,

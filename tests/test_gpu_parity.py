@@ -609,8 +609,100 @@ def test_ctr_bulk_build_from_routed_keys(hctx, oracle, monkeypatch, k, log2cap):
     ctr.close()
 
 
+def _random_reads(seed, n, L=150):
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    return [alpha[rng.integers(0, 4, size=L)].tobytes() for _ in range(n)]
+
+
+@pytest.mark.parametrize("k,log2cap,load", [(31, 14, 0.5), (31, 14, 0.8), (31, 15, 0.93), (31, 16, 0.92), (15, 15, 0.9),
+                                            (21, 17, 0.97)])
+def test_ctr_range_build_high_load(hctx, oracle, monkeypatch, k, log2cap, load):
+    """the range build places keys where range-circular linear probing would (kt_table.hpp) at any load factor:
+    the export is the oracle's table, every key is found again by the lookups of cov and by the probing insert path
+    (entries that wrapped round the end of their range included), and the size counter follows"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    cap = 1 << log2cap
+    n = int(load * cap / (150 - k + 1)) + 1
+    seqs = _random_reads(1000 + k + log2cap, n)
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    ctr = device.Counter(hctx, k, cap)
+    assert ctr.capacity() == cap and abs(len(wk) / cap - load) < 0.03
+    ctr.add_reads_host(bases, offsets)                      # range build
+    assert ctr.size() == len(wk)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    oc = oracle.Counter(1)
+    oc.add_reads(bases, offsets, k)
+    probe = _random_reads(77, 50) + seqs[::7]              # absent k-mers and present ones
+    pb, po = device.to_csr(probe)
+    want = oc.cov_batch(pb, po, k, 1, 8, True)
+    got = ctr.cov_host(pb, po, 1, 8)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    monkeypatch.setenv("KT_BULK", "0")                      # the probing path on top of the built ranges
+    ctr.add_reads_host(bases, offsets)
+    assert ctr.size() == len(wk)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+    ctr.close()
+
+
+@pytest.mark.parametrize("k,log2cap", [(31, 17), (15, 16), (21, 18)])
+def test_ctr_range_rebuild_merges_batches(hctx, oracle, monkeypatch, k, log2cap):
+    """batches after the first are merged by rebuilding every range from what it holds + the new keys (no per-k-mer
+    atomics): four overlapping batches, a batch through the probing path in between, against the oracle"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    monkeypatch.setenv("KT_BULK_MERGE_DIV", "1000000000")   # every batch is worth a rebuild
+    monkeypatch.setenv("KT_BULK_VERBOSE", "1")
+    cap = 1 << log2cap
+    per = int(0.17 * cap / (150 - k + 1))
+    seqs = (ragged_reads(31 + k, 200, max_len=100 if log2cap < 18 else 400, special=log2cap >= 18)
+            + _random_reads(5 + k, 4 * per) + [b"A" * 2000, b"ACGT" * 500])
+    batches = [seqs[i::4] + seqs[:50] for i in range(4)]    # the first 50 reads are in every batch
+    oc = oracle.Counter(3)
+    ctr = device.Counter(hctx, k, cap)
+    for i, b in enumerate(batches):
+        bb, bo = device.to_csr(b)
+        oc.add_reads(bb, bo, k)
+        if i == 2:
+            monkeypatch.setenv("KT_BULK", "0")              # one batch through the atomics, then rebuilds again
+        ctr.add_reads_host(bb, bo)
+        monkeypatch.setenv("KT_BULK", "1")
+        wk, wc = oc.export()
+        assert ctr.size() == len(wk)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    assert 0.6 < len(wk) / cap < 0.9
+    # routed keys (no counts) merge the same way
+    f, r, _ = hctx.kmers_host(*device.to_csr(batches[0]), k)
+    canon = np.minimum(f, r)
+    ctr.add_pairs_host(canon, None)
+    oc.add_pairs(canon, np.ones(len(canon), np.uint32))
+    wk, wc = oc.export()
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    ctr.close()
+
+
+def test_ctr_range_build_full_table_is_loud(hctx, monkeypatch):
+    """more distinct k-mers than slots: the range build must report KT_ERR_FULL, not drop keys or hang"""
+    from kmertools_amd import device, _lib
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    seqs = _random_reads(3, 300)                             # 36 000 distinct 31-mers into 16 384 slots
+    bases, offsets = device.to_csr(seqs)
+    ctr = device.Counter(hctx, 31, 1 << 14)
+    ctr.add_reads_host(bases, offsets)
+    with pytest.raises(_lib.KmertoolsError) as e:
+        ctr.size()
+    assert e.value.code == _lib.KT_ERR_FULL
+    ctr.close()
+
+
 def test_ctr_bulk_overfull_ranges_spill(hctx, oracle, monkeypatch):
-    """load factor ~0.85: many keys run off the end of their 4096-slot range -> spill path"""
+    """load factor ~0.85: keys run past the end of their range and wrap to its front"""
     from kmertools_amd import device
     monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
     rng = np.random.default_rng(11)
