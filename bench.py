@@ -396,7 +396,8 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
             cap = 1 << args.cap_log2
         if args.cap_slots:
             cap = int(args.cap_slots)
-        counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else env.dist.group.WORLD)
+        counter = ktdist.ShardedCounter(ctx, k, cap, group=None if world == 1 else env.dist.group.WORLD,
+                                        max_batch_bases=n * L)
         with_export = not args.no_export
         xk = torch.empty(max_distinct if with_export else 1, dtype=torch.int64, device="cuda")
         xc = torch.empty(max_distinct if with_export else 1, dtype=torch.int32, device="cuda")
@@ -404,14 +405,16 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         state = {"distinct": 0}
         dominant = ("ctr k=%d step: clear + bulk table build (scatter1p, part2, build kernels)%s"
                     % (k, " + size + export (table_export_kernel)" if with_export else ""))
-        parallelism = "hash-prefix key ownership, RCCL all-to-all of routed k-mers"
+        parallelism = ("hash-prefix key ownership: route -> grouped ncclSend/ncclRecv of per-owner regions (librccl, "
+                       "called from the C ABI) -> partition + range build, pipelined in slices")
         finish = counter.close
         if with_export:
             alg_extra = lambda: state["distinct"] * 12
 
         def step():
             counter.clear()
-            counter.add_reads(bases, offsets, n)
+            counter.add_reads(bases, offsets, n)   # N > 1: route + exchange + count, in slices (kt_sharded_add_reads)
+            counter.finalize()
             if with_export:
                 d = counter.size_local()
                 got = counter.table.export(xk, xc, max_distinct)
@@ -450,6 +453,8 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     if wl["kind"] == "ctr":
         extra["distinct_rank0"] = state["distinct"] if not args.no_export else counter.size_local()
         extra["table_slots_rank0"] = counter.table.capacity()
+        if world > 1:
+            extra["exchanged_bytes_per_step_rank0"] = counter.sharded.exchanged_bytes() // (steps + warmup)
     res = {
         "value": round(value, 3),
         "unit": "Gbases/s",

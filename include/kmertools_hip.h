@@ -122,7 +122,9 @@ int kt_kmers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_
  * norm: divide every bin by max(1, total), total = total_step * (#k-mers of the read).
  * total_step: 1 (CLI crate, oligo.rs:248,251) or 2 (python raw mode, pybindings
  * oligo.rs:61).  KT_F64 results are bit-identical to the reference (integer counts,
- * one IEEE division).  3 <= k <= 7 (the CLI range, kmertools/src/args.rs:85). */
+ * one IEEE division).  1 <= k <= 12: 3..7 (the CLI range, kmertools/src/args.rs:85) is the LDS kernel; the Python
+ * class takes any k (pybindings/src/oligo.rs:22-31), so the other values count in global memory - correct, not
+ * fast - up to the k whose 4^k-entry rank map the reference itself could still allocate comfortably. */
 int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                    int k, int count_min, int norm, int total_step, int out_dtype, void *out,
                    int mem);
@@ -213,6 +215,51 @@ int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, u
  * (upper bound).  owner_counts follows `mem`.  1 <= n_owners <= 64. */
 int kt_ctr_route(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                  int k, int n_owners, uint64_t *keys_out, uint64_t *owner_counts, int mem);
+
+/* ---- one table sharded over the GPUs of a node (hash-prefix ownership) -------------------------------------------
+ * replaces: the `n_parts` partitioning of counter/src/lib.rs:100,127,243-247 and the per-partition merge of
+ * :188-231 - the partitions are GPUs.  Rank o (one process or thread, one kt_ctx, one GPU) owns every canonical k-mer
+ * with kt_owner_of(kmer, n_ranks) == o.  kt_sharded_add_reads and kt_sharded_finalize are COLLECTIVE: every rank
+ * calls them the same number of times (a rank without reads passes n_reads = 0).  Each rank routes the canonical
+ * k-mers of its reads into per-owner regions, exchanges the regions with every peer (grouped ncclSend / ncclRecv
+ * from librccl over xGMI, or the caller's host all-to-all), and counts what it received into its own shard with the
+ * same partition + range build as a single-GPU table; the batch is cut into slices so that routing, the exchange
+ * and the counting overlap.  Results stay sharded: the union of the ranks' exports is the answer (the reference's
+ * output order is unspecified anyway).  With n_ranks == 1 everything degenerates to kt_ctr_add_reads. */
+typedef struct kt_sharded kt_sharded;
+
+/* 128-byte RCCL unique id (ncclGetUniqueId): rank 0 makes it, the caller hands it to the other ranks (any channel:
+ * MPI, a file, torch.distributed's store) */
+int kt_rccl_unique_id(uint8_t *id128);
+
+/* capacity_slots: slots of THIS rank's shard (kt_ctr_create); max_batch_bases: the largest batch any rank will pass
+ * to kt_sharded_add_reads - it fixes the size of the exchanged regions, so it must be the same on every rank. */
+int kt_sharded_create_rccl(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t max_batch_bases, int n_ranks, int rank,
+                           const uint8_t *id128, kt_sharded **out);
+
+/* host transport: `fn(user, send, recv, bytes_per_rank)` must move block p of `send` (host memory, n_ranks blocks of
+ * bytes_per_rank) to rank p and fill block p of `recv` with what rank p sent to this rank; returns 0 on success.
+ * The library stages the device regions through page-locked host memory around the call. */
+typedef int (*kt_alltoall_fn)(void *user, const void *send, void *recv, uint64_t bytes_per_rank);
+int kt_sharded_create_host(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t max_batch_bases, int n_ranks, int rank,
+                           kt_alltoall_fn fn, void *user, kt_sharded **out);
+int kt_sharded_destroy(kt_sharded *s);
+int kt_sharded_clear(kt_sharded *s);
+
+/* collective.  replaces: count_chunk's loop for one chunk of this rank's records, counter/src/lib.rs:119-131 */
+int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int mem);
+
+/* collective; call once after the last kt_sharded_add_reads and before reading the shard: delivers the k-mers that
+ * did not fit their exchange region (batches dominated by few k-mers).  replaces: merge, counter/src/lib.rs:172-234 */
+int kt_sharded_finalize(kt_sharded *s);
+
+/* this rank's shard, an ordinary table: kt_ctr_size / kt_ctr_export / kt_cov_batch work on it (owned by `s`) */
+int kt_sharded_table(kt_sharded *s, kt_ctr **table);
+
+/* bytes this rank has sent to other ranks so far; size of one exchanged region (host helper: lets a caller size
+ * its transport buffers) */
+int kt_sharded_exchanged_bytes(kt_sharded *s, uint64_t *bytes);
+uint64_t kt_sharded_message_bytes(uint64_t max_batch_bases, int n_ranks, int n_slices);
 
 /* owner rank of a canonical k-mer among n_owners (host helper, same function the
  * device uses): high bits of a 64-bit mix, independent of the table's slot bits. */

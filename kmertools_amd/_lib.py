@@ -51,8 +51,21 @@ SYMBOLS = {
     "kt_cov_batch": (_i, [_vp, _vp, _vp, _u64, _u64, _u64, _i, _i, _vp, _i]),
     "kt_ctr_route": (_i, [_vp, _vp, _vp, _u64, _i, _i, _vp, _vp, _i]),
     "kt_owner_of": (_u32, [_u64, _u32]),
+    "kt_rccl_unique_id": (_i, [_vp]),
+    "kt_sharded_create_rccl": (_i, [_vp, _i, _u64, _u64, _i, _i, _vp, C.POINTER(_vp)]),
+    "kt_sharded_create_host": (_i, [_vp, _i, _u64, _u64, _i, _i, _vp, _vp, C.POINTER(_vp)]),
+    "kt_sharded_destroy": (_i, [_vp]),
+    "kt_sharded_clear": (_i, [_vp]),
+    "kt_sharded_add_reads": (_i, [_vp, _vp, _vp, _u64, _i]),
+    "kt_sharded_finalize": (_i, [_vp]),
+    "kt_sharded_table": (_i, [_vp, C.POINTER(_vp)]),
+    "kt_sharded_exchanged_bytes": (_i, [_vp, C.POINTER(_u64)]),
+    "kt_sharded_message_bytes": (_u64, [_u64, _i, _i]),
     "kt_synth_reads": (_i, [_vp, _u64, _u64, _u64, _u32, _i, _u64, _vp, _vp]),
 }
+
+
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)  # kt_alltoall_fn
 
 
 class KmertoolsError(RuntimeError):

@@ -34,6 +34,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <new>
+#include <vector>
+
 #include "kt_segment.hpp"
 #include "kt_table.hpp"
 
@@ -85,6 +88,7 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
     uint64_t *gcur;     // [B1] paged level 1: keys of bucket room handed out so far (page allocator)
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
+    uint32_t *wcur;     // [G][B1] paged level 1: every workgroup's position in its current page of every bucket
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -141,37 +145,46 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_
 // ---- where the level-1 passes get their keys ---------------------------------------------------------------
 // A source hands every workgroup "units" of up to 8192 canonical k-mers, 32 per thread in registers
 // (bit j of `ok` = keys[j] is a k-mer).
-struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segment (kt_segment.hpp)
+struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segment (kt_segment.hpp), segments [seg_lo, seg_hi)
     SegArgs a;
-    __device__ uint64_t n_units() const { return a.n_seg; }
+    uint64_t seg_lo, seg_hi;
+    __device__ uint64_t n_units() const { return seg_hi - seg_lo; }
     __device__ void collect(uint64_t g, SegShared &sm, uint64_t (&keys)[ktseg::PER_THREAD], uint32_t &ok) const {
-        ktseg::collect_kmers(a, g, sm, keys, ok);
+        ktseg::collect_kmers(a, seg_lo + g, sm, keys, ok);
     }
     template <class Sink>
     __device__ void for_each(uint64_t g, SegShared &sm, Sink &&sink) const {  // rolling walk: few registers
-        ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) { sink(f < r ? f : r); });
+        ktseg::for_each_kmer(a, seg_lo + g, sm, [&](uint64_t f, uint64_t r, uint64_t) { sink(f < r ? f : r); });
     }
 };
 struct KeysSource {  // canonical k-mers that are already an array (routed here from other GPUs): unit = 8192 keys
     const uint64_t *keys;
     uint64_t n;
-    __device__ uint64_t n_units() const { return (n + ktseg::SEG - 1) / ktseg::SEG; }
+    const uint64_t *n_dev;  // when set: the array holds min(*n_dev, n) keys (the count header of an exchanged region)
+    __device__ uint64_t count() const {
+        if (!n_dev) return n;
+        const uint64_t c = *n_dev;
+        return c < n ? c : n;
+    }
+    __device__ uint64_t n_units() const { return (count() + ktseg::SEG - 1) / ktseg::SEG; }
     __device__ void collect(uint64_t g, SegShared &, uint64_t (&out)[ktseg::PER_THREAD], uint32_t &ok) const {
+        const uint64_t cnt = count();
         ok = 0;
 #pragma unroll
         for (uint32_t j = 0; j < ktseg::PER_THREAD; j++) {  // consecutive lanes read consecutive keys
             const uint64_t i = g * ktseg::SEG + (uint64_t)j * BLOCK + threadIdx.x;
-            const uint64_t key = i < n ? keys[i] : KT_EMPTY_KEY;
+            const uint64_t key = i < cnt ? keys[i] : KT_EMPTY_KEY;
             out[j] = key;
             ok |= (key != KT_EMPTY_KEY ? 1u : 0u) << j;
         }
     }
     template <class Sink>
     __device__ void for_each(uint64_t g, SegShared &, Sink &&sink) const {
+        const uint64_t cnt = count();
 #pragma unroll 8
         for (uint32_t j = 0; j < ktseg::PER_THREAD; j++) {
             const uint64_t i = g * ktseg::SEG + (uint64_t)j * BLOCK + threadIdx.x;
-            const uint64_t key = i < n ? keys[i] : KT_EMPTY_KEY;
+            const uint64_t key = i < cnt ? keys[i] : KT_EMPTY_KEY;
             if (key != KT_EMPTY_KEY) sink(key);
         }
     }
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(BLOCK) void hist1_kernel(Source src, Plan p, uint32
         src.for_each(g, sm, [&](uint64_t key) { atomicAdd(&cnt[digit1(key, p)], 1u); });
     }
     ktd::lds_barrier();
-    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) H[(uint64_t)blockIdx.x * p.B1 + i] = cnt[i];
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) H[(uint64_t)blockIdx.x * p.B1 + i] += cnt[i];  // (a job may have several sources)
 }
 
 // ---- scan1: O[g][d] = (k-mers in buckets < d) + (k-mers of workgroups < g in bucket d) ------------
@@ -244,7 +257,7 @@ static_assert(sizeof(Scatter1Shared<uint64_t>) <= 80 * 1024 && sizeof(Scatter1Sh
               "two scatter1 workgroups per CU");
 
 template <class Source, class K>
-__global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, const uint64_t *__restrict__ O,
+__global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, uint64_t *__restrict__ O,
                                                          K *__restrict__ keys1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Scatter1Shared<K> &sm = *reinterpret_cast<Scatter1Shared<K> *>(smem_raw);
@@ -288,6 +301,8 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, con
             ktd::lds_barrier();
         }
     }
+    // the next source of the job carries on where this one stopped
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) O[(uint64_t)blockIdx.x * p.B1 + i] = sm.cursor[i];
 }
 
 // ---- scatter1, paged: no hist1 --------------------------------------------------------------------------
@@ -326,13 +341,16 @@ static_assert(sizeof(Scatter1PShared<uint64_t>) <= 80 * 1024 && sizeof(Scatter1P
 
 template <class Source, class K>
 __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, uint64_t *__restrict__ gcur,
-                                                          uint32_t *__restrict__ ovf, K *__restrict__ keys1) {
+                                                          uint32_t *__restrict__ ovf, uint32_t *__restrict__ wcur,
+                                                          K *__restrict__ keys1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Scatter1PShared<K> &sm = *reinterpret_cast<Scatter1PShared<K> *>(smem_raw);
     constexpr int ROUNDS = ktseg::SEG / round_keys<K>(), PERR = ktseg::PER_THREAD / ROUNDS;
     constexpr uint32_t PAGE = page_keys<K>();
     constexpr int OWN = MAX_B1 / BLOCK;  // buckets a thread looks after: d = tid + it * BLOCK
-    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cur[i] = 0;
+    // where this workgroup stands in its current page of every bucket: kept in global memory between the launches
+    // of one job (a job has one launch per source), so a partly used page is carried on instead of being abandoned
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cur[i] = wcur[(uint64_t)blockIdx.x * p.B1 + i];
     if (threadIdx.x == 0) sm.ovf = 0;
     const uint64_t n_units = src.n_units();
     bool stop = false;
@@ -413,10 +431,16 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
     }
     ktd::lds_barrier();
     if (sm.ovf) return;
-    // the unused tail of every bucket's last page
+    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) wcur[(uint64_t)blockIdx.x * p.B1 + i] = sm.cur[i];
+}
+
+// after the last source of a job: the unused tail of every workgroup's last page of every bucket gets the empty key
+template <class K>
+__global__ __launch_bounds__(BLOCK) void page_tails_kernel(Plan p, const uint32_t *__restrict__ wcur, K *__restrict__ keys1) {
+    constexpr uint32_t PAGE = page_keys<K>();
     for (uint32_t idx = threadIdx.x; idx < p.B1 * PAGE; idx += BLOCK) {
         const uint32_t d = idx / PAGE, q = idx % PAGE;
-        const uint32_t cur = sm.cur[d];
+        const uint32_t cur = wcur[(uint64_t)blockIdx.x * p.B1 + d];
         if (q < ((0u - cur) & (PAGE - 1u))) keys1[(uint64_t)d * p.cap1 + cur + q] = empty_of<K>();
     }
 }
@@ -819,19 +843,155 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
     return strtoull(s, nullptr, 10);
 }
 
-// plans the partition, carves the buffers and runs hist1 .. build for `n_units` units of `src` that hold at
-// most `max_keys` k-mers in total
-template <class Source, class K>
-int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t max_keys, int *done) {
-    *done = 0;
+}  // namespace
+
+// ---- host side: a job = plan + buffers + level 1 over one or more sources + level 2 + range build ----------------
+struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be redone with exact offsets)
+    bool reads;
+    ReadsSource rs;
+    KeysSource ks;
+    uint64_t n_units;  // upper bound (device-side counts may make it smaller)
+};
+
+struct kt_bulk_job {
+    Plan p{};
+    Meta m{};
+    bool narrow = false;  // 32-bit keys through the partition passes (k <= 16)
+    bool paged = false, merge = false, open = false;
+    uint64_t max_keys = 0, added_bound = 0;
+    std::vector<SourceRec> srcs;
+};
+
+void kt_bulk_job_free(kt_bulk_job *job) { delete job; }
+
+namespace {
+
+template <class K>
+int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
     kt_ctx *ctx = ctr->ctx;
-    const bool merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
+    K *keys1 = (K *)ctr->b_keys1.p;
+    if (r.reads) {
+        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<ReadsSource, K>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
+        hipLaunchKernelGGL((scatter1p_kernel<ReadsSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>),
+                           ctx->stream, r.rs, j.p, j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+    } else {
+        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<KeysSource, K>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
+        hipLaunchKernelGGL((scatter1p_kernel<KeysSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>),
+                           ctx->stream, r.ks, j.p, j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+    }
+    KT_HIP(hipGetLastError());
+    return KT_OK;
+}
+
+template <class K>
+int level1_exact(kt_ctr *ctr, kt_bulk_job &j) {  // hist1 over every source, scan1, scatter1 over every source
+    kt_ctx *ctx = ctr->ctx;
+    K *keys1 = (K *)ctr->b_keys1.p;
+    KT_HIP(hipMemsetAsync(j.m.H, 0, (size_t)j.p.G * j.p.B1 * 4, ctx->stream));
+    for (const SourceRec &r : j.srcs) {
+        if (r.reads) hipLaunchKernelGGL(hist1_kernel<ReadsSource>, dim3(j.p.G), dim3(BLOCK), 0, ctx->stream, r.rs, j.p, j.m.H);
+        else hipLaunchKernelGGL(hist1_kernel<KeysSource>, dim3(j.p.G), dim3(BLOCK), 0, ctx->stream, r.ks, j.p, j.m.H);
+    }
+    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, j.m.H, j.p, j.m.O, j.m.bstart);
+    for (const SourceRec &r : j.srcs) {
+        if (r.reads) {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<ReadsSource, K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
+            hipLaunchKernelGGL((scatter1_kernel<ReadsSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>),
+                               ctx->stream, r.rs, j.p, j.m.O, keys1);
+        } else {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<KeysSource, K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
+            hipLaunchKernelGGL((scatter1_kernel<KeysSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>),
+                               ctx->stream, r.ks, j.p, j.m.O, keys1);
+        }
+    }
+    KT_HIP(hipGetLastError());
+    return KT_OK;
+}
+
+template <class K>
+int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
+    kt_ctx *ctx = ctr->ctx;
+    Plan &p = j.p;
+    Meta &m = j.m;
+    K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
+    if (j.paged) {
+        hipLaunchKernelGGL(page_tails_kernel<K>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, p, m.wcur, keys1);
+        // the one host round trip of the build: did every bucket fit its region?
+        uint32_t ovf = 0;
+        KT_HIP(hipMemcpyAsync(&ovf, m.ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        if (ovf) {  // skewed batch: exact offsets after all, and no more paged attempts on this table
+            j.paged = false;
+            ctr->paged_failed = true;
+            p.cap1 = 0;
+            p.cap2 = 0;
+            if (j.added_bound > ctr->b_keys1.cap / sizeof(K)) {  // (the paged room is always the larger)
+                return kt::fail(KT_ERR_NOMEM, "bulk build: key buffers too small for the exact layout");
+            }
+            if (int rc = level1_exact<K>(ctr, j)) return rc;
+        }
+    }
+    const size_t part2_lds = Part2Shared<K>::bytes(p.B2);
+    auto part2 = p.cap2 ? part2_kernel<K, true> : part2_kernel<K, false>;
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)part2_lds));
+    hipLaunchKernelGGL(part2, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur, p,
+                       keys2, m.fstart, m.fend);
+    const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
+    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 12);  // persistent workgroups; three are resident per CU
+    if (gb > n_fine) gb = n_fine;
+    const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
+    auto build = j.merge ? build_kernel<K, true> : build_kernel<K, false>;
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)build_lds));
+    hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend,
+                       p, (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_counts, m.spill_cap, ctr->flags,
+                       ctr->distinct);
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+    hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
+                       m.spill_counts, m.spill_cap, t, ctr->distinct);
+    KT_HIP(hipGetLastError());
+    if (env_u64("KT_BULK_VERBOSE", 0)) {
+        uint64_t spilled = 0;
+        KT_HIP(hipMemcpyAsync(&spilled, m.spill_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s %s spilled=%llu\n", ctr->k,
+                (unsigned long long)j.max_keys, j.paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact",
+                j.merge ? "merge" : "build", (unsigned long long)spilled);
+    }
+    return KT_OK;
+}
+
+}  // namespace
+
+// Plans the partition of at most `max_keys` k-mers into the table's ranges and reserves the buffers.  *eligible = 0:
+// the table shape or the batch does not suit the bulk path (or HBM is short) and the caller uses the probing path.
+int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
+    *eligible = 0;
+    kt_ctx *ctx = ctr->ctx;
+    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
+    if (max_keys < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
+    if (!ctr->job) ctr->job = new (std::nothrow) kt_bulk_job();
+    if (!ctr->job) return kt::fail(KT_ERR_NOMEM, "bulk build: host alloc");
+    kt_bulk_job &j = *ctr->job;
+    j.open = false;
+    j.srcs.clear();
+    j.merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
+    j.narrow = ctr->k <= 16 && env_u64("KT_BULK_NARROW", 1);
+    j.max_keys = max_keys;
+    j.added_bound = 0;
+    const size_t ksz = j.narrow ? 4 : 8;
     Plan p{};
     p.n = 64 - ctr->shift;
     p.m8 = ctr->m8;
     p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
-    if (merge && max_keys < ctr->cap / env_u64("KT_BULK_MERGE_DIV", 8)) return KT_OK;  // a rebuild moves the whole table: small batches are cheaper through the atomics
+    // a rebuild moves the whole table: small batches are cheaper through the atomics
+    if (j.merge && max_keys < ctr->cap / env_u64("KT_BULK_MERGE_DIV", 8)) return KT_OK;
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
     if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
@@ -839,14 +999,12 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     if (p.b2 > 11) return KT_OK;
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
-    uint64_t G = (uint64_t)ctx->n_cu * 2;
-    if (G > n_units) G = n_units;
-    p.G = (uint32_t)G;
+    p.G = (uint32_t)ctx->n_cu * 2;  // persistent level-1 workgroups (the same for every source of the job)
     // paged level 1 (no hist1): room per bucket = its share of the most keys there can be + 1/8 + a page per
     // workgroup (every workgroup leaves at most one partly used page per bucket)
     bool paged = env_u64("KT_BULK_PAGED", 1) != 0 && !ctr->paged_failed;
-    const uint64_t PAGE = page_keys<K>();
-    uint64_t cap1 = (max_keys / p.B1 + max_keys / p.B1 / 8 + (G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
+    const uint64_t PAGE = KT_PAGE_BYTES / ksz;
+    uint64_t cap1 = (max_keys / p.B1 + max_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
     if (cap1 >= (1ull << 32)) paged = false;
     uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
 
@@ -856,6 +1014,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     size_t meta = 0;
     const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_wc = meta;      meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_bs = meta;      meta += ((size_t)(p.B1 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fs = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fe = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
@@ -865,7 +1024,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
     const size_t off_sc = meta;      meta += (spill_cap * 4 + 255) & ~(size_t)255;
     auto reserve_all = [&]() {
-        return ctr->b_keys1.reserve(key_room * sizeof(K)) == KT_OK && ctr->b_keys2.reserve(key_room * sizeof(K)) == KT_OK &&
+        return ctr->b_keys1.reserve(key_room * ksz) == KT_OK && ctr->b_keys2.reserve(key_room * ksz) == KT_OK &&
                ctr->b_meta.reserve(meta) == KT_OK;
     };
     bool have = reserve_all();
@@ -886,6 +1045,7 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     Meta m{};
     m.H = (uint32_t *)(mb + off_H);
     m.O = (uint64_t *)(mb + off_O);
+    m.wcur = (uint32_t *)(mb + off_wc);
     m.bstart = (uint64_t *)(mb + off_bs);
     m.fstart = (uint64_t *)(mb + off_fs);
     m.fend = (uint64_t *)(mb + off_fe);
@@ -895,107 +1055,104 @@ int bulk_build_typed(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t 
     m.spill_keys = (uint64_t *)(mb + off_sk);
     m.spill_counts = (uint32_t *)(mb + off_sc);
     m.spill_cap = spill_cap;
-    K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
-
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
     if (paged) {
         p.cap1 = cap1;
         p.cap2 = env_u64("KT_BULK_FIXED2", 1) ? cap1 / p.B2 : 0;
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
-        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<Source, K>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
-        hipLaunchKernelGGL((scatter1p_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>), ctx->stream,
-                           src, p, m.gcur, m.ovf, keys1);
-        KT_HIP(hipGetLastError());
-        // the one host round trip of the build: did every bucket fit its region?
-        uint32_t ovf = 0;
-        KT_HIP(hipMemcpyAsync(&ovf, m.ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
-        KT_HIP(hipStreamSynchronize(ctx->stream));
-        if (ovf) {  // skewed batch: exact offsets after all, and no more paged attempts on this table
-            paged = false;
-            ctr->paged_failed = true;
-            p.cap1 = 0;
-            p.cap2 = 0;
-        }
+        KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)p.G * p.B1 * 4, ctx->stream));
     }
-    if (!paged) {
-        hipLaunchKernelGGL(hist1_kernel<Source>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, src, p, m.H);
-        hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.H, p, m.O, m.bstart);
-        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<Source, K>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
-        hipLaunchKernelGGL((scatter1_kernel<Source, K>), dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>), ctx->stream,
-                           src, p, m.O, keys1);
-    }
-    const size_t part2_lds = Part2Shared<K>::bytes(p.B2);
-    auto part2 = p.cap2 ? part2_kernel<K, true> : part2_kernel<K, false>;
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)part2_lds));
-    hipLaunchKernelGGL(part2, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur, p,
-                       keys2, m.fstart, m.fend);
-    const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
-    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 12);  // persistent workgroups; three are resident per CU
-    if (gb > n_fine) gb = n_fine;
-    const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
-    auto build = merge ? build_kernel<K, true> : build_kernel<K, false>;
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)build_lds));
-    hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend,
-                       p, (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_counts, m.spill_cap, ctr->flags,
-                       ctr->distinct);
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
-    hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
-                       m.spill_counts, m.spill_cap, t, ctr->distinct);
-    KT_HIP(hipGetLastError());
-    if (env_u64("KT_BULK_VERBOSE", 0)) {
-        uint64_t spilled = 0;
-        KT_HIP(hipMemcpyAsync(&spilled, m.spill_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-        KT_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s %s spilled=%llu\n", ctr->k, (unsigned long long)max_keys,
-                paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact", merge ? "merge" : "build",
-                (unsigned long long)spilled);
-    }
-    *done = 1;
+    j.p = p;
+    j.m = m;
+    j.paged = paged;
+    j.open = true;
+    *eligible = 1;
     return KT_OK;
 }
 
-template <class Source>
-int bulk_build_from(kt_ctr *ctr, const Source &src, uint64_t n_units, uint64_t max_keys, int *done) {
-    if (ctr->k <= 16 && env_u64("KT_BULK_NARROW", 1))
-        return bulk_build_typed<Source, uint32_t>(ctr, src, n_units, max_keys, done);
-    return bulk_build_typed<Source, uint64_t>(ctr, src, n_units, max_keys, done);
+static int job_add(kt_ctr *ctr, const SourceRec &r, uint64_t bound) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->open) return kt::fail(KT_ERR_ARG, "bulk build: no open job");
+    if (job->added_bound + bound > job->max_keys) return kt::fail(KT_ERR_ARG, "bulk build: more keys than the job was planned for");
+    job->added_bound += bound;
+    job->srcs.push_back(r);
+    if (!job->paged) return KT_OK;  // exact offsets: level 1 runs in finish, over all the sources
+    return job->narrow ? level1_paged<uint32_t>(ctr, *job, r) : level1_paged<uint64_t>(ctr, *job, r);
 }
 
-}  // namespace
+// level 1 over the k-mers that start in segments [seg_lo, seg_hi) of a read batch (seg_first: ktseg::seg_index_kernel)
+int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
+                      uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi) {
+    SourceRec r{};
+    r.reads = true;
+    r.rs.a.bases = d_bases;
+    r.rs.a.offsets = d_offsets;
+    r.rs.a.seg_first = seg_first;
+    r.rs.a.n_reads = n_reads;
+    r.rs.a.n_seg = n_seg;
+    r.rs.a.k = (uint32_t)ctr->k;
+    r.rs.seg_lo = seg_lo;
+    r.rs.seg_hi = seg_hi;
+    r.n_units = seg_hi - seg_lo;
+    return job_add(ctr, r, (seg_hi - seg_lo) * ktseg::SEG);  // at most one k-mer per base
+}
+
+// level 1 over an array of canonical k-mers (KT_EMPTY_KEY entries are skipped); d_n (may be null) = device-side count
+int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n) {
+    SourceRec r{};
+    r.reads = false;
+    r.ks = KeysSource{d_keys, n_keys, d_n};
+    r.n_units = (n_keys + ktseg::SEG - 1) / ktseg::SEG;
+    return job_add(ctr, r, n_keys);
+}
+
+// level 2 + the range builds; the sources must still be readable (a skewed batch is redone from them)
+int kt_bulk_finish(kt_ctr *ctr) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->open) return kt::fail(KT_ERR_ARG, "bulk build: no open job");
+    job->open = false;
+    if (!job->paged) {
+        if (int rc = job->narrow ? level1_exact<uint32_t>(ctr, *job) : level1_exact<uint64_t>(ctr, *job)) return rc;
+    }
+    const int rc = job->narrow ? finish_typed<uint32_t>(ctr, *job) : finish_typed<uint64_t>(ctr, *job);
+    job->srcs.clear();
+    if (rc == KT_OK) {
+        ctr->empty = false;
+        ctr->needs_clear = false;  // every slot was written
+    }
+    return rc;
+}
 
 int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                   uint64_t total_bases, int *done) {
     *done = 0;
     kt_ctx *ctx = ctr->ctx;
-    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
-    if (total_bases < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
+    int eligible = 0;
     const uint64_t n_seg = (total_bases + ktseg::SEG - 1) / ktseg::SEG;
+    if (total_bases < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
+    if (int rc = kt_bulk_begin(ctr, n_seg * ktseg::SEG, &eligible)) return rc;  // at most one k-mer per base
+    if (!eligible) return KT_OK;
     // the segment index (seg_first) lives in ctx scratch; same helper kernel as the other paths
     if (int rc = ctx->s_aux0.reserve((n_seg + 2) * sizeof(uint64_t))) return rc;
     uint64_t *seg_first = (uint64_t *)ctx->s_aux0.p;
     hipLaunchKernelGGL(ktseg::seg_index_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_offsets, n_reads, seg_first, n_seg);
-    ReadsSource src;
-    src.a.bases = d_bases;
-    src.a.offsets = d_offsets;
-    src.a.seg_first = seg_first;
-    src.a.n_reads = n_reads;
-    src.a.n_seg = n_seg;
-    src.a.k = (uint32_t)ctr->k;
-    return bulk_build_from(ctr, src, n_seg, total_bases, done);  // at most one k-mer per base
+    if (int rc = kt_bulk_add_reads(ctr, d_bases, d_offsets, seg_first, n_reads, n_seg, 0, n_seg)) return rc;
+    if (int rc = kt_bulk_finish(ctr)) return rc;
+    *done = 1;
+    return KT_OK;
 }
 
 // same construction from canonical k-mers that already are an array (KT_EMPTY_KEY entries are skipped):
-// the k-mers another GPU routed here.  The table must be empty; counts are one per array entry.
+// the k-mers another GPU routed here.  Counts are one per array entry.
 int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int *done) {
     *done = 0;
-    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
-    if (n_keys < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;
-    KeysSource src{d_keys, n_keys};
-    return bulk_build_from(ctr, src, (n_keys + ktseg::SEG - 1) / ktseg::SEG, n_keys, done);
+    int eligible = 0;
+    if (int rc = kt_bulk_begin(ctr, n_keys, &eligible)) return rc;
+    if (!eligible) return KT_OK;
+    if (int rc = kt_bulk_add_keys(ctr, d_keys, n_keys, nullptr)) return rc;
+    if (int rc = kt_bulk_finish(ctr)) return rc;
+    *done = 1;
+    return KT_OK;
 }

@@ -65,6 +65,22 @@ __global__ __launch_bounds__(BLOCK) void add_pairs_kernel(const uint64_t *__rest
     publish_fresh(fresh, distinct);
 }
 
+// the same for an array whose length is a device-side count (a region of the sharded counter's exchange)
+__global__ __launch_bounds__(BLOCK) void add_keys_counted_kernel(const uint64_t *__restrict__ keys, uint64_t cap,
+                                                                 const uint64_t *__restrict__ n_dev, TableRef t,
+                                                                 uint64_t *__restrict__ distinct) {
+    const uint64_t n = *n_dev < cap ? *n_dev : cap;
+    uint32_t fresh = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t key = keys[i];
+        if (key == KT_EMPTY_KEY) continue;
+        const uint32_t st = table_add(t, key, 1u);
+        if (st == 0u) atomicOr(t.flags, 1u);
+        fresh += st == 2u;
+    }
+    publish_fresh(fresh, distinct);
+}
+
 __global__ __launch_bounds__(BLOCK) void table_clear_kernel(Slot *__restrict__ slots, uint64_t cap) {
     const uint4 empty = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK)
@@ -320,6 +336,7 @@ int kt_ctr_destroy(kt_ctr *ctr) {
     ctr->b_keys1.release();
     ctr->b_keys2.release();
     ctr->b_meta.release();
+    kt_bulk_job_free(ctr->job);
     delete ctr;
     return KT_OK;
 }
@@ -372,8 +389,6 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
         int done = 0;
         if (int rc = kt_bulk_build(ctr, d_bases, d_offsets, n_reads, total, &done)) return rc;
         if (done) {
-            ctr->empty = false;
-            ctr->needs_clear = false;  // every slot was written
             if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
             return KT_OK;
         }
@@ -413,8 +428,6 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
         int done = 0;
         if (int rc = kt_bulk_build_keys(ctr, d_keys, n, &done)) return rc;
         if (done) {
-            ctr->empty = false;
-            ctr->needs_clear = false;  // every slot was written
             if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
             return KT_OK;
         }
@@ -428,6 +441,24 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
     return KT_OK;
 }
+
+}  // extern "C"
+
+// table[keys[i]] += 1 for i < min(*d_n, cap_keys), through the probing path (kt_shard.hip, when the bulk build
+// does not apply)
+int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_keys, const uint64_t *d_n) {
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    ctr->empty = false;
+    if (int rc = ensure_cleared(ctr)) return rc;
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+    hipLaunchKernelGGL(add_keys_counted_kernel, dim3(grid_for(ctx, (cap_keys + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
+                       ctx->stream, d_keys, cap_keys, d_n, t, ctr->distinct);
+    KT_HIP(hipGetLastError());
+    return KT_OK;
+}
+
+extern "C" {
 
 int kt_ctr_capacity(kt_ctr *ctr, uint64_t *slots) {
     if (!ctr || !slots) return kt::fail(KT_ERR_ARG, "kt_ctr_capacity: null");

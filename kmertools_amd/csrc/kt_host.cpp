@@ -146,6 +146,8 @@ int kt_ctx_destroy(kt_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->lut_dev)
         if (p) (void)hipFree(p);
+    for (auto &p : ctx->lut32_dev)
+        if (p) (void)hipFree(p);
     ctx->s_bases.release();
     ctx->s_offsets.release();
     ctx->s_out.release();

@@ -39,10 +39,15 @@ struct kt_ctx {
     // device copies of the canonical-bin LUT (u16[4^k], lut[f] = 4 * rank(min(f, rc f)): the byte offset of the
     // bin's u32 counter inside a row), k = 1..7
     uint16_t *lut_dev[kt::KT_MAX_OLIGO_K + 1] = {};
+    uint32_t *lut32_dev[13] = {};  // canonical rank of every k-mer, k = 1..12 (the generic oligo path, kt_oligo_generic.hip)
     kt::Scratch s_bases, s_offsets, s_out, s_aux0, s_aux1, s_aux2;
     int use();  // hipSetDevice
     int canon_lut(int k, const uint16_t **out);
+    int canon_lut32(int k, const uint32_t **out);
 };
+
+struct kt_bulk_job;  // kt_bulk.hip: the plan and buffers of a partition + range build in progress
+void kt_bulk_job_free(kt_bulk_job *job);
 
 struct kt_ctr {
     kt_ctx *ctx = nullptr;
@@ -54,11 +59,16 @@ struct kt_ctr {
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls
+    kt_bulk_job *job = nullptr;
     void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}
     uint32_t *flags = nullptr; // [0] = overflow flag, device
     uint64_t *cursor = nullptr; // device scalar for export
     uint64_t *distinct = nullptr; // device scalar: occupied slots (kept by every insert path, so kt_ctr_size is one 8-byte read)
 };
+
+// kt_oligo_generic.hip: histograms for k outside 3..7, counted in global memory (device pointers, enqueued)
+int kt_oligo_generic_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k,
+                            int count_min, int norm, int total_step, int dt, void *out);
 
 namespace kt {
 // host-side table builders (kt_host.cpp)

@@ -683,6 +683,8 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
 // Enqueue the histogram kernel for device-resident inputs/outputs.
 static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                         int k, int count_min, int norm, int total_step, int dt, void *out) {
+    if (k < 3 || k > 7)  // rows beyond LDS: the global-memory path (kt_oligo_generic.hip)
+        return kt_oligo_generic_launch(ctx, bases, offsets, n_reads, k, count_min, norm, total_step, dt, out);
     uint64_t bins64 = 0;
     kt_bins(k, count_min, &bins64);
     const uint32_t bins = (uint32_t)bins64;
@@ -804,7 +806,7 @@ extern "C" int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t 
                               uint64_t n_reads, int k, int count_min, int norm, int total_step,
                               int out_dtype, void *out, int mem) {
     if (!ctx) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: null ctx");
-    if (k < 3 || k > 7) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: k must be in 3..7");
+    if (k < 1 || k > 12) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: k must be in 1..12");
     if (out_dtype != KT_F64 && out_dtype != KT_F32 && out_dtype != KT_U32)
         return kt::fail(KT_ERR_ARG, "kt_oligo_batch: unknown out_dtype");
     if (out_dtype == KT_U32 && norm) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: KT_U32 output needs norm = 0");

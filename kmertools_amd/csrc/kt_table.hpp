@@ -114,3 +114,14 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
                   uint64_t total_bases, int *done);
 // same, from an array of canonical k-mers (one count each; KT_EMPTY_KEY entries are skipped)
 int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int *done);
+// The same build in phases, for batches that arrive in pieces (the sharded counter's slices, kt_shard.hip):
+// begin (plan + buffers for at most max_keys k-mers; *eligible = 0: use the probing path), level 1 over any number of
+// sources (segments [seg_lo, seg_hi) of a read batch / arrays of canonical k-mers, optionally with a device-side
+// count), finish (level 2 + range builds; one host round trip).  Sources must stay readable until finish.
+int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible);
+int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
+                      uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi);
+int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n);
+int kt_bulk_finish(kt_ctr *ctr);
+// kt_ctr.hip: one count for each of the first min(*d_n, cap_keys) keys of an array, through the probing path
+int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_keys, const uint64_t *d_n);

@@ -301,3 +301,70 @@ class Counter:
             order = np.argsort(keys, kind="stable")
             keys, counts = keys[order], counts[order]
         return keys, counts
+
+
+class Sharded:
+    """This rank's part of a table sharded over n_ranks GPUs by hash prefix (kt_sharded).  add_reads and finalize are
+    collective: every rank calls them the same number of times.  `transport`: ("rccl", id128 bytes) or
+    ("host", alltoall) where alltoall(send_addr, recv_addr, bytes_per_rank) moves host memory and returns 0."""
+
+    def __init__(self, ctx, k, capacity_slots, max_batch_bases, n_ranks=1, rank=0, transport=None):
+        self.ctx, self.k, self.n_ranks, self.rank = ctx, k, n_ranks, rank
+        self._h = C.c_void_p()
+        self._cb = None
+        L = _lib.lib()
+        if n_ranks > 1 and transport is None:
+            raise ValueError("a sharded counter over several ranks needs a transport")
+        if n_ranks == 1 or transport[0] == "rccl":
+            idb = None if n_ranks == 1 else (C.c_uint8 * 128).from_buffer_copy(bytes(transport[1]))
+            check(L.kt_sharded_create_rccl(ctx._h, k, int(capacity_slots), int(max_batch_bases), n_ranks, rank, idb,
+                                           C.byref(self._h)))
+        elif transport[0] == "host":
+            fn = transport[1]
+            self._cb = _lib.ALLTOALL_FN(lambda user, send, recv, nbytes: int(fn(send, recv, nbytes)))
+            check(L.kt_sharded_create_host(ctx._h, k, int(capacity_slots), int(max_batch_bases), n_ranks, rank,
+                                           C.cast(self._cb, C.c_void_p), None, C.byref(self._h)))
+        else:
+            raise ValueError("unknown transport %r" % (transport[0],))
+        t = C.c_void_p()
+        check(L.kt_sharded_table(self._h, C.byref(t)))
+        self.table = Counter.__new__(Counter)   # a view of the shard: owned by the kt_sharded
+        self.table.ctx, self.table.k, self.table._h = ctx, k, t
+        self.table.close = lambda: None
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(_lib.lib().kt_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.table._h = C.c_void_p()
+            _lib.lib().kt_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        check(_lib.lib().kt_sharded_clear(self._h))
+
+    def add_reads(self, bases, offsets, n_reads, mem=KT_MEM_DEVICE):
+        check(_lib.lib().kt_sharded_add_reads(self._h, _ptr(bases), _ptr(offsets), n_reads, mem))
+
+    def add_reads_host(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        self.add_reads(bases if bases.size else np.zeros(1, np.uint8), offsets, len(offsets) - 1, KT_MEM_HOST)
+
+    def finalize(self):
+        check(_lib.lib().kt_sharded_finalize(self._h))
+
+    def exchanged_bytes(self):
+        n = C.c_uint64()
+        check(_lib.lib().kt_sharded_exchanged_bytes(self._h, C.byref(n)))
+        return n.value

@@ -36,10 +36,11 @@ class OligoComputer:
 
     def __init__(self, ksize):
         self.ksize = int(ksize)
-        if not 3 <= self.ksize <= 7:
-            # the reference CLI restricts k to 3..=7 (kmertools/src/args.rs:85); the GPU
-            # kernels are instantiated for exactly that range
-            raise ValueError("ksize must be in 3..=7")
+        # the reference takes any usize here (pybindings/src/oligo.rs:22-31; only the CLI restricts k to 3..=7,
+        # kmertools/src/args.rs:85) and allocates a 4^k-entry rank map: this build goes as far as k = 12 (k = 3..7 on
+        # the LDS kernel, the others counted in global memory)
+        if not 1 <= self.ksize <= 12:
+            raise ValueError("ksize must be in 1..=12")
         self.kcount = device.bins(self.ksize, True)
 
     def vectorise_one(self, seq, norm=True, mins=True):
@@ -153,3 +154,17 @@ class _Utils:
 
 
 utils = _Utils()
+
+
+def run_cli(argv=None):
+    """The `kmertools` command line with this process's arguments (pip/src/lib.rs:11-18: `run_cli` parses
+    std::env::args_os().skip(1) and runs the CLI).  Here the CLI is the C++ binary built next to the library; it is
+    started as a fresh child process (never exec'ed from a process that may have initialised the GPU) and its exit
+    status is returned."""
+    import subprocess
+    import sys
+    exe = _lib._HERE / "bin" / "kmertools"
+    if not exe.exists():
+        raise FileNotFoundError("%s is missing - build it with `make -C kmertools_amd/csrc`" % exe)
+    args = list(sys.argv[1:] if argv is None else argv)
+    return subprocess.call([str(exe)] + args)

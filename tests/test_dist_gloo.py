@@ -1,7 +1,8 @@
-"""world_size-2 CPU (gloo) test of the multi-GPU counting schedule: ownership by hash prefix,
-the all-to-all split bookkeeping and the sharded result.  The GPU kernels are replaced here
-by the oracle (test infrastructure) - what is under test is kmertools_amd.dist.exchange_keys
-and kt_owner_of, the host logic every N>1 run goes through."""
+"""world_size-2 CPU (gloo) test of the multi-GPU counting schedule's host side: ownership by hash prefix, the layout
+of the exchanged regions (kt_sharded_message_bytes: a 64-byte header with the key count, then the keys) and the host
+all-to-all transport that kt_sharded_create_host drives (kmertools_amd.dist.host_alltoall over torch.distributed).
+The GPU kernels are replaced here by the oracle (test infrastructure): every rank fills its regions the way
+route_regions_kernel does, the transport moves them, and the received regions are counted."""
 import os
 import socket
 
@@ -39,25 +40,35 @@ def _worker(rank, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
-        from kmertools_amd import device, dist as ktdist
+        from kmertools_amd import _lib, device, dist as ktdist
         from oracle import kt_oracle as oracle
         bases, offsets = oracle.synth_reads(SEED, N_PER_RANK, L, noise=True, genome_len=20000,
                                             first_read=rank * N_PER_RANK)
         canon = _canonical_kmers(oracle, bases, offsets, K)
         owners = np.array([device.owner_of(int(x), WORLD) for x in canon], dtype=np.int64)
-        order = np.argsort(owners, kind="stable")
-        grouped = canon[order]
-        send = np.bincount(owners, minlength=WORLD).tolist()
-        keys_t = torch.from_numpy(grouped.view(np.int64).copy())
-        recv, recv_counts = ktdist.exchange_keys(keys_t, send, None)
-        got = recv.numpy().view(np.uint64)
-        assert sum(recv_counts) == len(got)
+        # one slice: WORLD regions of the size the library would use for a batch of this many bases
+        msg_bytes = int(_lib.lib().kt_sharded_message_bytes(N_PER_RANK * L, WORLD, 1))
+        words = msg_bytes // 8
+        assert msg_bytes % 8 == 0 and words - 8 >= (canon.size // WORLD)
+        send = np.zeros(WORLD * words, np.uint64)
+        for o in range(WORLD):
+            mine = canon[owners == o]
+            send[o * words] = len(mine)                       # header: key count
+            send[o * words + 8:o * words + 8 + len(mine)] = mine
+        recv = np.full(WORLD * words, 0xDEAD, np.uint64)
+        fn = ktdist.host_alltoall(dist.group.WORLD)          # what kt_sharded_create_host is given
+        assert fn(send.ctypes.data, recv.ctypes.data, msg_bytes) == 0
+        got = []
+        for p in range(WORLD):
+            n = int(recv[p * words])
+            got.append(recv[p * words + 8:p * words + 8 + n])
+        got = np.concatenate(got)
         # everything received is owned by this rank
         assert all(device.owner_of(int(x), WORLD) == rank for x in got[:500])
         ctr = oracle.Counter(1)
         ctr.add_pairs(got, np.ones(len(got), np.uint32))
         k_, c_ = ctr.export()
-        q.put((rank, k_, c_, int(sum(send))))
+        q.put((rank, k_, c_, int(len(canon))))
     finally:
         dist.destroy_process_group()
 

@@ -391,13 +391,13 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 # N > 1 path on one GPU: two ranks share cuda:0, route on the GPU, exchange (gloo, host-staged),
 # count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
 
-def _two_rank_worker(rank, port, q):
+def _two_rank_worker(rank, port, q, case):
     import os
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["KT_BULK_MIN_BASES"] = "0"   # the first batch of routed k-mers takes the bulk build, the second the atomics
+    os.environ["KT_BULK_MIN_BASES"] = "0"   # the received k-mers take the partition + range build even at this size
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
         from kmertools_amd import device, dist as ktdist
@@ -407,19 +407,28 @@ def _two_rank_worker(rank, port, q):
         bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
         offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         ctx.synth_reads(4242, n, L, bases, offsets, noise=True, genome_len=200000, first_read=rank * n)
-        sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD)
+        if case == "skewed" and rank == 1:
+            bases[: 8000 * L] = ord("A")           # 40 % of rank 1's batch is one k-mer: its owner's regions overflow
+        sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD, max_batch_bases=n * L)
         sc.add_reads(bases, offsets, n)
-        sc.add_reads(bases[: 100 * L], offsets[:101], 100)      # a second "chunk"
+        m = 100 if rank == 0 else 0                 # a second "chunk" that only rank 0 has reads for
+        sc.add_reads(bases[: 100 * L], offsets[:101], m)
+        sc.finalize()
         keys, counts = sc.export_local()
         total = sc.size_global()
-        q.put((rank, keys, counts, total))
+        q.put((rank, keys, counts, total, sc.sharded.exchanged_bytes()))
         sc.close()
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_sharded_ctr(oracle):
+@pytest.mark.parametrize("case", ["genome", "skewed"])
+def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
+    """the C ABI's sharded counter with two ranks on cuda:0 and the host all-to-all transport over gloo: route on
+    the GPU, exchange fixed-size regions, partition + range build of what arrived, finalize; the union of the shards
+    is the oracle's table of all reads.  `skewed`: one k-mer floods its owner's regions, so the pending list and
+    several finalize rounds run"""
     import socket
     import torch.multiprocessing as mp
     from kmertools_amd import device
@@ -429,7 +438,7 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle):
     s.close()
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
-    procs = [mpctx.Process(target=_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    procs = [mpctx.Process(target=_two_rank_worker, args=(r, port, q, case)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
@@ -440,16 +449,45 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle):
     ctr = oracle.Counter(4)
     for rank in range(2):
         hb, ho = oracle.synth_reads(4242, n, L, noise=True, genome_len=200000, first_read=rank * n)
+        if case == "skewed" and rank == 1:
+            hb = hb.copy()
+            hb[: 8000 * L] = ord("A")
         ctr.add_reads(hb, ho, k, threads=4)
-        ctr.add_reads(hb[: 100 * L], ho[:101], k)
+        if rank == 0:
+            ctr.add_reads(hb[: 100 * L], ho[:101], k)
     wk, wc = ctr.export()
     keys = np.concatenate([r[1] for r in res])
     counts = np.concatenate([r[2] for r in res])
-    for rank, rk, _, total in res:
-        assert total == len(wk)
+    for rank, rk, _, total, sent in res:
+        assert total == len(wk) and sent > 0
         assert all(device.owner_of(int(x), 2) == rank for x in rk[:300])
     order = np.argsort(keys)
     assert np.array_equal(keys[order], wk) and np.array_equal(counts[order], wc)
+
+
+def test_sharded_single_rank_through_rccl(torch_mod, ctx, oracle, monkeypatch):
+    """librccl really is loaded and driven from the C ABI: a one-rank communicator (ncclCommInitRank), and with
+    KT_SHARD_FORCE=1 the routed path (route -> exchange with itself -> level 1 per slice -> range build) instead of
+    the single-GPU shortcut; the table must be the oracle's"""
+    torch = torch_mod
+    from kmertools_amd import device
+    assert len(device.Sharded.unique_id()) == 128
+    monkeypatch.setenv("KT_SHARD_FORCE", "1")
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    n, L, k = 30000, 150, 21
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(77, n, L, bases, offsets, noise=True, genome_len=300000)
+    sh = device.Sharded(ctx, k, 1 << 23, n * L, 1, 0, None)
+    for _ in range(2):
+        sh.add_reads(bases, offsets, n)
+        sh.finalize()
+        hb, ho = oracle.synth_reads(77, n, L, noise=True, genome_len=300000)
+        wk, wc = oracle.count_reads(hb, ho, k, n_parts=4, threads=4)
+        gk, gc = sh.table.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        sh.clear()
+    sh.close()
 
 
 # ---------------------------------------------------------------------------------------------
