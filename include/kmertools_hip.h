@@ -153,6 +153,15 @@ int kt_ctr_capacity(kt_ctr *ctr, uint64_t *slots);
 int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
                      uint64_t n_reads, int mem);
 
+/* The same, restricted to one of n_parts hash partitions: only k-mers with kt_owner_of(kmer, n_parts) == part are
+ * counted.  replaces: the reference's answer to "the k-mers do not fit memory" - it cuts the input into chunks, spills
+ * every chunk's partitions (`min_mer % n_parts`) to temp files and merges partition by partition
+ * (counter/src/lib.rs:114-118, :127, :151-167, :188-231).  Here a table that cannot hold every distinct k-mer is
+ * filled n_parts times, pass p with partition p of the whole input, exported and cleared in between: the union of
+ * the exports is the complete answer (every k-mer lives in exactly one partition, with all of its occurrences). */
+int kt_ctr_add_reads_part(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int mem,
+                          uint32_t n_parts, uint32_t part);
+
 /* replaces: merge's arithmetic, counter/src/lib.rs:201-210: table[keys[i]] += counts[i]
  * (counts == NULL means 1 each: raw canonical k-mers routed from another GPU). */
 int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, uint64_t n,

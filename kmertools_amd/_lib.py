@@ -42,6 +42,7 @@ SYMBOLS = {
     "kt_ctr_destroy": (_i, [_vp]),
     "kt_ctr_clear": (_i, [_vp]),
     "kt_ctr_add_reads": (_i, [_vp, _vp, _vp, _u64, _i]),
+    "kt_ctr_add_reads_part": (_i, [_vp, _vp, _vp, _u64, _i, _u32, _u32]),
     "kt_ctr_add_pairs": (_i, [_vp, _vp, _vp, _u64, _i]),
     "kt_ctr_size": (_i, [_vp, C.POINTER(_u64)]),
     "kt_ctr_capacity": (_i, [_vp, C.POINTER(_u64)]),

@@ -174,6 +174,11 @@ struct Work {
     // From its second batch on (i.e. for files of many batches, where the cost of locking is repaid) the row
     // buffer of a work item is page-locked, so the device-to-host copy of the rows - by far the largest
     // transfer - runs by DMA instead of through the driver's pageable staging.
+    // (a resize that reallocates frees the registered buffer: release the page lock first, not afterwards)
+    void resize_rows(size_t n) {
+        if (n > rows.capacity()) unpin();
+        rows.resize(n);
+    }
     void pin_rows(kt_ctx *ctx) {
         if (++uses_ < 2) return;
         void *p = rows.data();
@@ -352,7 +357,7 @@ double debug_emit_bench(uint64_t n_rows, uint64_t bins, bool norm, int threads, 
     Work w;
     w.b.clear();
     for (uint64_t r = 0; r < n_rows; r++) w.b.offsets.push_back(r + 1);
-    w.rows.resize(n_rows * bins);
+    w.resize_rows(n_rows * bins);
     for (uint64_t i = 0; i < n_rows * bins; i++) {
         const double c = (double)((i * 2654435761ull >> 7) % 5);
         w.rows[i] = norm ? c / 147.0 : c;
@@ -431,7 +436,7 @@ std::string OligoComputer::vectorise() {
         reader, batch_bases(memory_), 1ull << 19, pt,
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
-            w.rows.resize(n * bins);
+            w.resize_rows(n * bins);
             w.pin_rows(dev_.ctx);
             if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, count_min_, norm_, 1, KT_F64,
                                w.rows.data(), KT_MEM_HOST) != KT_OK)
@@ -480,7 +485,7 @@ std::string OligoCgrComputer::vectorise() {
         reader, batch_bases(memory_), max_reads, pt,
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
-            w.rows.resize(n * bins);
+            w.resize_rows(n * bins);
             w.pin_rows(dev_.ctx);
             if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, 1, norm_, 1, KT_F64, w.rows.data(),
                                KT_MEM_HOST) != KT_OK)
@@ -529,7 +534,7 @@ std::string CgrComputer::vectorise() {
         reader, 16ull << 20, 1ull << 18, pt,
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
-            w.rows.resize(2 * w.b.bases.size() + 2);
+            w.resize_rows(2 * w.b.bases.size() + 2);
             w.pin_rows(dev_.ctx);
             if (kt_cgr_points(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, (double)vecsize_, w.rows.data(), nullptr,
                               KT_MEM_HOST) != KT_OK)
@@ -569,84 +574,10 @@ CountComputer::~CountComputer() {
     if (ctr_) kt_ctr_destroy(ctr_);
 }
 
-std::string CountComputer::count() {
-    // init(): pre-pass for record count and total length (counter/src/lib.rs:236-249); here it
-    // sizes the HBM table instead of the reference's partition count
-    std::string err;
-    Lap setup;
-    // An upper bound of the number of bases is all the sizing needs.  A plain file gives one without being read:
-    // its size (FASTA), or half of it (FASTQ: as many quality bytes as bases).  Compressed input keeps the pre-pass.
-    struct stat st;
-    const bool plain = in_path_ != "-" && !(in_path_.size() > 3 && in_path_.compare(in_path_.size() - 3, 3, ".gz") == 0) &&
-                       stat(in_path_.c_str(), &st) == 0 && S_ISREG(st.st_mode);
-    if (plain) {
-        seq_count_ = 0;
-        total_length_ = format_from_path(in_path_) == SeqFormat::Fastq ? (uint64_t)st.st_size / 2 : (uint64_t)st.st_size;
-    } else if (!SeqReader::seq_stats(in_path_, seq_count_, total_length_, err)) {
-        return err;
-    }
-    const double t_stats = setup();
-    if (std::string e = dev_.ensure(); !e.empty()) return e;
-    const double t_dev = setup();
-    uint64_t max_distinct = total_length_;
-    if (ksize_ <= 15) {
-        const uint64_t n4k = 1ull << (2 * ksize_);
-        const uint64_t canon = (ksize_ & 1) ? n4k / 2 : (n4k + (1ull << ksize_)) / 2;
-        if (canon < max_distinct) max_distinct = canon;
-    }
-    // ~1.9 slots per possible key (the library rounds up to m * 2^j, m in 5..8; 2x of the canonical 15-mers would
-    // land just past a power of two)
-    uint64_t cap = max_distinct + max_distinct / 10 * 9;
-    if (cap < 1024) cap = 1024;
-    // the reference spills to disk when memory is short; here the table is capped at what HBM holds next to the
-    // bulk-build buffers, and running out of slots is reported (KT_ERR_FULL) rather than silently mis-counted
-    uint64_t free_b = 0, total_b = 0;
-    if (kt_device_memory(dev_.ctx, &free_b, &total_b) == KT_OK)
-        while (cap > 1024 && cap * 16 > free_b / 2) cap >>= 1;
-    if (kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_) != KT_OK) return kt_last_error();
-    if (getenv("KT_CLI_TIMING")) {
-        uint64_t slots = cap;
-        (void)kt_ctr_capacity(ctr_, &slots);
-        fprintf(stderr, "[timing] ctr setup: sizing (pre-pass only for compressed input) %.3f s, device init %.3f s, table of %llu slots %.3f s\n", t_stats,
-                t_dev, (unsigned long long)slots, setup());
-    }
-    SeqReader reader;
-    if (!reader.open(in_path_, false)) return reader.error();
-    Batch b;
-    PhaseTimer pt("ctr count (after the seq_stats pre-pass)");
-    Lap lap;
-    for (;;) {
-        const bool more = reader.next_batch(b, 256ull << 20, 1ull << 22);
-        pt.t[0] += lap();
-        if (b.n_reads() && !b.bases.empty()) {
-            if (kt_ctr_add_reads(ctr_, b.bases.data(), b.offsets.data(), b.n_reads(), KT_MEM_HOST) != KT_OK)
-                return kt_last_error();
-        }
-        pt.t[1] += lap();
-        if (!more) break;
-    }
-    if (reader.failed()) return reader.error();
-    return "";
-}
-
-std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
-    if (!ctr_) return "count() has not run";
-    PhaseTimer pt("ctr merge");
-    Lap lap;
-    uint64_t n = 0;
-    if (kt_ctr_size(ctr_, &n) != KT_OK) return kt_last_error();
-    std::vector<uint64_t> keys(n ? n : 1);
-    std::vector<uint32_t> counts(n ? n : 1);
-    uint64_t got = 0;
-    if (n && kt_ctr_export(ctr_, keys.data(), counts.data(), n, &got, KT_MEM_HOST) != KT_OK) return kt_last_error();
-    pt.t[1] += lap();
-    const std::string path = out_dir_ + "/kmers.counts";
-    FILE *out = fopen(path.c_str(), "wb");
-    if (!out) return "Unable to write to file: " + path;
+// "{kmer}\t{count}\n" (or the ACGT form) for n table entries, appended to `out` (counter/src/lib.rs:220-230)
+static void write_counts(FILE *out, const uint64_t *keys, const uint32_t *counts, uint64_t n, bool acgt, int k, int threads) {
     std::vector<std::string> pieces;
-    const bool acgt = acgt_;
-    const int k = ksize_;
-    format_rows(got, threads_, acgt_ ? (size_t)ksize_ + 4 : 24, pieces, [&](uint64_t i, std::string &s) {
+    format_rows(n, threads, acgt ? (size_t)k + 4 : 24, pieces, [&](uint64_t i, std::string &s) {
         char buf[40];
         if (acgt) {
             kt_numeric_to_kmer(keys[i], k, buf);  // counter/src/lib.rs:221-226
@@ -660,8 +591,269 @@ std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
         s.append(buf, (size_t)(r2.ptr - buf));
         s += '\n';
     });
-    pt.t[2] += lap();
     for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+}
+
+static uint64_t env_u64_host(const char *name, uint64_t dflt) {
+    const char *v = getenv(name);
+    return v && *v ? strtoull(v, nullptr, 10) : dflt;
+}
+
+std::string CountComputer::count() {
+    // init(): pre-pass for record count and total length (counter/src/lib.rs:236-249); here it
+    // sizes the HBM table instead of the reference's partition count
+    std::string err;
+    Lap setup;
+    if (in_path_ == "-") return "ctr reads its input more than once and cannot take stdin";  // (the reference panics
+                                                                                            // on SeqFormat::get("-"))
+    // An upper bound of the number of bases is all the sizing needs.  A plain file gives one without being read:
+    // its size (FASTA), or half of it (FASTQ: as many quality bytes as bases).  Compressed input keeps the pre-pass.
+    struct stat st;
+    const bool plain = !(in_path_.size() > 3 && in_path_.compare(in_path_.size() - 3, 3, ".gz") == 0) &&
+                       stat(in_path_.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+    if (plain) {
+        seq_count_ = 0;
+        total_length_ = format_from_path(in_path_) == SeqFormat::Fastq ? (uint64_t)st.st_size / 2 : (uint64_t)st.st_size;
+    } else if (!SeqReader::seq_stats(in_path_, seq_count_, total_length_, err)) {
+        return err;
+    }
+    const double t_stats = setup();
+    uint64_t max_distinct = total_length_;
+    if (ksize_ <= 15) {
+        const uint64_t n4k = 1ull << (2 * ksize_);
+        const uint64_t canon = (ksize_ & 1) ? n4k / 2 : (n4k + (1ull << ksize_)) / 2;
+        if (canon < max_distinct) max_distinct = canon;
+    }
+    if (n_devices_ > 1) return count_sharded(max_distinct);
+    if (std::string e = dev_.ensure(); !e.empty()) return e;
+    const double t_dev = setup();
+    // 1.4 slots per possible key = load factor 0.7 at worst (the library rounds up to m * 2^j, m in 5..8)
+    uint64_t want = max_distinct + max_distinct / 5 * 2;
+    if (want < 1024) want = 1024;
+    // The reference bounds its memory with -m: chunks of the input, partitions spilled to disk, merged partition by
+    // partition (counter/src/lib.rs:114-118, 151-167, 188-231).  Here the bound is the HBM next to the build's
+    // buffers; a table that cannot hold every distinct k-mer is filled in `passes` passes over the input, pass p
+    // counting hash partition p only (kt_ctr_add_reads_part), each pass's table written out and cleared.
+    const uint64_t batch_bases = 256ull << 20;
+    uint64_t free_b = 0, total_b = 0, fit = want;
+    if (kt_device_memory(dev_.ctx, &free_b, &total_b) == KT_OK) {
+        const uint64_t reserve = batch_bases * 20 + (1ull << 30);  // two key arrays + staging of a batch
+        const uint64_t usable = free_b > 2 * reserve ? free_b - reserve : free_b / 2;
+        fit = usable / 10 * 9 / 16;
+    }
+    fit = env_u64_host("KT_CTR_MAX_SLOTS", fit);  // (tests: force the out-of-core passes)
+    if (fit < 1024) fit = 1024;
+    passes_ = (uint32_t)((want + fit - 1) / fit);
+    if (passes_ < 1) passes_ = 1;
+    // a partition's share of the keys varies a little: 1 / passes + 5 sigma of room
+    uint64_t cap = passes_ == 1 ? want : want / passes_ + want / passes_ / 16 + 4096;
+    if (kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_) != KT_OK) return kt_last_error();
+    if (getenv("KT_CLI_TIMING")) {
+        uint64_t slots = cap;
+        (void)kt_ctr_capacity(ctr_, &slots);
+        fprintf(stderr, "[timing] ctr setup: sizing (pre-pass only for compressed input) %.3f s, device init %.3f s, table of %llu slots, %u pass(es) %.3f s\n",
+                t_stats, t_dev, (unsigned long long)slots, passes_, setup());
+    }
+    FILE *out = nullptr;
+    const std::string path = out_dir_ + "/kmers.counts";
+    PhaseTimer pt("ctr count (after the seq_stats pre-pass)");
+    for (uint32_t pass = 0; pass < passes_; pass++) {
+        SeqReader reader;
+        if (!reader.open(in_path_, false)) return reader.error();
+        Batch b;
+        Lap lap;
+        for (;;) {
+            const bool more = reader.next_batch(b, batch_bases, 1ull << 22);
+            pt.t[0] += lap();
+            if (b.n_reads() && !b.bases.empty()) {
+                if (kt_ctr_add_reads_part(ctr_, b.bases.data(), b.offsets.data(), b.n_reads(), KT_MEM_HOST, passes_, pass) != KT_OK)
+                    return kt_last_error();
+            }
+            pt.t[1] += lap();
+            if (!more) break;
+        }
+        if (reader.failed()) return reader.error();
+        if (passes_ == 1) break;  // the table stays resident: merge() (and cov) read it
+        // out of core: this partition is complete - its lines go to kmers.counts now, the table is reused
+        uint64_t n = 0, got = 0;
+        if (kt_ctr_size(ctr_, &n) != KT_OK) return kt_last_error();
+        std::vector<uint64_t> keys(n ? n : 1);
+        std::vector<uint32_t> counts(n ? n : 1);
+        if (n && kt_ctr_export(ctr_, keys.data(), counts.data(), n, &got, KT_MEM_HOST) != KT_OK) return kt_last_error();
+        pt.t[1] += lap();
+        if (!out) out = fopen(path.c_str(), "wb");
+        if (!out) return "Unable to write to file: " + path;
+        write_counts(out, keys.data(), counts.data(), got, acgt_, ksize_, threads_);
+        pt.t[3] += lap();
+        if (kt_ctr_clear(ctr_) != KT_OK) return kt_last_error();
+    }
+    if (out) fclose(out);
+    return "";
+}
+
+// ---- several GPUs: the table sharded by hash prefix, one worker thread (= one rank) per device -----------------
+namespace {
+// host all-to-all between the rank threads of one process (KT_CLI_SHARE_GPU=1: every rank on one GPU, where RCCL
+// refuses to run - tests): everybody publishes its buffers, waits, copies its blocks, waits again
+struct LocalFabric {
+    int n;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    std::vector<const char *> send;
+    explicit LocalFabric(int n_) : n(n_), send(n_) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = gen;
+        if (++arrived == n) {
+            arrived = 0;
+            gen++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+};
+struct FabricEnd { LocalFabric *f; int rank; };
+int local_alltoall(void *user, const void *send, void *recv, uint64_t bytes) {
+    FabricEnd *e = (FabricEnd *)user;
+    e->f->send[e->rank] = (const char *)send;
+    e->f->barrier();
+    for (int p = 0; p < e->f->n; p++) memcpy((char *)recv + (uint64_t)p * bytes, e->f->send[p] + (uint64_t)e->rank * bytes, bytes);
+    e->f->barrier();
+    return 0;
+}
+}  // namespace
+
+std::string CountComputer::count_sharded(uint64_t max_distinct) {
+    const int N = n_devices_;
+    const bool share = getenv("KT_CLI_SHARE_GPU") != nullptr;
+    const uint64_t batch_bases = 256ull << 20, max_batch = batch_bases * 2;  // (a batch ends with a whole record)
+    uint64_t per_rank = max_distinct / N + max_distinct / N / 16 + 4096;
+    uint64_t cap = per_rank + per_rank / 5 * 2;
+    uint8_t id[128] = {};
+    if (!share && kt_rccl_unique_id(id) != KT_OK) return kt_last_error();
+    LocalFabric fabric(N);
+    std::vector<FabricEnd> ends(N);
+    shard_keys_.assign(N, {});
+    shard_counts_.assign(N, {});
+    // rounds: the reader fills one batch per rank, the ranks add them collectively (a rank without a batch adds 0 reads)
+    std::vector<Batch> batches[2];
+    batches[0].resize(N);
+    batches[1].resize(N);
+    std::mutex m;
+    std::condition_variable cv;
+    int ready_round = -1, done_count[2] = {0, 0};
+    bool last_round[2] = {false, false};
+    std::vector<std::string> errs(N);
+    auto worker = [&](int rank) {
+        kt_ctx *ctx = nullptr;
+        kt_sharded *sh = nullptr;
+        auto fail = [&](const std::string &e) { errs[rank] = e.empty() ? "error" : e; };
+        int rc = kt_ctx_create(share ? dev_.index : dev_.index + rank, nullptr, 1, &ctx);
+        if (rc == KT_OK) {
+            ends[rank] = FabricEnd{&fabric, rank};
+            rc = share ? kt_sharded_create_host(ctx, ksize_, cap, max_batch, N, rank, local_alltoall, &ends[rank], &sh)
+                       : kt_sharded_create_rccl(ctx, ksize_, cap, max_batch, N, rank, id, &sh);
+        }
+        if (rc != KT_OK) fail(kt_last_error());
+        for (int round = 0;; round++) {
+            bool last;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return ready_round >= round; });
+                last = last_round[round & 1];
+            }
+            Batch &b = batches[round & 1][rank];
+            // every rank takes part in every collective call, failed or not (the others would wait for ever)
+            if (sh) {
+                const uint64_t n = b.bases.empty() ? 0 : b.n_reads();
+                if (kt_sharded_add_reads(sh, b.bases.data(), b.offsets.data(), n, KT_MEM_HOST) != KT_OK && errs[rank].empty())
+                    fail(kt_last_error());
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                done_count[round & 1]++;
+            }
+            cv.notify_all();
+            if (last) break;
+        }
+        if (sh) {
+            if (kt_sharded_finalize(sh) != KT_OK && errs[rank].empty()) fail(kt_last_error());
+            kt_ctr *t = nullptr;
+            uint64_t n = 0, got = 0;
+            if (errs[rank].empty() && (kt_sharded_table(sh, &t) != KT_OK || kt_ctr_size(t, &n) != KT_OK)) fail(kt_last_error());
+            if (errs[rank].empty()) {
+                shard_keys_[rank].resize(n ? n : 1);
+                shard_counts_[rank].resize(n ? n : 1);
+                if (n && kt_ctr_export(t, shard_keys_[rank].data(), shard_counts_[rank].data(), n, &got, KT_MEM_HOST) != KT_OK)
+                    fail(kt_last_error());
+                shard_keys_[rank].resize(got);
+                shard_counts_[rank].resize(got);
+            }
+            kt_sharded_destroy(sh);
+        }
+        if (ctx) kt_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> threads;
+    for (int r = 0; r < N; r++) threads.emplace_back(worker, r);
+    SeqReader reader;
+    std::string err;
+    if (!reader.open(in_path_, false)) err = reader.error();
+    bool more = err.empty();
+    for (int round = 0;; round++) {
+        {   // the buffers of this parity are free once the round that used them last has been processed
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return round < 2 || done_count[round & 1] == N; });
+            done_count[round & 1] = 0;
+        }
+        for (int r = 0; r < N; r++) {
+            Batch &b = batches[round & 1][r];
+            b.clear();
+            if (more) more = reader.next_batch(b, batch_bases, 1ull << 22);
+        }
+        if (reader.failed() && err.empty()) err = reader.error();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            last_round[round & 1] = !more;
+            ready_round = round;
+        }
+        cv.notify_all();
+        if (!more) break;
+    }
+    for (auto &t : threads) t.join();
+    for (const auto &e : errs)
+        if (!e.empty() && err.empty()) err = e;
+    sharded_done_ = err.empty();
+    return err;
+}
+
+std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
+    if (passes_ > 1) return "";  // out of core: count() wrote every partition's lines as it completed
+    const std::string path = out_dir_ + "/kmers.counts";
+    if (sharded_done_) {  // the shards' exports, one after the other (the reference's line order is unspecified)
+        FILE *out = fopen(path.c_str(), "wb");
+        if (!out) return "Unable to write to file: " + path;
+        for (size_t r = 0; r < shard_keys_.size(); r++)
+            write_counts(out, shard_keys_[r].data(), shard_counts_[r].data(), shard_keys_[r].size(), acgt_, ksize_, threads_);
+        fclose(out);
+        return "";
+    }
+    if (!ctr_) return "count() has not run";
+    PhaseTimer pt("ctr merge");
+    Lap lap;
+    uint64_t n = 0;
+    if (kt_ctr_size(ctr_, &n) != KT_OK) return kt_last_error();
+    std::vector<uint64_t> keys(n ? n : 1);
+    std::vector<uint32_t> counts(n ? n : 1);
+    uint64_t got = 0;
+    if (n && kt_ctr_export(ctr_, keys.data(), counts.data(), n, &got, KT_MEM_HOST) != KT_OK) return kt_last_error();
+    pt.t[1] += lap();
+    FILE *out = fopen(path.c_str(), "wb");
+    if (!out) return "Unable to write to file: " + path;
+    write_counts(out, keys.data(), counts.data(), got, acgt_, ksize_, threads_);
+    pt.t[2] += lap();
     fclose(out);
     pt.t[3] += lap();
     return "";
@@ -701,7 +893,7 @@ std::string CovComputer::compute_coverages() {
         reader, batch_bases(256ull << 20), bins >= 2048 ? 8192 : 1ull << 19, pt,
         [&](Work &w) -> std::string {
             const uint64_t n = w.b.n_reads();
-            w.rows.resize(n * bins);
+            w.resize_rows(n * bins);
             w.pin_rows(ctr_->context());
             if (kt_cov_batch(ctr_->table(), bases_ptr(w.b), w.b.offsets.data(), n, bin_size_, bin_count_, norm_, KT_F64,
                              w.rows.data(), KT_MEM_HOST) != KT_OK)

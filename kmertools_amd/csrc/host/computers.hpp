@@ -96,10 +96,14 @@ class CountComputer {
     void set_max_memory(double gb) { memory_ceil_gb_ = gb; }  // accepted; the table is HBM-resident
     void set_acgt_output(bool a) { acgt_ = a; }
     void set_device(int d) { dev_.index = d; }
-    std::string count();             // counter/src/lib.rs:69-90 (no temp files: one resident table)
+    void set_devices(int n) { n_devices_ = n < 1 ? 1 : n; }  // --devices N: the table sharded over N GPUs (kt_sharded_*)
+    // counter/src/lib.rs:69-90.  No temp files: one resident table - or, when the distinct k-mers cannot fit the HBM,
+    // `passes()` passes over the input, one hash partition each, written to kmers.counts as they complete.
+    std::string count();
     std::string merge(bool del);     // counter/src/lib.rs:172-234: writes {out_dir}/kmers.counts
     uint64_t seq_count() const { return seq_count_; }  // 0 when the sizing pre-pass was skipped (plain files)
-    kt_ctr *table() const { return ctr_; }  // the resident table (valid after count())
+    uint32_t passes() const { return passes_; }
+    kt_ctr *table() const { return passes_ == 1 && !sharded_done_ ? ctr_ : nullptr; }  // the resident table (after count())
     kt_ctx *context() const { return dev_.ctx; }
 
   private:
@@ -110,6 +114,12 @@ class CountComputer {
     uint64_t seq_count_ = 0, total_length_ = 0;
     Device dev_;
     kt_ctr *ctr_ = nullptr;
+    int n_devices_ = 1;
+    uint32_t passes_ = 1;
+    bool sharded_done_ = false;
+    std::vector<std::vector<uint64_t>> shard_keys_;
+    std::vector<std::vector<uint32_t>> shard_counts_;
+    std::string count_sharded(uint64_t max_distinct);
 };
 
 // `min -p s2m`: one line per record, "id\tMMER:start-end\t...\t\n" (misc/src/minimisers.rs:93-160).

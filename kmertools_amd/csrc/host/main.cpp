@@ -165,10 +165,12 @@ const char *HELP_CTR =
     "  -i, --input <INPUT>      Input file path\n"
     "  -o, --output <OUTPUT>    Output directory path\n"
     "  -k, --k-size <K_SIZE>    k size for counting\n"
-    "  -m, --memory <MEMORY>    Max memory in GB [default: 6] (accepted; the table lives in HBM)\n"
+    "  -m, --memory <MEMORY>    Max memory in GB [default: 6] (accepted; the bound is the GPU's free HBM: a table\n"
+    "                           that cannot hold every distinct k-mer is filled in several passes over the input)\n"
     "  -a, --acgt               Output ACGT instead of numeric values\n"
     "  -t, --threads <THREADS>  Thread count for computations 0=auto [default: 0]\n"
     "      --device <DEVICE>    GPU index [default: 0]\n"
+    "      --devices <N>        Shard the table over N GPUs, --device .. --device + N - 1 [default: 1]\n"
     "  -h, --help               Print help\n";
 
 const char *HELP_COV =
@@ -218,7 +220,7 @@ int cmd_cov(int argc, char **argv, int from) {
     if (int rc = make_out_dir(out)) return rc;
     const std::string kin = f.count("alt-input") ? f.at("alt-input") : in;
     for (const std::string &p : {in, kin}) {
-        if (format_from_path(p) == SeqFormat::Unknown && p != "-") {
+        if (format_from_path(p) == SeqFormat::Unknown) {  // "-" included: both inputs are read more than once
             fprintf(stderr, "Error: unsupported input extension (expected .fa/.fasta/.fna/.fq/.fastq[.gz]): %s\n", p.c_str());
             return 101;  // SeqFormat::get(...).unwrap()
         }
@@ -344,19 +346,20 @@ int cmd_cgr(int argc, char **argv, int from) {
 int cmd_ctr(int argc, char **argv, int from) {
     const std::vector<Spec> specs = {{'i', "input", true},  {'o', "output", true}, {'k', "k-size", true},
                                      {'m', "memory", true}, {'a', "acgt", false},  {'t', "threads", true},
-                                     {0, "device", true}};
+                                     {0, "device", true},   {0, "devices", true}};
     const auto f = parse_flags(argc, argv, from, specs, HELP_CTR);
     const std::string in = required_str(f, "input"), out = required_str(f, "output");
     const int k = (int)ranged(f, "k-size", 10, 31, true, 0);
     const uint64_t mem = ranged(f, "memory", 6, 128, false, 6);
     const int threads = (int)ranged(f, "threads", 0, 1 << 20, false, 0);
     if (int rc = make_out_dir(out)) return rc;
-    if (format_from_path(in) == SeqFormat::Unknown && in != "-") {
-        // CountComputer::new unwraps SeqFormat::get (counter/src/lib.rs:38): unknown extension panics
+    if (format_from_path(in) == SeqFormat::Unknown) {
+        // CountComputer::new unwraps SeqFormat::get (counter/src/lib.rs:38): unknown extension - "-" included - panics
         fprintf(stderr, "Error: unsupported input extension (expected .fa/.fasta/.fna/.fq/.fastq[.gz]): %s\n", in.c_str());
         return 101;
     }
     CountComputer ctr(in, out, k);
+    ctr.set_devices((int)ranged(f, "devices", 1, 64, false, 1));
     if (threads > 0) ctr.set_threads(threads);
     if (f.count("acgt")) ctr.set_acgt_output(true);
     ctr.set_max_memory((double)mem);

@@ -148,13 +148,22 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_
 struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segment (kt_segment.hpp), segments [seg_lo, seg_hi)
     SegArgs a;
     uint64_t seg_lo, seg_hi;
+    uint32_t n_parts, part;  // n_parts > 1: only the k-mers of hash partition `part` (out-of-core passes)
     __device__ uint64_t n_units() const { return seg_hi - seg_lo; }
     __device__ void collect(uint64_t g, SegShared &sm, uint64_t (&keys)[ktseg::PER_THREAD], uint32_t &ok) const {
         ktseg::collect_kmers(a, seg_lo + g, sm, keys, ok);
+        if (n_parts > 1) {
+#pragma unroll
+            for (uint32_t j = 0; j < ktseg::PER_THREAD; j++)
+                if (ktd::owner_of(keys[j], n_parts) != part) ok &= ~(1u << j);
+        }
     }
     template <class Sink>
     __device__ void for_each(uint64_t g, SegShared &sm, Sink &&sink) const {  // rolling walk: few registers
-        ktseg::for_each_kmer(a, seg_lo + g, sm, [&](uint64_t f, uint64_t r, uint64_t) { sink(f < r ? f : r); });
+        ktseg::for_each_kmer(a, seg_lo + g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
+            const uint64_t m = f < r ? f : r;
+            if (n_parts <= 1 || ktd::owner_of(m, n_parts) == part) sink(m);
+        });
     }
 };
 struct KeysSource {  // canonical k-mers that are already an array (routed here from other GPUs): unit = 8192 keys
@@ -1083,7 +1092,7 @@ static int job_add(kt_ctr *ctr, const SourceRec &r, uint64_t bound) {
 
 // level 1 over the k-mers that start in segments [seg_lo, seg_hi) of a read batch (seg_first: ktseg::seg_index_kernel)
 int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
-                      uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi) {
+                      uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_parts, uint32_t part) {
     SourceRec r{};
     r.reads = true;
     r.rs.a.bases = d_bases;
@@ -1094,6 +1103,8 @@ int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_off
     r.rs.a.k = (uint32_t)ctr->k;
     r.rs.seg_lo = seg_lo;
     r.rs.seg_hi = seg_hi;
+    r.rs.n_parts = n_parts;
+    r.rs.part = part;
     r.n_units = seg_hi - seg_lo;
     return job_add(ctr, r, (seg_hi - seg_lo) * ktseg::SEG);  // at most one k-mer per base
 }
@@ -1125,7 +1136,7 @@ int kt_bulk_finish(kt_ctr *ctr) {
 }
 
 int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                  uint64_t total_bases, int *done) {
+                  uint64_t total_bases, uint32_t n_parts, uint32_t part, int *done) {
     *done = 0;
     kt_ctx *ctx = ctr->ctx;
     int eligible = 0;
@@ -1138,7 +1149,7 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     uint64_t *seg_first = (uint64_t *)ctx->s_aux0.p;
     hipLaunchKernelGGL(ktseg::seg_index_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_offsets, n_reads, seg_first, n_seg);
-    if (int rc = kt_bulk_add_reads(ctr, d_bases, d_offsets, seg_first, n_reads, n_seg, 0, n_seg)) return rc;
+    if (int rc = kt_bulk_add_reads(ctr, d_bases, d_offsets, seg_first, n_reads, n_seg, 0, n_seg, n_parts, part)) return rc;
     if (int rc = kt_bulk_finish(ctr)) return rc;
     *done = 1;
     return KT_OK;

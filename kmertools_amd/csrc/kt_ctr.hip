@@ -36,12 +36,14 @@ __device__ __forceinline__ void publish_fresh(uint32_t fresh, uint64_t *distinct
         atomicAdd(reinterpret_cast<unsigned long long *>(distinct), (unsigned long long)fresh);
 }
 
-__global__ __launch_bounds__(BLOCK) void count_reads_kernel(SegArgs a, TableRef t, uint64_t *__restrict__ distinct) {
+__global__ __launch_bounds__(BLOCK) void count_reads_kernel(SegArgs a, TableRef t, uint32_t n_parts, uint32_t part,
+                                                            uint64_t *__restrict__ distinct) {
     __shared__ SegShared sm;
     uint32_t fresh = 0;
     for (uint64_t g = blockIdx.x; g < a.n_seg; g += gridDim.x) {
         ktseg::for_each_kmer(a, g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
             const uint64_t m = f < r ? f : r;  // counter/src/lib.rs:124
+            if (n_parts > 1 && ktd::owner_of(m, n_parts) != part) return;  // another pass counts this one
             const uint32_t st = table_add(t, m, 1u);
             if (st == 0u) atomicOr(t.flags, 1u);
             fresh += st == 2u;
@@ -369,7 +371,13 @@ int kt_ctr_clear(kt_ctr *ctr) {
 }
 
 int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int mem) {
+    return kt_ctr_add_reads_part(ctr, bases, offsets, n_reads, mem, 1, 0);
+}
+
+int kt_ctr_add_reads_part(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int mem,
+                          uint32_t n_parts, uint32_t part) {
     if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads: null ctr");
+    if (n_parts < 1 || part >= n_parts) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads_part: need part < n_parts");
     if (n_reads == 0) return KT_OK;
     if (!offsets) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads: null offsets");
     kt_ctx *ctx = ctr->ctx;
@@ -387,7 +395,7 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
         // a whole batch: partition by hash prefix + one LDS build per range of the table, no global atomics.  Into a
         // table that holds data the ranges are rebuilt from what they have + the batch (worth it for large batches)
         int done = 0;
-        if (int rc = kt_bulk_build(ctr, d_bases, d_offsets, n_reads, total, &done)) return rc;
+        if (int rc = kt_bulk_build(ctr, d_bases, d_offsets, n_reads, total, n_parts, part, &done)) return rc;
         if (done) {
             if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
             return KT_OK;
@@ -398,8 +406,8 @@ int kt_ctr_add_reads(kt_ctr *ctr, const uint8_t *bases, const uint64_t *offsets,
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
     TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
-    hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t,
-                       ctr->distinct);
+    hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t, n_parts,
+                       part, ctr->distinct);
     KT_HIP(hipGetLastError());
     if (mem == KT_MEM_HOST) KT_HIP(hipStreamSynchronize(ctx->stream));
     return KT_OK;

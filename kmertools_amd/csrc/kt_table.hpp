@@ -110,8 +110,9 @@ __device__ __forceinline__ uint32_t table_add(const TableRef &t, uint64_t key, u
 // range is built - or rebuilt with what it already holds - in LDS).
 // Returns KT_OK, or an error; `*done` = 0 when the batch / table shape is not eligible and
 // the caller must use the incremental path.
+// n_parts > 1: only the k-mers of hash partition `part` (ktd::owner_of(kmer, n_parts) == part) are counted
 int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                  uint64_t total_bases, int *done);
+                  uint64_t total_bases, uint32_t n_parts, uint32_t part, int *done);
 // same, from an array of canonical k-mers (one count each; KT_EMPTY_KEY entries are skipped)
 int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int *done);
 // The same build in phases, for batches that arrive in pieces (the sharded counter's slices, kt_shard.hip):
@@ -120,7 +121,7 @@ int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int
 // count), finish (level 2 + range builds; one host round trip).  Sources must stay readable until finish.
 int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible);
 int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
-                      uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi);
+                      uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_parts, uint32_t part);
 int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n);
 int kt_bulk_finish(kt_ctr *ctr);
 // kt_ctr.hip: one count for each of the first min(*d_n, cap_keys) keys of an array, through the probing path

@@ -244,10 +244,15 @@ class Counter:
     def add_reads(self, bases, offsets, n_reads, mem=KT_MEM_DEVICE):
         check(_lib.lib().kt_ctr_add_reads(self._h, _ptr(bases), _ptr(offsets), n_reads, mem))
 
-    def add_reads_host(self, bases, offsets):
+    def add_reads_host(self, bases, offsets, n_parts=1, part=0):
         bases = np.ascontiguousarray(bases, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
-        self.add_reads(bases if bases.size else np.zeros(1, np.uint8), offsets, len(offsets) - 1, KT_MEM_HOST)
+        self.add_reads_part(bases if bases.size else np.zeros(1, np.uint8), offsets, len(offsets) - 1, n_parts, part,
+                            KT_MEM_HOST)
+
+    def add_reads_part(self, bases, offsets, n_reads, n_parts, part, mem=KT_MEM_DEVICE):
+        """only the k-mers of hash partition `part` of `n_parts` (out-of-core passes)"""
+        check(_lib.lib().kt_ctr_add_reads_part(self._h, _ptr(bases), _ptr(offsets), n_reads, mem, n_parts, part))
 
     def add_pairs(self, keys, counts, n, mem=KT_MEM_DEVICE):
         check(_lib.lib().kt_ctr_add_pairs(self._h, _ptr(keys), _ptr(counts), n, mem))

@@ -238,3 +238,40 @@ def test_cli_larger_file_matches_oracle(cli, oracle, tmp_path):
     assert run(cli, "min", "-i", fa4, "-o", mo, "-p", "m2s").stderr == ""
     assert sorted(mo.read_text().splitlines(keepends=True)) == sorted(oracle.bin_sequences_lines(long_enough, 0, 10))
     assert mo.read_text().splitlines() == sorted(mo.read_text().splitlines())
+
+
+@pytest.mark.gpu
+def test_ctr_out_of_core_passes_and_devices(cli, oracle, tmp_path):
+    """a table 4x too small for the input's distinct k-mers: `ctr` runs hash-partition passes over the input
+    (kt_ctr_add_reads_part; the reference spills chunks and merges partitions, counter/src/lib.rs:114-118,151-167,
+    188-231) and kmers.counts is still the oracle's; `--devices 2` (two rank threads, here on one GPU through the
+    in-process host all-to-all) gives the same lines; stdin is refused like the reference's SeqFormat::get("-")"""
+    import os
+    import numpy as np
+    rng = np.random.default_rng(17)
+    seqs = ["".join(rng.choice(list("ACGTN"), size=int(L), p=[.2475, .2475, .2475, .2475, .01]))
+            for L in rng.integers(100, 600, size=6000)]
+    seqs += ["A" * 3000, "ACGT" * 500] + seqs[:300]            # heavy hitters and repeats
+    fq = tmp_path / "r.fastq"
+    fq.write_text("".join("@s%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in enumerate(seqs)))
+    bases, offsets = oracle.to_csr(seqs)
+    keys, counts = oracle.count_reads(bases, offsets, 21, n_parts=4, threads=4)
+    want = oracle.counts_lines(keys, counts)
+    env = dict(os.environ, KT_CLI_TIMING="1", KT_BULK_MIN_BASES="0")
+    d1 = tmp_path / "one"
+    r = run(cli, "ctr", "-i", fq, "-o", d1, "-k", "21", env=env)
+    assert r.returncode == 0 and ", 1 pass(es)" in r.stderr
+    assert sorted((d1 / "kmers.counts").read_text().splitlines()) == want
+    small = max(1024, int(1.4 * len(keys) / 4))                 # slots for a quarter of the distinct k-mers
+    d4 = tmp_path / "four"
+    r = run(cli, "ctr", "-i", fq, "-o", d4, "-k", "21", "-a", env=dict(env, KT_CTR_MAX_SLOTS=str(small)))
+    assert r.returncode == 0, r.stderr
+    passes = int(r.stderr.split(" pass(es)")[0].split()[-1])
+    assert passes >= 4
+    assert sorted((d4 / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(keys, counts, k=21, acgt=True)
+    d2 = tmp_path / "two"
+    r = run(cli, "ctr", "-i", fq, "-o", d2, "-k", "21", "--devices", "2", env=dict(env, KT_CLI_SHARE_GPU="1"))
+    assert r.returncode == 0, r.stderr
+    assert sorted((d2 / "kmers.counts").read_text().splitlines()) == want
+    r = run(cli, "ctr", "-i", "-", "-o", tmp_path / "x", "-k", "21", input=fq.read_text())
+    assert r.returncode == 101 and "Error" in r.stderr
