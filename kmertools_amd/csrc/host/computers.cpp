@@ -352,6 +352,33 @@ static void emit_matrix(AsyncWriter &writer, const Work &w, uint64_t bins, bool 
     writer.write(pieces);
 }
 
+// the same for raw counts delivered as u32 (`-c`: half the device-to-host bytes of f64 rows, integers print bare)
+static void emit_counts(AsyncWriter &writer, const Work &w, uint64_t bins, const std::string &delim, int threads,
+                        std::vector<std::string> &pieces, PhaseTimer &pt) {
+    Lap lap;
+    const uint32_t *rows = reinterpret_cast<const uint32_t *>(w.rows.data());
+    const char d0 = delim.size() == 1 ? delim[0] : ' ';
+    format_rows(w.b.n_reads(), threads, bins * 4 + 1, pieces, [&](uint64_t r, std::string &s) {
+        const uint32_t *row = rows + r * bins;
+        char buf[16];
+        for (uint64_t i = 0; i < bins; i++) {
+            if (i) {
+                if (delim.size() == 1) s += d0; else s += delim;
+            }
+            const uint32_t v = row[i];
+            if (v < 10) {
+                s += (char)('0' + v);
+            } else {
+                const auto res = std::to_chars(buf, buf + sizeof buf, v);
+                s.append(buf, (size_t)(res.ptr - buf));
+            }
+        }
+        s += '\n';
+    });
+    pt.t[2] += lap();
+    writer.write(pieces);
+}
+
 // hidden `kmertools debug-emit`: times the text stage alone on fabricated count-ratio rows
 double debug_emit_bench(uint64_t n_rows, uint64_t bins, bool norm, int threads, int reps) {
     Work w;
@@ -413,10 +440,8 @@ std::string OligoComputer::vectorise() {
     if (!reader.open(in_path_, in_path_ == "-" || !norm_)) return reader.error();
     FILE *out = fopen(out_path_.c_str(), "wb");
     if (!out) return "Unable to write to file: " + out_path_;
-    if (std::string e = dev_.ensure(); !e.empty()) {
-        fclose(out);
-        return e;
-    }
+    // (the device context is created by the first device call: HIP start-up, 0.1-0.3 s, then runs while the reader
+    // thread parses the first batch)
     uint64_t bins = 0;
     kt_bins(ksize_, count_min_, &bins);
     if (header_) {
@@ -435,15 +460,20 @@ std::string OligoComputer::vectorise() {
     const std::string err = run_pipeline(
         reader, batch_bases(memory_), 1ull << 19, pt,
         [&](Work &w) -> std::string {
+            if (std::string e = dev_.ensure(); !e.empty()) return e;
             const uint64_t n = w.b.n_reads();
-            w.resize_rows(n * bins);
+            // normalised rows are f64 (the reference's type, bit-identical); raw counts travel as u32
+            w.resize_rows(norm_ ? n * bins : (n * bins + 1) / 2);
             w.pin_rows(dev_.ctx);
-            if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, count_min_, norm_, 1, KT_F64,
-                               w.rows.data(), KT_MEM_HOST) != KT_OK)
+            if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, count_min_, norm_, 1,
+                               norm_ ? KT_F64 : KT_U32, w.rows.data(), KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
             return "";
         },
-        [&](Work &w) { emit_matrix(writer, w, bins, norm_, delim_, threads_, pieces, pt); });
+        [&](Work &w) {
+            if (norm_) emit_matrix(writer, w, bins, true, delim_, threads_, pieces, pt);
+            else emit_counts(writer, w, bins, delim_, threads_, pieces, pt);
+        });
     writer.finish();
     fclose(out);
     return err;
