@@ -388,10 +388,10 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         # the most distinct keys this rank can end up owning (its share of the hash space; 3 % head room for the
         # imbalance between owners)
         max_distinct = min(int(n * kmers_per_read * (1.03 if world > 1 else 1.0)), (4 ** k + 2 ** k) // 2)
-        # slots: 1.4x the most distinct keys (load factor 0.7; measured sweep in DESIGN.md: the table image is what the
-        # build writes and the export reads, but the LDS insert slows down with the load); the library rounds up to
-        # m * 2^j, m in 5..8
-        cap = max(1 << 20, int(float(os.environ.get("KT_BENCH_CAP_FACTOR", "1.4")) * max_distinct))
+        # slots: 1.9x the most distinct keys (load factor ~0.5; measured sweep in DESIGN.md: the table image is what the
+        # build writes and the export reads, but the LDS insert slows down steeply with the load); the library rounds
+        # up to m * 2^j, m in 5..8 (1.9x, not 2x: the canonical 15-mers are 2^29 + 2^14, 2x is just past a power of two)
+        cap = max(1 << 20, int(float(os.environ.get("KT_BENCH_CAP_FACTOR", "1.9")) * max_distinct))
         if args.cap_log2:
             cap = 1 << args.cap_log2
         if args.cap_slots:

@@ -657,8 +657,8 @@ std::string CountComputer::count() {
     if (n_devices_ > 1) return count_sharded(max_distinct);
     if (std::string e = dev_.ensure(); !e.empty()) return e;
     const double t_dev = setup();
-    // 1.4 slots per possible key = load factor 0.7 at worst (the library rounds up to m * 2^j, m in 5..8)
-    uint64_t want = max_distinct + max_distinct / 5 * 2;
+    // 1.9 slots per possible key = load factor ~0.5 at worst (the library rounds up to m * 2^j, m in 5..8)
+    uint64_t want = max_distinct + max_distinct / 10 * 9;
     if (want < 1024) want = 1024;
     // The reference bounds its memory with -m: chunks of the input, partitions spilled to disk, merged partition by
     // partition (counter/src/lib.rs:114-118, 151-167, 188-231).  Here the bound is the HBM next to the build's
@@ -761,7 +761,7 @@ std::string CountComputer::count_sharded(uint64_t max_distinct) {
     const bool share = getenv("KT_CLI_SHARE_GPU") != nullptr;
     const uint64_t batch_bases = 256ull << 20, max_batch = batch_bases * 2;  // (a batch ends with a whole record)
     uint64_t per_rank = max_distinct / N + max_distinct / N / 16 + 4096;
-    uint64_t cap = per_rank + per_rank / 5 * 2;
+    uint64_t cap = per_rank + per_rank / 10 * 9;
     uint8_t id[128] = {};
     if (!share && kt_rccl_unique_id(id) != KT_OK) return kt_last_error();
     LocalFabric fabric(N);

@@ -49,10 +49,10 @@ using kttab::TableRef;
 
 constexpr int BLOCK = ktseg::BLOCK;       // 256
 #ifndef KT_BUILD_T
-#define KT_BUILD_T 512
+#define KT_BUILD_T 1024
 #endif
 constexpr uint32_t LOG2_S = kttab::LOG2_RANGE;  // hash positions per fine bucket = per range of the table
-constexpr uint32_t S = 1u << LOG2_S;            // 4096 positions: 512 * m8 slots, 40 - 64 KB of table
+constexpr uint32_t S = 1u << LOG2_S;            // 8192 positions: 1024 * m8 slots, 80 - 128 KB of table
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 #ifndef KT_P2T
 #define KT_P2T 512
@@ -625,28 +625,28 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
 }
 
 // ---- build: one workgroup per fine bucket = one range of the table ---------------------------------------
-// A range (kt_table.hpp) is a closed, circular linear-probing table of RS = 512 * m8 slots, so its image fits LDS
-// (48 KB of keys + counts): the bucket's keys - and, when the table already holds data, the range's current entries
-// with their counts - are inserted into that image with LDS atomics and the image is written out with coalesced
-// non-temporal 16-byte stores (empty slots included, so an empty table needs no clear).  Nothing ever leaves its
-// range, so nothing goes through the global atomic path afterwards, and an existing range can be rebuilt in place.
-// The insert is latency bound, not throughput bound (tools/ubench/lds_atomics.hip: 2.9 random 64-bit CAS per clock
-// and CU, 4.9 32-bit ones; one probe at a time per wave reached a sixth of that), so every lane runs KT_BUILD_U
-// independent insert state machines: their CAS are issued back to back and only then looked at (one CAS per probe:
-// it reports what the slot holds; a machine that has placed its key takes its next one at once; next keys are
-// prefetched).  That also makes the table's load factor nearly free: 0.8 instead of round 1's 0.47, whose
-// one-probe-at-a-time insert slowed down 1.5x at 0.7.
-// A first version of this round deduplicated in a sparser LDS table and computed the probing layout with a counting
-// sort + prefix maximum instead of probing (git history: 57 ms; dedupe 20, placement 10, image 6 - all of it
-// barrier and latency, none of it overlapping): the direct insert needs three barriers per range.
+// A range (kt_table.hpp) is a closed, circular linear-probing table of RS = 1024 * m8 slots, so its image fits LDS
+// (<= 96 KB of keys + counts): the bucket's keys - on top of the range's current image when the table already holds
+// data - are inserted with LDS atomics and the image is written out with coalesced non-temporal 16-byte stores (empty
+// slots included, so an empty table needs no clear).  Nothing ever leaves its range: no clean-up pass through the
+// global atomic path, and an existing range can be rebuilt in place (later batches merge without global atomics).
 // More distinct keys than slots in a range (a table that is too small) go to the spill list and fail there, loudly.
+//
+// Measured this round on the way here (ctr k=31, 25 M reads, build kernel alone; profiles/r2_build_sweep.txt):
+//  * the insert is not bound by LDS atomic throughput (tools/ubench/lds_atomics.hip: 2.9 random 64-bit CAS per clock
+//    and CU; the kernel needs a tenth of that) but by the longest probe walk of a workgroup: at load 0.8 a range's
+//    longest run of taken slots is a few hundred, and one lane walks it a slot per LDS round trip while the
+//    workgroup waits at the barrier.  Load 0.47 / 0.56 / 0.70 / 0.80: 24.9 / 27.8 / 38.0 / 61.6 ms.
+//  * several insert machines per lane (more CAS in flight) made it worse (0.8: 61.6 -> 84.7 -> 116.8 ms for 1 / 2 / 4):
+//    fewer keys per machine, same longest walk.  Handing finished lanes the wave's next keys (ballot + rank +
+//    ds_bpermute) and reading before the CAS: 53.8 ms.  A wave-wide 64-slot scan for walks past 16 slots: 40.2 ms.
+//  * deduplicating in a sparser LDS table and computing the probing layout with a counting sort + prefix maximum
+//    instead of probing (load-independent): 39.6 ms - dedupe 20, placement 10, image 6, none of it overlapping.
+//  * so the table keeps a load factor near 0.5, where the plain state machine below is bound by the image it writes
+//    (103 GB at 5 TB/s), and the image is what a smaller-slot layout would have to shrink.
 static_assert(LOG2_S == kttab::LOG2_RANGE, "a fine bucket is a range of the table");
 
 constexpr int BUILD_T = KT_BUILD_T;
-#ifndef KT_BUILD_COOP
-#define KT_BUILD_COOP 16
-#endif
-constexpr uint32_t COOP = KT_BUILD_COOP;  // single-lane probes before a key's walk gets the whole wave
 
 template <class K>
 struct lds_word;
@@ -706,100 +706,40 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         }
         ktd::lds_barrier();
         {
-            // Every wave owns a contiguous share [wlo, whi) of the bucket's keys and reads it in 64-key chunks (one
-            // coalesced load, the next chunk prefetched).  A lane is an insert state machine: one probe per trip (a
-            // plain LDS read; the CAS only when the slot looks free), and the lanes that have placed their key are
-            // handed the next keys of the chunk at once (ballot + rank + ds_bpermute), so no lane idles while the wave
-            // has keys left - with a fixed key list per lane the wave waited for the lane whose keys drew the longest
-            // probe chains (2x the mean at load 0.5, 5x at 0.8).
-            constexpr uint32_t NW = BUILD_T / 64;
-            const uint32_t wave = tid >> 6;
-            const uint64_t per = ((hi - lo + NW - 1) / NW + 63) & ~63ull;
-            const uint64_t wlo = lo + wave * per < hi ? lo + wave * per : hi;
-            const uint64_t whi = wlo + per < hi ? wlo + per : hi;
-            uint64_t cpos = wlo;
-            auto load_chunk = [&]() {
-                const K k = cpos + lane < whi ? keys2[cpos + lane] : EMPTY;
-                cpos += 64;
+            // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
+            // trip (the CAS itself reports what the slot holds), and a lane that has placed its key moves on to its
+            // next one at once; four keys are kept prefetched so the loads are never waited for.  ("For each key:
+            // probe until placed" makes the wave wait for its longest probe chain on every key.)
+            uint64_t idx = lo + tid;
+            auto fetch = [&]() {
+                const K k = idx < hi ? keys2[idx] : EMPTY;
+                idx += BUILD_T;
                 return k;
             };
-            K chunk = load_chunk(), ahead = load_chunk();
-            uint32_t taken = 0;  // keys of `chunk` handed out so far (wave uniform)
-            bool more = wlo < whi && !(p.dbg & 1u);  // `chunk` may still hold keys
-            K cur = EMPTY;
-            uint32_t s = 0, probes = 0;
-            bool stuck = false;
-            for (;;) {
-                if (more) {
-                    const uint64_t idle = __ballot(cur == EMPTY);
-                    if (idle) {
-                        const uint32_t want = taken + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                        const K k = (K)__shfl(chunk, (int)(want & 63u), 64);
-                        if (cur == EMPTY && want < 64u) {
-                            cur = k;
-                            s = home((uint64_t)k);
-                            probes = 0;
-                        }
-                        taken += (uint32_t)__popcll(idle);
-                        if (taken >= 64u) {  // chunk used up (lanes that got nothing are served next trip)
-                            chunk = ahead;
-                            ahead = load_chunk();
-                            taken = 0;
-                            more = cpos - 128 < whi;  // the new chunk starts inside the share
-                        }
-                    }
+            K cur = fetch(), q0 = fetch(), q1 = fetch(), q2 = fetch();
+            if (p.dbg & 1u) cur = EMPTY;
+            uint32_t s = home((uint64_t)cur), probes = 0;
+            while (cur != EMPTY) {
+                const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
+                bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
+                if (!done && v == cur) {
+                    atomicAdd(&scounts[s], 1u);
+                    done = true;
                 }
-                if (__ballot(cur != EMPTY) == 0) {
-                    if (!more) break;
-                    continue;
-                }
-                // a lane whose key has walked KT_BUILD_COOP slots is in one of the long clusters of a well filled range
-                // (load 0.8: the longest run of taken slots in a range is a few hundred).  One such lane per trip gets
-                // the whole wave: 64 consecutive slots read at once, the lane jumps to the first that is free or
-                // holds its key.  Without this the workgroup waits for its longest walk, one LDS round trip per slot.
-                const uint64_t stuck_mask = __ballot(stuck);
-                if (stuck_mask) {
-                    const int L = __ffsll((unsigned long long)stuck_mask) - 1;
-                    const K lk = (K)__shfl(cur, L, 64);
-                    const uint32_t ls = (uint32_t)__shfl((int)s, L, 64);
-                    uint32_t at = ls + lane;
-                    at = at >= RS ? at - RS : at;
-                    const K v = skeys[at];
-                    const uint64_t hit = __ballot(v == EMPTY || v == lk);
-                    if ((int)lane == L) {
-                        const uint32_t adv = hit ? (uint32_t)(__ffsll((unsigned long long)hit) - 1) : 64u;
-                        s = ls + adv;
-                        s = s >= RS ? s - RS : s;
-                        probes += adv;
-                        stuck = hit == 0;
-                        if (probes >= RS) {  // once round the range: it is full, the table is too small
-                            spill((uint64_t)cur, 1u);
-                            cur = EMPTY;
-                            stuck = false;
-                        }
-                    }
-                }
-                if (cur != EMPTY && !stuck) {
-                    K v = skeys[s];
-                    if (v == EMPTY) v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
-                    bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
-                    if (!done && v == cur) {
-                        atomicAdd(&scounts[s], 1u);
+                if (!done) {
+                    s = s + 1 == RS ? 0 : s + 1;  // round the range (kttab::Probe)
+                    if (++probes >= RS) {          // the range is full: the table is too small
+                        spill((uint64_t)cur, 1u);
                         done = true;
                     }
-                    if (!done) {
-                        s = s + 1 == RS ? 0 : s + 1;  // round the range (kttab::Probe)
-                        probes++;
-                        stuck = probes >= COOP && RS >= 64u;
-                        if (probes >= RS) {
-                            spill((uint64_t)cur, 1u);
-                            done = true;
-                        }
-                    }
-                    if (done) {
-                        cur = EMPTY;
-                        stuck = false;
-                    }
+                }
+                if (done) {
+                    cur = q0;
+                    q0 = q1;
+                    q1 = q2;
+                    q2 = fetch();
+                    s = home((uint64_t)cur);
+                    probes = 0;
                 }
             }
         }
@@ -951,7 +891,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     hipLaunchKernelGGL(part2, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur, p,
                        keys2, m.fstart, m.fend);
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
-    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 12);  // persistent workgroups; three are resident per CU
+    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 8);  // persistent workgroups; up to two are resident per CU
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
     auto build = j.merge ? build_kernel<K, true> : build_kernel<K, false>;

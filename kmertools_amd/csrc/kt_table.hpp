@@ -2,16 +2,17 @@
 // path in kt_ctr.hip, the lookups of kt_cov.hip and the bulk (partition + LDS build) path in kt_bulk.hip.
 //
 // Layout: 16-byte slots {u64 key, u32 occurrences-1, u32 pad}; KT_EMPTY_KEY marks a free slot.  The table is a
-// row of independent RANGES: with x = the top n bits of khash(key), the top n - 12 bits of x select the range
-// and the low 12 bits the home position inside it; a range has 512 * m8 slots (m8 = 5..8 eighths of 4096, so that
+// row of independent RANGES: with x = the top n bits of khash(key), the top n - 13 bits of x select the range
+// and the low 13 bits the home position inside it; a range has 1024 * m8 slots (m8 = 5..8 eighths of 8192, so that
 // a table is at most 1.25x - not 2x - what was asked for) and is a closed linear-probing table of its own: probing
 // runs forward from the home slot and wraps at the END OF THE RANGE, never into the next range.
-//   cap = m8 * 2^(n-3) slots     home = (x >> 12) * (512 * m8) + ((x & 4095) * m8 >> 3)
+//   cap = m8 * 2^(n-3) slots     home = (x >> 13) * (1024 * m8) + ((x & 8191) * m8 >> 3)
 // Why ranges: "all keys of hash prefix p" is one contiguous, self-contained piece of the table, so the bulk path can
 // build (or rebuild: merge a new batch into) every range in LDS on its own and write it with streaming stores - no
-// key of one range ever lives in another, no clean-up pass through the atomic path, a load factor of 0.8 instead
-// of 0.5 (round 1's ranges spilled into their successors, which kept them half empty).  The price is one compare
-// per probe step.  Tables of fewer than 4096 slots are a single range of `cap` slots.
+// key of one range ever lives in another, no clean-up pass through the atomic path (round 1's ranges spilled into
+// their successors), and a full table is noticed after at most one trip round a range.  The price is one compare
+// per probe step, and that a range - not the table - must have room: keep distinct keys below ~0.85 of the slots.
+// Tables of fewer than 8192 slots are a single range of `cap` slots.
 // GPU ownership (ktd::owner_of) uses the LOW 32 bits of the same hash, so a shard's keys still spread over
 // its whole table.
 #pragma once
@@ -28,14 +29,14 @@ struct Slot {
 static_assert(sizeof(Slot) == 16, "slot layout");
 
 #ifndef KT_LOG2_RANGE
-#define KT_LOG2_RANGE 12
+#define KT_LOG2_RANGE 13
 #endif
 constexpr uint32_t LOG2_RANGE = KT_LOG2_RANGE, RANGE_FULL = 1u << LOG2_RANGE;
 
 struct Geom {
     uint64_t cap;
     uint32_t shift;  // 64 - n
-    uint32_t m8;     // slots per range / 512
+    uint32_t m8;     // slots per range / 1024
     // slots of one range (the whole table when it is smaller than a range)
     __host__ __device__ uint32_t range_slots() const {
         return shift > 64 - LOG2_RANGE ? (uint32_t)cap : m8 << (LOG2_RANGE - 3);
@@ -80,7 +81,7 @@ __host__ __device__ __forceinline__ Probe probe_of(uint64_t key, const Geom &g) 
 // A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe can only show EMPTY for a slot that is now
 // taken, and the CAS (device scope, coherent across XCDs) settles that case.  A k-mer seen once costs one probing load
 // + one CAS (claiming the slot is its first count); a repeat costs one load + one 32-bit atomic add.  At most one
-// trip round the key's range (<= 4096 probes), so a full table fails fast instead of being scanned end to end.
+// trip round the key's range (<= 8192 probes), so a full table fails fast instead of being scanned end to end.
 __device__ __forceinline__ uint32_t table_add(const TableRef &t, uint64_t key, uint32_t add) {
     Probe p = probe_of(key, t.g);
     for (uint32_t probe = 0; probe < p.rs; probe++) {

@@ -653,8 +653,8 @@ def _random_reads(seed, n, L=150):
     return [alpha[rng.integers(0, 4, size=L)].tobytes() for _ in range(n)]
 
 
-@pytest.mark.parametrize("k,log2cap,load", [(31, 14, 0.5), (31, 14, 0.8), (31, 15, 0.93), (31, 16, 0.92), (15, 15, 0.9),
-                                            (21, 17, 0.97)])
+@pytest.mark.parametrize("k,log2cap,load", [(31, 15, 0.5), (31, 15, 0.8), (31, 16, 0.92), (31, 17, 0.93), (15, 15, 0.9),
+                                            (21, 17, 0.94)])
 def test_ctr_range_build_high_load(hctx, oracle, monkeypatch, k, log2cap, load):
     """the range build places keys where range-circular linear probing would (kt_table.hpp) at any load factor:
     the export is the oracle's table, every key is found again by the lookups of cov and by the probing insert path
@@ -729,9 +729,9 @@ def test_ctr_range_build_full_table_is_loud(hctx, monkeypatch):
     """more distinct k-mers than slots: the range build must report KT_ERR_FULL, not drop keys or hang"""
     from kmertools_amd import device, _lib
     monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
-    seqs = _random_reads(3, 300)                             # 36 000 distinct 31-mers into 16 384 slots
+    seqs = _random_reads(3, 600)                             # 72 000 distinct 31-mers into 32 768 slots
     bases, offsets = device.to_csr(seqs)
-    ctr = device.Counter(hctx, 31, 1 << 14)
+    ctr = device.Counter(hctx, 31, 1 << 15)
     ctr.add_reads_host(bases, offsets)
     with pytest.raises(_lib.KmertoolsError) as e:
         ctr.size()
