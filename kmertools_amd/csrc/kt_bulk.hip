@@ -655,7 +655,11 @@ struct lds_word<uint64_t> { using type = unsigned long long; };
 template <>
 struct lds_word<uint32_t> { using type = unsigned int; };
 
-template <class K, bool MERGE>
+// DENSE (a fresh table only): instead of the range's image, its occupied slots alone are written, packed at the front
+// of the range's slots, and their number goes to range_counts[range].  That is all kt_ctr_size / kt_ctr_export need
+// (the usual fate of a table: counted once, written out), and it is 48 GB instead of 103 GB at k=31 / 25 M reads; the
+// probing image is produced from it in place (materialize_kernel) the first time something has to probe.
+template <class K, bool MERGE, bool DENSE>
 __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ keys2,
                                                         const uint64_t *__restrict__ fstart,
                                                         const uint64_t *__restrict__ fend, Plan p,
@@ -663,7 +667,9 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
                                                         uint64_t *__restrict__ spill_keys,
                                                         uint32_t *__restrict__ spill_counts, uint64_t spill_cap,
                                                         uint32_t *__restrict__ spill_ovf,
-                                                        uint64_t *__restrict__ distinct) {
+                                                        uint64_t *__restrict__ distinct,
+                                                        uint32_t *__restrict__ range_counts) {
+    static_assert(!(MERGE && DENSE), "a dense build starts from an empty table");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using W = typename lds_word<K>::type;
     constexpr K EMPTY = empty_of<K>();
@@ -677,6 +683,10 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         return (((uint32_t)(ktd::khash(key) >> shift) & (S - 1)) * p.m8) >> 3;
     };
     auto spill = [&](uint64_t key, uint32_t occurrences) {
+        if (DENSE) {  // (no image to probe afterwards: a full range is reported at once)
+            atomicOr(spill_ovf, 1u);
+            return;
+        }
         const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(spill_n), 1ull);
         if (at < spill_cap) {
             spill_keys[at] = key;
@@ -685,6 +695,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             atomicOr(spill_ovf, 1u);
         }
     };
+    __shared__ uint32_t runs[BUILD_T / 64 * (S / BUILD_T) + 1];  // DENSE: occupied slots per (wave, pass), then their prefix
     long long placed = 0;  // per thread: occupied slots written - occupied slots found (MERGE)
     for (uint64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
         const uint64_t lo = fstart[fb], hi = fend[fb];
@@ -745,7 +756,47 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         }
         ktd::lds_barrier();
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * RS);
-        if (!(p.dbg & 8u)) {
+        if (DENSE) {
+            // the occupied slots, packed, straight from the LDS image: every (wave, pass) ballots its 64 slots, one
+            // wave scans the 128 popcounts, and each store instruction then writes one contiguous run
+            constexpr uint32_t PT = S / BUILD_T;  // passes over the image (RS <= S)
+            uint64_t bal[PT];
+#pragma unroll
+            for (uint32_t j = 0; j < PT; j++) {
+                const uint32_t i = j * BUILD_T + tid;
+                bal[j] = __ballot(i < RS && skeys[i] != EMPTY);
+                if (lane == 0) runs[(tid >> 6) * PT + j] = (uint32_t)__popcll(bal[j]);
+            }
+            ktd::lds_barrier();
+            if (tid < 64) {  // NRUN = 2 * 64 runs: two per lane
+                static_assert(BUILD_T / 64 * PT == 128, "two runs per lane of the scanning wave");
+                const uint32_t a = runs[2 * tid], b2 = runs[2 * tid + 1];
+                uint32_t inc = a + b2;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = __shfl_up(inc, off, 64);
+                    if (lane >= (uint32_t)off) inc += v;
+                }
+                runs[2 * tid] = inc - a - b2;
+                runs[2 * tid + 1] = inc - b2;
+                if (tid == 63) {
+                    runs[128] = inc;  // D: distinct keys of the range
+                    range_counts[fb] = inc;
+                    placed += inc;
+                }
+            }
+            ktd::lds_barrier();
+#pragma unroll
+            for (uint32_t j = 0; j < PT; j++) {
+                if ((bal[j] >> lane) & 1ull) {
+                    const uint32_t i = j * BUILD_T + tid;
+                    const uint32_t pos = runs[(tid >> 6) * PT + j] + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull));
+                    const uint64_t key = (uint64_t)skeys[i];
+                    // (plain stores: the runs start and end inside cache lines, which the L2 has to merge)
+                    dst[pos] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u);
+                }
+            }
+        } else if (!(p.dbg & 8u)) {
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
                 const K kk = skeys[i];
                 const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : (uint64_t)kk;
@@ -784,6 +835,127 @@ __global__ __launch_bounds__(BLOCK) void spill_insert_kernel(const uint64_t *__r
     for (int o = 32; o > 0; o >>= 1) fresh += __shfl_down(fresh, o, 64);
     if ((threadIdx.x & 63) == 0 && fresh)
         atomicAdd(reinterpret_cast<unsigned long long *>(distinct), (unsigned long long)fresh);
+}
+
+// dense -> image, in place: one workgroup per range reads the range's packed entries, inserts them into the LDS image
+// (distinct keys: plain CAS probing, counts carried along) and writes the whole range
+__global__ __launch_bounds__(BUILD_T) void materialize_kernel(Slot *__restrict__ slots, uint32_t RS, uint64_t n_ranges,
+                                                              uint32_t shift, uint32_t m8,
+                                                              const uint32_t *__restrict__ range_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long *const skeys = reinterpret_cast<unsigned long long *>(smem_raw);
+    uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)RS * 8);
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        for (uint32_t i = tid; i < RS; i += BUILD_T) {
+            skeys[i] = KT_EMPTY_KEY;
+            scounts[i] = 0;
+        }
+        ktd::lds_barrier();
+        const uint32_t D = range_counts[r];
+        uint4 *rs = reinterpret_cast<uint4 *>(slots + r * RS);
+        for (uint32_t i = tid; i < D; i += BUILD_T) {
+            const uint4 v = rs[i];
+            const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+            uint32_t s = (((uint32_t)(ktd::khash(key) >> shift) & (S - 1)) * m8) >> 3;
+            while (atomicCAS(&skeys[s], (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key) != KT_EMPTY_KEY)
+                s = s + 1 == RS ? 0 : s + 1;  // (D <= RS: a free slot exists)
+            scounts[s] = v.z;
+        }
+        ktd::lds_barrier();
+        for (uint32_t i = tid; i < RS; i += BUILD_T) {
+            const uint64_t key = skeys[i];
+            typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+            const raw4 raw = {(uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u};
+            __builtin_nontemporal_store(raw, reinterpret_cast<raw4 *>(rs + i));
+        }
+        ktd::lds_barrier();
+    }
+}
+
+// ---- dense table -> (keys, counts) ----------------------------------------------------------------------------
+// Ranges are taken in tiles of 256: tile sums (coalesced), a one-workgroup scan of the tile sums, and the copy kernel
+// scans the 256 counts of its tile itself - every read and write coalesced, no atomics, output in range order.
+constexpr uint32_t XT = 256;
+__global__ __launch_bounds__(XT) void tile_sums_kernel(const uint32_t *__restrict__ counts, uint64_t n,
+                                                       uint64_t *__restrict__ tile_sums) {
+    __shared__ uint32_t part[XT / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * XT + threadIdx.x;
+    uint32_t v = i < n ? counts[i] : 0u;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = (uint64_t)part[0] + part[1] + part[2] + part[3];
+}
+// tile_sums[t] -> exclusive prefix; tile_sums[n_tiles] = total.  One workgroup, tiles in chunks of 1024.
+__global__ __launch_bounds__(1024) void tile_scan_kernel(uint64_t *__restrict__ tile_sums, uint64_t n_tiles) {
+    __shared__ uint64_t wtot[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t c0 = 0; c0 < n_tiles; c0 += 1024) {
+        const uint64_t i = c0 + threadIdx.x;
+        const uint64_t v = i < n_tiles ? tile_sums[i] : 0;
+        uint64_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t u = __shfl_up(inc, off, 64);
+            if ((threadIdx.x & 63) >= (uint32_t)off) inc += u;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint64_t base = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wtot[w];
+        if (i < n_tiles) tile_sums[i] = base + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
+}
+__global__ __launch_bounds__(XT) void dense_export_kernel(const Slot *__restrict__ slots, uint32_t RS, uint64_t n_ranges,
+                                                          const uint32_t *__restrict__ range_counts,
+                                                          const uint64_t *__restrict__ tile_offsets,
+                                                          uint64_t *__restrict__ out_keys,
+                                                          uint32_t *__restrict__ out_counts, uint64_t max_out) {
+    __shared__ uint32_t offs[XT + 1], cnt[XT], wt[XT / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * XT;
+    const uint32_t c = r0 + tid < n_ranges ? range_counts[r0 + tid] : 0u;
+    uint32_t inc = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(inc, off, 64);
+        if ((tid & 63) >= (uint32_t)off) inc += u;
+    }
+    if ((tid & 63) == 63) wt[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) base += wt[w];
+    offs[tid] = base + inc - c;
+    cnt[tid] = c;
+    __syncthreads();
+    const uint64_t t0 = tile_offsets[blockIdx.x];
+    // every wave copies ranges of its own (no workgroup barrier in the loop), four loads in flight per lane
+    for (uint32_t r = tid >> 6; r < XT && r0 + r < n_ranges; r += XT / 64) {
+        const uint32_t D = cnt[r];
+        const uint64_t o = t0 + offs[r];
+        const uint4 *rs = reinterpret_cast<const uint4 *>(slots + (r0 + r) * RS);
+        for (uint32_t i0 = tid & 63u; i0 < D; i0 += 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + 64u * u;
+                v[u] = i < D ? rs[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + 64u * u;
+                if (i < D && o + i < max_out) {
+                    out_keys[o + i] = ((uint64_t)v[u].y << 32) | v[u].x;
+                    out_counts[o + i] = v[u].z + 1u;  // stored value is occurrences - 1
+                }
+            }
+        }
+    }
 }
 
 uint64_t env_u64(const char *name, uint64_t dflt) {
@@ -894,15 +1066,21 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 8);  // persistent workgroups; up to two are resident per CU
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
-    auto build = j.merge ? build_kernel<K, true> : build_kernel<K, false>;
+    // (off by default: measured slower - dense build 34 ms + dense export 16 ms against image build 22 ms + export 27.5 ms
+    // at ctr k=31, 18.6 + 3.1 against 13.0 + 4.7 ms at k=15; profiles/r2_build_sweep.txt)
+    const bool dense = !j.merge && env_u64("KT_BULK_DENSE", 0) != 0;
+    auto build = j.merge ? build_kernel<K, true, false> : dense ? build_kernel<K, false, true> : build_kernel<K, false, false>;
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)build_lds));
     hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend,
                        p, (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_counts, m.spill_cap, ctr->flags,
-                       ctr->distinct);
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
-    hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
-                       m.spill_counts, m.spill_cap, t, ctr->distinct);
+                       ctr->distinct, ctr->range_counts);
+    ctr->dense = dense;
+    if (!dense) {
+        TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+        hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
+                           m.spill_counts, m.spill_cap, t, ctr->distinct);
+    }
     KT_HIP(hipGetLastError());
     if (env_u64("KT_BULK_VERBOSE", 0)) {
         uint64_t spilled = 0;
@@ -930,6 +1108,8 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     j.open = false;
     j.srcs.clear();
     j.merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
+    if (j.merge)
+        if (int rc = kt_table_image(ctr)) return rc;  // (a densely packed table gets its probing image first)
     j.narrow = ctr->k <= 16 && env_u64("KT_BULK_NARROW", 1);
     j.max_keys = max_keys;
     j.added_bound = 0;
@@ -1105,5 +1285,41 @@ int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int
     if (int rc = kt_bulk_add_keys(ctr, d_keys, n_keys, nullptr)) return rc;
     if (int rc = kt_bulk_finish(ctr)) return rc;
     *done = 1;
+    return KT_OK;
+}
+
+// the probing image of a table that the last build left densely packed (in place; no-op otherwise)
+int kt_table_image(kt_ctr *ctr) {
+    if (!ctr->dense) return KT_OK;
+    kt_ctx *ctx = ctr->ctx;
+    const uint32_t RS = ctr->m8 << (LOG2_S - 3);
+    const uint64_t n_ranges = ctr->cap / RS;
+    const size_t lds = (size_t)RS * 12;
+    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(materialize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    uint64_t g = (uint64_t)ctx->n_cu * 4;
+    if (g > n_ranges) g = n_ranges;
+    hipLaunchKernelGGL(materialize_kernel, dim3((uint32_t)g), dim3(BUILD_T), lds, ctx->stream, (Slot *)ctr->slots, RS, n_ranges,
+                       ctr->shift, ctr->m8, ctr->range_counts);
+    KT_HIP(hipGetLastError());
+    ctr->dense = false;
+    return KT_OK;
+}
+
+// kt_ctr_export of a densely packed table: d_keys / d_counts are device arrays of max_out entries; *n = entries in the table
+int kt_table_dense_export(kt_ctr *ctr, uint64_t *d_keys, uint32_t *d_counts, uint64_t max_out, uint64_t *n) {
+    kt_ctx *ctx = ctr->ctx;
+    const uint32_t RS = ctr->m8 << (LOG2_S - 3);
+    const uint64_t n_ranges = ctr->cap / RS, n_tiles = (n_ranges + XT - 1) / XT;
+    if (int rc = ctx->s_aux0.reserve((n_tiles + 1) * 8)) return rc;
+    uint64_t *tiles = (uint64_t *)ctx->s_aux0.p;
+    hipLaunchKernelGGL(tile_sums_kernel, dim3((uint32_t)n_tiles), dim3(XT), 0, ctx->stream, ctr->range_counts, n_ranges, tiles);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tiles, n_tiles);
+    if (max_out)
+        hipLaunchKernelGGL(dense_export_kernel, dim3((uint32_t)n_tiles), dim3(XT), 0, ctx->stream, (const Slot *)ctr->slots, RS,
+                           n_ranges, ctr->range_counts, tiles, d_keys, d_counts, max_out);
+    KT_HIP(hipGetLastError());
+    KT_HIP(hipMemcpyAsync(n, tiles + n_tiles, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
     return KT_OK;
 }

@@ -317,6 +317,7 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->distinct, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->range_counts, (cap / geom.range_slots() + 1) * sizeof(uint32_t));
     if (e != hipSuccess) {
         kt_ctr_destroy(c);
         return kt::fail(KT_ERR_NOMEM, std::string("kt_ctr_create: hipMalloc: ") + hipGetErrorString(e));
@@ -335,6 +336,7 @@ int kt_ctr_destroy(kt_ctr *ctr) {
     if (ctr->flags) (void)hipFree(ctr->flags);
     if (ctr->cursor) (void)hipFree(ctr->cursor);
     if (ctr->distinct) (void)hipFree(ctr->distinct);
+    if (ctr->range_counts) (void)hipFree(ctr->range_counts);
     ctr->b_keys1.release();
     ctr->b_keys2.release();
     ctr->b_meta.release();
@@ -346,6 +348,7 @@ int kt_ctr_destroy(kt_ctr *ctr) {
 // Clearing is deferred: the bulk build (kt_bulk.hip) overwrites every slot, so a clear that is
 // followed by a whole-batch kt_ctr_add_reads never has to touch the table.
 static int ensure_cleared(kt_ctr *ctr) {
+    if (ctr->dense) return kt_table_image(ctr);  // (a dense table is never pending a clear)
     if (!ctr->needs_clear) return KT_OK;
     hipLaunchKernelGGL(table_clear_kernel, dim3(grid_for(ctr->ctx, (ctr->cap + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctr->ctx->stream, (Slot *)ctr->slots, ctr->cap);
@@ -367,6 +370,7 @@ int kt_ctr_clear(kt_ctr *ctr) {
     KT_HIP(hipMemsetAsync(ctr->distinct, 0, 8, ctr->ctx->stream));
     ctr->needs_clear = true;
     ctr->empty = true;
+    ctr->dense = false;
     return KT_OK;
 }
 
@@ -490,7 +494,8 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
     if (max_out && (!keys || !counts)) return kt::fail(KT_ERR_ARG, "kt_ctr_export: null output");
     kt_ctx *ctx = ctr->ctx;
     if (int rc = ctx->use()) return rc;
-    if (int rc = ensure_cleared(ctr)) return rc;
+    if (!ctr->dense)
+        if (int rc = ensure_cleared(ctr)) return rc;
     if (int rc = check_overflow(ctr)) return rc;
     uint64_t *d_keys = keys;
     uint32_t *d_counts = counts;
@@ -499,6 +504,18 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
         if (int rc = ctx->s_aux2.reserve(max_out * 4)) return rc;
         d_keys = (uint64_t *)ctx->s_aux1.p;
         d_counts = (uint32_t *)ctx->s_aux2.p;
+    }
+    if (ctr->dense) {  // packed ranges: a coalesced copy, no compaction
+        uint64_t n = 0;
+        if (int rc = kt_table_dense_export(ctr, d_keys, d_counts, max_out, &n)) return rc;
+        const uint64_t written = n < max_out ? n : max_out;
+        if (mem == KT_MEM_HOST && written) {
+            KT_HIP(hipMemcpy(keys, d_keys, written * 8, hipMemcpyDeviceToHost));
+            KT_HIP(hipMemcpy(counts, d_counts, written * 4, hipMemcpyDeviceToHost));
+        }
+        *n_out = written;
+        if (n > max_out) return kt::fail(KT_ERR_ARG, "kt_ctr_export: max_out smaller than the table's size");
+        return KT_OK;
     }
     KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
     hipLaunchKernelGGL(table_export_kernel, dim3(grid_for(ctx, (ctr->cap + XTILE - 1) / XTILE, 8)), dim3(BLOCK), 0,

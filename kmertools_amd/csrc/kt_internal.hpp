@@ -58,6 +58,8 @@ struct kt_ctr {
     bool paged_failed = false; // a bulk build overflowed a paged level-1 bucket: exact offsets from now on
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
+    bool dense = false;        // the last (bulk) build left every range packed, not as a probing image (kt_table.hpp)
+    uint32_t *range_counts = nullptr;  // device, one per range: entries of the range while the table is dense
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls
     kt_bulk_job *job = nullptr;
     void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}

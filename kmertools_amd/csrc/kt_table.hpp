@@ -127,3 +127,9 @@ int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const
 int kt_bulk_finish(kt_ctr *ctr);
 // kt_ctr.hip: one count for each of the first min(*d_n, cap_keys) keys of an array, through the probing path
 int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_keys, const uint64_t *d_n);
+// A fresh bulk build leaves the table DENSE: every range holds its entries packed at the front of its slots
+// (kt_ctr.range_counts says how many) instead of a probing image - all that size / export need.  kt_table_image turns
+// it into the probing layout in place (called by whatever has to probe: incremental adds, merges, cov);
+// kt_table_dense_export writes the (key, count) pairs of a dense table to device arrays.
+int kt_table_image(kt_ctr *ctr);
+int kt_table_dense_export(kt_ctr *ctr, uint64_t *d_keys, uint32_t *d_counts, uint64_t max_out, uint64_t *n);

@@ -725,6 +725,40 @@ def test_ctr_range_rebuild_merges_batches(hctx, oracle, monkeypatch, k, log2cap)
     ctr.close()
 
 
+@pytest.mark.parametrize("k", [31, 15])
+def test_ctr_dense_table_state(hctx, oracle, monkeypatch, k):
+    """KT_BULK_DENSE=1: a fresh range build leaves every range packed (no probing image): size and export read that
+    directly, and the first thing that probes (cov, an incremental add, a merge) turns it into the image in place"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    monkeypatch.setenv("KT_BULK_DENSE", "1")
+    monkeypatch.setenv("KT_BULK_VERBOSE", "1")
+    seqs = ragged_reads(9 + k, 400) + _random_reads(k, 300) + [b"A" * 3000]
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    for after in ("export", "cov", "atomic", "merge"):
+        ctr = device.Counter(hctx, k, 1 << 18)
+        ctr.add_reads_host(bases, offsets)
+        assert ctr.size() == len(wk)
+        if after == "cov":
+            oc = oracle.Counter(1)
+            oc.add_reads(bases, offsets, k)
+            pb, po = device.to_csr(seqs[::5] + _random_reads(1, 20))
+            got = ctr.cov_host(pb, po, 2, 6)
+            assert np.array_equal(got.view(np.uint64), oc.cov_batch(pb, po, k, 2, 6, True).view(np.uint64))
+        mult = 1
+        if after in ("atomic", "merge"):
+            monkeypatch.setenv("KT_BULK", "0" if after == "atomic" else "1")
+            monkeypatch.setenv("KT_BULK_MERGE_DIV", "1000000000")
+            ctr.add_reads_host(bases, offsets)
+            monkeypatch.setenv("KT_BULK", "1")
+            mult = 2
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, mult * wc)
+        assert ctr.size() == len(wk)
+        ctr.close()
+
+
 def test_ctr_range_build_full_table_is_loud(hctx, monkeypatch):
     """more distinct k-mers than slots: the range build must report KT_ERR_FULL, not drop keys or hang"""
     from kmertools_amd import device, _lib
