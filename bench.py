@@ -391,7 +391,8 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         # slots: 1.9x the most distinct keys (load factor ~0.5; measured sweep in DESIGN.md: the table image is what the
         # build writes and the export reads, but the LDS insert slows down steeply with the load); the library rounds
         # up to m * 2^j, m in 5..8 (1.9x, not 2x: the canonical 15-mers are 2^29 + 2^14, 2x is just past a power of two)
-        cap = max(1 << 20, int(float(os.environ.get("KT_BENCH_CAP_FACTOR", "1.9")) * max_distinct))
+        # (N > 1: 1.5x - next to the exchange regions and the partition buffers a 1.9x shard does not fit 288 GB)
+        cap = max(1 << 20, int(float(os.environ.get("KT_BENCH_CAP_FACTOR", "1.9" if world == 1 else "1.5")) * max_distinct))
         if args.cap_log2:
             cap = 1 << args.cap_log2
         if args.cap_slots:

@@ -241,7 +241,7 @@ int sharded_alloc(kt_sharded *s) {
     s->msg_u64 = HDR_U64 + s->cap_keys;
     const size_t msg = s->msg_u64 * 8;
     const uint64_t fin_u64 = HDR_U64 + FIN_CAP;
-    s->pend_cap = s->max_batch_bases / 2 + (1u << 16);  // (a batch that sends more than half of its k-mers past the
+    s->pend_cap = s->max_batch_bases / 4 + (1u << 16);  // (a batch that sends more than a quarter of its k-mers past the
                                                          // regions' room - one k-mer making up most of it - fails loudly)
     hipError_t e = hipSuccess;
     for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipMalloc((void **)&s->send[b], msg * s->n_ranks);
