@@ -1,7 +1,12 @@
 #include "seqio.hpp"
 
 #include <ctype.h>
+#include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace kthost {
 
@@ -20,12 +25,173 @@ SeqFormat format_from_path(const std::string &path_in) {
     return SeqFormat::Unknown;
 }
 
+// ---- parallel parse of a mapped plain file -----------------------------------------------------------------------
+void SeqReader::open_range(const unsigned char *p, size_t n, SeqFormat fmt) {
+    err_.clear();
+    base_ = p;
+    mem_ = true;
+    pos_ = 0;
+    end_ = n;
+    eof_ = false;
+    fmt_ = fmt;
+    have_pending_ = false;
+    n_records_ = 0;
+}
+
+struct SeqReader::Parallel {
+    const unsigned char *map = nullptr;
+    size_t size = 0;
+    SeqFormat fmt = SeqFormat::Fasta;
+    std::vector<size_t> cuts;  // piece i = [cuts[i], cuts[i + 1])
+    uint64_t max_bases = 0, max_reads = 0;
+    bool keep_ids = false, started = false;
+    // pieces are parsed by `workers` threads in order of their index; a piece's batches wait in `done` until the
+    // consumer has taken every earlier piece (at most `window` pieces are parsed ahead of the consumer)
+    struct Piece {
+        std::vector<Batch> batches;
+        std::string err;
+        bool ready = false;
+    };
+    std::vector<Piece> pieces;
+    std::mutex m;
+    std::condition_variable cv;
+    size_t next_piece = 0, consume_piece = 0, consume_batch = 0, window = 0;
+    bool stop = false;
+    std::vector<std::thread> workers;
+    uint64_t records = 0;
+
+    ~Parallel() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+        if (map) munmap((void *)map, size);
+    }
+
+    // first record start at or after `from` (FASTA: a line that begins with '>'; FASTQ: a line that begins with '@'
+    // whose third line begins with '+' and whose fourth is as long as its second - two such records in a row)
+    size_t boundary(size_t from) const {
+        size_t p = from;
+        if (p == 0) return 0;
+        const unsigned char *nl = (const unsigned char *)memchr(map + p - 1, '\n', size - (p - 1));
+        if (!nl) return size;
+        p = (size_t)(nl - map) + 1;
+        auto line_end = [&](size_t q) {
+            const unsigned char *e = q < size ? (const unsigned char *)memchr(map + q, '\n', size - q) : nullptr;
+            return e ? (size_t)(e - map) : size;
+        };
+        while (p < size) {
+            if (fmt == SeqFormat::Fasta) {
+                if (map[p] == '>') return p;
+            } else if (map[p] == '@') {
+                size_t q = p;
+                bool ok = true;
+                for (int rec = 0; rec < 2 && ok && q < size; rec++) {
+                    if (map[q] != '@') { ok = false; break; }
+                    const size_t e0 = line_end(q), s1 = e0 + 1, e1 = line_end(s1), s2 = e1 + 1, e2 = line_end(s2),
+                                 s3 = e2 + 1, e3 = line_end(s3);
+                    if (s2 >= size || map[s2] != '+' || s3 > size) { ok = false; break; }
+                    size_t l1 = e1 - s1, l3 = e3 > s3 ? e3 - s3 : 0;
+                    if (l1 && map[s1 + l1 - 1] == '\r') l1--;
+                    if (l3 && map[s3 + l3 - 1] == '\r') l3--;
+                    if (l1 != l3) { ok = false; break; }
+                    q = e3 + 1;
+                }
+                if (ok) return p;
+            }
+            p = line_end(p) + 1;
+        }
+        return size;
+    }
+
+    void work() {
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || (next_piece < pieces.size() && next_piece < consume_piece + window); });
+                if (stop || next_piece >= pieces.size()) return;
+                i = next_piece++;
+            }
+            SeqReader r;
+            r.open_range(map + cuts[i], cuts[i + 1] - cuts[i], fmt);
+            std::vector<Batch> out;
+            std::string err;
+            for (;;) {
+                out.emplace_back();
+                const bool more = r.next_batch(out.back(), max_bases, max_reads, keep_ids);
+                if (out.back().n_reads() == 0) out.pop_back();
+                if (!more) break;
+            }
+            if (r.failed()) err = r.error();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                pieces[i].batches = std::move(out);
+                pieces[i].err = std::move(err);
+                pieces[i].ready = true;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+static int reader_threads() {
+    if (const char *e = getenv("KT_READER_THREADS")) return atoi(e) > 0 ? atoi(e) : 1;
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // a container's CPU quota, not the host's thread count
+        char q[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long c = (atol(q) + period - 1) / period;
+            if (c > 0 && c < n) n = c;
+        }
+        fclose(f);
+    }
+    if (n > 8) n = 8;  // the parse is memory bound well before that
+    return n < 1 ? 1 : (int)n;
+}
+
 SeqReader::~SeqReader() {
     if (gz_) gzclose(gz_);
 }
 
 bool SeqReader::open(const std::string &path, bool sniff) {
     err_.clear();
+    par_.reset();
+    // a plain regular file of some size: map it and parse pieces of it concurrently
+    if (path != "-" && reader_threads() > 1) {
+        struct stat st;
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= (32 << 20)) {
+            unsigned char magic[2] = {0, 0};
+            const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+            void *m = gz ? MAP_FAILED : mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                auto P = std::make_shared<Parallel>();
+                P->map = (const unsigned char *)m;
+                P->size = (size_t)st.st_size;
+                SeqFormat f = sniff ? SeqFormat::Unknown : format_from_path(path);
+                if (f == SeqFormat::Unknown) f = P->map[0] == '>' ? SeqFormat::Fasta : SeqFormat::Fastq;
+                P->fmt = f;
+                const size_t piece = 32u << 20;
+                P->cuts.push_back(0);
+                for (size_t at = piece; at < P->size; at += piece) {
+                    const size_t c = P->boundary(at);
+                    if (c > P->cuts.back() && c < P->size) P->cuts.push_back(c);
+                }
+                P->cuts.push_back(P->size);
+                P->pieces.resize(P->cuts.size() - 1);
+                fmt_ = f;
+                par_ = P;
+                ::close(fd);
+                return true;
+            }
+        }
+        if (fd >= 0) ::close(fd);
+    }
     if (path == "-") {
         gz_ = gzdopen(0, "rb");
     } else {
@@ -52,6 +218,10 @@ bool SeqReader::open(const std::string &path, bool sniff) {
 
 bool SeqReader::fill() {
     if (eof_) return false;
+    if (mem_) {  // a mapped range has been handed over whole
+        eof_ = true;
+        return false;
+    }
     const int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
     if (n < 0) {
         int e = 0;
@@ -63,6 +233,7 @@ bool SeqReader::fill() {
         eof_ = true;
         return false;
     }
+    base_ = buf_.data();
     pos_ = 0;
     end_ = (size_t)n;
     return true;
@@ -70,7 +241,7 @@ bool SeqReader::fill() {
 
 bool SeqReader::peek(int &c) {
     if (pos_ == end_ && !fill()) return false;
-    c = buf_[pos_];
+    c = base_[pos_];
     return true;
 }
 
@@ -80,7 +251,7 @@ bool SeqReader::read_line(std::string &line) {
     for (;;) {
         if (pos_ == end_ && !fill()) return any;
         any = true;
-        const unsigned char *p = buf_.data() + pos_;
+        const unsigned char *p = base_ + pos_;
         const unsigned char *nl = (const unsigned char *)memchr(p, '\n', end_ - pos_);
         if (nl) {
             line.append((const char *)p, (size_t)(nl - p));
@@ -94,7 +265,7 @@ bool SeqReader::read_line(std::string &line) {
 
 bool SeqReader::read_line_view(const char *&p, size_t &n) {
     if (pos_ == end_ && !fill()) return false;
-    const unsigned char *b = buf_.data() + pos_;
+    const unsigned char *b = base_ + pos_;
     const unsigned char *nl = (const unsigned char *)memchr(b, '\n', end_ - pos_);
     if (nl) {  // the common case: the line ends inside the buffer
         p = (const char *)b;
@@ -131,7 +302,57 @@ static std::string first_token(const std::string &hdr) {
     return hdr.substr(i, j - i);
 }
 
+bool SeqReader::next_batch_parallel(Batch &b, bool keep_ids) {
+    Parallel &P = *par_;
+    if (!P.started) {
+        P.started = true;
+        P.keep_ids = keep_ids;
+        const int T = reader_threads();
+        P.window = (size_t)T + 2;
+        for (int t = 0; t < T; t++) P.workers.emplace_back([&P] { P.work(); });
+    }
+    b.clear();
+    b.first_record = P.records;
+    std::unique_lock<std::mutex> lk(P.m);
+    for (;;) {
+        if (P.consume_piece >= P.pieces.size()) return false;  // end of input
+        Parallel::Piece &pc = P.pieces[P.consume_piece];
+        P.cv.wait(lk, [&] { return pc.ready; });
+        if (P.consume_batch < pc.batches.size()) {
+            Batch &src = pc.batches[P.consume_batch++];
+            b.bases.swap(src.bases);
+            b.offsets.swap(src.offsets);
+            b.ids.swap(src.ids);
+            b.first_record = P.records;
+            P.records += b.n_reads();
+            n_records_ = P.records;
+            // is anything left after this batch?  (next_batch returns false with the last records of the input)
+            bool more = P.consume_batch < pc.batches.size() || !pc.err.empty();
+            for (size_t j = P.consume_piece + 1; !more && j < P.pieces.size(); j++) more = true;
+            if (more) return true;
+            std::vector<Batch>().swap(pc.batches);
+            P.consume_piece++;
+            return false;
+        }
+        if (!pc.err.empty()) {
+            err_ = pc.err;
+            return false;
+        }
+        std::vector<Batch>().swap(pc.batches);  // piece exhausted: its memory goes, the window moves on
+        P.consume_piece++;
+        P.consume_batch = 0;
+        P.cv.notify_all();
+    }
+}
+
 bool SeqReader::next_batch(Batch &b, uint64_t max_bases, uint64_t max_reads, bool keep_ids) {
+    if (par_) {
+        if (!par_->started) {
+            par_->max_bases = max_bases;
+            par_->max_reads = max_reads;
+        }
+        return next_batch_parallel(b, keep_ids);
+    }
     b.clear();
     b.first_record = n_records_;
     if (!err_.empty()) return false;

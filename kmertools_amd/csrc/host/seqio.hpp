@@ -13,11 +13,19 @@
 //   * FASTQ: '@' header, sequence lines up to the '+' line, then as many quality lines
 // Unlike the reference (one heap Sequence per record, single consumer behind a mutex) records
 // are appended straight into a reusable batch: `bases` (concatenated) + `offsets`.
+// Plain (uncompressed, seekable) files of some size are mapped and parsed by several threads: the file is cut at
+// record boundaries into pieces of ~32 MB, a pool parses pieces concurrently, and next_batch hands the pieces'
+// batches out in file order (KT_READER_THREADS=1 forces the serial reader; gzip and stdin always take it).
 #pragma once
 #include <stdint.h>
 #include <zlib.h>
 
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace kthost {
@@ -59,7 +67,13 @@ class SeqReader {
     // Sequences::seq_stats (seq.rs:69-94): record count and total length of a whole file
     static bool seq_stats(const std::string &path, uint64_t &seq_count, uint64_t &total_length, std::string &err);
 
+    // parses the records that lie in [p, p + n) of a mapped file (the parallel reader's workers)
+    void open_range(const unsigned char *p, size_t n, SeqFormat fmt);
+
   private:
+    struct Parallel;  // the mapped file, its pieces, the worker pool (seqio.cpp)
+    std::shared_ptr<Parallel> par_;
+    bool next_batch_parallel(Batch &b, bool keep_ids);
     bool fill();
     bool read_line(std::string &line);  // without the trailing '\n'; false at EOF
     // same, without a copy when the whole line sits in the read buffer: [p, p + n) stays valid until the next call
@@ -67,6 +81,8 @@ class SeqReader {
     bool peek(int &c);
     gzFile gz_ = nullptr;  // zlib reads plain files transparently
     std::vector<unsigned char> buf_;
+    const unsigned char *base_ = nullptr;  // what is being parsed: buf_ (stream) or a mapped range
+    bool mem_ = false;                     // a fixed memory range: nothing to refill
     size_t pos_ = 0, end_ = 0;
     bool eof_ = false;
     SeqFormat fmt_ = SeqFormat::Unknown;

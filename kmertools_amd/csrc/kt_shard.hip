@@ -254,7 +254,11 @@ int sharded_alloc(kt_sharded *s) {
     if (e != hipSuccess) return kt::fail(KT_ERR_NOMEM, std::string("sharded counter: hipMalloc: ") + hipGetErrorString(e));
     s->fin_left = s->pend_n + 8;
     s->flags = reinterpret_cast<uint32_t *>(s->pend_n + 16);
-    KT_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+    {   // the exchange's kernels should start the moment their slice is routed, whatever the main stream is running
+        int lo = 0, hi = 0;
+        KT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        KT_HIP(hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, hi));
+    }
     for (int b = 0; b < 2; b++) {
         KT_HIP(hipEventCreateWithFlags(&s->ev_routed[b], hipEventDisableTiming));
         KT_HIP(hipEventCreateWithFlags(&s->ev_sent[b], hipEventDisableTiming));

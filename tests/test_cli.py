@@ -275,3 +275,48 @@ def test_ctr_out_of_core_passes_and_devices(cli, oracle, tmp_path):
     assert sorted((d2 / "kmers.counts").read_text().splitlines()) == want
     r = run(cli, "ctr", "-i", "-", "-o", tmp_path / "x", "-k", "21", input=fq.read_text())
     assert r.returncode == 101 and "Error" in r.stderr
+
+
+def test_parallel_reader_matches_serial(cli, tmp_path):
+    """plain files of >= 32 MB are mapped and parsed piecewise by several threads: the records must be exactly the
+    serial reader's (KT_READER_THREADS=1), in order, with their ordinals - multi-line FASTA with CRLF and blank
+    lines, and FASTQ whose quality lines begin with '@' or '+' (the classic trap for boundary detection)"""
+    import hashlib
+    import os
+    import numpy as np
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ACGTNacgt", np.uint8)
+    qual = np.frombuffer(b"@+IIIIFFFF#5", np.uint8)
+
+    def digest(path, threads):
+        env = dict(os.environ, KT_READER_THREADS=str(threads))
+        r = subprocess.run([cli, "debug-read", str(path)], capture_output=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-500:]
+        lines = r.stdout.splitlines()
+        meta = [ln for ln in lines if ln.startswith(b"#")]
+        return hashlib.sha256(r.stdout).hexdigest(), len(lines) - len(meta), meta
+
+    fa = tmp_path / "big.fasta"
+    with open(fa, "wb") as f:
+        for i in range(90_000):
+            L = int(rng.integers(0, 900))
+            s = alpha[rng.integers(0, 9, size=L)].tobytes()
+            eol = b"\r\n" if i % 7 == 0 else b"\n"
+            f.write(b">r%d some text%s" % (i, eol))
+            for j in range(0, L, 70):
+                f.write(s[j:j + 70] + eol)
+            if i % 11 == 0:
+                f.write(eol)
+    fq = tmp_path / "big.fastq"
+    with open(fq, "wb") as f:
+        for i in range(140_000):
+            L = int(rng.integers(1, 260))
+            s = alpha[rng.integers(0, 4, size=L)].tobytes()
+            q = qual[rng.integers(0, len(qual), size=L)].tobytes()
+            f.write(b"@q%d extra\n%s\n+\n%s\n" % (i, s, q))
+    assert fa.stat().st_size > (32 << 20) and fq.stat().st_size > (32 << 20)
+    for path, n in ((fa, 90_000), (fq, 140_000)):
+        serial = digest(path, 1)
+        assert serial[1] == n
+        for threads in (2, 5):
+            assert digest(path, threads) == serial

@@ -391,19 +391,25 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 # N > 1 path on one GPU: two ranks share cuda:0, route on the GPU, exchange (gloo, host-staged),
 # count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
 
+_SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15)}   # case -> (ranks, k)
+
+
 def _two_rank_worker(rank, port, q, case):
     import os
     import torch
     import torch.distributed as dist
+    world, k = _SHARD_CASES[case]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["KT_BULK_MIN_BASES"] = "0"   # the received k-mers take the partition + range build even at this size
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    if case == "narrow3":
+        os.environ["KT_SHARD_SLICES"] = "3"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from kmertools_amd import device, dist as ktdist
         torch.cuda.set_device(0)
         ctx = device.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-        n, L, k = 20000, 150, 31
+        n, L = 20000, 150
         bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
         offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         ctx.synth_reads(4242, n, L, bases, offsets, noise=True, genome_len=200000, first_read=rank * n)
@@ -423,31 +429,32 @@ def _two_rank_worker(rank, port, q, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["genome", "skewed"])
+@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3"])
 def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     """the C ABI's sharded counter with two ranks on cuda:0 and the host all-to-all transport over gloo: route on
     the GPU, exchange fixed-size regions, partition + range build of what arrived, finalize; the union of the shards
     is the oracle's table of all reads.  `skewed`: one k-mer floods its owner's regions, so the pending list and
-    several finalize rounds run"""
+    several finalize rounds run; `narrow3`: three ranks, three slices, k=15 (32-bit keys through the partition)"""
     import socket
     import torch.multiprocessing as mp
     from kmertools_amd import device
+    world, k = _SHARD_CASES[case]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
-    procs = [mpctx.Process(target=_two_rank_worker, args=(r, port, q, case)) for r in range(2)]
+    procs = [mpctx.Process(target=_two_rank_worker, args=(r, port, q, case)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    n, L, k = 20000, 150, 31
+    n, L = 20000, 150
     ctr = oracle.Counter(4)
-    for rank in range(2):
+    for rank in range(world):
         hb, ho = oracle.synth_reads(4242, n, L, noise=True, genome_len=200000, first_read=rank * n)
         if case == "skewed" and rank == 1:
             hb = hb.copy()
@@ -460,7 +467,7 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     counts = np.concatenate([r[2] for r in res])
     for rank, rk, _, total, sent in res:
         assert total == len(wk) and sent > 0
-        assert all(device.owner_of(int(x), 2) == rank for x in rk[:300])
+        assert all(device.owner_of(int(x), world) == rank for x in rk[:300])
     order = np.argsort(keys)
     assert np.array_equal(keys[order], wk) and np.array_equal(counts[order], wc)
 
