@@ -39,8 +39,8 @@ void SeqReader::open_range(const unsigned char *p, size_t n, SeqFormat fmt) {
 }
 
 struct SeqReader::Parallel {
-    const unsigned char *map = nullptr;
-    size_t size = 0;
+    int fd = -1;       // pieces are pread() into per-worker buffers (mapping the file made the parsers' page faults
+    size_t size = 0;   // and the HIP runtime's pinning of pageable copies fight over the address space lock)
     SeqFormat fmt = SeqFormat::Fasta;
     std::vector<size_t> cuts;  // piece i = [cuts[i], cuts[i + 1])
     uint64_t max_bases = 0, max_reads = 0;
@@ -58,6 +58,7 @@ struct SeqReader::Parallel {
     size_t next_piece = 0, consume_piece = 0, consume_batch = 0, window = 0;
     bool stop = false;
     std::vector<std::thread> workers;
+    std::vector<Batch> spare;  // buffers of batches the consumer has taken, for the workers to fill again
     uint64_t records = 0;
 
     ~Parallel() {
@@ -67,39 +68,56 @@ struct SeqReader::Parallel {
         }
         cv.notify_all();
         for (auto &t : workers) t.join();
-        if (map) munmap((void *)map, size);
+        if (fd >= 0) ::close(fd);
+    }
+    bool read_at(size_t at, size_t n, std::vector<unsigned char> &buf) const {
+        buf.resize(n);
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t r = pread(fd, buf.data() + got, n - got, (off_t)(at + got));
+            if (r <= 0) return false;
+            got += (size_t)r;
+        }
+        return true;
     }
 
     // first record start at or after `from` (FASTA: a line that begins with '>'; FASTQ: a line that begins with '@'
-    // whose third line begins with '+' and whose fourth is as long as its second - two such records in a row)
+    // whose third line begins with '+' and whose fourth is as long as its second - two such records in a row).
+    // Looks at a window of the file; a record start is always found within it for records below ~8 MB.
     size_t boundary(size_t from) const {
-        size_t p = from;
-        if (p == 0) return 0;
-        const unsigned char *nl = (const unsigned char *)memchr(map + p - 1, '\n', size - (p - 1));
+        if (from == 0) return 0;
+        std::vector<unsigned char> win;
+        const size_t w0 = from - 1, wn = size - w0 < (16u << 20) ? size - w0 : (16u << 20);
+        if (!read_at(w0, wn, win)) return size;
+        const unsigned char *map = win.data();
+        const size_t wsize = wn;
+        const bool to_eof = w0 + wn == size;
+        const unsigned char *nl = (const unsigned char *)memchr(map, '\n', wsize);
         if (!nl) return size;
-        p = (size_t)(nl - map) + 1;
+        size_t p = (size_t)(nl - map) + 1;
         auto line_end = [&](size_t q) {
-            const unsigned char *e = q < size ? (const unsigned char *)memchr(map + q, '\n', size - q) : nullptr;
-            return e ? (size_t)(e - map) : size;
+            const unsigned char *e = q < wsize ? (const unsigned char *)memchr(map + q, '\n', wsize - q) : nullptr;
+            return e ? (size_t)(e - map) : wsize;
         };
-        while (p < size) {
+        while (p < wsize) {
             if (fmt == SeqFormat::Fasta) {
-                if (map[p] == '>') return p;
+                if (map[p] == '>') return w0 + p;
             } else if (map[p] == '@') {
                 size_t q = p;
                 bool ok = true;
-                for (int rec = 0; rec < 2 && ok && q < size; rec++) {
+                for (int rec = 0; rec < 2 && ok && q < wsize; rec++) {
                     if (map[q] != '@') { ok = false; break; }
                     const size_t e0 = line_end(q), s1 = e0 + 1, e1 = line_end(s1), s2 = e1 + 1, e2 = line_end(s2),
                                  s3 = e2 + 1, e3 = line_end(s3);
-                    if (s2 >= size || map[s2] != '+' || s3 > size) { ok = false; break; }
+                    if (e3 >= wsize && !to_eof) { ok = false; break; }  // the window ended inside the record
+                    if (s2 >= wsize || map[s2] != '+' || s3 > wsize) { ok = false; break; }
                     size_t l1 = e1 - s1, l3 = e3 > s3 ? e3 - s3 : 0;
                     if (l1 && map[s1 + l1 - 1] == '\r') l1--;
                     if (l3 && map[s3 + l3 - 1] == '\r') l3--;
                     if (l1 != l3) { ok = false; break; }
                     q = e3 + 1;
                 }
-                if (ok) return p;
+                if (ok) return w0 + p;
             }
             p = line_end(p) + 1;
         }
@@ -107,6 +125,7 @@ struct SeqReader::Parallel {
     }
 
     void work() {
+        std::vector<unsigned char> buf;  // this worker's piece of the file, reused
         for (;;) {
             size_t i;
             {
@@ -116,11 +135,20 @@ struct SeqReader::Parallel {
                 i = next_piece++;
             }
             SeqReader r;
-            r.open_range(map + cuts[i], cuts[i + 1] - cuts[i], fmt);
             std::vector<Batch> out;
             std::string err;
+            if (!read_at(cuts[i], cuts[i + 1] - cuts[i], buf)) err = "read error";
+            r.open_range(buf.data(), err.empty() ? buf.size() : 0, fmt);
             for (;;) {
                 out.emplace_back();
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    if (!spare.empty()) {
+                        out.back().bases.swap(spare.back().bases);
+                        out.back().offsets.swap(spare.back().offsets);
+                        spare.pop_back();
+                    }
+                }
                 const bool more = r.next_batch(out.back(), max_bases, max_reads, keep_ids);
                 if (out.back().n_reads() == 0) out.pop_back();
                 if (!more) break;
@@ -149,7 +177,8 @@ static int reader_threads() {
         }
         fclose(f);
     }
-    if (n > 8) n = 8;  // the parse is memory bound well before that
+    n = n / 4;        // a quarter of the CPUs: the formatters and the runtime's staging copies need the rest
+    if (n > 4) n = 4;  // (four parsers deliver ~8 GB/s, more than any later stage takes)
     return n < 1 ? 1 : (int)n;
 }
 
@@ -167,26 +196,16 @@ bool SeqReader::open(const std::string &path, bool sniff) {
         if (fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= (32 << 20)) {
             unsigned char magic[2] = {0, 0};
             const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-            void *m = gz ? MAP_FAILED : mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) {
-                (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+            if (!gz) {
+                (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
                 auto P = std::make_shared<Parallel>();
-                P->map = (const unsigned char *)m;
+                P->fd = fd;
                 P->size = (size_t)st.st_size;
                 SeqFormat f = sniff ? SeqFormat::Unknown : format_from_path(path);
-                if (f == SeqFormat::Unknown) f = P->map[0] == '>' ? SeqFormat::Fasta : SeqFormat::Fastq;
+                if (f == SeqFormat::Unknown) f = magic[0] == '>' ? SeqFormat::Fasta : SeqFormat::Fastq;
                 P->fmt = f;
-                const size_t piece = 32u << 20;
-                P->cuts.push_back(0);
-                for (size_t at = piece; at < P->size; at += piece) {
-                    const size_t c = P->boundary(at);
-                    if (c > P->cuts.back() && c < P->size) P->cuts.push_back(c);
-                }
-                P->cuts.push_back(P->size);
-                P->pieces.resize(P->cuts.size() - 1);
                 fmt_ = f;
                 par_ = P;
-                ::close(fd);
                 return true;
             }
         }
@@ -307,6 +326,35 @@ bool SeqReader::next_batch_parallel(Batch &b, bool keep_ids) {
     if (!P.started) {
         P.started = true;
         P.keep_ids = keep_ids;
+        // one piece should parse into one batch of the caller's size (small batches cost every later stage a call, a
+        // thread start, a synchronisation): bytes per record and the share of sequence bytes from the head of the file
+        {
+            const size_t head = P.size < (4u << 20) ? P.size : (4u << 20);
+            std::vector<unsigned char> hb;
+            size_t lines = 0, recs = 0;
+            if (P.read_at(0, head, hb)) {
+                for (size_t i = 0; i < head; i++) {
+                    if (hb[i] == '\n') lines++;
+                    if (P.fmt == SeqFormat::Fasta && hb[i] == '>' && (i == 0 || hb[i - 1] == '\n')) recs++;
+                }
+            }
+            if (P.fmt == SeqFormat::Fastq) recs = lines / 4;
+            if (recs < 1) recs = 1;
+            const double bytes_per_rec = (double)head / (double)recs;
+            const double seq_share = P.fmt == SeqFormat::Fastq ? 0.48 : 0.9;
+            double piece_d = 0.9 * (double)P.max_reads * bytes_per_rec;
+            const double by_bases = 0.9 * (double)P.max_bases / seq_share;
+            if (by_bases < piece_d) piece_d = by_bases;
+            size_t piece = piece_d > 1e12 ? (size_t)1e12 : (size_t)piece_d;
+            if (piece < (8u << 20)) piece = 8u << 20;
+            P.cuts.push_back(0);
+            for (size_t at = piece; at < P.size; at += piece) {
+                const size_t c = P.boundary(at);
+                if (c > P.cuts.back() && c < P.size) P.cuts.push_back(c);
+            }
+            P.cuts.push_back(P.size);
+            P.pieces.resize(P.cuts.size() - 1);
+        }
         const int T = reader_threads();
         P.window = (size_t)T + 2;
         for (int t = 0; t < T; t++) P.workers.emplace_back([&P] { P.work(); });
@@ -320,9 +368,17 @@ bool SeqReader::next_batch_parallel(Batch &b, bool keep_ids) {
         P.cv.wait(lk, [&] { return pc.ready; });
         if (P.consume_batch < pc.batches.size()) {
             Batch &src = pc.batches[P.consume_batch++];
-            b.bases.swap(src.bases);
-            b.offsets.swap(src.offsets);
+            // copied, not swapped: the caller's buffers keep their addresses from batch to batch (the HIP runtime
+            // moves pageable memory it has seen before markedly faster, and page-locked callers stay page-locked);
+            // the piece's buffers go back to the workers
+            lk.unlock();
+            b.bases.assign(src.bases.begin(), src.bases.end());
+            b.offsets.assign(src.offsets.begin(), src.offsets.end());
             b.ids.swap(src.ids);
+            lk.lock();
+            P.spare.emplace_back();
+            P.spare.back().bases.swap(src.bases);
+            P.spare.back().offsets.swap(src.offsets);
             b.first_record = P.records;
             P.records += b.n_reads();
             n_records_ = P.records;

@@ -1,28 +1,26 @@
-// kt_bulk.hip - bulk construction of the k-mer table from a whole read batch without global
-// atomics.
+// kt_bulk.hip - adding a whole batch of k-mers to the table without global atomics: partition by hash prefix, then
+// build (or rebuild) every range of the table in LDS.
 //
 // Why: global atomics on this chip are capped at ~27 G/s wherever they land
-// (tools/ubench/atomic_region.hip, profiles/r1_ctr_notes.txt), so the incremental path
-// (one CAS or atomic add per k-mer, kt_ctr.hip) cannot exceed ~20 G k-mers/s.  An EMPTY table
-// can instead be built by streaming passes:
+// (tools/ubench/atomic_region.hip, profiles/r1_ctr_notes.txt), so the probing path
+// (one CAS or atomic add per k-mer, kt_ctr.hip) cannot exceed ~20 G k-mers/s.  A batch can instead go through
+// streaming passes (a job: kt_bulk_begin, level 1 over one or more sources, kt_bulk_finish):
 //
-//   scatter1p persistent workgroups run the segment front end over their reads; each unit's <= 8192 keys are
-//             counting-sorted in LDS by d1 = top b1 bits of khash(key) and every d1 run is appended to the
-//             bucket's fixed region of the key array through the workgroup's private aligned pages (one global
-//             atomic per page, no counting pass)
+//   scatter1p persistent workgroups run a source's units (8192-base segments of reads, or 8192 keys of an array that
+//             another GPU routed here); each unit's keys are counting-sorted in LDS by d1 = top b1 bits of
+//             khash(key) and every d1 run is appended to the bucket's fixed region of the key array through the
+//             workgroup's private aligned pages (one global atomic per page, no counting pass; a partly used page
+//             is carried over to the job's next source)
 //   part2     one workgroup per level-1 bucket: the bucket is read in 8192 / 16384-key chunks, each chunk
 //             counting-sorted in LDS by d2 (next b2 hash bits) and its runs appended to the fine buckets, which
 //             own fixed shares of the bucket's region; a bucket whose keys do not spread that evenly is noticed
 //             during the pass and redone with exact fine boundaries (see part2_kernel)
-//   build     one workgroup per fine bucket (d1,d2): its keys are counted in an LDS
-//             open-addressing table that *is* the image of the global slot range of that hash prefix
-//             (kt_table.hpp), and the range is written out with 16-byte coalesced stores - including the
-//             empty slots, so the bulk build needs no cleared table.  Keys that would probe past the
-//             end of their range go to a spill list, which is inserted afterwards through
-//             the ordinary (probing, atomic) path.
+//   build     one workgroup per fine bucket (d1,d2) = one range of the table (kt_table.hpp): its keys are inserted
+//             into the range's image in LDS - on top of what the range already holds when the table has data - and
+//             the range is written out with 16-byte coalesced stores, empty slots included (see build_kernel)
 //
-// Fixed regions assume the hash spreads the batch; a batch dominated by a few k-mers overflows a level-1 region or
-// the spill list, is noticed (two 4-byte reads by the host), and is redone with exact offsets:
+// Fixed regions assume the hash spreads the batch; a batch dominated by a few k-mers overflows a level-1 region,
+// is noticed (one 4-byte read by the host), and is redone from its sources with exact offsets:
 //   hist1     a front-end pass that counts k-mers per (workgroup, d1)          (LDS counters)
 //   scan1     exact output offset of every (workgroup, d1) pair
 //   scatter1  as scatter1p, every run copied to its exact place
@@ -30,7 +28,7 @@
 //
 // Traffic ~ 1 B/base + 8 B/k-mer x 4 + 16 B/slot, all streaming.  The intermediate key arrays and the LDS
 // sort / insert arrays hold 32-bit keys when k <= 16 (template parameter K): half the partition traffic, whole
-// units sorted at once in level 1, and 32-bit LDS atomics in build (64-bit ones run at about a lane per clock).
+// units sorted at once in level 1, and 32-bit LDS atomics in build.
 #include <stdio.h>
 #include <stdlib.h>
 
