@@ -252,7 +252,6 @@ const char *HELP_MIN =
     "                           \n"
     "                           0 - emits one minimiser per sequence (useful for sequencing reads)\n"
     "                           w_size must be longer than m_size [default: 0]\n"
-    "                           (this build: at most m_size + 4095; wider windows are refused)\n"
     "  -p, --preset <PRESET>    Output type to write [default: s2m] [possible values: s2m, m2s]\n"
     "  -t, --threads <THREADS>  Thread count for computations 0=auto [default: 0]\n"
     "      --device <DEVICE>    GPU index [default: 0]\n"

@@ -657,6 +657,108 @@ __global__ __launch_bounds__(BLOCK) void min_whole_kernel(const uint8_t *__restr
     }
 }
 
+// ---- windows of more than 4096 m-mers: one thread per read ---------------------------------------------------------
+// The tile kernel's halo stops at 4096 positions; wider windows (whole-contig scale) are rare enough that the
+// iterator itself is run, one read per thread: MinimiserGenerator::next (kmer/src/minimiser.rs:61-175) with its ring
+// buffer in global memory (a read of n bases never holds more than min(n, W) m-mers: ring r lives at
+// ring[offsets[r] + r ...]).  The window's rescans are O(W) but happen once per ~W/2 positions, so a read costs
+// O(n); parallelism is across reads only.  count != null: count[r] = triples of read r; else they are written.
+__global__ __launch_bounds__(BLOCK) void min_serial_kernel(const uint8_t *__restrict__ bases,
+                                                           const uint64_t *__restrict__ offsets, uint64_t n_reads,
+                                                           uint64_t wsize, uint32_t m, uint64_t *__restrict__ ring_all,
+                                                           uint64_t *__restrict__ count,
+                                                           const uint64_t *__restrict__ ev_offsets, uint64_t capacity,
+                                                           uint64_t *__restrict__ kmers, uint64_t *__restrict__ starts,
+                                                           uint64_t *__restrict__ ends) {
+    const uint64_t rd = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (rd >= n_reads) return;
+    const uint64_t s0 = offsets[rd], len = offsets[rd + 1] - s0;
+    const uint64_t full = wsize - m + 1;                 // m-mers of a full window
+    const uint64_t cap = (len < full ? len : full) + 1;  // ring slots this read can ever need
+    uint64_t *ring = ring_all + s0 + rd;
+    const uint64_t mask = (1ull << (2 * m)) - 1ull;
+    const uint32_t rsh = 2 * (m - 1);
+    uint64_t f = 0, rv = 0, vl = 0;                      // rolling m-mer and its length
+    uint64_t head = 0, blen = 0, buff_pos = 0;           // the window's m-mers, position of the active minimum
+    uint64_t active = NONE, wstart = 0;
+    uint64_t n_out = 0;
+    const uint64_t out0 = count ? 0 : ev_offsets[rd];
+    auto emit = [&](uint64_t km, uint64_t ws, uint64_t we) {
+        if (!count && out0 + n_out < capacity) {
+            kmers[out0 + n_out] = km;
+            starts[out0 + n_out] = ws;
+            ends[out0 + n_out] = we;
+        }
+        n_out++;
+    };
+    auto at = [&](uint64_t j) -> uint64_t & { return ring[(head + j) % cap]; };
+    for (uint64_t pos = 0; pos < len; pos++) {
+        const uint32_t c = ktd::nt4(bases[s0 + pos]);
+        if (c > 3) {                                     // :81-101: an ambiguous base ends the run
+            const bool ret = blen == full;
+            const uint64_t pm = active, pws = wstart;
+            buff_pos = 0;
+            active = NONE;
+            f = rv = vl = 0;
+            wstart = pos + 1;
+            blen = 0;
+            head = 0;
+            if (ret) emit(pm, pws, pos);
+            continue;
+        }
+        f = ((f << 2) | c) & mask;                       // :75-80
+        rv = (rv >> 2) | ((uint64_t)(3u - c) << rsh);
+        vl++;
+        if (vl < m) continue;                            // :103-106
+        vl--;
+        const uint64_t mv = f < rv ? f : rv;             // :110
+        bool emitted = false;
+        if (blen == full) {                              // :113
+            head = (head + 1) % cap;                     // pop_front
+            at(blen - 1) = mv;                           // push_back
+            if (buff_pos == 0) {                         // :119-138: the minimum left the window
+                uint64_t nm = NONE;
+                for (uint64_t j = 0; j < blen; j++) {
+                    const uint64_t v = at(j);
+                    if (v < nm) {
+                        buff_pos = j;
+                        nm = v;
+                    }
+                }
+                if (nm != active) {
+                    emit(active, wstart, pos);
+                    active = nm;
+                    wstart = pos - wsize + 1;
+                    emitted = true;
+                }
+            } else if (mv < active) {                    // :139-149
+                emit(active, wstart, pos);
+                active = mv;
+                buff_pos = blen - 1;
+                wstart = pos - wsize + 1;
+                emitted = true;
+            } else {
+                buff_pos--;                              // :150-152
+            }
+        } else {
+            at(blen) = mv;                               // :153-156
+            blen++;
+        }
+        if (emitted) continue;                           // (the iterator returned: the checks below are skipped)
+        if (active == NONE && blen == full) {            // :158-166: the first full window
+            for (uint64_t j = 0; j < blen; j++) {
+                const uint64_t v = at(j);
+                if (v < active) {
+                    buff_pos = j;
+                    active = v;
+                }
+            }
+        }
+        if (pos == len - 1) emit(active, wstart, len);   // :168-171
+    }
+    if (count) count[rd] = n_out;
+}
+
 __global__ void set_last_kernel(uint64_t *__restrict__ ev_offsets, uint64_t n_reads, const uint64_t *__restrict__ total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) ev_offsets[n_reads] = *total;
 }
@@ -676,8 +778,7 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     if (msize < 1 || msize > 31) return kt::fail(KT_ERR_ARG, "kt_minimisers: msize must be in 1..31");
     if (wsize != 0 && wsize < (uint64_t)msize)
         return kt::fail(KT_ERR_ARG, "kt_minimisers: wsize must be 0 or >= msize");
-    if (wsize != 0 && wsize - (uint64_t)msize + 1 > MAX_HG * GRAN)
-        return kt::fail(KT_ERR_ARG, "kt_minimisers: windows of more than 4096 m-mers are not supported by this build");
+    const bool wide = wsize != 0 && wsize - (uint64_t)msize + 1 > MAX_HG * GRAN;  // one thread per read (min_serial_kernel)
     if (n_reads == 0) return KT_OK;
     if (!offsets || !ev_offsets) return kt::fail(KT_ERR_ARG, "kt_minimisers: null offsets");
     if (capacity && (!kmers || !starts || !ends)) return kt::fail(KT_ERR_ARG, "kt_minimisers: null output");
@@ -713,7 +814,7 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     const size_t o_carry = off;   off += align256((n_gran + 1) * 8);
     const size_t o_tcount = off;  off += align256((n_tiles + 1) * 8);
     const size_t o_tbase = off;   off += align256((n_tiles + 1) * 8);
-    const size_t o_rcount = off;  off += align256((wsize == 0 ? n_reads + 1 : 1) * 8);
+    const size_t o_rcount = off;  off += align256((wsize == 0 || wide ? n_reads + 1 : 1) * 8);
     const size_t o_part = off;    off += align256((n_scan / 1024 + 2) * 8);
     const size_t o_total = off;   off += 256;
     if (int rc = ctx->s_aux1.reserve(off)) return rc;
@@ -724,7 +825,23 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     uint64_t *partial = (uint64_t *)(ib + o_part), *d_total = (uint64_t *)(ib + o_total);
 
     uint64_t n_ev = 0;
-    if (wsize == 0) {
+    if (wide) {
+        if (int rc = ctx->s_aux2.reserve((total + n_reads + 1) * 8)) return rc;
+        uint64_t *ring = (uint64_t *)ctx->s_aux2.p;
+        const uint32_t nb = (uint32_t)((n_reads + BLOCK - 1) / BLOCK);
+        hipLaunchKernelGGL(min_serial_kernel, dim3(nb), dim3(BLOCK), 0, ctx->stream, d_bases, d_offsets, n_reads, wsize,
+                           (uint32_t)msize, ring, rcount, (const uint64_t *)nullptr, (uint64_t)0, (uint64_t *)nullptr,
+                           (uint64_t *)nullptr, (uint64_t *)nullptr);
+        if (int rc = device_excl_scan<false>(ctx, rcount, n_reads, d_evoff, partial, d_total)) return rc;
+        hipLaunchKernelGGL(set_last_kernel, dim3(1), dim3(64), 0, ctx->stream, d_evoff, n_reads, d_total);
+        KT_HIP(hipMemcpyAsync(&n_ev, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        if (capacity) {
+            hipLaunchKernelGGL(min_serial_kernel, dim3(nb), dim3(BLOCK), 0, ctx->stream, d_bases, d_offsets, n_reads, wsize,
+                               (uint32_t)msize, ring, (uint64_t *)nullptr, d_evoff, capacity, d_k, d_s, d_e);
+            KT_HIP(hipGetLastError());
+        }
+    } else if (wsize == 0) {
         const uint32_t nb = (uint32_t)((n_reads + BLOCK - 1) / BLOCK);
         hipLaunchKernelGGL(min_whole_kernel<false>, dim3(nb), dim3(BLOCK), 0, ctx->stream, d_bases, d_offsets, n_reads,
                            (uint32_t)msize, rcount, (const uint64_t *)nullptr, (uint64_t)0, (uint64_t *)nullptr,

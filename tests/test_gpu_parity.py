@@ -1036,11 +1036,36 @@ def test_minimisers_vs_oracle(hctx, oracle, w, m):
 def test_minimisers_arguments(hctx):
     from kmertools_amd import device
     b, o = device.to_csr(["ACGTACGTACGT"])
-    for w, m in ((3, 5), (5000, 7), (10, 0), (10, 32)):
+    for w, m in ((3, 5), (10, 0), (10, 32)):
         with pytest.raises(Exception):
             hctx.minimisers_host(b, o, w, m)
     evo, k, s, e = hctx.minimisers_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 31, 7)
     assert len(k) == 0 and list(evo) == [0]
+
+
+@pytest.mark.parametrize("w,m", [(5000, 7), (4200, 17), (9000, 31), (20000, 10)])
+def test_minimisers_windows_wider_than_4096(hctx, oracle, w, m):
+    """windows of more than 4096 m-mers run the iterator itself, one read per thread (min_serial_kernel): reads
+    shorter than, equal to and several times the window, N runs, lower case, the quirks on the last base"""
+    from kmertools_amd import device
+    rng = np.random.default_rng(w + m)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seqs = []
+    for L in [0, 1, m - 1, m, w - 1, w, w + 1, w + m, 2 * w + 17, 3 * w, 60, 25_000, 61_000]:
+        s = alpha[rng.integers(0, 4, size=L)].copy()
+        if L > 200 and rng.random() < 0.7:
+            for at in rng.integers(0, L, size=3):
+                s[at:at + int(rng.integers(1, 4))] = ord("N")
+        if L > 10:
+            s[rng.integers(0, L, size=L // 50 + 1)] |= 0x20
+        seqs.append(s.tobytes())
+    seqs.append(b"A" * (w + 500))                       # one m-mer all along: ties everywhere
+    seqs.append((b"ACGTTGCA" * (w // 4))[: 2 * w + 3])
+    bases, offsets = device.to_csr(seqs)
+    evo, k, s_, e = hctx.minimisers_host(bases, offsets, w, m)
+    for i, seq in enumerate(seqs):
+        got = [(int(k[j]), int(s_[j]), int(e[j])) for j in range(int(evo[i]), int(evo[i + 1]))]
+        assert got == oracle.minimisers(seq, w, m), (i, len(seq))
 
 
 def test_minimisers_full_size(torch_mod, ctx, oracle):
@@ -1163,7 +1188,7 @@ def test_minimisers_wide_window_run_start_before_halo(hctx, oracle):
 
 def test_minimisers_windows_wider_than_a_granule(hctx, oracle):
     """1024 < W <= 4096 runs on tiles with a four-granule halo: reads that span several tiles, breaks near the tile
-    and halo boundaries, windows right up to the limit; one m-mer more is refused"""
+    and halo boundaries, windows right up to the tile path's limit; one m-mer more takes the one-read-per-thread path"""
     rng = np.random.default_rng(11)
     alpha = np.array(list("ACGT"))
     seqs = []
@@ -1177,10 +1202,9 @@ def test_minimisers_windows_wider_than_a_granule(hctx, oracle):
         got = _min_triples(hctx, seqs, w, m)
         for i, s in enumerate(seqs):
             assert got[i] == oracle.minimisers(s, w, m), (i, w, m)
-    from kmertools_amd import device, _lib
-    bases, offsets = device.to_csr(seqs)
-    with pytest.raises(_lib.KmertoolsError):
-        hctx.minimisers_host(bases, offsets, 4127, 31)
+    got = _min_triples(hctx, seqs, 4127, 31)
+    for i, s in enumerate(seqs):
+        assert got[i] == oracle.minimisers(s, 4127, 31), (i, 4127, 31)
 
 
 def test_all_empty_reads_everywhere(hctx, oracle):
