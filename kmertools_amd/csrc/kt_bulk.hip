@@ -693,11 +693,39 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             atomicOr(spill_ovf, 1u);
         }
     };
-    __shared__ uint32_t runs[BUILD_T / 64 * (S / BUILD_T) + 1];  // DENSE: occupied slots per (wave, pass), then their prefix
+    __shared__ uint32_t runs[BUILD_T / 64];  // DENSE: entries packed by each wave
     long long placed = 0;  // per thread: occupied slots written - occupied slots found (MERGE)
-    for (uint64_t fb = blockIdx.x; fb < n_fine; fb += gridDim.x) {
-        const uint64_t lo = fstart[fb], hi = fend[fb];
-        if (MERGE && lo == hi) continue;  // nothing new for this range: it stays as it is
+    // A range starts with two dependent global reads (its bounds, then its first keys): ~4 us during which the
+    // workgroup would do nothing, 1500 times over.  Both are taken one range ahead: the next range's bounds are
+    // requested before this range's insert, its first four keys per lane before this range's copy-out.
+    uint64_t lo = 0, hi = 0;
+    K head[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
+    auto load_head = [&](uint64_t l, uint64_t h, K (&dst)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = l + tid + (uint64_t)u * BUILD_T;
+            dst[u] = i < h ? keys2[i] : EMPTY;
+        }
+    };
+    if (blockIdx.x < n_fine) {
+        lo = fstart[blockIdx.x];
+        hi = fend[blockIdx.x];
+        load_head(lo, hi, head);
+    }
+    for (uint64_t fb = blockIdx.x; fb < n_fine;) {
+        const uint64_t nfb = fb + gridDim.x;
+        uint64_t nlo = 0, nhi = 0;
+        if (nfb < n_fine) {
+            nlo = fstart[nfb];
+            nhi = fend[nfb];
+        }
+        if (MERGE && lo == hi) {  // nothing new for this range: it stays as it is
+            fb = nfb;
+            lo = nlo;
+            hi = nhi;
+            load_head(lo, hi, head);
+            continue;
+        }
         if (MERGE) {
             // what the range holds already goes back where it is: the old image is a valid probing layout
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
@@ -719,13 +747,13 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             // trip (the CAS itself reports what the slot holds), and a lane that has placed its key moves on to its
             // next one at once; four keys are kept prefetched so the loads are never waited for.  ("For each key:
             // probe until placed" makes the wave wait for its longest probe chain on every key.)
-            uint64_t idx = lo + tid;
+            uint64_t idx = lo + tid + 4ull * BUILD_T;
             auto fetch = [&]() {
                 const K k = idx < hi ? keys2[idx] : EMPTY;
                 idx += BUILD_T;
                 return k;
             };
-            K cur = fetch(), q0 = fetch(), q1 = fetch(), q2 = fetch();
+            K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
             if (p.dbg & 1u) cur = EMPTY;
             uint32_t s = home((uint64_t)cur), probes = 0;
             while (cur != EMPTY) {
@@ -753,46 +781,53 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             }
         }
         ktd::lds_barrier();
+        load_head(nlo, nhi, head);  // the next range's first keys travel while this range is written out
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * RS);
         if (DENSE) {
-            // the occupied slots, packed, straight from the LDS image: every (wave, pass) ballots its 64 slots, one
-            // wave scans the 128 popcounts, and each store instruction then writes one contiguous run
-            constexpr uint32_t PT = S / BUILD_T;  // passes over the image (RS <= S)
-            uint64_t bal[PT];
-#pragma unroll
-            for (uint32_t j = 0; j < PT; j++) {
-                const uint32_t i = j * BUILD_T + tid;
-                bal[j] = __ballot(i < RS && skeys[i] != EMPTY);
-                if (lane == 0) runs[(tid >> 6) * PT + j] = (uint32_t)__popcll(bal[j]);
+            // The occupied slots, packed.  Every wave first packs its own sixteenth of the image in place (wave
+            // synchronous: 64 slots into registers, ballot, back at the wave's cursor - entries only move towards the
+            // front of the wave's share, so no other wave is involved), then the sixteen packed runs are copied out as
+            // one sequence: thread t writes element t, t + 1024, ... - aligned, coalesced, non-temporal.  (Writing
+            // each (wave, pass) run straight to global memory left the stores starting and ending inside cache lines:
+            // 36 GB took 14 ms.)
+            constexpr uint32_t NW = BUILD_T / 64;
+            const uint32_t wave = tid >> 6, share = RS / NW;  // RS = 1024 * m8: a multiple of 64 per wave
+            uint32_t wc = 0;                                  // entries this wave has packed so far (wave uniform)
+            for (uint32_t i0 = 0; i0 < share; i0 += 64) {
+                const uint32_t i = wave * share + i0 + lane;
+                const K kk = skeys[i];
+                const uint32_t cc = scounts[i];
+                const uint64_t bal = __ballot(kk != EMPTY);
+                if (kk != EMPTY) {
+                    const uint32_t at = wave * share + wc + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    skeys[at] = kk;      // at <= i: behind or at what this wave has read (LDS executes a wave's
+                    scounts[at] = cc;    // accesses in order)
+                }
+                wc += (uint32_t)__popcll(bal);
             }
+            if (lane == 0) runs[wave] = wc;
             ktd::lds_barrier();
-            if (tid < 64) {  // NRUN = 2 * 64 runs: two per lane
-                static_assert(BUILD_T / 64 * PT == 128, "two runs per lane of the scanning wave");
-                const uint32_t a = runs[2 * tid], b2 = runs[2 * tid + 1];
-                uint32_t inc = a + b2;
+            uint32_t pre[NW + 1];
+            pre[0] = 0;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t v = __shfl_up(inc, off, 64);
-                    if (lane >= (uint32_t)off) inc += v;
-                }
-                runs[2 * tid] = inc - a - b2;
-                runs[2 * tid + 1] = inc - b2;
-                if (tid == 63) {
-                    runs[128] = inc;  // D: distinct keys of the range
-                    range_counts[fb] = inc;
-                    placed += inc;
-                }
+            for (uint32_t w = 0; w < NW; w++) pre[w + 1] = pre[w] + runs[w];
+            const uint32_t D = pre[NW];
+            for (uint32_t e = tid; e < D; e += BUILD_T) {
+                uint32_t w = 0;
+#pragma unroll
+                for (uint32_t q = 1; q < NW; q++) w += e >= pre[q] ? 1u : 0u;  // the run that holds element e
+                uint32_t pw = 0;
+#pragma unroll
+                for (uint32_t q = 1; q < NW; q++) pw = e >= pre[q] ? pre[q] : pw;
+                const uint32_t src = w * share + (e - pw);
+                const uint64_t key = (uint64_t)skeys[src];
+                typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+                const raw4 raw = {(uint32_t)key, (uint32_t)(key >> 32), scounts[src], 0u};
+                __builtin_nontemporal_store(raw, reinterpret_cast<raw4 *>(dst + e));
             }
-            ktd::lds_barrier();
-#pragma unroll
-            for (uint32_t j = 0; j < PT; j++) {
-                if ((bal[j] >> lane) & 1ull) {
-                    const uint32_t i = j * BUILD_T + tid;
-                    const uint32_t pos = runs[(tid >> 6) * PT + j] + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull));
-                    const uint64_t key = (uint64_t)skeys[i];
-                    // (plain stores: the runs start and end inside cache lines, which the L2 has to merge)
-                    dst[pos] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), scounts[i], 0u);
-                }
+            if (tid == 0) {
+                range_counts[fb] = D;
+                placed += D;
             }
         } else if (!(p.dbg & 8u)) {
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
@@ -809,6 +844,9 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             }
         }
         ktd::lds_barrier();
+        fb = nfb;
+        lo = nlo;
+        hi = nhi;
     }
     // the table's distinct counter: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) placed += __shfl_down(placed, o, 64);
@@ -1064,9 +1102,9 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 8);  // persistent workgroups; up to two are resident per CU
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
-    // (off by default: measured slower - dense build 34 ms + dense export 16 ms against image build 22 ms + export 27.5 ms
-    // at ctr k=31, 18.6 + 3.1 against 13.0 + 4.7 ms at k=15; profiles/r2_build_sweep.txt)
-    const bool dense = !j.merge && env_u64("KT_BULK_DENSE", 0) != 0;
+    // (ctr k=31: dense build 29.0 ms + dense export 17.4 ms against image build 22-23.5 ms + export 27.5 ms; k=15: 13.8 +
+    // 3.2 against 12.5 + 4.7 ms; profiles/r2_build_sweep.txt.  KT_BULK_DENSE=0 builds the probing image at once.)
+    const bool dense = !j.merge && env_u64("KT_BULK_DENSE", 1) != 0;
     auto build = j.merge ? build_kernel<K, true, false> : dense ? build_kernel<K, false, true> : build_kernel<K, false, false>;
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)build_lds));

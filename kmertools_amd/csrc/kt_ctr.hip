@@ -93,12 +93,19 @@ __global__ __launch_bounds__(BLOCK) void table_clear_kernel(Slot *__restrict__ s
 // thread, all in flight at once), ballots every load, scans the 64 (wave, load) popcounts and reserves the tile's
 // output range with ONE cursor atomic; every store instruction then writes one contiguous run.  (The first version
 // took one atomic per wave and 64 slots: 100 M atomics on one address for a 6.4 G-slot table = 1.2 s.)
-constexpr uint32_t XPT = 16, XTILE = BLOCK * XPT;
+#ifndef KT_EXPORT_NT
+#define KT_EXPORT_NT 0  // bit 0: non-temporal loads of the slots, bit 1: non-temporal stores of the pairs (measured, see DESIGN)
+#endif
+#ifndef KT_EXPORT_XPT
+#define KT_EXPORT_XPT 16
+#endif
+constexpr uint32_t XPT = KT_EXPORT_XPT, XTILE = BLOCK * XPT;
 __global__ __launch_bounds__(BLOCK) void table_export_kernel(const Slot *__restrict__ slots, uint64_t cap,
                                                              uint64_t *__restrict__ out_keys,
                                                              uint32_t *__restrict__ out_counts, uint64_t max_out,
                                                              uint64_t *__restrict__ cursor) {
     __shared__ uint32_t runs[BLOCK / 64 * XPT];  // occupied slots per (wave, load), then their exclusive prefix
+    static_assert(BLOCK / 64 * XPT == 64, "one wave scans the runs, one per lane");
     __shared__ uint64_t tile_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t n_tiles = (cap + XTILE - 1) / XTILE;
@@ -107,7 +114,17 @@ __global__ __launch_bounds__(BLOCK) void table_export_kernel(const Slot *__restr
 #pragma unroll
         for (uint32_t j = 0; j < XPT; j++) {
             const uint64_t i = tile * XTILE + (uint64_t)j * BLOCK + tid;
+#if KT_EXPORT_NT & 1
+            typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+            if (i < cap) {
+                const raw4 r = __builtin_nontemporal_load(reinterpret_cast<const raw4 *>(slots) + i);
+                v[j] = make_uint4(r.x, r.y, r.z, r.w);
+            } else {
+                v[j] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+            }
+#else
             v[j] = i < cap ? reinterpret_cast<const uint4 *>(slots)[i] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+#endif
         }
         uint64_t bal[XPT];
 #pragma unroll
@@ -135,8 +152,13 @@ __global__ __launch_bounds__(BLOCK) void table_export_kernel(const Slot *__restr
             if ((bal[j] >> lane) & 1ull) {
                 const uint64_t pos = base + runs[wave * XPT + j] + __popcll(bal[j] & ((1ull << lane) - 1ull));
                 if (pos < max_out) {
+#if KT_EXPORT_NT & 2
+                    __builtin_nontemporal_store(((uint64_t)v[j].y << 32) | v[j].x, out_keys + pos);
+                    __builtin_nontemporal_store(v[j].z + 1u, out_counts + pos);
+#else
                     out_keys[pos] = ((uint64_t)v[j].y << 32) | v[j].x;
                     out_counts[pos] = v[j].z + 1u;  // stored value is occurrences - 1
+#endif
                 }
             }
         }

@@ -9,8 +9,8 @@ mkdir -p ../variants build
 make -s >/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -I. "$@" -x hip -c $tu.hip -o build/${tu}_$name.o
 objs=""
-for o in kt_host kt_oligo kt_ctr kt_bulk kt_cov kt_cgr kt_min kt_synth; do
+for o in kt_host kt_oligo kt_oligo_generic kt_ctr kt_bulk kt_shard kt_cov kt_cgr kt_min kt_synth; do
   if [ $o = $tu ]; then objs="$objs build/${tu}_$name.o"; else objs="$objs build/$o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/lib$name.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/lib$name.so $objs -ldl
 echo built ../variants/lib$name.so
