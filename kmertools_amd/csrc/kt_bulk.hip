@@ -62,9 +62,12 @@ constexpr int P2T = KT_P2T;               // threads of a part2 workgroup
 #ifndef KT_P2_PER32
 #define KT_P2_PER32 32
 #endif
-// keys sorted at a time in part2: 16 per thread (KT_P2_PER32 for 32-bit keys)
+#ifndef KT_P2_PER64
+#define KT_P2_PER64 16
+#endif
+// keys sorted at a time in part2: KT_P2_PER64 per thread (KT_P2_PER32 for 32-bit keys)
 template <class K>
-constexpr uint32_t chunk2() { return (sizeof(K) == 8 ? 16 : KT_P2_PER32) * P2T; }
+constexpr uint32_t chunk2() { return (sizeof(K) == 8 ? KT_P2_PER64 : KT_P2_PER32) * P2T; }
 
 struct Plan {
     uint32_t n;       // hash bits that address the table: cap = m8 * 2^(n-3) (kttab::Geom)
