@@ -815,6 +815,10 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
 #pragma unroll
             for (uint32_t w = 0; w < NW; w++) pre[w + 1] = pre[w] + runs[w];
             const uint32_t D = pre[NW];
+            // a dense range is keys[D] at the front of the range's bytes and counts[D] from byte 8 * RS on: 12 bytes
+            // per entry instead of a 16-byte slot (nothing probes this layout; materialize_kernel reads it back)
+            uint64_t *const dkeys = reinterpret_cast<uint64_t *>(dst);
+            uint32_t *const dcounts = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst) + (size_t)RS * 8);
             for (uint32_t e = tid; e < D; e += BUILD_T) {
                 uint32_t w = 0;
 #pragma unroll
@@ -823,10 +827,8 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
 #pragma unroll
                 for (uint32_t q = 1; q < NW; q++) pw = e >= pre[q] ? pre[q] : pw;
                 const uint32_t src = w * share + (e - pw);
-                const uint64_t key = (uint64_t)skeys[src];
-                typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
-                const raw4 raw = {(uint32_t)key, (uint32_t)(key >> 32), scounts[src], 0u};
-                __builtin_nontemporal_store(raw, reinterpret_cast<raw4 *>(dst + e));
+                __builtin_nontemporal_store((uint64_t)skeys[src], dkeys + e);
+                __builtin_nontemporal_store(scounts[src], dcounts + e);
             }
             if (tid == 0) {
                 range_counts[fb] = D;
@@ -893,15 +895,17 @@ __global__ __launch_bounds__(BUILD_T) void materialize_kernel(Slot *__restrict__
         ktd::lds_barrier();
         const uint32_t D = range_counts[r];
         uint4 *rs = reinterpret_cast<uint4 *>(slots + r * RS);
+        const uint64_t *dkeys = reinterpret_cast<const uint64_t *>(rs);  // the dense layout: keys[D], counts[D] at 8 * RS
+        const uint32_t *dcounts = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(rs) + (size_t)RS * 8);
         for (uint32_t i = tid; i < D; i += BUILD_T) {
-            const uint4 v = rs[i];
-            const uint64_t key = ((uint64_t)v.y << 32) | v.x;
+            const uint64_t key = dkeys[i];
+            const uint32_t cnt = dcounts[i];
             uint32_t s = (((uint32_t)(ktd::khash(key) >> shift) & (S - 1)) * m8) >> 3;
             while (atomicCAS(&skeys[s], (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key) != KT_EMPTY_KEY)
                 s = s + 1 == RS ? 0 : s + 1;  // (D <= RS: a free slot exists)
-            scounts[s] = v.z;
+            scounts[s] = cnt;
         }
-        ktd::lds_barrier();
+        ktd::lds_barrier();  // (the image below overwrites what was just read: everything is in LDS by now)
         for (uint32_t i = tid; i < RS; i += BUILD_T) {
             const uint64_t key = skeys[i];
             typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
@@ -977,20 +981,24 @@ __global__ __launch_bounds__(XT) void dense_export_kernel(const Slot *__restrict
     for (uint32_t r = tid >> 6; r < XT && r0 + r < n_ranges; r += XT / 64) {
         const uint32_t D = cnt[r];
         const uint64_t o = t0 + offs[r];
-        const uint4 *rs = reinterpret_cast<const uint4 *>(slots + (r0 + r) * RS);
+        const char *rs = reinterpret_cast<const char *>(slots + (r0 + r) * RS);
+        const uint64_t *dkeys = reinterpret_cast<const uint64_t *>(rs);
+        const uint32_t *dcounts = reinterpret_cast<const uint32_t *>(rs + (size_t)RS * 8);
         for (uint32_t i0 = tid & 63u; i0 < D; i0 += 256) {
-            uint4 v[4];
+            uint64_t vk[4];
+            uint32_t vc[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t i = i0 + 64u * u;
-                v[u] = i < D ? rs[i] : make_uint4(0, 0, 0, 0);
+                vk[u] = i < D ? dkeys[i] : 0;
+                vc[u] = i < D ? dcounts[i] : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t i = i0 + 64u * u;
                 if (i < D && o + i < max_out) {
-                    out_keys[o + i] = ((uint64_t)v[u].y << 32) | v[u].x;
-                    out_counts[o + i] = v[u].z + 1u;  // stored value is occurrences - 1
+                    out_keys[o + i] = vk[u];
+                    out_counts[o + i] = vc[u] + 1u;  // stored value is occurrences - 1
                 }
             }
         }
