@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "kt_segment.hpp"
@@ -52,22 +53,19 @@ constexpr int BLOCK = ktseg::BLOCK;       // 256
 constexpr uint32_t LOG2_S = kttab::LOG2_RANGE;  // hash positions per fine bucket = per range of the table
 constexpr uint32_t S = 1u << LOG2_S;            // 8192 positions: 1024 * m8 slots, 80 - 128 KB of table
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
-#ifndef KT_P2T
-#define KT_P2T 512
-#endif
-constexpr int P2T = KT_P2T;               // threads of a part2 workgroup
-#ifndef KT_P2_WPE
-#define KT_P2_WPE 2                       // waves per SIMD part2 is compiled for (4 = two workgroups per CU: spills, slower)
-#endif
-#ifndef KT_P2_PER32
-#define KT_P2_PER32 32
-#endif
-#ifndef KT_P2_PER64
-#define KT_P2_PER64 16
-#endif
-// keys sorted at a time in part2: KT_P2_PER64 per thread (KT_P2_PER32 for 32-bit keys)
-template <class K>
-constexpr uint32_t chunk2() { return (sizeof(K) == 8 ? KT_P2_PER64 : KT_P2_PER32) * P2T; }
+// part2's shape per key type.  The pass is bound by the short runs it scatters (one per fine bucket and chunk; PMC and
+// sweeps in profiles/r2_ctr_k31_pmc.txt), so 64-bit keys take chunks of 16384 keys = 128 KB of LDS in one 1024-thread
+// workgroup per CU - the 2-byte digit that used to sit beside every sorted key is hashed again instead, which is what
+// makes the room (ctr k=31: 19.5 -> 16.2 ms).  32-bit keys already sort 16384 at a time with 512 threads (the wider
+// shape measured 6 % slower there).
+// (BIG = that shape; it needs B2 <= 1024 to fit 160 KB, otherwise - and for 32-bit keys - the 512-thread shape runs)
+template <class K, bool BIG>
+constexpr int p2t() { return BIG ? 1024 : 512; }           // threads of a part2 workgroup
+template <class K, bool BIG>
+constexpr bool p2_sdig() { return !BIG; }                  // digit kept beside every sorted key
+// keys sorted at a time in part2
+template <class K, bool BIG>
+constexpr uint32_t chunk2() { return sizeof(K) == 8 ? 16u * p2t<K, BIG>() : 32u * p2t<K, BIG>(); }
 
 struct Plan {
     uint32_t n;       // hash bits that address the table: cap = m8 * 2^(n-3) (kttab::Geom)
@@ -458,27 +456,28 @@ __global__ __launch_bounds__(BLOCK) void page_tails_kernel(Plan p, const uint32_
 // ---- part2: one workgroup per level-1 bucket -----------------------------------------------------------
 // LDS of part2, carved at run time so that the per-digit arrays take B2 entries, not MAX_B: with 32-bit keys and
 // B2 <= 1024 two workgroups fit a CU
-template <class K>
+template <class K, bool BIG>
 struct Part2Shared {
-    K *sorted;         // [chunk2<K>()]
+    K *sorted;         // [chunk2<K, BIG>()]
     uint64_t *cursor;  // [B2]
     uint32_t *cnt, *start, *fill;  // [B2] each
-    uint32_t *tmp;     // [P2T]
+    uint32_t *tmp;     // [p2t<K, BIG>()]
     uint32_t *flag;    // [1] (+1 pad) fixed fine regions: a fine bucket is outgrowing its room
-    uint16_t *sdig;    // [chunk2<K>()]
+    uint16_t *sdig;    // [chunk2<K, BIG>()]
     static size_t bytes(uint32_t B2) {
-        return (size_t)chunk2<K>() * sizeof(K) + (size_t)B2 * (8 + 3 * 4) + (size_t)P2T * 4 + 8 + (size_t)chunk2<K>() * 2;
+        return (size_t)chunk2<K, BIG>() * sizeof(K) + (size_t)B2 * (8 + 3 * 4) + (size_t)p2t<K, BIG>() * 4 + 8 +
+               (p2_sdig<K, BIG>() ? (size_t)chunk2<K, BIG>() * 2 : 0);
     }
     __device__ Part2Shared(unsigned char *raw, uint32_t B2) {
         sorted = reinterpret_cast<K *>(raw);
-        raw += (size_t)chunk2<K>() * sizeof(K);
+        raw += (size_t)chunk2<K, BIG>() * sizeof(K);
         cursor = reinterpret_cast<uint64_t *>(raw);
         raw += (size_t)B2 * 8;
         cnt = reinterpret_cast<uint32_t *>(raw);
         start = cnt + B2;
         fill = start + B2;
         tmp = fill + B2;
-        flag = tmp + P2T;
+        flag = tmp + p2t<K, BIG>();
         sdig = reinterpret_cast<uint16_t *>(flag + 2);
     }
 };
@@ -490,16 +489,17 @@ struct Part2Shared {
 // processed so far, and as soon as one is heading past its room it stops placing keys, finishes the pass counting
 // only (which is exactly the histogram), and the bucket is redone with the exact boundaries - the price of a
 // wrong guess is the part of the pass done before it was noticed.
-template <class K, bool FIXED>
-__global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restrict__ keys1,
+template <class K, bool FIXED, bool BIG>
+__global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restrict__ keys1,
                                                       const uint64_t *__restrict__ bstart,
                                                       const uint64_t *__restrict__ gcur, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart,
                                                       uint64_t *__restrict__ fend) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const Part2Shared<K> sm(smem_raw, p.B2);
+    const Part2Shared<K, BIG> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
-    constexpr int PER = chunk2<K>() / P2T;  // 16 (32) keys per thread, held in registers
+    constexpr int P2T = p2t<K, BIG>();
+    constexpr int PER = chunk2<K, BIG>() / P2T;  // 16 (32) keys per thread, held in registers
     const uint32_t tid = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
         // exact level 1: keys1 is dense; paged level 1 (cap1 != 0): the bucket's region, empty keys in the gaps
@@ -512,15 +512,15 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
                 dst[u] = i < hi ? keys1[i] : EMPTY;
             }
         };
-        // one pass over the bucket in chunks of chunk2<K>() keys: counting sort in LDS, runs appended at the fine
+        // one pass over the bucket in chunks of chunk2<K, BIG>() keys: counting sort in LDS, runs appended at the fine
         // buckets' cursors.  The next chunk's keys are loaded while the current one is sorted; digits are hashed once.
         // attempt = fixed fine regions (cursors may run past their room: then nothing is stored any more)
         auto run_pass = [&](const bool attempt) {
             K kcur[PER], knxt[PER];
             bool counting_only = false;
             if (lo < hi) load_chunk(lo, kcur);
-            for (uint64_t c0 = lo; c0 < hi; c0 += chunk2<K>()) {
-                if (c0 + chunk2<K>() < hi) load_chunk(c0 + chunk2<K>(), knxt);
+            for (uint64_t c0 = lo; c0 < hi; c0 += chunk2<K, BIG>()) {
+                if (c0 + chunk2<K, BIG>() < hi) load_chunk(c0 + chunk2<K, BIG>(), knxt);
                 for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
                 ktd::lds_barrier();
                 if (attempt) counting_only = *sm.flag != 0;  // (written before the barrier above; same for every thread)
@@ -542,14 +542,17 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
                             const uint32_t d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
                             const uint32_t pos = atomicAdd(&sm.fill[d], 1u);
                             sm.sorted[pos] = kcur[u];
-                            sm.sdig[pos] = (uint16_t)d;
+                            if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
                         }
                     }
                     ktd::lds_barrier();
                     for (uint32_t i = tid; i < nc; i += P2T) {
-                        const uint32_t d = sm.sdig[i];
+                        const K key = sm.sorted[i];
+                        uint32_t d;
+                        if constexpr (p2_sdig<K, BIG>()) d = sm.sdig[i];
+                        else d = digit2((uint64_t)key, p);
                         const uint64_t pos = sm.cursor[d] + (i - sm.start[d]);
-                        if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = sm.sorted[i];
+                        if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = key;
                     }
                     ktd::lds_barrier();
                 }
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(P2T, KT_P2_WPE) void part2_kernel(const K *__restri
                 // the part of the level-1 bucket seen so far (+ 6 sigma): hashed distinct keys never get there
                 float allowed = 0.f;
                 if (attempt) {
-                    const float seen = (float)(c0 + chunk2<K>() - lo) / (float)(hi - lo);
+                    const float seen = (float)(c0 + chunk2<K, BIG>() - lo) / (float)(hi - lo);
                     const float room = (float)p.cap2 * (seen < 1.f ? seen : 1.f);
                     allowed = 0.93f * room + 6.f * sqrtf(room) + 32.f;
                 }
@@ -1103,12 +1106,18 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             if (int rc = level1_exact<K>(ctr, j)) return rc;
         }
     }
-    const size_t part2_lds = Part2Shared<K>::bytes(p.B2);
-    auto part2 = p.cap2 ? part2_kernel<K, true> : part2_kernel<K, false>;
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)part2_lds));
-    hipLaunchKernelGGL(part2, dim3(p.B1), dim3(P2T), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur, p,
-                       keys2, m.fstart, m.fend);
+    const bool big2 = sizeof(K) == 8 && env_u64("KT_P2_BIG64", 1) != 0 && Part2Shared<K, true>::bytes(p.B2) <= 160 * 1024;
+    auto run_part2 = [&](auto big) -> int {
+        constexpr bool BIG = decltype(big)::value;
+        const size_t part2_lds = Part2Shared<K, BIG>::bytes(p.B2);
+        auto part2 = p.cap2 ? part2_kernel<K, true, BIG> : part2_kernel<K, false, BIG>;
+        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)part2_lds));
+        hipLaunchKernelGGL(part2, dim3(p.B1), dim3(p2t<K, BIG>()), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur,
+                           p, keys2, m.fstart, m.fend);
+        return KT_OK;
+    };
+    if (int rc = big2 ? run_part2(std::true_type{}) : run_part2(std::false_type{})) return rc;
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 8);  // persistent workgroups; up to two are resident per CU
     if (gb > n_fine) gb = n_fine;
