@@ -792,10 +792,9 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         if (DENSE) {
             // The occupied slots, packed.  Every wave first packs its own sixteenth of the image in place (wave
             // synchronous: 64 slots into registers, ballot, back at the wave's cursor - entries only move towards the
-            // front of the wave's share, so no other wave is involved), then the sixteen packed runs are copied out as
-            // one sequence: thread t writes element t, t + 1024, ... - aligned, coalesced, non-temporal.  (Writing
-            // each (wave, pass) run straight to global memory left the stores starting and ending inside cache lines:
-            // 36 GB took 14 ms.)
+            // front of the wave's share, so no other wave is involved), then the sixteen packed runs are copied out
+            // one after the other.  (Writing each (wave, pass) run of <= 64 entries straight to global memory left
+            // every store starting and ending inside cache lines: 36 GB took 14 ms.)
             constexpr uint32_t NW = BUILD_T / 64;
             const uint32_t wave = tid >> 6, share = RS / NW;  // RS = 1024 * m8: a multiple of 64 per wave
             uint32_t wc = 0;                                  // entries this wave has packed so far (wave uniform)
@@ -813,25 +812,33 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             }
             if (lane == 0) runs[wave] = wc;
             ktd::lds_barrier();
-            uint32_t pre[NW + 1];
-            pre[0] = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < NW; w++) pre[w + 1] = pre[w] + runs[w];
-            const uint32_t D = pre[NW];
+            // where this wave's run goes = the runs before it: an inclusive scan of the sixteen counts in lanes 0..15
+            // (row_shr inside one DPP row)
+            static_assert(NW == 16, "the wave counts are scanned inside one DPP row");
+            uint32_t inc = lane < NW ? runs[lane] : 0u;
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);
+            const uint32_t D = (uint32_t)__builtin_amdgcn_readlane((int)inc, NW - 1);
+            const uint32_t uw = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+            const uint32_t pre = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)uw) - wc;
             // a dense range is keys[D] at the front of the range's bytes and counts[D] from byte 8 * RS on: 12 bytes
-            // per entry instead of a 16-byte slot (nothing probes this layout; materialize_kernel reads it back)
+            // per entry instead of a 16-byte slot (nothing probes this layout; materialize_kernel reads it back).
+            // Every wave copies its own run: ~240 consecutive entries, with the lanes lined up on 32-entry
+            // boundaries of the destination (256 bytes of keys, 128 of counts), so that only the two ends of a run
+            // share cache lines with the neighbouring waves' runs.  (Finding the run of element e by a 16-way
+            // compare chain, so that thread t could write element t, t + 1024, ..., took a third of the kernel's
+            // VALU instructions.)
             uint64_t *const dkeys = reinterpret_cast<uint64_t *>(dst);
             uint32_t *const dcounts = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst) + (size_t)RS * 8);
-            for (uint32_t e = tid; e < D; e += BUILD_T) {
-                uint32_t w = 0;
-#pragma unroll
-                for (uint32_t q = 1; q < NW; q++) w += e >= pre[q] ? 1u : 0u;  // the run that holds element e
-                uint32_t pw = 0;
-#pragma unroll
-                for (uint32_t q = 1; q < NW; q++) pw = e >= pre[q] ? pre[q] : pw;
-                const uint32_t src = w * share + (e - pw);
-                __builtin_nontemporal_store((uint64_t)skeys[src], dkeys + e);
-                __builtin_nontemporal_store(scounts[src], dcounts + e);
+            const uint32_t skew = pre & 31u;
+            for (uint32_t j = lane; j < wc + skew; j += 64) {
+                if (j >= skew) {
+                    const uint32_t src = wave * share + (j - skew);
+                    __builtin_nontemporal_store((uint64_t)skeys[src], dkeys + pre + (j - skew));
+                    __builtin_nontemporal_store(scounts[src], dcounts + pre + (j - skew));
+                }
             }
             if (tid == 0) {
                 range_counts[fb] = D;
