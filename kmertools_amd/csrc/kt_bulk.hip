@@ -96,11 +96,38 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint64_t spill_cap;
 };
 
-__device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) {
-    return (uint32_t)(ktd::khash(key) >> (64 - p.b1));
+__device__ __forceinline__ uint32_t digit1h(uint64_t h, const Plan &p) { return (uint32_t)(h >> (64 - p.b1)); }
+__device__ __forceinline__ uint32_t digit2h(uint64_t h, const Plan &p) {
+    return (uint32_t)(h >> (64 - p.b1 - p.b2)) & (p.B2 - 1);
 }
-__device__ __forceinline__ uint32_t digit2(uint64_t key, const Plan &p) {
-    return (uint32_t)(ktd::khash(key) >> (64 - p.b1 - p.b2)) & (p.B2 - 1);
+__device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) { return digit1h(ktd::khash(key), p); }
+// What travels through the partition passes ("stored form" of a canonical k-mer): 64-bit keys travel as
+// khash(key) - the hash is a bijection (an odd multiply and an xor of the high half into the low half), so the
+// digits and the home slot of every later pass are bit fields of what is already there and the key comes back once,
+// where build writes the table (the hash used to be evaluated seven times per k-mer); 32-bit keys (k <= 16) travel
+// as they are (their 64-bit hash would not fit).  The empty marker stays all ones in both forms: the only key
+// that hashes to it is 0x66c88cc300000000, not a k-mer of k <= 31.
+#ifndef KT_STORE_HASH
+#define KT_STORE_HASH 1
+#endif
+static_assert(KT_KHASH == 1 || !KT_STORE_HASH,
+              "the empty marker must not be the hash of a k-mer (true for the multiplicative hash)");
+template <class K>
+constexpr bool stores_hash() { return sizeof(K) == 8 && KT_STORE_HASH; }
+template <class K>
+__device__ __forceinline__ K to_stored(uint64_t key) {
+    if constexpr (stores_hash<K>()) return (K)ktd::khash(key);
+    else return (K)key;
+}
+template <class K>
+__device__ __forceinline__ uint64_t hash_of_stored(K s) {
+    if constexpr (stores_hash<K>()) return (uint64_t)s;
+    else return ktd::khash((uint64_t)s);
+}
+template <class K>
+__device__ __forceinline__ uint64_t from_stored(K s) {
+    if constexpr (stores_hash<K>()) return ktd::khash_inv((uint64_t)s);
+    else return (uint64_t)s;
 }
 
 // exclusive prefix sum of cnt[0..B) into out[0..B) (LDS arrays), B <= MAX_B; returns the total.
@@ -283,7 +310,11 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, uin
             ktd::lds_barrier();
 #pragma unroll
             for (int j = 0; j < PERR; j++)
-                if ((ok >> (half * PERR + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * PERR + j], p)], 1u);
+            {  // (the keys take their stored form here, where the first digit is needed)
+                keys[half * PERR + j] = (uint64_t)to_stored<K>(keys[half * PERR + j]);
+                if ((ok >> (half * PERR + j)) & 1u)
+                    atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>((K)keys[half * PERR + j]), p)], 1u);
+            }
             ktd::lds_barrier();
             const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
             for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.fill[i] = sm.start[i];
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, uin
             for (int j = 0; j < PERR; j++) {
                 if ((ok >> (half * PERR + j)) & 1u) {
                     const uint64_t m = keys[half * PERR + j];
-                    const uint32_t d = digit1(m, p);
+                    const uint32_t d = digit1h(hash_of_stored<K>((K)m), p);
                     const uint32_t pos = atomicAdd(&sm.fill[d], 1u);
                     sm.sorted[pos] = (K)m;
                     sm.sdig[pos] = (uint16_t)d;
@@ -372,7 +403,11 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
             ktd::lds_barrier();
 #pragma unroll
             for (int j = 0; j < PERR; j++)
-                if ((ok >> (half * PERR + j)) & 1u) atomicAdd(&sm.cnt[digit1(keys[half * PERR + j], p)], 1u);
+            {  // (the keys take their stored form here, where the first digit is needed)
+                keys[half * PERR + j] = (uint64_t)to_stored<K>(keys[half * PERR + j]);
+                if ((ok >> (half * PERR + j)) & 1u)
+                    atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>((K)keys[half * PERR + j]), p)], 1u);
+            }
             ktd::lds_barrier();
             const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
             // every bucket's run is laid out: what fits goes to the current page, the rest to new pages.  The
@@ -407,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
             for (int j = 0; j < PERR; j++) {
                 if ((ok >> (half * PERR + j)) & 1u) {
                     const uint64_t m = keys[half * PERR + j];
-                    const uint32_t d = digit1(m, p);
+                    const uint32_t d = digit1h(hash_of_stored<K>((K)m), p);
                     const uint32_t pos = atomicAdd(&sm.start[d], 1u);
                     sm.sorted[pos] = (K)m;
                     sm.sdig[pos] = (uint16_t)d;
@@ -527,7 +562,7 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
                 uint32_t dgp[PER / 2];  // digits, two per register
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
-                    const uint32_t d = digit2(kcur[u], p);
+                    const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
                     dgp[u / 2] = (u & 1) ? dgp[u / 2] | (d << 16) : d;
                     if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[d], 1u);
                 }
@@ -550,7 +585,7 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
                         const K key = sm.sorted[i];
                         uint32_t d;
                         if constexpr (p2_sdig<K, BIG>()) d = sm.sdig[i];
-                        else d = digit2((uint64_t)key, p);
+                        else d = digit2h(hash_of_stored<K>(key), p);
                         const uint64_t pos = sm.cursor[d] + (i - sm.start[d]);
                         if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = key;
                     }
@@ -609,7 +644,7 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++)
-                    if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2(kk[u], p)], 1u);
+                    if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2h(hash_of_stored<K>(kk[u]), p)], 1u);
             }
             ktd::lds_barrier();
         }
@@ -683,8 +718,9 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
     const uint32_t shift = 64 - p.n;
-    auto home = [&](uint64_t key) {  // home position inside the range (kttab::probe_of)
-        return (((uint32_t)(ktd::khash(key) >> shift) & (S - 1)) * p.m8) >> 3;
+    // (the image in LDS holds keys in their stored form, like the key arrays: to_stored / from_stored)
+    auto home = [&](K stored) {  // home position inside the range (kttab::probe_of)
+        return __umul24((uint32_t)(hash_of_stored<K>(stored) >> shift) & (S - 1), p.m8) >> 3;
     };
     auto spill = [&](uint64_t key, uint32_t occurrences) {
         if (DENSE) {  // (no image to probe afterwards: a full range is reported at once)
@@ -737,7 +773,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
                 const uint4 v = reinterpret_cast<const uint4 *>(slots + fb * RS)[i];
                 const bool occ = (v.x & v.y) != 0xFFFFFFFFu;
-                skeys[i] = occ ? (K)(((uint64_t)v.y << 32) | v.x) : EMPTY;
+                skeys[i] = occ ? to_stored<K>(((uint64_t)v.y << 32) | v.x) : EMPTY;
                 scounts[i] = v.z;
                 placed -= occ;
             }
@@ -761,7 +797,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             };
             K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
             if (p.dbg & 1u) cur = EMPTY;
-            uint32_t s = home((uint64_t)cur), probes = 0;
+            uint32_t s = home(cur), probes = 0;
             while (cur != EMPTY) {
                 const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
                 bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
@@ -772,7 +808,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
                 if (!done) {
                     s = s + 1 == RS ? 0 : s + 1;  // round the range (kttab::Probe)
                     if (++probes >= RS) {          // the range is full: the table is too small
-                        spill((uint64_t)cur, 1u);
+                        spill(from_stored<K>(cur), 1u);
                         done = true;
                     }
                 }
@@ -781,7 +817,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
                     q0 = q1;
                     q1 = q2;
                     q2 = fetch();
-                    s = home((uint64_t)cur);
+                    s = home(cur);
                     probes = 0;
                 }
             }
@@ -836,7 +872,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             for (uint32_t j = lane; j < wc + skew; j += 64) {
                 if (j >= skew) {
                     const uint32_t src = wave * share + (j - skew);
-                    __builtin_nontemporal_store((uint64_t)skeys[src], dkeys + pre + (j - skew));
+                    __builtin_nontemporal_store(from_stored<K>(skeys[src]), dkeys + pre + (j - skew));
                     __builtin_nontemporal_store(scounts[src], dcounts + pre + (j - skew));
                 }
             }
@@ -847,7 +883,7 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         } else if (!(p.dbg & 8u)) {
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
                 const K kk = skeys[i];
-                const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : (uint64_t)kk;
+                const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : from_stored<K>(kk);
                 placed += kk != EMPTY;
 #if KT_BUILD_NT
                 typedef uint32_t raw4 __attribute__((ext_vector_type(4)));

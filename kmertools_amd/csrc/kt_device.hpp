@@ -62,6 +62,19 @@ __host__ __device__ __forceinline__ uint64_t khash(uint64_t key) {
 #endif
 }
 
+// khash is a bijection of the 64-bit words: the key of a hash (kt_bulk.hip moves hashes through its passes)
+__host__ __device__ __forceinline__ uint64_t khash_inv(uint64_t x) {
+#if KT_KHASH == 0
+    x = (x ^ (x >> 31) ^ (x >> 62)) * 0x319642b2d24d8ec3ull;
+    x = (x ^ (x >> 27) ^ (x >> 54)) * 0x96de1b173f119089ull;
+    x = x ^ (x >> 30) ^ (x >> 60);
+    return x - 0x9e3779b97f4a7c15ull;
+#else
+    const uint64_t h = x ^ (x >> 32);
+    return h * 0xf1de83e19937733dull;  // the inverse of 0x9e3779b97f4a7c15 modulo 2^64
+#endif
+}
+
 // owner of a canonical k-mer among n owners: LOW 32 bits of the hash, multiply-shift (the
 // table's home slot uses the top bits of the same hash, kt_table.hpp)
 __host__ __device__ __forceinline__ uint32_t owner_of(uint64_t kmer, uint32_t n) {
