@@ -184,6 +184,29 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
                 if (ktd::owner_of(keys[j], n_parts) != part) ok &= ~(1u << j);
         }
     }
+    // the same k-mers a few at a time (scatter1w): open() stages the segment for the 256 threads of a group (t = index
+    // in the group; whole-workgroup barriers inside), take<N>() hands out the thread's next N window starts
+    struct Walk {
+        ktseg::Window w;
+        uint32_t at;
+    };
+    __device__ Walk open(uint64_t g, SegShared &sm, uint32_t t) const {
+        ktseg::stage_segment(a, seg_lo + g, sm, t);
+        return Walk{ktseg::Window(sm, t, a.k), 0u};
+    }
+    template <int N>
+    __device__ void take(Walk &wk, uint32_t, uint64_t (&keys)[N], uint32_t &ok) const {
+        ok = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            keys[j] = wk.w.f < wk.w.r ? wk.w.f : wk.w.r;
+            bool good = wk.w.ok(wk.at + j);
+            if (n_parts > 1) good = good && ktd::owner_of(keys[j], n_parts) == part;
+            ok |= (good ? 1u : 0u) << j;
+            wk.w.step();
+        }
+        wk.at += N;
+    }
     template <class Sink>
     __device__ void for_each(uint64_t g, SegShared &sm, Sink &&sink) const {  // rolling walk: few registers
         ktseg::for_each_kmer(a, seg_lo + g, sm, [&](uint64_t f, uint64_t r, uint64_t) {
@@ -212,6 +235,23 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
             out[j] = key;
             ok |= (key != KT_EMPTY_KEY ? 1u : 0u) << j;
         }
+    }
+    struct Walk {
+        uint64_t base, cnt;
+        uint32_t at;
+    };
+    __device__ Walk open(uint64_t g, SegShared &, uint32_t) const { return Walk{g * ktseg::SEG, count(), 0u}; }
+    template <int N>
+    __device__ void take(Walk &wk, uint32_t t, uint64_t (&out)[N], uint32_t &ok) const {
+        ok = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {  // consecutive lanes read consecutive keys
+            const uint64_t i = wk.base + (uint64_t)(wk.at + j) * BLOCK + t;
+            const uint64_t key = i < wk.cnt ? keys[i] : KT_EMPTY_KEY;
+            out[j] = key;
+            ok |= (key != KT_EMPTY_KEY ? 1u : 0u) << j;
+        }
+        wk.at += N;
     }
     template <class Sink>
     __device__ void for_each(uint64_t g, SegShared &, Sink &&sink) const {
@@ -475,6 +515,125 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
     ktd::lds_barrier();
     if (sm.ovf) return;
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) wcur[(uint64_t)blockIdx.x * p.B1 + i] = sm.cur[i];
+}
+
+// ---- scatter1, paged, wide: the kernel the bulk path runs ------------------------------------------------------
+// scatter1p sorts 4096 64-bit keys (8192 32-bit ones) per round with 1024 buckets: 4-key = 32-byte runs, written by
+// 8 waves per CU that hold their 32 k-mers per thread in ~200 VGPRs.  Here a workgroup is FOUR 256-thread groups,
+// each staging its own segment (or unit of keys), and the thread's walk over its 32 window starts is cut into
+// quarters (halves for 32-bit keys): a round sorts 1024 x 8 (16) keys = 8192 (16384) - runs twice as long, half as
+// many rounds per segment, 16 (32) key registers instead of 64, so 16 waves fit a CU (one workgroup, ~107 / 139 KB of
+// LDS).  Same pages, same allocator, same carried state (wcur) as scatter1p, which stays for comparison
+// (KT_S1_WIDE=0).
+constexpr int WIDE_T = 1024, WIDE_GROUPS = WIDE_T / BLOCK;
+template <class K>
+constexpr int wide_per() { return sizeof(K) == 8 ? 8 : 16; }  // keys per thread and round
+template <class K>
+constexpr uint32_t wide_round() { return (uint32_t)WIDE_T * wide_per<K>(); }
+static_assert(MAX_B1 <= WIDE_T, "one bucket per thread");
+
+template <class K>
+struct Scatter1WShared {
+    SegShared seg[WIDE_GROUPS];
+    K sorted[wide_round<K>()];
+    uint16_t sdig[stores_hash<K>() ? 2 : wide_round<K>()];  // (a stored hash carries its digit)
+    uint16_t split[MAX_B1];
+    uint32_t cur[MAX_B1];
+    uint32_t to_cur[MAX_B1];
+    uint32_t to_new[MAX_B1];
+    uint32_t cnt[MAX_B1];
+    uint32_t start[MAX_B1];
+    uint32_t tmp[WIDE_T];
+    uint32_t ovf;
+};
+static_assert(sizeof(Scatter1WShared<uint64_t>) <= 160 * 1024 && sizeof(Scatter1WShared<uint32_t>) <= 160 * 1024, "LDS of a CU");
+
+template <class Source, class K>
+__global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, uint64_t *__restrict__ gcur,
+                                                           uint32_t *__restrict__ ovf, uint32_t *__restrict__ wcur,
+                                                           K *__restrict__ keys1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Scatter1WShared<K> &sm = *reinterpret_cast<Scatter1WShared<K> *>(smem_raw);
+    constexpr int PER = wide_per<K>(), NQ = ktseg::PER_THREAD / PER;
+    constexpr uint32_t PAGE = page_keys<K>();
+    const uint32_t tid = threadIdx.x, grp = tid / BLOCK, t = tid % BLOCK;
+    if (tid < p.B1) sm.cur[tid] = wcur[(uint64_t)blockIdx.x * p.B1 + tid];
+    if (tid == 0) sm.ovf = 0;
+    const uint64_t n_units = src.n_units();
+    bool stop = false;
+    for (uint64_t g0 = (uint64_t)blockIdx.x * WIDE_GROUPS; g0 < n_units && !stop; g0 += (uint64_t)gridDim.x * WIDE_GROUPS) {
+        const bool valid = g0 + grp < n_units;  // (a group past the end walks the last unit and keeps nothing)
+        auto wk = src.open(valid ? g0 + grp : n_units - 1, sm.seg[grp], t);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {  // (no early exit in here: the loop must stay unrolled)
+            uint64_t keys[PER];
+            uint32_t ok;
+            src.template take<PER>(wk, t, keys, ok);
+            if (!valid) ok = 0;
+            if (tid < p.B1) sm.cnt[tid] = 0;
+            ktd::lds_barrier();
+#pragma unroll
+            for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
+                keys[j] = (uint64_t)to_stored<K>(keys[j]);
+                if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>((K)keys[j]), p)], 1u);
+            }
+            ktd::lds_barrier();
+            const uint32_t nk = block_excl_scan<WIDE_T>(sm.cnt, sm.start, p.B1, sm.tmp);
+            // every bucket's run is laid out: what fits goes to the current page, the rest to new pages.  The
+            // allocator's answer is only looked at after the placement pass, which hides its round trip.
+            uint64_t got = 0;
+            uint32_t room = 0, spl = 0, nxt = 0;
+            if (tid < p.B1) {
+                const uint32_t d = tid, c = sm.cnt[d], rs = sm.start[d], cur = sm.cur[d];
+                const uint32_t left = (0u - cur) & (PAGE - 1u);
+                sm.to_cur[d] = cur - rs;
+                spl = rs + (c < left ? c : left);
+                sm.split[d] = (uint16_t)spl;
+                if (c > left) {
+                    const uint32_t need = c - left;
+                    room = (need + PAGE - 1u) / PAGE * PAGE;  // whole pages; the last one may stay partly used
+                    got = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[d]), (unsigned long long)room);
+                    nxt = need;
+                } else {
+                    sm.cur[d] = cur + c;
+                }
+            }
+            ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                if ((ok >> j) & 1u) {
+                    const uint32_t d = digit1h(hash_of_stored<K>((K)keys[j]), p);
+                    const uint32_t pos = atomicAdd(&sm.start[d], 1u);
+                    sm.sorted[pos] = (K)keys[j];
+                    if constexpr (!stores_hash<K>()) sm.sdig[pos] = (uint16_t)d;
+                }
+            }
+            if (room) {
+                if (got + room > p.cap1) {
+                    sm.ovf = 1;
+                    atomicOr(ovf, 1u);
+                }
+                sm.to_new[tid] = (uint32_t)got - spl;
+                sm.cur[tid] = (uint32_t)got + nxt;
+            }
+            ktd::lds_barrier();
+            stop = sm.ovf != 0;  // the same for every thread
+            if (!stop) {
+                for (uint32_t i = tid; i < nk; i += WIDE_T) {
+                    const K key = sm.sorted[i];
+                    uint32_t d;
+                    if constexpr (stores_hash<K>()) d = digit1h((uint64_t)key, p);
+                    else d = sm.sdig[i];
+                    const uint32_t at = (i < sm.split[d] ? sm.to_cur[d] : sm.to_new[d]) + i;
+                    keys1[(uint64_t)d * p.cap1 + at] = key;
+                }
+            }
+            ktd::lds_barrier();
+        }
+    }
+    ktd::lds_barrier();
+    if (sm.ovf) return;
+    if (tid < p.B1) wcur[(uint64_t)blockIdx.x * p.B1 + tid] = sm.cur[tid];
 }
 
 // after the last source of a job: the unused tail of every workgroup's last page of every bucket gets the empty key
@@ -1084,6 +1243,23 @@ template <class K>
 int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
     kt_ctx *ctx = ctr->ctx;
     K *keys1 = (K *)ctr->b_keys1.p;
+    if (env_u64("KT_S1_WIDE", 1)) {
+        const uint32_t wgs = j.p.G / 2 ? j.p.G / 2 : 1;  // one resident workgroup per CU (its rows of wcur are [0, wgs))
+        const size_t lds = sizeof(Scatter1WShared<K>);
+        if (r.reads) {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1w_kernel<ReadsSource, K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((scatter1w_kernel<ReadsSource, K>), dim3(wgs), dim3(WIDE_T), lds, ctx->stream, r.rs, j.p,
+                               j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+        } else {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1w_kernel<KeysSource, K>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((scatter1w_kernel<KeysSource, K>), dim3(wgs), dim3(WIDE_T), lds, ctx->stream, r.ks, j.p,
+                               j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+        }
+        KT_HIP(hipGetLastError());
+        return KT_OK;
+    }
     if (r.reads) {
         KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<ReadsSource, K>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));

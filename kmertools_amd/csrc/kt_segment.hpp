@@ -55,8 +55,9 @@ struct SegShared {
 // Stages segment `g` into LDS (codes, invalid-base mask, read-boundary mask).  Must be called by
 // all 256 threads; ends with a barrier.  The caller needs another barrier before the next
 // stage_segment() reuses the LDS (for_each_kmer / collect_kmers do that themselves).
-__device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegShared &sm) {
-    const uint32_t tid = threadIdx.x;
+// (`tid` = the thread's index among the 256 that stage this segment: a workgroup of several 256-thread groups
+// stages one segment per group, every group into its own SegShared; the barriers are the whole workgroup's.)
+__device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegShared &sm, const uint32_t tid) {
     const uint64_t total = a.offsets[a.n_reads];
     const uint64_t B0 = g * SEG;
 
@@ -112,6 +113,10 @@ __device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegS
         }
     }
     ktd::lds_barrier();
+}
+
+__device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegShared &sm) {
+    stage_segment(a, g, sm, threadIdx.x);
 }
 
 // The thread's walk over its 32 window starts [32*tid, 32*tid + 32) of a staged segment: a

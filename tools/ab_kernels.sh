@@ -3,7 +3,7 @@
 # per variant: rocprofv3 kernel stats of one bench run, the matching kernels' average ms
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-vars=$1; bargs=$2; pat=${3:-build_kernel|scatter1p|part2|export}
+vars=$1; bargs=$2; pat=${3:-build_kernel|scatter1|part2|export}
 for v in $vars; do
   out=gpurun_out/abk_$v; rm -rf $out; mkdir -p $out
   lib=$PWD/kmertools_amd/variants/lib$v.so; [ $v = base ] && lib=$PWD/kmertools_amd/libkmertools_hip.so
