@@ -404,8 +404,8 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         xc = torch.empty(max_distinct if with_export else 1, dtype=torch.int32, device="cuda")
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
         state = {"distinct": 0}
-        dominant = ("ctr k=%d step: clear + bulk table build (scatter1p, part2, build kernels)%s"
-                    % (k, " + size + export (table_export_kernel)" if with_export else ""))
+        dominant = ("ctr k=%d step: clear + bulk table build (scatter1w, part2, build kernels)%s"
+                    % (k, " + size + export (dense_export_kernel)" if with_export else ""))
         parallelism = ("hash-prefix key ownership: route -> grouped ncclSend/ncclRecv of per-owner regions (librccl, "
                        "called from the C ABI) -> partition + range build, pipelined in slices")
         finish = counter.close

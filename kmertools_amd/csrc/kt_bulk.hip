@@ -526,16 +526,21 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
 // LDS).  Same pages, same allocator, same carried state (wcur) as scatter1p, which stays for comparison
 // (KT_S1_WIDE=0).
 constexpr int WIDE_T = 1024, WIDE_GROUPS = WIDE_T / BLOCK;
+#ifndef KT_WIDE_PER64
+#define KT_WIDE_PER64 16
+#endif
 template <class K>
-constexpr int wide_per() { return sizeof(K) == 8 ? 8 : 16; }  // keys per thread and round
+constexpr int wide_per() { return sizeof(K) == 8 ? KT_WIDE_PER64 : 16; }  // keys per thread and round
 template <class K>
 constexpr uint32_t wide_round() { return (uint32_t)WIDE_T * wide_per<K>(); }
 static_assert(MAX_B1 <= WIDE_T, "one bucket per thread");
 
 template <class K>
 struct Scatter1WShared {
-    SegShared seg[WIDE_GROUPS];
-    K sorted[wide_round<K>()];
+    union {  // (the staged segments are dead once every thread has loaded its window words: open())
+        SegShared seg[WIDE_GROUPS];
+        K sorted[wide_round<K>()];
+    };
     uint16_t sdig[stores_hash<K>() ? 2 : wide_round<K>()];  // (a stored hash carries its digit)
     uint16_t split[MAX_B1];
     uint32_t cur[MAX_B1];
@@ -543,7 +548,7 @@ struct Scatter1WShared {
     uint32_t to_new[MAX_B1];
     uint32_t cnt[MAX_B1];
     uint32_t start[MAX_B1];
-    uint32_t tmp[WIDE_T];
+    uint32_t tmp[WIDE_T / 64];
     uint32_t ovf;
 };
 static_assert(sizeof(Scatter1WShared<uint64_t>) <= 160 * 1024 && sizeof(Scatter1WShared<uint32_t>) <= 160 * 1024, "LDS of a CU");
