@@ -194,14 +194,15 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
         ktseg::stage_segment(a, seg_lo + g, sm, t);
         return Walk{ktseg::Window(sm, t, a.k), 0u};
     }
-    template <int N>
-    __device__ void take(Walk &wk, uint32_t, uint64_t (&keys)[N], uint32_t &ok) const {
+    template <int N, class KR>  // KR = uint32_t when k <= 16: half the registers
+    __device__ void take(Walk &wk, uint32_t, KR (&keys)[N], uint32_t &ok) const {
         ok = 0;
 #pragma unroll
         for (int j = 0; j < N; j++) {
-            keys[j] = wk.w.f < wk.w.r ? wk.w.f : wk.w.r;
+            const uint64_t m = wk.w.f < wk.w.r ? wk.w.f : wk.w.r;
+            keys[j] = (KR)m;
             bool good = wk.w.ok(wk.at + j);
-            if (n_parts > 1) good = good && ktd::owner_of(keys[j], n_parts) == part;
+            if (n_parts > 1) good = good && ktd::owner_of(m, n_parts) == part;
             ok |= (good ? 1u : 0u) << j;
             wk.w.step();
         }
@@ -241,14 +242,14 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
         uint32_t at;
     };
     __device__ Walk open(uint64_t g, SegShared &, uint32_t) const { return Walk{g * ktseg::SEG, count(), 0u}; }
-    template <int N>
-    __device__ void take(Walk &wk, uint32_t t, uint64_t (&out)[N], uint32_t &ok) const {
+    template <int N, class KR>
+    __device__ void take(Walk &wk, uint32_t t, KR (&out)[N], uint32_t &ok) const {
         ok = 0;
 #pragma unroll
         for (int j = 0; j < N; j++) {  // consecutive lanes read consecutive keys
             const uint64_t i = wk.base + (uint64_t)(wk.at + j) * BLOCK + t;
             const uint64_t key = i < wk.cnt ? keys[i] : KT_EMPTY_KEY;
-            out[j] = key;
+            out[j] = (KR)key;
             ok |= (key != KT_EMPTY_KEY ? 1u : 0u) << j;
         }
         wk.at += N;
@@ -521,16 +522,16 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
 // scatter1p sorts 4096 64-bit keys (8192 32-bit ones) per round with 1024 buckets: 4-key = 32-byte runs, written by
 // 8 waves per CU that hold their 32 k-mers per thread in ~200 VGPRs.  Here a workgroup is FOUR 256-thread groups,
 // each staging its own segment (or unit of keys), and the thread's walk over its 32 window starts is cut into
-// quarters (halves for 32-bit keys): a round sorts 1024 x 8 (16) keys = 8192 (16384) - runs twice as long, half as
-// many rounds per segment, 16 (32) key registers instead of 64, so 16 waves fit a CU (one workgroup, ~107 / 139 KB of
-// LDS).  Same pages, same allocator, same carried state (wcur) as scatter1p, which stays for comparison
+// halves (32-bit keys: taken whole, in 32-bit registers): a round sorts 1024 x 16 (32) keys - 128-byte runs instead
+// of 32-byte ones, a quarter of the rounds per segment, 32 key registers instead of 64, so 16 waves fit a CU (one
+// workgroup, ~150 KB of LDS: the sort buffer takes over the staged segments' space).  Same pages, same allocator, same carried state (wcur) as scatter1p, which stays for comparison
 // (KT_S1_WIDE=0).
 constexpr int WIDE_T = 1024, WIDE_GROUPS = WIDE_T / BLOCK;
 #ifndef KT_WIDE_PER64
 #define KT_WIDE_PER64 16
 #endif
 template <class K>
-constexpr int wide_per() { return sizeof(K) == 8 ? KT_WIDE_PER64 : 16; }  // keys per thread and round
+constexpr int wide_per() { return sizeof(K) == 8 ? KT_WIDE_PER64 : 32; }  // keys per thread and round
 template <class K>
 constexpr uint32_t wide_round() { return (uint32_t)WIDE_T * wide_per<K>(); }
 static_assert(MAX_B1 <= WIDE_T, "one bucket per thread");
@@ -541,7 +542,6 @@ struct Scatter1WShared {
         SegShared seg[WIDE_GROUPS];
         K sorted[wide_round<K>()];
     };
-    uint16_t sdig[stores_hash<K>() ? 2 : wide_round<K>()];  // (a stored hash carries its digit)
     uint16_t split[MAX_B1];
     uint32_t cur[MAX_B1];
     uint32_t to_cur[MAX_B1];
@@ -571,16 +571,16 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
         auto wk = src.open(valid ? g0 + grp : n_units - 1, sm.seg[grp], t);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {  // (no early exit in here: the loop must stay unrolled)
-            uint64_t keys[PER];
+            K keys[PER];
             uint32_t ok;
-            src.template take<PER>(wk, t, keys, ok);
+            src.template take<PER, K>(wk, t, keys, ok);
             if (!valid) ok = 0;
             if (tid < p.B1) sm.cnt[tid] = 0;
             ktd::lds_barrier();
 #pragma unroll
             for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
-                keys[j] = (uint64_t)to_stored<K>(keys[j]);
-                if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>((K)keys[j]), p)], 1u);
+                keys[j] = to_stored<K>((uint64_t)keys[j]);
+                if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>(keys[j]), p)], 1u);
             }
             ktd::lds_barrier();
             const uint32_t nk = block_excl_scan<WIDE_T>(sm.cnt, sm.start, p.B1, sm.tmp);
@@ -607,10 +607,9 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
 #pragma unroll
             for (int j = 0; j < PER; j++) {
                 if ((ok >> j) & 1u) {
-                    const uint32_t d = digit1h(hash_of_stored<K>((K)keys[j]), p);
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
                     const uint32_t pos = atomicAdd(&sm.start[d], 1u);
-                    sm.sorted[pos] = (K)keys[j];
-                    if constexpr (!stores_hash<K>()) sm.sdig[pos] = (uint16_t)d;
+                    sm.sorted[pos] = keys[j];
                 }
             }
             if (room) {
@@ -626,9 +625,8 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
             if (!stop) {
                 for (uint32_t i = tid; i < nk; i += WIDE_T) {
                     const K key = sm.sorted[i];
-                    uint32_t d;
-                    if constexpr (stores_hash<K>()) d = digit1h((uint64_t)key, p);
-                    else d = sm.sdig[i];
+                    const uint32_t d = digit1h(hash_of_stored<K>(key), p);  // (one shift of a stored hash; 32-bit
+                                                                            // keys are hashed again: no room for digits)
                     const uint32_t at = (i < sm.split[d] ? sm.to_cur[d] : sm.to_new[d]) + i;
                     keys1[(uint64_t)d * p.cap1 + at] = key;
                 }
