@@ -59,13 +59,16 @@ constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 // makes the room (ctr k=31: 19.5 -> 16.2 ms).  32-bit keys already sort 16384 at a time with 512 threads (the wider
 // shape measured 6 % slower there).
 // (BIG = that shape; it needs B2 <= 1024 to fit 160 KB, otherwise - and for 32-bit keys - the 512-thread shape runs)
+#ifndef KT_P2_BIG32_PER
+#define KT_P2_BIG32_PER 16  // keys per thread of the 1024-thread shape with 32-bit keys (KT_P2_BIG32=1; measured at k=15:
+#endif                      // 18.8 ms with 16, 33.2 ms with 32, against 18.3 ms for the 512-thread shape - off by default)
 template <class K, bool BIG>
 constexpr int p2t() { return BIG ? 1024 : 512; }           // threads of a part2 workgroup
 template <class K, bool BIG>
 constexpr bool p2_sdig() { return !BIG; }                  // digit kept beside every sorted key
 // keys sorted at a time in part2
 template <class K, bool BIG>
-constexpr uint32_t chunk2() { return sizeof(K) == 8 ? 16u * p2t<K, BIG>() : 32u * p2t<K, BIG>(); }
+constexpr uint32_t chunk2() { return (sizeof(K) == 8 ? 16u : BIG ? (uint32_t)KT_P2_BIG32_PER : 32u) * p2t<K, BIG>(); }
 
 struct Plan {
     uint32_t n;       // hash bits that address the table: cap = m8 * 2^(n-3) (kttab::Geom)
@@ -845,6 +848,9 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
 //    instead of probing (load-independent): 39.6 ms - dedupe 20, placement 10, image 6, none of it overlapping.
 //  * so the table keeps a load factor near 0.5, where the plain state machine below is bound by the image it writes
 //    (103 GB at 5 TB/s), and the image is what a smaller-slot layout would have to shrink.
+//  * dense state, end of the round: giving the four prefetched keys of a lane their first probe together (four CAS in
+//    flight, the collided ones queued ahead of the rest) made the kernel slower again, 20.8 against 18.8 ms; reading
+//    2 or 4 of the pack phase's 64-slot passes before writing any back changed nothing (18.7 ms).
 static_assert(LOG2_S == kttab::LOG2_RANGE, "a fine bucket is a range of the table");
 
 constexpr int BUILD_T = KT_BUILD_T;
@@ -1328,7 +1334,8 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             if (int rc = level1_exact<K>(ctr, j)) return rc;
         }
     }
-    const bool big2 = sizeof(K) == 8 && env_u64("KT_P2_BIG64", 1) != 0 && Part2Shared<K, true>::bytes(p.B2) <= 160 * 1024;
+    const bool big2 = (sizeof(K) == 8 ? env_u64("KT_P2_BIG64", 1) : env_u64("KT_P2_BIG32", 0)) != 0 &&
+                      Part2Shared<K, true>::bytes(p.B2) <= 160 * 1024;
     auto run_part2 = [&](auto big) -> int {
         constexpr bool BIG = decltype(big)::value;
         const size_t part2_lds = Part2Shared<K, BIG>::bytes(p.B2);
