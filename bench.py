@@ -406,8 +406,8 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         state = {"distinct": 0}
         dominant = ("ctr k=%d step: clear + bulk table build (scatter1w, part2, build kernels)%s"
                     % (k, " + size + export (dense_export_kernel)" if with_export else ""))
-        parallelism = ("hash-prefix key ownership: route -> grouped ncclSend/ncclRecv of per-owner regions (librccl, "
-                       "called from the C ABI) -> partition + range build, pipelined in slices")
+        parallelism = ("hash-prefix key ownership: route -> exchange of per-owner regions -> partition + range build, "
+                       "pipelined in slices; transport: " + counter.transport)
         finish = counter.close
         if with_export:
             alg_extra = lambda: state["distinct"] * 12

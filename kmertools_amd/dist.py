@@ -37,16 +37,60 @@ class ShardedCounter:
         self.ctx, self.k, self.group = ctx, k, group
         self.world = 1 if group is None else dist.get_world_size(group)
         self.rank = 0 if group is None else dist.get_rank(group)
-        transport = None
-        if self.world > 1:
-            if dist.get_backend(group) == "nccl":
-                box = [device.Sharded.unique_id() if self.rank == 0 else None]
-                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                transport = ("rccl", box[0])
+        self.transport = "none (one rank)"
+        self.sharded = None
+        if self.world > 1 and dist.get_backend(group) == "nccl":
+            self.sharded = self._try_rccl(ctx, k, capacity_slots, max_batch_bases)
+            if self.sharded is not None:
+                self.transport = "librccl ncclSend/ncclRecv from the C ABI"
             else:
-                transport = ("host", host_alltoall(group))
-        self.sharded = device.Sharded(ctx, k, capacity_slots, max_batch_bases, self.world, self.rank, transport)
+                # the library could not bring up its own communicator on every rank: the exchange goes through the
+                # host all-to-all callback over a gloo group instead (slow, staged through host memory - said loudly)
+                import sys
+                if self.rank == 0:
+                    print("kmertools_amd: librccl communicator unavailable on some rank - sharded counting falls back "
+                          "to the host all-to-all transport (gloo)", file=sys.stderr)
+                ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+                self._host_group = dist.new_group(ranks=ranks, backend="gloo")
+                self.transport = "host all-to-all over gloo (fallback: librccl communicator unavailable)"
+                self.sharded = device.Sharded(ctx, k, capacity_slots, max_batch_bases, self.world, self.rank,
+                                              ("host", host_alltoall(self._host_group)))
+        elif self.world > 1:
+            self.transport = "host all-to-all over torch.distributed"
+            self.sharded = device.Sharded(ctx, k, capacity_slots, max_batch_bases, self.world, self.rank,
+                                          ("host", host_alltoall(group)))
+        else:
+            self.sharded = device.Sharded(ctx, k, capacity_slots, max_batch_bases, 1, 0, None)
         self.table = self.sharded.table
+
+    def _try_rccl(self, ctx, k, capacity_slots, max_batch_bases):
+        """the library's own RCCL communicator, or None - decided by all ranks together, so that no rank waits in
+        ncclCommInitRank for one that could not even load librccl"""
+        group = self.group
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(t.item())
+
+        try:
+            uid = device.Sharded.unique_id()   # every rank: loads librccl and resolves its symbols
+            ok = True
+        except Exception:
+            uid, ok = None, False
+        if not all_ok(ok):
+            return None
+        box = [uid if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        try:
+            sh = device.Sharded(ctx, k, capacity_slots, max_batch_bases, self.world, self.rank, ("rccl", box[0]))
+        except Exception:
+            sh = None
+        if not all_ok(sh is not None):
+            if sh is not None:
+                sh.close()
+            return None
+        return sh
 
     def clear(self):
         self.sharded.clear()
