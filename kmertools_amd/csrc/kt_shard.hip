@@ -141,6 +141,112 @@ __global__ __launch_bounds__(BLOCK) void route_regions_kernel(SegArgs a, uint64_
     }
 }
 
+// The same routing with the shape of kt_bulk.hip's scatter1w: a workgroup is four 256-thread groups, each staging its
+// own segment; the thread's walk over its 32 window starts is cut in halves, so a round handles 16 K k-mers with 32 key
+// registers and 16 waves fit a CU.  The round's keys are counting-sorted by owner in LDS (ranks from LDS atomics on
+// per-wave counters: a wave's lanes only contend with each other), one global atomic per owner reserves the run in
+// the owner's region, and the runs - ~2000 keys per owner with 8 owners - are copied out with consecutive lanes on
+// consecutive keys.  (route_regions_kernel has every lane store its own 8 bytes somewhere in an 8 KB run: 25 ms for
+// the 25 M-read batch against 18 ms for level 1 itself.)  Up to RW_MAXO owners; more take the kernel above.
+constexpr int RW_T = 1024, RW_PER = 16, RW_MAXO = 16;
+struct RouteWShared {
+    union {  // (the staged segments are dead once every thread has loaded its window words)
+        SegShared seg[RW_T / BLOCK];
+        uint64_t sorted[RW_T * RW_PER];
+    };
+    uint32_t wcnt[RW_T / 64][RW_MAXO];  // keys of (wave, owner) this round; then where the wave's keys of the owner start
+    uint32_t tot[RW_MAXO];              // keys of the owner this round
+    uint32_t start[RW_MAXO + 1];        // the owners' runs in sorted[]
+    uint64_t gbase[RW_MAXO];            // where the owner's run goes in its region
+};
+static_assert(sizeof(RouteWShared) <= 160 * 1024, "LDS of a CU");
+
+__global__ __launch_bounds__(RW_T) void route_wide_kernel(SegArgs a, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_owners,
+                                                          uint64_t cap_keys, uint64_t msg_stride,
+                                                          uint64_t *__restrict__ msgs, uint64_t *__restrict__ pend_keys,
+                                                          uint64_t pend_cap, uint64_t *__restrict__ pend_n,
+                                                          uint32_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    RouteWShared &sm = *reinterpret_cast<RouteWShared *>(smem_raw);
+    constexpr int NQ = ktseg::PER_THREAD / RW_PER;
+    constexpr uint32_t GROUPS = RW_T / BLOCK;
+    const uint32_t tid = threadIdx.x, grp = tid / BLOCK, t = tid % BLOCK, wave = tid >> 6;
+    for (uint64_t g0 = seg_lo + (uint64_t)blockIdx.x * GROUPS; g0 < seg_hi; g0 += (uint64_t)gridDim.x * GROUPS) {
+        const bool valid = g0 + grp < seg_hi;  // (a group past the end walks the last segment and keeps nothing)
+        ktseg::stage_segment(a, valid ? g0 + grp : seg_hi - 1, sm.seg[grp], t);
+        ktseg::Window w(sm.seg[grp], t, a.k);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            uint64_t keys[RW_PER];
+            uint32_t ok = 0;
+#pragma unroll
+            for (int j = 0; j < RW_PER; j++) {
+                keys[j] = w.f < w.r ? w.f : w.r;
+                ok |= (valid && w.ok((uint32_t)(q * RW_PER + j)) ? 1u : 0u) << j;
+                w.step();
+            }
+            if (tid < (RW_T / 64) * RW_MAXO) (&sm.wcnt[0][0])[tid] = 0;
+            ktd::lds_barrier();
+            uint32_t rk[RW_PER / 2];  // rank of the key among its wave's keys of the same owner, two per register
+            uint64_t own = 0;         // owners, four bits each
+#pragma unroll
+            for (int j = 0; j < RW_PER; j++) {
+                uint32_t r = 0;
+                if ((ok >> j) & 1u) {
+                    const uint32_t o = ktd::owner_of(keys[j], n_owners);
+                    own |= (uint64_t)o << (4 * j);
+                    r = atomicAdd(&sm.wcnt[wave][o], 1u);
+                }
+                rk[j / 2] = (j & 1) ? rk[j / 2] | (r << 16) : r;
+            }
+            ktd::lds_barrier();
+            if (tid < n_owners) {  // the owner's keys of the sixteen waves, in wave order; its run in the region
+                uint32_t run = 0;
+                for (uint32_t v = 0; v < RW_T / 64; v++) {
+                    const uint32_t c = sm.wcnt[v][tid];
+                    sm.wcnt[v][tid] = run;
+                    run += c;
+                }
+                sm.tot[tid] = run;
+                sm.gbase[tid] = run ? atomicAdd(reinterpret_cast<unsigned long long *>(msgs + tid * msg_stride),
+                                                (unsigned long long)run)
+                                    : 0;
+            }
+            ktd::lds_barrier();
+            if (tid <= n_owners) {
+                uint32_t before = 0;
+                for (uint32_t o = 0; o < tid; o++) before += sm.tot[o];
+                sm.start[tid] = before;
+            }
+            ktd::lds_barrier();
+#pragma unroll
+            for (int j = 0; j < RW_PER; j++) {
+                if ((ok >> j) & 1u) {
+                    const uint32_t o = (uint32_t)(own >> (4 * j)) & 15u;
+                    const uint32_t r = (j & 1) ? rk[j / 2] >> 16 : rk[j / 2] & 0xFFFFu;
+                    sm.sorted[sm.start[o] + sm.wcnt[wave][o] + r] = keys[j];
+                }
+            }
+            ktd::lds_barrier();
+            for (uint32_t o = 0; o < n_owners; o++) {
+                const uint32_t s0 = sm.start[o], c = sm.start[o + 1] - s0;
+                const uint64_t b = sm.gbase[o];
+                for (uint32_t i = tid; i < c; i += RW_T) {
+                    const uint64_t key = sm.sorted[s0 + i], pos = b + i;
+                    if (pos < cap_keys) {
+                        msgs[o * msg_stride + HDR_U64 + pos] = key;
+                    } else {
+                        const uint64_t at = atomicAdd(reinterpret_cast<unsigned long long *>(pend_n), 1ull);
+                        if (at < pend_cap) pend_keys[at] = key;
+                        else atomicOr(flags, 1u);
+                    }
+                }
+            }
+            ktd::lds_barrier();
+        }
+    }
+}
+
 // finalize round: up to FIN_CAP pending keys per owner into the round's messages; the rest stays (compacted by
 // leaving KT_EMPTY_KEY holes: the list is rescanned next round).  left[0] = keys still pending after this round.
 __global__ __launch_bounds__(BLOCK) void pack_pending_kernel(uint64_t *__restrict__ pend_keys, uint64_t n,
@@ -439,7 +545,17 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
         for (int p = 0; p < s->n_ranks; p++)
             KT_HIP(hipMemsetAsync(s->send[b] + (uint64_t)p * words, 0, HDR_U64 * 8, ctx->stream));
         const uint64_t lo = a.n_seg * (uint64_t)i / (uint64_t)P, hi = a.n_seg * (uint64_t)(i + 1) / (uint64_t)P;
-        if (hi > lo) {
+        const char *rw = getenv("KT_ROUTE_WIDE");  // 0: the one-lane-one-key kernel (comparison)
+        if (hi > lo && s->n_ranks <= RW_MAXO && !(rw && atoi(rw) == 0)) {
+            const uint64_t quads = (hi - lo + RW_T / BLOCK - 1) / (RW_T / BLOCK);
+            const uint32_t wgs = (uint32_t)(quads < (uint64_t)ctx->n_cu ? quads : (uint64_t)ctx->n_cu);
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(route_wide_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RouteWShared)));
+            hipLaunchKernelGGL(route_wide_kernel, dim3(wgs), dim3(RW_T), sizeof(RouteWShared), ctx->stream, a, lo, hi,
+                               (uint32_t)s->n_ranks, s->cap_keys, words, s->send[b], s->pend_keys, s->pend_cap, s->pend_n,
+                               s->flags);
+            KT_HIP(hipGetLastError());
+        } else if (hi > lo) {
             hipLaunchKernelGGL(route_regions_kernel, dim3(ktl::grid_for(ctx, hi - lo, 4)), dim3(BLOCK), 0, ctx->stream, a,
                                lo, hi, (uint32_t)s->n_ranks, s->cap_keys, words, s->send[b], s->pend_keys, s->pend_cap,
                                s->pend_n, s->flags);
