@@ -59,13 +59,17 @@ constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 // makes the room (ctr k=31: 19.5 -> 16.2 ms).  32-bit keys already sort 16384 at a time with 512 threads (the wider
 // shape measured 6 % slower there).
 // (BIG = that shape; it needs B2 <= 1024 to fit 160 KB, otherwise - and for 32-bit keys - the 512-thread shape runs)
+#ifndef KT_STORE_HASH
+#define KT_STORE_HASH 1  // 64-bit keys travel through the partition passes as khash(key) (to_stored / from_stored below)
+#endif
 #ifndef KT_P2_BIG32_PER
 #define KT_P2_BIG32_PER 16  // keys per thread of the 1024-thread shape with 32-bit keys (KT_P2_BIG32=1; measured at k=15:
 #endif                      // 18.8 ms with 16, 33.2 ms with 32, against 18.3 ms for the 512-thread shape - off by default)
 template <class K, bool BIG>
 constexpr int p2t() { return BIG ? 1024 : 512; }           // threads of a part2 workgroup
 template <class K, bool BIG>
-constexpr bool p2_sdig() { return !BIG; }                  // digit kept beside every sorted key
+constexpr bool p2_sdig() { return !BIG && !(sizeof(K) == 8 && KT_STORE_HASH); }  // digit kept beside every sorted key
+                                                           // (not when it is a bit field of the stored hash)
 // keys sorted at a time in part2
 template <class K, bool BIG>
 constexpr uint32_t chunk2() { return (sizeof(K) == 8 ? 16u : BIG ? (uint32_t)KT_P2_BIG32_PER : 32u) * p2t<K, BIG>(); }
@@ -110,9 +114,6 @@ __device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) { return
 // where build writes the table (the hash used to be evaluated seven times per k-mer); 32-bit keys (k <= 16) travel
 // as they are (their 64-bit hash would not fit).  The empty marker stays all ones in both forms: the only key
 // that hashes to it is 0x66c88cc300000000, not a k-mer of k <= 31.
-#ifndef KT_STORE_HASH
-#define KT_STORE_HASH 1
-#endif
 static_assert(KT_KHASH == 1 || !KT_STORE_HASH,
               "the empty marker must not be the hash of a k-mer (true for the multiplicative hash)");
 template <class K>
@@ -659,25 +660,25 @@ __global__ __launch_bounds__(BLOCK) void page_tails_kernel(Plan p, const uint32_
 template <class K, bool BIG>
 struct Part2Shared {
     K *sorted;         // [chunk2<K, BIG>()]
-    uint64_t *cursor;  // [B2]
-    uint32_t *cnt, *start, *fill;  // [B2] each
-    uint32_t *tmp;     // [p2t<K, BIG>()]
+    uint32_t *cur;     // [B2] where the fine bucket's next key goes, relative to the level-1 bucket's first key
+    uint32_t *cnt;     // [B2] keys of the chunk per fine bucket; while a chunk is placed: cur - start (copy-out adds i)
+    uint32_t *start;   // [B2] the chunk's runs in sorted[]; the placement pass moves them to the runs' ends
+    uint32_t *tmp;     // [16] block scan scratch
     uint32_t *flag;    // [1] (+1 pad) fixed fine regions: a fine bucket is outgrowing its room
     uint16_t *sdig;    // [chunk2<K, BIG>()]
+    // 12 bytes per fine bucket: with 64-bit keys, 8 K-key chunks and B2 <= 1024 two 512-thread workgroups fit a CU
     static size_t bytes(uint32_t B2) {
-        return (size_t)chunk2<K, BIG>() * sizeof(K) + (size_t)B2 * (8 + 3 * 4) + (size_t)p2t<K, BIG>() * 4 + 8 +
+        return (size_t)chunk2<K, BIG>() * sizeof(K) + (size_t)B2 * 12 + 16 * 4 + 8 +
                (p2_sdig<K, BIG>() ? (size_t)chunk2<K, BIG>() * 2 : 0);
     }
     __device__ Part2Shared(unsigned char *raw, uint32_t B2) {
         sorted = reinterpret_cast<K *>(raw);
         raw += (size_t)chunk2<K, BIG>() * sizeof(K);
-        cursor = reinterpret_cast<uint64_t *>(raw);
-        raw += (size_t)B2 * 8;
-        cnt = reinterpret_cast<uint32_t *>(raw);
+        cur = reinterpret_cast<uint32_t *>(raw);
+        cnt = cur + B2;
         start = cnt + B2;
-        fill = start + B2;
-        tmp = fill + B2;
-        flag = tmp + p2t<K, BIG>();
+        tmp = start + B2;
+        flag = tmp + 16;
         sdig = reinterpret_cast<uint16_t *>(flag + 2);
     }
 };
@@ -690,7 +691,7 @@ struct Part2Shared {
 // only (which is exactly the histogram), and the bucket is redone with the exact boundaries - the price of a
 // wrong guess is the part of the pass done before it was noticed.
 template <class K, bool FIXED, bool BIG>
-__global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restrict__ keys1,
+__global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void part2_kernel(const K *__restrict__ keys1,
                                                       const uint64_t *__restrict__ bstart,
                                                       const uint64_t *__restrict__ gcur, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart,
@@ -734,13 +735,15 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
                 ktd::lds_barrier();
                 if (!counting_only) {
                     const uint32_t nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
-                    for (uint32_t i = tid; i < p.B2; i += P2T) sm.fill[i] = sm.start[i];
+                    // (cnt has been summed: from here to the cursor update it holds cur - start, what the copy-out adds
+                    // to a sorted key's index to get its place in the level-1 bucket)
+                    for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = sm.cur[i] - sm.start[i];
                     ktd::lds_barrier();
 #pragma unroll
                     for (int u = 0; u < PER; u++) {
                         if (kcur[u] != EMPTY) {
                             const uint32_t d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
-                            const uint32_t pos = atomicAdd(&sm.fill[d], 1u);
+                            const uint32_t pos = atomicAdd(&sm.start[d], 1u);
                             sm.sorted[pos] = kcur[u];
                             if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
                         }
@@ -751,7 +754,7 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
                         uint32_t d;
                         if constexpr (p2_sdig<K, BIG>()) d = sm.sdig[i];
                         else d = digit2h(hash_of_stored<K>(key), p);
-                        const uint64_t pos = sm.cursor[d] + (i - sm.start[d]);
+                        const uint64_t pos = lo + (uint32_t)(sm.cnt[d] + i);
                         if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = key;
                     }
                     ktd::lds_barrier();
@@ -765,9 +768,10 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
                     allowed = 0.93f * room + 6.f * sqrtf(room) + 32.f;
                 }
                 for (uint32_t i = tid; i < p.B2; i += P2T) {
-                    const uint64_t c = sm.cursor[i] + sm.cnt[i];
-                    sm.cursor[i] = c;
-                    if (attempt && !counting_only && (float)(c - (lo + (uint64_t)i * p.cap2)) > allowed) *sm.flag = 1;
+                    // placed: start[] stands at the runs' ends, so start + (cur - start at their beginnings) = cur + count
+                    const uint32_t c = counting_only ? sm.cur[i] + sm.cnt[i] : sm.start[i] + sm.cnt[i];
+                    sm.cur[i] = c;
+                    if (attempt && !counting_only && (float)(c - i * (uint32_t)p.cap2) > allowed) *sm.flag = 1;
                 }
 #pragma unroll
                 for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
@@ -778,21 +782,21 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
 
         bool exact = !FIXED;
         if constexpr (FIXED) {
-            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cursor[i] = lo + (uint64_t)i * p.cap2;
+            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cur[i] = i * (uint32_t)p.cap2;  // (cap1 = B2 * cap2 < 2^32)
             if (tid == 0) *sm.flag = 0;
             ktd::lds_barrier();
             run_pass(true);
             // did every fine bucket stay inside its room?  (the running check is a prediction; this is the fact)
             for (uint32_t i = tid; i < p.B2; i += P2T)
-                if (sm.cursor[i] - (lo + (uint64_t)i * p.cap2) > p.cap2) *sm.flag = 1;
+                if (sm.cur[i] - i * (uint32_t)p.cap2 > p.cap2) *sm.flag = 1;
             ktd::lds_barrier();
             if (*sm.flag == 0) {
                 for (uint32_t i = tid; i < p.B2; i += P2T) {
                     fstart[(uint64_t)j * p.B2 + i] = lo + (uint64_t)i * p.cap2;
-                    fend[(uint64_t)j * p.B2 + i] = sm.cursor[i];
+                    fend[(uint64_t)j * p.B2 + i] = lo + sm.cur[i];
                 }
             } else {  // no: the cursors hold the exact sizes now
-                for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = (uint32_t)(sm.cursor[i] - (lo + (uint64_t)i * p.cap2));
+                for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = sm.cur[i] - i * (uint32_t)p.cap2;
                 exact = true;
             }
             ktd::lds_barrier();
@@ -818,7 +822,7 @@ __global__ __launch_bounds__((p2t<K, BIG>())) void part2_kernel(const K *__restr
             block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);
             for (uint32_t i = tid; i < p.B2; i += P2T) {
                 const uint64_t pos = lo + sm.start[i];
-                sm.cursor[i] = pos;
+                sm.cur[i] = sm.start[i];
                 fstart[(uint64_t)j * p.B2 + i] = pos;
                 fend[(uint64_t)j * p.B2 + i] = pos + sm.cnt[i];
             }
