@@ -854,7 +854,9 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
 //    (103 GB at 5 TB/s), and the image is what a smaller-slot layout would have to shrink.
 //  * dense state, end of the round: giving the four prefetched keys of a lane their first probe together (four CAS in
 //    flight, the collided ones queued ahead of the rest) made the kernel slower again, 20.8 against 18.8 ms; reading
-//    2 or 4 of the pack phase's 64-slot passes before writing any back changed nothing (18.7 ms).
+//    2 or 4 of the pack phase's 64-slot passes before writing any back changed nothing (18.7 ms).  The machine written
+//    with selects instead of branches (the branchy loop spends ~25 scalar instructions per trip on exec-mask
+//    bookkeeping, and the CU's scalar unit is busy half of the kernel's time): 27.6 against 18.5 ms.
 static_assert(LOG2_S == kttab::LOG2_RANGE, "a fine bucket is a range of the table");
 
 constexpr int BUILD_T = KT_BUILD_T;
