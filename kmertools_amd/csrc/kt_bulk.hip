@@ -6,29 +6,32 @@
 // (one CAS or atomic add per k-mer, kt_ctr.hip) cannot exceed ~20 G k-mers/s.  A batch can instead go through
 // streaming passes (a job: kt_bulk_begin, level 1 over one or more sources, kt_bulk_finish):
 //
-//   scatter1p persistent workgroups run a source's units (8192-base segments of reads, or 8192 keys of an array that
-//             another GPU routed here); each unit's keys are counting-sorted in LDS by d1 = top b1 bits of
-//             khash(key) and every d1 run is appended to the bucket's fixed region of the key array through the
-//             workgroup's private aligned pages (one global atomic per page, no counting pass; a partly used page
-//             is carried over to the job's next source)
-//   part2     one workgroup per level-1 bucket: the bucket is read in 8192 / 16384-key chunks, each chunk
+//   scatter1w persistent workgroups (one per CU, four 256-thread groups) run a source's units (8192-base segments of
+//             reads, or 8192 keys of an array that another GPU routed here), four at a time; a round's 16 K keys
+//             (32 K 32-bit ones) are counting-sorted in LDS by d1 = top b1 bits of khash(key) and every d1 run is
+//             appended to the bucket's fixed region of the key array through the workgroup's private aligned pages
+//             (one global atomic per page, no counting pass; a partly used page is carried over to the job's next
+//             source).  64-bit keys are stored as khash(key) from here on (to_stored / from_stored).
+//             (scatter1p: the round-1 shape, one 256-thread workgroup per unit; KT_S1_WIDE=0)
+//   part2     one workgroup per level-1 bucket: the bucket is read in 16384-key chunks, each chunk
 //             counting-sorted in LDS by d2 (next b2 hash bits) and its runs appended to the fine buckets, which
 //             own fixed shares of the bucket's region; a bucket whose keys do not spread that evenly is noticed
 //             during the pass and redone with exact fine boundaries (see part2_kernel)
 //   build     one workgroup per fine bucket (d1,d2) = one range of the table (kt_table.hpp): its keys are inserted
 //             into the range's image in LDS - on top of what the range already holds when the table has data - and
-//             the range is written out with 16-byte coalesced stores, empty slots included (see build_kernel)
+//             the range is written out: its occupied entries only, packed (a fresh table: the "dense" state), or the
+//             whole image with 16-byte coalesced stores, empty slots included (see build_kernel)
 //
 // Fixed regions assume the hash spreads the batch; a batch dominated by a few k-mers overflows a level-1 region,
 // is noticed (one 4-byte read by the host), and is redone from its sources with exact offsets:
 //   hist1     a front-end pass that counts k-mers per (workgroup, d1)          (LDS counters)
 //   scan1     exact output offset of every (workgroup, d1) pair
-//   scatter1  as scatter1p, every run copied to its exact place
+//   scatter1  one 256-thread workgroup per unit, every run copied to its exact place
 //   part2     first histograms the whole bucket by d2 (a second read) to get the fine boundaries
 //
-// Traffic ~ 1 B/base + 8 B/k-mer x 4 + 16 B/slot, all streaming.  The intermediate key arrays and the LDS
-// sort / insert arrays hold 32-bit keys when k <= 16 (template parameter K): half the partition traffic, whole
-// units sorted at once in level 1, and 32-bit LDS atomics in build.
+// Traffic ~ 1 B/base + 8 B/k-mer x 4 + 12 B per distinct k-mer (dense) or 16 B/slot (image), all streaming.  The
+// intermediate key arrays and the LDS sort / insert arrays hold 32-bit keys when k <= 16 (template parameter K): half
+// the partition traffic, and 32-bit LDS atomics in build.
 #include <stdio.h>
 #include <stdlib.h>
 
