@@ -563,6 +563,54 @@ def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap, pa
 
 
 @pytest.mark.parametrize("k", [31, 15])
+@pytest.mark.parametrize("shape", ["wide", "per_unit", "part2_small", "image"])
+def test_ctr_bulk_kernel_shapes_and_odd_batches(hctx, oracle, monkeypatch, k, shape):
+    """every shape of the partition kernels on batches that do not fill them: one short read, a batch of less than one
+    segment, segments in numbers that are not a multiple of the four a wide workgroup takes, a read that ends a
+    segment exactly, N runs, an empty read - and an empty batch.  wide = scatter1w + the 1024-thread part2 (default),
+    per_unit = the one-workgroup-per-segment level 1, part2_small = the 512-thread level 2 for 64-bit keys,
+    image = the probing image written at once instead of the dense state"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    if shape == "per_unit":
+        monkeypatch.setenv("KT_S1_WIDE", "0")
+    if shape == "part2_small":
+        monkeypatch.setenv("KT_P2_BIG64", "0")
+        monkeypatch.setenv("KT_P2_BIG32", "1")
+    if shape == "image":
+        monkeypatch.setenv("KT_BULK_DENSE", "0")
+    rng = np.random.default_rng(77 + k)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def read(n):
+        return bytes(rng.choice(acgt, size=n))
+    batches = [
+        [read(k)],                                            # one k-mer
+        [read(k - 1), b"", read(40)],                         # a read too short for a k-mer, an empty read
+        [read(8192), read(8192 - 7), read(7)],                # reads ending on / straddling segment boundaries
+        [read(300) for _ in range(137)],                      # 5.02 segments
+        [read(150) + b"NNNN" + read(90) for _ in range(400)],  # ~12 segments, N runs
+        [read(1000) for _ in range(74)],                      # 9.03 segments
+    ]
+    for seqs in batches:
+        bases, offsets = device.to_csr(seqs)
+        wk, wc = oracle.count_reads(bases, offsets, k)
+        ctr = device.Counter(hctx, k, 1 << 18)
+        ctr.add_reads_host(bases, offsets)
+        assert ctr.size() == len(wk)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        ctr.add_reads_host(bases, offsets)                    # and on top of itself (merge or probing path)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+        ctr.close()
+    ctr = device.Counter(hctx, k, 1 << 18)                    # an empty batch leaves an empty table
+    ctr.add_reads_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert ctr.size() == 0
+    ctr.close()
+
+
+@pytest.mark.parametrize("k", [31, 15])
 def test_ctr_bulk_build_skewed_batch_falls_back(hctx, oracle, monkeypatch, k):
     """a batch dominated by one k-mer overflows its paged level-1 bucket: the build must notice and redo level 1
     with exact offsets; the table keeps working (and stops trying pages) afterwards"""
