@@ -422,6 +422,13 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
                 assert got == d
                 state["distinct"] = d
 
+    # Ramp: untimed launches ahead of the W warm-up steps.  The store-bound kernels reach their steady rate only after
+    # ~20 launches (clocks / power state after the idle set-up phase): oligo k=4 measured 2.115 ms per step with
+    # --steps 10 --warmup 3, 2.03 with 20 / 5, 2.00 with 100 / 20 and with 10 / 60, same box, same minute.  The count
+    # is fixed per workload so that every rank of a collective step runs it the same number of times.
+    ramp = 1 if wl["kind"] == "ctr" else 60
+    for _ in range(ramp):
+        step()
     for _ in range(warmup):
         step()
     env.barrier()
@@ -455,13 +462,14 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         extra["distinct_rank0"] = state["distinct"] if not args.no_export else counter.size_local()
         extra["table_slots_rank0"] = counter.table.capacity()
         if world > 1:
-            extra["exchanged_bytes_per_step_rank0"] = counter.sharded.exchanged_bytes() // (steps + warmup)
+            extra["exchanged_bytes_per_step_rank0"] = counter.sharded.exchanged_bytes() // (steps + warmup + ramp)
     res = {
         "value": round(value, 3),
         "unit": "Gbases/s",
         "ms_per_step": round(ms_per_step, 4),
         "ms_median": round(statistics.median(per_step_ms), 4),
         "ms_min": round(min(per_step_ms), 4),
+        "ramp_steps": ramp,
         "dtype": wl.get("dtype", "u64 keys / u32 counts"),
         "config": {"workload": wl["desc"] + (", reads sampled from a random %d bp genome (1 %% substitutions)" % genome
                                              if genome else ""),
