@@ -1357,7 +1357,10 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     };
     if (int rc = big2 ? run_part2(std::true_type{}) : run_part2(std::false_type{})) return rc;
     const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
-    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 8);  // persistent workgroups; up to two are resident per CU
+    // workgroups per CU over the launch; up to two are resident per CU.  Each takes ranges b, b + grid, ... with the next
+    // one's bounds and first keys prefetched, so a few ranges per workgroup are enough - and a smaller static share evens
+    // out what the compute units get (k=31: 2 / 4 / 8 / 16 / 32 / 128 per CU = 19.4 / 19.0 / 18.6 / 18.2 / 18.0 / 17.9 ms)
+    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 64);
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
     // (ctr k=31: dense build 29.0 ms + dense export 17.4 ms against image build 22-23.5 ms + export 27.5 ms; k=15: 13.8 +
