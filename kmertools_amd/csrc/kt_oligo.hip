@@ -751,9 +751,9 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     // reads; same fill rate, same clocks): with 32 per slot (5 tiles per workgroup) the kernel takes 2.05 ms in one kind
     // and 2.28-2.44 ms in the other; with 96 per slot (1.7 tiles per workgroup) 2.10 and 2.06-2.21 ms, the same at 128
     // and at one tile per workgroup.  Whether a workgroup's tiles are strided by the grid or contiguous makes no
-    // difference (tried), so it is not where the resident workgroups write but that a static share per workgroup lets
-    // the slowest compute unit set the time where the dispatcher's dynamic hand-out does not.  Small rows take 96; the
-    // big-row shapes (k >= 6: a few reads per tile) keep the 32 they were measured with.
+    // difference, and neither does handing tiles to long-lived workgroups through a counter (both tried): what helps
+    // the slow kind is workgroups that do not live long.  Small rows take 96; the big-row shapes (k >= 6: a few reads
+    // per tile) keep the 32 they were measured with.  (profiles/r2_box_variance.txt)
     uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", bins <= 1024 ? 96 : 32);
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
