@@ -753,9 +753,11 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     // and at one tile per workgroup.  Whether a workgroup's tiles are strided by the grid or contiguous makes no
     // difference, and neither does handing tiles to long-lived workgroups through a counter (both tried): what helps
     // the slow kind is workgroups that do not live long.  k = 4 takes 96; k = 3 and k = 5 measured the same with 32 and
-    // 96 in processes where k = 4 differed by 10 % (1.22 / 1.24 ms and 7.18 / 7.20 ms) and keep 32, like the big-row
-    // shapes (k >= 6: a few reads per tile).  (profiles/r2_box_variance.txt)
-    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", k == 4 ? 96 : 32);
+    // 96 in processes where k = 4 differed by 10 % (1.22 / 1.24 ms and 7.18 / 7.20 ms) and keep 32.
+    // (profiles/r2_box_variance.txt)
+    // The big-row shapes (k >= 6: a few reads per tile, one or two workgroups per CU) go the other way: k=7 f32, 1 M
+    // reads: 2 / 4 / 8 / 16 / 32 / 64 / 128 per slot = 5.30 / 5.33 / 5.28 / 5.41 / 5.58 / 5.72 / 5.97 ms (two processes alike).
+    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", k == 4 ? 96 : bins > 1024 ? 8 : 32);
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(nthreads), lds, ctx->stream, a);
