@@ -1425,7 +1425,9 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     if (p.b2 > 11) return KT_OK;
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
-    p.G = (uint32_t)ctx->n_cu * 2;  // persistent level-1 workgroups (the same for every source of the job)
+    // persistent level-1 workgroups (the same for every source of the job): two per CU for the per-unit kernels; the wide
+    // kernel launches G / 2 of them, one resident per CU (KT_BULK_G_MULT > 1: more, shorter-lived workgroups)
+    p.G = (uint32_t)ctx->n_cu * 2 * (uint32_t)env_u64("KT_BULK_G_MULT", 1);
     // paged level 1 (no hist1): room per bucket = its share of the most keys there can be + 1/8 + a page per
     // workgroup (every workgroup leaves at most one partly used page per bucket)
     bool paged = env_u64("KT_BULK_PAGED", 1) != 0 && !ctr->paged_failed;
