@@ -12,7 +12,14 @@ Default (no --workload) = BASELINE.json's whole headline metric, one after the o
     `value` / `roofline` / `cpu_baseline`;
   * `ctr k=31`, 25 M x 150 bp reads per GPU (at --gpus 8 that is configs[3]) - the `ctr_k31` object with
     its own `value`, `ms_per_step`, `roofline`, `cpu_baseline` and the genome-sampled read distribution.
-Both run W warm-up and exactly K timed steps between barrier + synchronize brackets (max over ranks).
+  * `ctr k=15` (configs[2]) and `comp cgr k=7` f32 (configs[4]) as the `ctr_k15` / `comp_cgr_k7` objects, each
+    with its own `roofline`.
+All run W warm-up and exactly K timed steps between barrier + synchronize brackets (max over ranks).
+
+Self-certification: the line's `kt_env` lists every KT_* variable the process saw; a variable that can switch
+work off (ablation builds only) makes bench.py exit non-zero before anything is timed.  After each timed loop,
+untimed, the output is checked (`output_check`): oligo rows sum to 1 over the whole output and a 4096-row slice
+is compared with the CPU oracle inside the cpu_baseline leg; ctr's exported counts sum to reads x (L - k + 1).
 
 ctr's step is what SURVEY.md 8d puts inside it: clear + insert (+ the key exchange at N > 1) +
 kt_ctr_size + kt_ctr_export into device arrays; algorithmic bytes = L + kmers*16 per read + distinct*12.
@@ -59,7 +66,11 @@ WORKLOADS = {
     "min_w31_m7": dict(kind="min", k=7, n=10_000_000, L=150, dtype="u64", cfg=7, w=31,
                        desc="min w=31 m=7, 10M x 150bp per GPU, (minimiser, start, end) triples in read order"),
 }
-HEADLINE = ("comp_oligo_k4", "ctr_k31")
+HEADLINE = ("comp_oligo_k4", "ctr_k31", "ctr_k15", "comp_cgr_k7")
+# environment variables that (in an ablation build of the library, kmertools_amd/variants/) switch phases of the
+# timed kernels off; the default build ignores them, the benchmark refuses to run with them
+WORK_SKIPPING_ENV = ("KT_OLIGO_DEBUG", "KT_BUILD_DBG")
+CHECK_ROWS = 4096
 GENOME_LEN = 1_000_000_000   # second ctr distribution, reads sampled from a random 1 Gbp genome
 
 
@@ -78,6 +89,16 @@ def parse():
     ap.add_argument("--cap-slots", type=float, default=0, help="ctr: override the requested table capacity (experiments)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
+
+
+def kt_environment():
+    """every KT_* variable this process sees (recorded in the line); exits on a work-skipping one"""
+    seen = {k: v for k, v in sorted(os.environ.items()) if k.startswith("KT_")}
+    bad = [k for k in WORK_SKIPPING_ENV if os.environ.get(k, "") not in ("", "0")]
+    if bad:
+        sys.exit("bench.py: %s set - these switch work off in ablation builds of the library; refusing to time "
+                 "anything (unset them)" % ", ".join(bad))
+    return seen
 
 
 def effective_cores():
@@ -404,8 +425,14 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         xc = torch.empty(max_distinct if with_export else 1, dtype=torch.int32, device="cuda")
         alg_bytes_per_launch = n * (L + kmers_per_read * 16)
         state = {"distinct": 0}
-        dominant = ("ctr k=%d step: clear + bulk table build (scatter1w, part2, build kernels)%s"
-                    % (k, " + size + export (dense_export_kernel)" if with_export else ""))
+        fused = with_export and os.environ.get("KT_BENCH_EXPORT_TARGET", "1") != "0"
+        if fused:
+            # the export arrays are named before counting (kt_ctr_export_target): the range build writes its packed
+            # (key, count) pairs straight into them and kt_ctr_export has nothing left to copy
+            counter.table.export_target(xk, xc, max_distinct)
+        dominant = ("ctr k=%d step: clear + bulk table build (scatter1w, part2, build kernels%s)%s"
+                    % (k, " writing the export arrays" if fused else "",
+                       " + size + export" + ("" if fused else " (dense_export_kernel)") if with_export else ""))
         parallelism = ("hash-prefix key ownership: route -> exchange of per-owner regions -> partition + range build, "
                        "pipelined in slices; transport: " + counter.transport)
         finish = counter.close
@@ -458,6 +485,39 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     except (OSError, ValueError, KeyError):
         traffic = None
 
+    # ---- untimed: is the output the timed steps produced the right one? ------------------------------------------
+    check, check_slice = None, None
+    if wl["kind"] == "oligo":
+        # one more pass over every batch: every row must sum to 1 (synthetic reads have L - k + 1 k-mers each); the
+        # first CHECK_ROWS rows go to the host for the oracle comparison made in the cpu_baseline leg
+        tol = 1e-12 if wl["dtype"] == "f64" else 1e-6
+        bad, rows = 0, 0
+        for bi, (bb, oo, cnt) in enumerate(batch_args):
+            ctx.oligo(bb, oo, cnt, k, out, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+            sums = out[:cnt].sum(dim=1, dtype=torch.float64)
+            bad += int(((sums - 1.0).abs() > tol).sum().item())
+            rows += cnt
+            if bi == 0 and rank == 0:
+                m = min(CHECK_ROWS, cnt)
+                check_slice = dict(kind="oligo", k=k, dtype=wl["dtype"], rows=m,
+                                   bases=bb[:int(oo[m].item())].cpu().numpy(), offsets=oo[:m + 1].cpu().numpy(),
+                                   out=out[:m].cpu().numpy())
+            del sums
+        check = {"rows": rows, "rows_not_summing_to_1": bad, "tolerance": tol, "ok": bad == 0}
+    elif wl["kind"] == "ctr" and not args.no_export:
+        d = state["distinct"]
+        tot = torch.stack([xc[:d].sum(dtype=torch.int64), torch.tensor(d, device="cuda")])
+        if world > 1:
+            tot = tot.cpu() if env.share_gpu else tot
+            env.dist.all_reduce(tot)
+        want = world * n * kmers_per_read
+        check = {"sum_of_counts": int(tot[0].item()), "expected": want, "distinct_all_ranks": int(tot[1].item()),
+                 "ok": int(tot[0].item()) == want}
+    if check is not None:
+        extra["output_check"] = check
+        if not check["ok"]:
+            sys.exit("bench.py: %s produced a wrong output: %r" % (name, check))
+
     if wl["kind"] == "ctr":
         extra["distinct_rank0"] = state["distinct"] if not args.no_export else counter.size_local()
         extra["table_slots_rank0"] = counter.table.capacity()
@@ -483,11 +543,31 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     finish()
     del bases, offsets
     torch.cuda.empty_cache()
+    wl["_check_slice"] = check_slice
     return res, wl
+
+
+def oracle_slice_check(cs):
+    """the CHECK_ROWS rows run_workload kept, against the CPU oracle (part of the cpu_baseline leg: the only place
+    bench.py touches oracle/): f64 rows bit for bit, f32 rows within north_star's 1e-6"""
+    import numpy as np
+    from oracle import kt_oracle as oracle
+    want = oracle.oligo_batch(cs["bases"], cs["offsets"].astype(np.uint64), cs["k"], True, True, 1.0)
+    got = cs["out"]
+    if cs["dtype"] == "f64":
+        ok = bool(np.array_equal(got.view(np.uint64), want.view(np.uint64)))
+        how = "bit-exact"
+    else:
+        ok = bool(np.abs(got.astype(np.float64) - want).max() <= 1e-6)
+        how = "max abs difference <= 1e-6"
+    if not ok:
+        sys.exit("bench.py: %d-row slice differs from the CPU oracle" % cs["rows"])
+    return {"rows": cs["rows"], "against": "CPU oracle (oracle/kt_oracle.c)", "criterion": how, "ok": ok}
 
 
 def main():
     args = parse()
+    kt_env = kt_environment()
     env = Env(args)
     names = HEADLINE if args.workload == "headline" else (args.workload,)
     results = []
@@ -508,13 +588,19 @@ def main():
                 "warmup": args.warmup, "ms_per_step": top["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": top["dtype"], "data": "synthetic"}
         line.update({key: v for key, v in top.items() if key not in line})
+        line["kt_env"] = kt_env
         if env.world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline_for(wl, args, args.genome)
+            if wl.get("_check_slice"):
+                line["output_check"]["oracle_slice"] = oracle_slice_check(wl["_check_slice"])
         for name, res, wl in results[1:]:
             obj = dict(res)
             obj.update({"n_gpus": env.world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak"})
             if env.world == 1 and not args.no_cpu:
-                obj["cpu_baseline"] = cpu_baseline_for(wl, args, 0)
+                if name in ("ctr_k31",):   # the headline's second half has its own CPU leg; the extra configs do not
+                    obj["cpu_baseline"] = cpu_baseline_for(wl, args, 0)
+                if wl.get("_check_slice"):
+                    obj["output_check"]["oracle_slice"] = oracle_slice_check(wl["_check_slice"])
             line[name] = obj
         print(json.dumps(line), flush=True)
     env.close()

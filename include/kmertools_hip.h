@@ -176,6 +176,19 @@ int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct);
 int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_out,
                   uint64_t *n_out, int mem);
 
+/* Where the table's entries are wanted - told BEFORE counting, so that counting can deliver them there.
+ * replaces: the same map.scan as kt_ctr_export (counter/src/lib.rs:162-165, :220-230), for the usual life of a
+ * table: filled once, written out once.  keys_dev / counts_dev are DEVICE arrays of max_out entries owned by the
+ * caller.  From now on (sticky; NULL, NULL, 0 switches it off) every whole-batch count into an EMPTY table
+ * (kt_ctr_add_reads / kt_sharded_add_reads after creation or kt_ctr_clear) writes its (key, count) pairs straight
+ * into these arrays as the last step of the build, and kt_ctr_size / kt_ctr_export(keys_dev, counts_dev, ...) then
+ * only report the number of entries - no second pass over the table.  The table keeps referring to the arrays
+ * (entries [0, size) in unspecified order; what lies beyond them in the arrays is unspecified) until the next call that changes or probes it (a further add, kt_cov_batch,
+ * an export elsewhere, a new target), which first rebuilds its own probing copy from them: leave them untouched
+ * until then, or call kt_ctr_clear.  If the arrays turn out too small the next kt_ctr_size / kt_ctr_export returns
+ * KT_ERR_ARG and the table's contents are lost (clear, count again). */
+int kt_ctr_export_target(kt_ctr *ctr, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t max_out);
+
 /* replaces: CgrComputer::vectorise_one, composition/src/cgr.rs:127-144 (corners from cgr_maps,
  * :12-36) and python CgrComputer.vectorise_one/_batch, pybindings/src/cgr.rs:38-62.
  * Whole-sequence chaos game walk: xy[2*g], xy[2*g+1] = marker after base g of the batch

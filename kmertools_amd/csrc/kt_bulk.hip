@@ -53,6 +53,9 @@ constexpr int BLOCK = ktseg::BLOCK;       // 256
 #ifndef KT_BUILD_T
 #define KT_BUILD_T 1024
 #endif
+#ifndef KT_ABLATION
+#define KT_ABLATION 0  // 1 (tools/build_variant*.sh only): KT_BUILD_DBG bits can switch phases of build_kernel off for
+#endif                 // profiling.  The shipped library has no switch that skips work.
 constexpr uint32_t LOG2_S = kttab::LOG2_RANGE;  // hash positions per fine bucket = per range of the table
 constexpr uint32_t S = 1u << LOG2_S;            // 8192 positions: 1024 * m8 slots, 80 - 128 KB of table
 constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
@@ -875,8 +878,64 @@ struct lds_word<uint32_t> { using type = unsigned int; };
 // of the range's slots, and their number goes to range_counts[range].  That is all kt_ctr_size / kt_ctr_export need
 // (the usual fate of a table: counted once, written out), and it is 48 GB instead of 103 GB at k=31 / 25 M reads; the
 // probing image is produced from it in place (materialize_kernel) the first time something has to probe.
-template <class K, bool MERGE, bool DENSE>
-__global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ keys2,
+// EXT (dense only): the packed entries do not go to the range's own slots but straight into the caller's export
+// arrays (kt_ctr_export_target) as (key, occurrences) - the build's output IS the export, and the pass that copied
+// 36 GB of packed ranges into the export arrays (ctr k=31: 12-14 ms of a 65 ms step) is gone.
+// Where a range's entries go cannot be a prefix sum (the number of distinct keys of a range is known only once the range
+// has been built), and one global cursor bumped per range does not work either: a returning atomic on ONE address is
+// served at 83 M/s on this chip (tools/ubench/same_addr_atomic.hip) and waits behind the streaming traffic of its
+// memory channel; a million of them, each holding up a 1024-thread workgroup, took the build from 17.9 to 32.6 ms.
+// So output space is handed out in BLOCKS of XBLK entries, private to a workgroup: one cursor atomic per ~3 ranges,
+// requested a block ahead of need (thread 0 keeps the answer in a register until the current block is full, so its
+// round trip is never waited for), ranges packed back to back inside the blocks - a range that does not fit the rest
+// of its block continues at the front of the next one.  A workgroup that ends leaves the tail of its last block
+// unused (hole[block] says how much), and ext_patch_kernel afterwards moves the entries that lie beyond the packed
+// length n into those holes: 1-2 % of the entries move, the arrays end up holding exactly n entries in [0, n).
+// Positions are "virtual": [0, max) is the caller's arrays, [max, max + ovf_cap) the library's scratch behind them,
+// because blocks + holes may reach past n even when n <= max (the caller's arrays may be exactly n long).
+// Order of the entries: unspecified (kt_ctr_export's contract, like the reference's map scan).  The table keeps no
+// per-range record of where entries went: whatever needs the probing image afterwards re-inserts the exported pairs.
+constexpr uint32_t XBLK = 8192;  // >= the slots of a range: a range spans at most two blocks
+static_assert(XBLK >= (1u << LOG2_S), "a range's entries fit one block");
+constexpr uint64_t XNONE = ~0ull;
+struct ExtOut {
+    uint64_t *keys;
+    uint32_t *counts;
+    uint64_t max;           // entries of the caller's arrays
+    uint64_t *ovf_keys;     // scratch: virtual positions max ... max + ovf_cap
+    uint32_t *ovf_counts;
+    uint64_t ovf_cap;
+    uint64_t *cursor;       // virtual positions handed out so far (a multiple of XBLK)
+    uint32_t *hole;         // [blocks]: unused entries at the end of a block (0 = full)
+    __device__ __forceinline__ void put(uint64_t pos, uint64_t key, uint32_t occ) const {
+        if (pos < max) {
+            __builtin_nontemporal_store(key, keys + pos);
+            __builtin_nontemporal_store(occ, counts + pos);
+        } else if (pos - max < ovf_cap) {
+            ovf_keys[pos - max] = key;
+            ovf_counts[pos - max] = occ;
+        }  // (else: far more entries than the arrays hold - ext_scan_kernel reports it)
+    }
+    __device__ __forceinline__ void get(uint64_t pos, uint64_t &key, uint32_t &occ) const {
+        if (pos < max) {
+            key = keys[pos];
+            occ = counts[pos];
+        } else {
+            key = ovf_keys[pos - max];
+            occ = ovf_counts[pos - max];
+        }
+    }
+};
+
+// Two 16-wave workgroups per CU = 8 waves per SIMD, which the hardware grants only to kernels of at most 64 VGPRs AND at
+// most 80 SGPRs (MI355X_MICROARCH.md, "Residency": 82-96 SGPRs -> 7 waves per SIMD, whatever the occupancy API says).
+// The EXT variant first compiled to 82-85 SGPRs - one workgroup per CU, 32 instead of 18 ms, with every other
+// suspect (the cursor atomics, the stores, the claim counting) measured innocent one by one - hence the cap.
+#ifndef KT_BUILD_SGPRS
+#define KT_BUILD_SGPRS 80
+#endif
+template <class K, bool MERGE, bool DENSE, bool EXT = false>
+__global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SGPRS), amdgpu_waves_per_eu(8, 8))) void build_kernel(const K *__restrict__ keys2,
                                                         const uint64_t *__restrict__ fstart,
                                                         const uint64_t *__restrict__ fend, Plan p,
                                                         Slot *__restrict__ slots, uint64_t *__restrict__ spill_n,
@@ -884,8 +943,9 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
                                                         uint32_t *__restrict__ spill_counts, uint64_t spill_cap,
                                                         uint32_t *__restrict__ spill_ovf,
                                                         uint64_t *__restrict__ distinct,
-                                                        uint32_t *__restrict__ range_counts) {
+                                                        uint32_t *__restrict__ range_counts, ExtOut xo) {
     static_assert(!(MERGE && DENSE), "a dense build starts from an empty table");
+    static_assert(!EXT || DENSE, "only a dense build writes to the export arrays");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using W = typename lds_word<K>::type;
     constexpr K EMPTY = empty_of<K>();
@@ -913,6 +973,34 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         }
     };
     __shared__ uint32_t runs[BUILD_T / 64];  // DENSE: entries packed by each wave
+    __shared__ uint32_t claimed;             // EXT: distinct keys of the range (slots claimed during the insert)
+    __shared__ uint64_t xpiece[2];           // EXT: where the range's entries go: xpiece[0] + i for i < xlen1, then
+    __shared__ uint32_t xlen1;               //      xpiece[1] + (i - xlen1)
+    __shared__ unsigned long long xneed;     // EXT: upper bound of the entries this workgroup still has to place
+    // EXT, thread 0 only: the current block [xpos, xend) and the block requested ahead (XNONE: none).  xspare stays in
+    // a register on purpose: it is the result of a returning atomic that nobody waits for until the block is needed.
+    uint64_t xpos = 0, xend = 0, xspare = XNONE;
+#if KT_ABLATION && defined(KT_XA) && KT_XA == 4  // timing experiment: blocks b, b + G, ... - no cursor atomics at all
+    uint32_t xused = 0;
+#define XALLOC() ((uint64_t)(blockIdx.x + (xused++) * gridDim.x) * XBLK)
+#else
+#define XALLOC() atomicAdd(reinterpret_cast<unsigned long long *>(xo.cursor), (unsigned long long)XBLK)
+#endif
+    if (EXT) {
+        if (tid == 0) {
+            claimed = 0;  // (ordered before its first use by the barrier after the image is cleared)
+            xneed = 0;
+        }
+        ktd::lds_barrier();
+        unsigned long long ub = 0;  // keys (with repeats) of all the ranges this workgroup will build
+        for (uint64_t f = blockIdx.x + (uint64_t)tid * gridDim.x; f < n_fine; f += (uint64_t)BUILD_T * gridDim.x)
+            ub += fend[f] - fstart[f];
+        for (int o = 32; o > 0; o >>= 1) ub += __shfl_down(ub, o, 64);
+        if (lane == 0 && ub) atomicAdd(&xneed, ub);
+        ktd::lds_barrier();
+        if (tid == 0 && xneed)
+            xspare = XALLOC();
+    }
     long long placed = 0;  // per thread: occupied slots written - occupied slots found (MERGE)
     // A range starts with two dependent global reads (its bounds, then its first keys): ~4 us during which the
     // workgroup would do nothing, 1500 times over.  Both are taken one range ahead: the next range's bounds are
@@ -973,11 +1061,16 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
                 return k;
             };
             K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
+#if KT_ABLATION
             if (p.dbg & 1u) cur = EMPTY;
-            uint32_t s = home(cur), probes = 0;
+#endif
+            uint32_t s = home(cur), probes = 0, mine = 0;
             while (cur != EMPTY) {
                 const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
                 bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
+#if !(KT_ABLATION && defined(KT_XA) && KT_XA == 3)
+                if (EXT) mine += done;
+#endif
                 if (!done && v == cur) {
                     atomicAdd(&scounts[s], 1u);
                     done = true;
@@ -998,8 +1091,41 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
                     probes = 0;
                 }
             }
+            if (EXT) {  // the wave's claims, one LDS atomic per wave
+                for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+                if (lane == 0 && mine) atomicAdd(&claimed, mine);
+            }
         }
         ktd::lds_barrier();
+        // (thread 0's look at its spare block - the result of an atomic issued a range ago - comes BEFORE the next range's
+        // head loads are issued: a wait for the older operation is a wait for everything issued before the wait)
+        if (EXT && tid == 0) {
+            // where the range's `claimed` entries go: the rest of the current block, then the front of the spare one
+#if KT_ABLATION && defined(KT_XA) && KT_XA == 3  // timing experiment: no claim counting (an upper bound instead)
+            const uint32_t Dx = (uint32_t)(hi - lo) < RS ? (uint32_t)(hi - lo) : RS;
+#else
+            const uint32_t Dx = claimed;
+#endif
+            claimed = 0;  // (the next range adds to it two barriers from here)
+            xpiece[0] = xpos;
+            if (xpos + Dx <= xend) {
+                xlen1 = Dx;
+                xpos += Dx;
+            } else {
+                const uint32_t l1 = (uint32_t)(xend - xpos);
+                if (xspare == XNONE)  // (only when the bound below was wrong: never, it is an upper bound)
+                    xspare = XALLOC();
+                xlen1 = l1;
+                xpiece[1] = xspare;
+                xpos = xspare + (Dx - l1);
+                xend = xspare + XBLK;
+                xspare = XNONE;
+            }
+            const unsigned long long left = xneed - (hi - lo);  // the ranges still to come hold at most this many
+            xneed = left;
+            if (xspare == XNONE && left > xend - xpos)  // they may not fit the current block: ask for the next one now
+                xspare = XALLOC();
+        }
         load_head(nlo, nhi, head);  // the next range's first keys travel while this range is written out
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * RS);
         if (DENSE) {
@@ -1043,21 +1169,45 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
             // share cache lines with the neighbouring waves' runs.  (Finding the run of element e by a 16-way
             // compare chain, so that thread t could write element t, t + 1024, ..., took a third of the kernel's
             // VALU instructions.)
-            uint64_t *const dkeys = reinterpret_cast<uint64_t *>(dst);
-            uint32_t *const dcounts = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst) + (size_t)RS * 8);
-            const uint32_t skew = pre & 31u;
-            for (uint32_t j = lane; j < wc + skew; j += 64) {
-                if (j >= skew) {
-                    const uint32_t src = wave * share + (j - skew);
-                    __builtin_nontemporal_store(from_stored<K>(skeys[src]), dkeys + pre + (j - skew));
-                    __builtin_nontemporal_store(scounts[src], dcounts + pre + (j - skew));
+            if constexpr (EXT) {
+                const uint64_t b1 = xpiece[0], b2 = xpiece[1];
+                const uint32_t l1 = xlen1;
+                const uint32_t skew = (uint32_t)(pre < l1 ? b1 + pre : b2 + (pre - l1)) & 31u;
+                for (uint32_t j = lane; j < wc + skew; j += 64) {
+                    if (j >= skew) {
+                        const uint32_t src = wave * share + (j - skew), i = pre + (j - skew);
+#if KT_ABLATION && defined(KT_XA) && KT_XA == 1  // timing experiment: the range's own slots as the destination
+                        reinterpret_cast<uint64_t *>(dst)[i] = from_stored<K>(skeys[src]);
+                        reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst) + (size_t)RS * 8)[i] = scounts[src] + 1u;
+#elif KT_ABLATION && defined(KT_XA) && KT_XA == 2  // timing experiment: no stores
+                        if (from_stored<K>(skeys[src]) == 12345u && scounts[src] == 77u) xo.put(0, 0, 0);
+#else
+                        xo.put(i < l1 ? b1 + i : b2 + (i - l1), from_stored<K>(skeys[src]), scounts[src] + 1u);
+#endif
+                    }
+                }
+                if (tid == 0) placed += D;
+            } else {
+                uint64_t *const dkeys = reinterpret_cast<uint64_t *>(dst);
+                uint32_t *const dcounts = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst) + (size_t)RS * 8);
+                const uint32_t skew = pre & 31u;
+                for (uint32_t j = lane; j < wc + skew; j += 64) {
+                    if (j >= skew) {
+                        const uint32_t src = wave * share + (j - skew);
+                        __builtin_nontemporal_store(from_stored<K>(skeys[src]), dkeys + pre + (j - skew));
+                        __builtin_nontemporal_store(scounts[src], dcounts + pre + (j - skew));
+                    }
+                }
+                if (tid == 0) {
+                    range_counts[fb] = D;
+                    placed += D;
                 }
             }
-            if (tid == 0) {
-                range_counts[fb] = D;
-                placed += D;
-            }
+#if KT_ABLATION
         } else if (!(p.dbg & 8u)) {
+#else
+        } else {
+#endif
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
                 const K kk = skeys[i];
                 const uint64_t key = kk == EMPTY ? KT_EMPTY_KEY : from_stored<K>(kk);
@@ -1076,9 +1226,88 @@ __global__ __launch_bounds__(BUILD_T) void build_kernel(const K *__restrict__ ke
         lo = nlo;
         hi = nhi;
     }
+    if (EXT && tid == 0) {  // what this workgroup leaves unused: the tail of its last block, a spare it never needed
+        if (xend > xpos) xo.hole[xend / XBLK - 1] = (uint32_t)(xend - xpos);
+        if (xspare != XNONE) xo.hole[xspare / XBLK] = XBLK;
+    }
     // the table's distinct counter: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) placed += __shfl_down(placed, o, 64);
     if (lane == 0 && placed) atomicAdd(reinterpret_cast<unsigned long long *>(distinct), (unsigned long long)placed);
+}
+
+// ---- after an EXT build: close the holes -----------------------------------------------------------------------
+// info[0] = T (virtual positions handed out), [1] = n (entries = packed length), [2] = M (hole slots below n = entries
+// at or beyond n), [3] = jn (block that holds position n)
+__global__ __launch_bounds__(1024) void ext_scan_kernel(ExtOut xo, uint64_t *__restrict__ hpre, uint64_t max_blocks,
+                                                         uint64_t *__restrict__ info, uint32_t *__restrict__ flags) {
+    __shared__ uint64_t wtot[16];
+    __shared__ uint64_t carry;
+    const uint64_t T = *xo.cursor;
+    uint64_t nb = T / XBLK;
+    if (nb > max_blocks) nb = max_blocks;  // (cannot happen: the hole array is sized for every block the build can take)
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t c0 = 0; c0 < nb; c0 += 1024) {  // hpre[j] = holes of blocks < j
+        const uint64_t i = c0 + threadIdx.x;
+        const uint64_t v = i < nb ? xo.hole[i] : 0;
+        uint64_t inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t u = __shfl_up(inc, off, 64);
+            if ((threadIdx.x & 63) >= (uint32_t)off) inc += u;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint64_t base = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wtot[w];
+        if (i < nb) hpre[i] = base + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t htot = carry, n = nb * XBLK - htot;
+        hpre[nb] = htot;
+        const uint64_t jn = n / XBLK;
+        uint64_t M = htot;  // n == T: no hole below n that is not counted ... (jn == nb)
+        if (jn < nb) {
+            const uint64_t fill_end = jn * XBLK + (XBLK - xo.hole[jn]);  // entries of block jn end here
+            M = hpre[jn] + (n > fill_end ? n - fill_end : 0);
+        }
+        info[0] = nb * XBLK;
+        info[1] = n;
+        info[2] = M;
+        info[3] = jn;
+        if (n > xo.max || (nb * XBLK > xo.max && nb * XBLK - xo.max > xo.ovf_cap)) atomicOr(flags, 2u);
+    }
+}
+
+// one workgroup per block at or beyond position n: its entries move into the hole slots below n, in order
+__global__ __launch_bounds__(256) void ext_patch_kernel(ExtOut xo, const uint64_t *__restrict__ hpre,
+                                                        const uint64_t *__restrict__ info,
+                                                        const uint32_t *__restrict__ flags) {
+    if (*flags & 2u) return;  // the arrays are too small: nothing can be packed
+    const uint64_t T = info[0], n = info[1], M = info[2], jn = info[3];
+    const uint64_t j = jn + blockIdx.x;
+    if (j * XBLK >= T) return;
+    const uint64_t b0 = j * XBLK;
+    const uint32_t fill = XBLK - xo.hole[j];
+    const uint32_t e0 = n > b0 ? (uint32_t)(n - b0) : 0u;  // block jn: only what lies at or beyond n
+    const uint64_t real_before = b0 - hpre[j], below_n = n - M;  // entries in blocks < j; entries at positions < n
+    for (uint32_t e = e0 + threadIdx.x; e < fill; e += 256) {
+        const uint64_t rho = real_before + e - below_n;  // this entry's rank among the entries at or beyond n
+        // the rho-th hole slot below n: the last block d <= jn with hpre[d] <= rho
+        uint64_t lo = 0, hi = jn;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi + 1) >> 1;
+            if (hpre[mid] <= rho) lo = mid; else hi = mid - 1;
+        }
+        const uint64_t dst = lo * XBLK + (XBLK - xo.hole[lo]) + (rho - hpre[lo]);
+        uint64_t key;
+        uint32_t occ;
+        xo.get(b0 + e, key, occ);
+        xo.keys[dst] = key;  // (dst < n <= max)
+        xo.counts[dst] = occ;
+    }
 }
 
 // what build could not place (a range with more distinct keys than slots): through the probing path, which reports
@@ -1244,8 +1473,31 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
     uint64_t n_units;  // upper bound (device-side counts may make it smaller)
 };
 
+struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
+    uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
+        verbose;
+};
+static BulkKnobs read_knobs() {
+    BulkKnobs k;
+    k.bulk = env_u64("KT_BULK", 1);
+    k.min_bases = env_u64("KT_BULK_MIN_BASES", 4ull << 20);
+    k.narrow = env_u64("KT_BULK_NARROW", 1);
+    k.merge_div = env_u64("KT_BULK_MERGE_DIV", 8);
+    k.g_mult = env_u64("KT_BULK_G_MULT", 1);
+    k.paged = env_u64("KT_BULK_PAGED", 1);
+    k.fixed2 = env_u64("KT_BULK_FIXED2", 1);
+    k.s1_wide = env_u64("KT_S1_WIDE", 1);
+    k.p2_big64 = env_u64("KT_P2_BIG64", 1);
+    k.p2_big32 = env_u64("KT_P2_BIG32", 0);
+    k.build_wgs = env_u64("KT_BUILD_WGS", 64);
+    k.dense = env_u64("KT_BULK_DENSE", 1);
+    k.verbose = env_u64("KT_BULK_VERBOSE", 0);
+    return k;
+}
+
 struct kt_bulk_job {
     Plan p{};
+    BulkKnobs kn{};
     Meta m{};
     bool narrow = false;  // 32-bit keys through the partition passes (k <= 16)
     bool paged = false, merge = false, open = false;
@@ -1261,7 +1513,7 @@ template <class K>
 int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
     kt_ctx *ctx = ctr->ctx;
     K *keys1 = (K *)ctr->b_keys1.p;
-    if (env_u64("KT_S1_WIDE", 1)) {
+    if (j.kn.s1_wide) {
         const uint32_t wgs = j.p.G / 2 ? j.p.G / 2 : 1;  // one resident workgroup per CU (its rows of wcur are [0, wgs))
         const size_t lds = sizeof(Scatter1WShared<K>);
         if (r.reads) {
@@ -1343,7 +1595,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             if (int rc = level1_exact<K>(ctr, j)) return rc;
         }
     }
-    const bool big2 = (sizeof(K) == 8 ? env_u64("KT_P2_BIG64", 1) : env_u64("KT_P2_BIG32", 0)) != 0 &&
+    const bool big2 = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 &&
                       Part2Shared<K, true>::bytes(p.B2) <= 160 * 1024;
     auto run_part2 = [&](auto big) -> int {
         constexpr bool BIG = decltype(big)::value;
@@ -1360,26 +1612,59 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     // workgroups per CU over the launch; up to two are resident per CU.  Each takes ranges b, b + grid, ... with the next
     // one's bounds and first keys prefetched, so a few ranges per workgroup are enough - and a smaller static share evens
     // out what the compute units get (k=31: 2 / 4 / 8 / 16 / 32 / 128 per CU = 19.4 / 19.0 / 18.6 / 18.2 / 18.0 / 17.9 ms)
-    uint64_t gb = (uint64_t)ctx->n_cu * env_u64("KT_BUILD_WGS", 64);
+    const bool dense = !j.merge && j.kn.dense != 0;
+    const bool ext = dense && ctr->xt_keys && ctr->xt_counts;  // the packed entries go straight to the export arrays
+    // (ext: every workgroup may leave up to two blocks of the export space unused, and the scratch behind the caller's
+    // arrays is sized for that - 16 per CU there: 18.2 against 17.9 ms)
+    uint64_t gb = (uint64_t)ctx->n_cu * (ext && j.kn.build_wgs > 16 ? 16 : j.kn.build_wgs);
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
     // (ctr k=31: dense build 29.0 ms + dense export 17.4 ms against image build 22-23.5 ms + export 27.5 ms; k=15: 13.8 +
     // 3.2 against 12.5 + 4.7 ms; profiles/r2_build_sweep.txt.  KT_BULK_DENSE=0 builds the probing image at once.)
-    const bool dense = !j.merge && env_u64("KT_BULK_DENSE", 1) != 0;
-    auto build = j.merge ? build_kernel<K, true, false> : dense ? build_kernel<K, false, true> : build_kernel<K, false, false>;
+    auto build = j.merge ? build_kernel<K, true, false>
+                 : ext   ? build_kernel<K, false, true, true>
+                 : dense ? build_kernel<K, false, true>
+                         : build_kernel<K, false, false>;
     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)build_lds));
+    ExtOut xo{};
+    uint64_t *hpre = nullptr, *xinfo = nullptr, max_blocks = 0;
+    if (ext) {
+        // scratch behind the caller's arrays (blocks + holes may reach past the packed length), the holes, their prefix
+        const uint64_t ovf_cap = (2 * gb + 2) * XBLK;
+        max_blocks = (ctr->xt_max + ovf_cap) / XBLK + 2;
+        size_t off = 0;
+        const size_t off_hole = off;  off += (max_blocks * 4 + 255) & ~(size_t)255;
+        const size_t off_hpre = off;  off += ((max_blocks + 1) * 8 + 255) & ~(size_t)255;
+        const size_t off_info = off;  off += 256;
+        const size_t off_ok = off;    off += (ovf_cap * 8 + 255) & ~(size_t)255;
+        const size_t off_oc = off;    off += (ovf_cap * 4 + 255) & ~(size_t)255;
+        if (int rc = ctr->b_ext.reserve(off)) return rc;
+        char *xb = (char *)ctr->b_ext.p;
+        hpre = (uint64_t *)(xb + off_hpre);
+        xinfo = (uint64_t *)(xb + off_info);
+        xo = ExtOut{ctr->xt_keys, ctr->xt_counts, ctr->xt_max, (uint64_t *)(xb + off_ok), (uint32_t *)(xb + off_oc),
+                    ovf_cap,      ctr->cursor,    (uint32_t *)(xb + off_hole)};
+        KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
+        KT_HIP(hipMemsetAsync(xo.hole, 0, max_blocks * 4, ctx->stream));
+    }
     hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend,
                        p, (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_counts, m.spill_cap, ctr->flags,
-                       ctr->distinct, ctr->range_counts);
+                       ctr->distinct, ctr->range_counts, xo);
+    if (ext) {  // close the holes: the entries beyond the packed length move into them
+        hipLaunchKernelGGL(ext_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, xo, hpre, max_blocks, xinfo, ctr->flags);
+        hipLaunchKernelGGL(ext_patch_kernel, dim3((uint32_t)(2 * gb + 3)), dim3(256), 0, ctx->stream, xo,
+                           (const uint64_t *)hpre, (const uint64_t *)xinfo, (const uint32_t *)ctr->flags);
+    }
     ctr->dense = dense;
+    ctr->dense_ext = ext;
     if (!dense) {
         TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
         hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
                            m.spill_counts, m.spill_cap, t, ctr->distinct);
     }
     KT_HIP(hipGetLastError());
-    if (env_u64("KT_BULK_VERBOSE", 0)) {
+    if (j.kn.verbose) {
         uint64_t spilled = 0;
         KT_HIP(hipMemcpyAsync(&spilled, m.spill_n, 8, hipMemcpyDeviceToHost, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -1397,27 +1682,31 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
 int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     *eligible = 0;
     kt_ctx *ctx = ctr->ctx;
-    if (env_u64("KT_BULK", 1) == 0) return KT_OK;
-    if (max_keys < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
+    const BulkKnobs kn = read_knobs();
+    if (kn.bulk == 0) return KT_OK;
+    if (max_keys < kn.min_bases) return KT_OK;  // small batches: atomics are fine
     if (!ctr->job) ctr->job = new (std::nothrow) kt_bulk_job();
     if (!ctr->job) return kt::fail(KT_ERR_NOMEM, "bulk build: host alloc");
     kt_bulk_job &j = *ctr->job;
+    j.kn = kn;
     j.open = false;
     j.srcs.clear();
     j.merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
     if (j.merge)
         if (int rc = kt_table_image(ctr)) return rc;  // (a densely packed table gets its probing image first)
-    j.narrow = ctr->k <= 16 && env_u64("KT_BULK_NARROW", 1);
+    j.narrow = ctr->k <= 16 && kn.narrow;
     j.max_keys = max_keys;
     j.added_bound = 0;
     const size_t ksz = j.narrow ? 4 : 8;
     Plan p{};
     p.n = 64 - ctr->shift;
     p.m8 = ctr->m8;
+#if KT_ABLATION
     p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);
+#endif
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
     // a rebuild moves the whole table: small batches are cheaper through the atomics
-    if (j.merge && max_keys < ctr->cap / env_u64("KT_BULK_MERGE_DIV", 8)) return KT_OK;
+    if (j.merge && max_keys < ctr->cap / (kn.merge_div ? kn.merge_div : 1)) return KT_OK;
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
     if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
@@ -1427,10 +1716,10 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     p.B2 = 1u << p.b2;
     // persistent level-1 workgroups (the same for every source of the job): two per CU for the per-unit kernels; the wide
     // kernel launches G / 2 of them, one resident per CU (KT_BULK_G_MULT > 1: more, shorter-lived workgroups)
-    p.G = (uint32_t)ctx->n_cu * 2 * (uint32_t)env_u64("KT_BULK_G_MULT", 1);
+    p.G = (uint32_t)ctx->n_cu * 2 * (uint32_t)(kn.g_mult ? kn.g_mult : 1);
     // paged level 1 (no hist1): room per bucket = its share of the most keys there can be + 1/8 + a page per
     // workgroup (every workgroup leaves at most one partly used page per bucket)
-    bool paged = env_u64("KT_BULK_PAGED", 1) != 0 && !ctr->paged_failed;
+    bool paged = kn.paged != 0 && !ctr->paged_failed;
     const uint64_t PAGE = KT_PAGE_BYTES / ksz;
     uint64_t cap1 = (max_keys / p.B1 + max_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
     if (cap1 >= (1ull << 32)) paged = false;
@@ -1486,7 +1775,7 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
     if (paged) {
         p.cap1 = cap1;
-        p.cap2 = env_u64("KT_BULK_FIXED2", 1) ? cap1 / p.B2 : 0;
+        p.cap2 = kn.fixed2 ? cap1 / p.B2 : 0;
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)p.G * p.B1 * 4, ctx->stream));
@@ -1560,7 +1849,6 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     kt_ctx *ctx = ctr->ctx;
     int eligible = 0;
     const uint64_t n_seg = (total_bases + ktseg::SEG - 1) / ktseg::SEG;
-    if (total_bases < env_u64("KT_BULK_MIN_BASES", 4ull << 20)) return KT_OK;  // small batches: atomics are fine
     if (int rc = kt_bulk_begin(ctr, n_seg * ktseg::SEG, &eligible)) return rc;  // at most one k-mer per base
     if (!eligible) return KT_OK;
     // the segment index (seg_first) lives in ctx scratch; same helper kernel as the other paths
@@ -1590,6 +1878,11 @@ int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int
 // the probing image of a table that the last build left densely packed (in place; no-op otherwise)
 int kt_table_image(kt_ctr *ctr) {
     if (!ctr->dense) return KT_OK;
+    if (ctr->dense_ext) {  // the entries are the caller's export arrays: back into an empty table, as (key, count) pairs
+        ctr->dense = false;
+        ctr->dense_ext = false;
+        return kt_ctr_reload_pairs(ctr, ctr->xt_keys, ctr->xt_counts);
+    }
     kt_ctx *ctx = ctr->ctx;
     const uint32_t RS = ctr->m8 << (LOG2_S - 3);
     const uint64_t n_ranges = ctr->cap / RS;
@@ -1608,6 +1901,17 @@ int kt_table_image(kt_ctr *ctr) {
 // kt_ctr_export of a densely packed table: d_keys / d_counts are device arrays of max_out entries; *n = entries in the table
 int kt_table_dense_export(kt_ctr *ctr, uint64_t *d_keys, uint32_t *d_counts, uint64_t max_out, uint64_t *n) {
     kt_ctx *ctx = ctr->ctx;
+    if (ctr->dense_ext) {
+        // the build wrote entries [0, *distinct) of the export target: nothing to do when that is where the caller
+        // wants them, a plain copy otherwise
+        KT_HIP(hipMemcpyAsync(n, ctr->distinct, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        const uint64_t w = *n < max_out ? *n : max_out;
+        if (w && d_keys != ctr->xt_keys) KT_HIP(hipMemcpyAsync(d_keys, ctr->xt_keys, w * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (w && d_counts != ctr->xt_counts) KT_HIP(hipMemcpyAsync(d_counts, ctr->xt_counts, w * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        return KT_OK;
+    }
     const uint32_t RS = ctr->m8 << (LOG2_S - 3);
     const uint64_t n_ranges = ctr->cap / RS, n_tiles = (n_ranges + XT - 1) / XT;
     if (int rc = ctx->s_aux0.reserve((n_tiles + 1) * 8)) return rc;

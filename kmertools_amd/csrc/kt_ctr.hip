@@ -253,6 +253,9 @@ int check_overflow(kt_ctr *ctr) {
     uint32_t flag = 0;
     KT_HIP(hipMemcpyAsync(&flag, ctr->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctr->ctx->stream));
     KT_HIP(hipStreamSynchronize(ctr->ctx->stream));
+    if (flag & 2u)  // (set by the range build that writes straight into the export target, kt_bulk.hip)
+        return kt::fail(KT_ERR_ARG, "kt_ctr_export_target: the arrays are smaller than the table (its contents are lost: "
+                                    "kt_ctr_clear, then count again with larger arrays or without a target)");
     if (flag) return kt::fail(KT_ERR_FULL, "k-mer table is full: raise capacity_slots");
     return KT_OK;
 }
@@ -359,6 +362,7 @@ int kt_ctr_destroy(kt_ctr *ctr) {
     if (ctr->cursor) (void)hipFree(ctr->cursor);
     if (ctr->distinct) (void)hipFree(ctr->distinct);
     if (ctr->range_counts) (void)hipFree(ctr->range_counts);
+    ctr->b_ext.release();
     ctr->b_keys1.release();
     ctr->b_keys2.release();
     ctr->b_meta.release();
@@ -393,6 +397,21 @@ int kt_ctr_clear(kt_ctr *ctr) {
     ctr->needs_clear = true;
     ctr->empty = true;
     ctr->dense = false;
+    ctr->dense_ext = false;
+    return KT_OK;
+}
+
+int kt_ctr_export_target(kt_ctr *ctr, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t max_out) {
+    if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_export_target: null ctr");
+    if ((keys_dev == nullptr) != (counts_dev == nullptr))
+        return kt::fail(KT_ERR_ARG, "kt_ctr_export_target: both arrays or neither");
+    if (int rc = ctr->ctx->use()) return rc;
+    // a table whose entries live in the current target gets its own copy (the probing image) before the target moves
+    if (ctr->dense_ext && (keys_dev != ctr->xt_keys || counts_dev != ctr->xt_counts))
+        if (int rc = kt_table_image(ctr)) return rc;
+    ctr->xt_keys = keys_dev;
+    ctr->xt_counts = counts_dev;
+    ctr->xt_max = keys_dev ? max_out : 0;
     return KT_OK;
 }
 
@@ -478,6 +497,26 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
 
 }  // extern "C"
 
+// an empty table filled from the (key, occurrences) pairs the export target holds (probing path; the rare road: a
+// table that was counted into its export arrays and is then added to or probed after all)
+int kt_ctr_reload_pairs(kt_ctr *ctr, const uint64_t *d_keys, const uint32_t *d_counts) {
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    uint64_t n = 0;
+    KT_HIP(hipMemcpyAsync(&n, ctr->distinct, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
+    if (int rc = check_overflow(ctr)) return rc;  // (arrays that were too small hold nothing usable)
+    ctr->needs_clear = true;
+    if (int rc = ensure_cleared(ctr)) return rc;
+    KT_HIP(hipMemsetAsync(ctr->distinct, 0, 8, ctx->stream));
+    if (n == 0) return KT_OK;
+    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+    hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0, ctx->stream,
+                       d_keys, d_counts, n, t, ctr->distinct);
+    KT_HIP(hipGetLastError());
+    return KT_OK;
+}
+
 // table[keys[i]] += 1 for i < min(*d_n, cap_keys), through the probing path (kt_shard.hip, when the bulk build
 // does not apply)
 int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_keys, const uint64_t *d_n) {
@@ -529,6 +568,10 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
     }
     if (ctr->dense) {  // packed ranges: a coalesced copy, no compaction
         uint64_t n = 0;
+        if (ctr->dense_ext) {  // ... or no copy at all: the build wrote the entries to the export target
+            d_keys = mem == KT_MEM_HOST ? ctr->xt_keys : keys;
+            d_counts = mem == KT_MEM_HOST ? ctr->xt_counts : counts;
+        }
         if (int rc = kt_table_dense_export(ctr, d_keys, d_counts, max_out, &n)) return rc;
         const uint64_t written = n < max_out ? n : max_out;
         if (mem == KT_MEM_HOST && written) {

@@ -41,6 +41,10 @@ struct kt_ctx {
     uint16_t *lut_dev[kt::KT_MAX_OLIGO_K + 1] = {};
     uint32_t *lut32_dev[13] = {};  // canonical rank of every k-mer, k = 1..12 (the generic oligo path, kt_oligo_generic.hip)
     kt::Scratch s_bases, s_offsets, s_out, s_aux0, s_aux1, s_aux2;
+    struct OligoKnobs {  // KT_OLIGO_* launch tunables, read once per context (kt_oligo.hip)
+        bool loaded = false, live = false;
+        uint32_t shape = 104, R = 0, oversub = 0, debug = 0;
+    } oligo_knobs;
     int use();  // hipSetDevice
     int canon_lut(int k, const uint16_t **out);
     int canon_lut32(int k, const uint32_t **out);
@@ -60,6 +64,13 @@ struct kt_ctr {
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
     bool dense = false;        // the last (bulk) build left every range packed, not as a probing image (kt_table.hpp)
     uint32_t *range_counts = nullptr;  // device, one per range: entries of the range while the table is dense
+    // export target (kt_ctr_export_target): device arrays of the caller that a fresh bulk build writes its packed
+    // entries to instead of the ranges' own slots - the build's output IS the export (no copy pass afterwards)
+    uint64_t *xt_keys = nullptr;
+    uint32_t *xt_counts = nullptr;
+    uint64_t xt_max = 0;
+    bool dense_ext = false;            // the table's entries ARE xt_keys / xt_counts [0, *distinct): (key, occurrences)
+    kt::Scratch b_ext;                 // the export-target build's holes and the scratch behind the caller's arrays
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls
     kt_bulk_job *job = nullptr;
     void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}

@@ -176,8 +176,8 @@ __device__ __forceinline__ ProdTile make_tile(const OligoArgs &a, uint64_t tile,
 }
 
 #ifndef KT_OLIGO_ABLATION
-#define KT_OLIGO_ABLATION 1  // 1: KT_OLIGO_DEBUG bits are honoured at run time; 0: compiled out
-#endif
+#define KT_OLIGO_ABLATION 0  // 1 (tools/build_variant*.sh only): KT_OLIGO_DEBUG bits switch phases off at run time for
+#endif                       // profiling.  The shipped library has no switch that skips work.
 #if KT_OLIGO_ABLATION
 #define KT_DBG(a) ((a).debug)
 #else
@@ -243,7 +243,9 @@ __device__ __forceinline__ uint4 load_chunk(const OligoArgs &a, const ProdTile &
                                             uint64_t total_bytes) {
     const uintptr_t base_addr = reinterpret_cast<uintptr_t>(a.bases);
     uint4 v = make_uint4(0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu);  // "NNNN": lanes outside the tile
+#if KT_OLIGO_ABLATION
     if (KT_DBG(a) & 4u) return make_uint4(0x54474341u + lane, 0x41434754u, 0x47474343u, 0x41544154u);  // ablation
+#endif
     if (!t.general) {
         const int32_t q = (int32_t)((uint32_t)ci * CHUNK) + (int32_t)NB * ((int32_t)lane - 1);
         if (q >= 0 && q < (int32_t)(uint32_t)t.flat_end) {
@@ -337,8 +339,13 @@ __device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t 
             const int i = h * 8 + j;
             const uint32_t step_b = ((gr >> (15 - i)) & 1u) ? rowstep_b : 0u;
             const uint32_t val = (ok >> (15 - i)) & 1u;
-            if (!(KT_DBG(a) & 8u)) atomicAdd(reinterpret_cast<uint32_t *>(hist_b + row0_b + step_b + bin[j]), val);
-            else if (val + bin[j] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
+#if KT_OLIGO_ABLATION
+            if (KT_DBG(a) & 8u) {
+                if (val + bin[j] == 0xFFFFFFFFu) hist[0] = 1;  // ablation: keep the values live
+                continue;
+            }
+#endif
+            atomicAdd(reinterpret_cast<uint32_t *>(hist_b + row0_b + step_b + bin[j]), val);
         }
     }
     atomicAdd(&tot[rsafe], (uint32_t)__popc(ok & ~gr));
@@ -678,6 +685,23 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
     return v > 0 ? (uint32_t)v : dflt;
 }
 
+// launch tunables: read from the environment once per context (KT_KNOBS_LIVE=1 at that moment - the sweep tools -
+// keeps reading them at every launch)
+const kt_ctx::OligoKnobs &oligo_knobs(kt_ctx *ctx) {
+    kt_ctx::OligoKnobs &kn = ctx->oligo_knobs;
+    if (!kn.loaded || kn.live) {
+        kn.live = env_u32("KT_KNOBS_LIVE", 0) != 0;
+        kn.shape = env_u32("KT_OLIGO_SHAPE", 104);
+        kn.R = env_u32("KT_OLIGO_R", 0);
+        kn.oversub = env_u32("KT_OLIGO_OVERSUB", 0);
+#if KT_OLIGO_ABLATION
+        kn.debug = env_u32("KT_OLIGO_DEBUG", 0);
+#endif
+        kn.loaded = true;
+    }
+    return kn;
+}
+
 }  // namespace
 
 // Enqueue the histogram kernel for device-resident inputs/outputs.
@@ -704,12 +728,13 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     a.total_step = (uint32_t)total_step;
     a.vec_per_row = bins / VEC;
     a.vec_magic = (uint32_t)((0x100000000ull + a.vec_per_row - 1) / a.vec_per_row);
-    a.debug = env_u32("KT_OLIGO_DEBUG", 0);
+    const kt_ctx::OligoKnobs &kn = oligo_knobs(ctx);
+    a.debug = kn.debug;
 
     // reads per tile: ~22 KB of LDS histogram, at most 64 reads; the flat
     // output index v < R * vec_per_row must keep the magic division exact: v * vec_per_row < 2^32.
     // wave layout: 104 = 4 waves per workgroup, 108 = 8
-    const uint32_t shape = env_u32("KT_OLIGO_SHAPE", 104);
+    const uint32_t shape = kn.shape;
     const uint32_t nbuf = 1;
     // small rows: ~22 KB of LDS rows (6 workgroups per CU); big rows (k >= 6, 8-64 KB each) are
     // pure store streams and measured best with one large tile per CU (cfg5: R=4, 0.56 of peak)
@@ -719,7 +744,7 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     if (R >= 8) R &= ~3u;  // k=4: 40 reads = 6 wave-chunks (1008 B) of 150-bp reads, 6 workgroups per CU
     if (R < 1) R = 1;
     if (R > MAX_R) R = MAX_R;
-    R = env_u32("KT_OLIGO_R", R);
+    if (kn.R) R = kn.R;
     if (R > MAX_R) R = MAX_R;
     while (R > 1 && (uint64_t)R * a.vec_per_row * a.vec_per_row >= 0x100000000ull) R--;
     a.R = R;
@@ -757,7 +782,7 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     // (profiles/r2_box_variance.txt)
     // The big-row shapes (k >= 6: a few reads per tile, one or two workgroups per CU) go the other way: k=7 f32, 1 M
     // reads: 2 / 4 / 8 / 16 / 32 / 64 / 128 per slot = 5.30 / 5.33 / 5.28 / 5.41 / 5.58 / 5.72 / 5.97 ms (two processes alike).
-    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * env_u32("KT_OLIGO_OVERSUB", k == 4 ? 96 : bins > 1024 ? 8 : 32);
+    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * (kn.oversub ? kn.oversub : k == 4 ? 96 : bins > 1024 ? 8 : 32);
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(nthreads), lds, ctx->stream, a);

@@ -132,4 +132,7 @@ int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_ke
 // it into the probing layout in place (called by whatever has to probe: incremental adds, merges, cov);
 // kt_table_dense_export writes the (key, count) pairs of a dense table to device arrays.
 int kt_table_image(kt_ctr *ctr);
+// kt_ctr.hip: an empty table filled from (key, occurrences) pairs on the device, *ctr->distinct of them (what
+// kt_table_image does for a table whose entries live in the export target)
+int kt_ctr_reload_pairs(kt_ctr *ctr, const uint64_t *d_keys, const uint32_t *d_counts);
 int kt_table_dense_export(kt_ctr *ctr, uint64_t *d_keys, uint32_t *d_counts, uint64_t max_out, uint64_t *n);

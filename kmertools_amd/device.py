@@ -280,6 +280,11 @@ class Counter:
         check(_lib.lib().kt_ctr_export(self._h, _ptr(keys), _ptr(counts), max_out, C.byref(n), mem))
         return n.value
 
+    def export_target(self, keys, counts, max_out):
+        """device arrays that the next whole-batch count into the empty table writes its (key, count) pairs to
+        (sticky; None, None switches it off): export(keys, counts, ...) afterwards copies nothing"""
+        check(_lib.lib().kt_ctr_export_target(self._h, _ptr(keys), _ptr(counts), int(max_out) if keys is not None else 0))
+
     # -- cov: per-read coverage histograms against this table ---------------------------------
     def cov(self, bases, offsets, n_reads, bin_size, bin_count, out, norm=True, dtype="f64", mem=KT_MEM_DEVICE):
         check(_lib.lib().kt_cov_batch(self._h, _ptr(bases), _ptr(offsets), n_reads, int(bin_size), int(bin_count),

@@ -814,6 +814,91 @@ def test_ctr_dense_table_state(hctx, oracle, monkeypatch, k):
         ctr.close()
 
 
+@pytest.mark.parametrize("k", [31, 15, 21])
+def test_ctr_export_target(torch_mod, ctx, oracle, monkeypatch, k):
+    """kt_ctr_export_target: the range build writes its packed (key, count) pairs straight into the caller's device
+    arrays (no export pass); the table stays usable - size, export to the same or to other arrays, cov, further adds
+    (probing path and range rebuild) first rebuild the probing image from those arrays; a target that is too small is
+    reported, not silently truncated; the target is sticky across clears"""
+    from kmertools_amd import device, _lib
+    torch = torch_mod
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    seqs = ragged_reads(19 + k, 500) + _random_reads(k + 1, 400) + [b"C" * 2500] + _random_reads(k + 1, 50)
+    hb, ho = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(hb, ho, k)
+    bases = torch.from_numpy(hb).cuda()
+    offsets = torch.from_numpy(ho.astype(np.int64)).cuda()
+    n = len(seqs)
+    room = len(wk) + 100
+    xk = torch.full((room,), -1, dtype=torch.int64, device="cuda")
+    xc = torch.zeros(room, dtype=torch.int32, device="cuda")
+
+    def sorted_pairs(tk, tc, cnt):
+        gk = tk[:cnt].cpu().numpy().view(np.uint64)
+        gc = tc[:cnt].cpu().numpy().view(np.uint32)
+        o = np.argsort(gk, kind="stable")
+        return gk[o], gc[o]
+
+    for after in ("same", "other", "host", "cov", "atomic", "merge", "retarget"):
+        ctr = device.Counter(ctx, k, 1 << 18)
+        ctr.export_target(xk, xc, room)
+        for rep in range(2):            # sticky: the second round (after a clear) takes the same road
+            xk.fill_(-1)
+            ctr.clear()
+            ctr.add_reads(bases, offsets, n)
+            assert ctr.size() == len(wk)
+            got = ctr.export(xk, xc, room)
+            assert got == len(wk)
+            gk, gc = sorted_pairs(xk, xc, got)
+            assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (after, rep)
+        mult = 1
+        if after == "other":
+            yk = torch.empty(room, dtype=torch.int64, device="cuda")
+            yc = torch.empty(room, dtype=torch.int32, device="cuda")
+            got = ctr.export(yk, yc, room)
+            gk, gc = sorted_pairs(yk, yc, got)
+            assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        elif after == "cov":
+            oc = oracle.Counter(1)
+            oc.add_reads(hb, ho, k)
+            pb, po = device.to_csr(seqs[::7] + _random_reads(2, 20))
+            got = ctr.cov_host(pb, po, 2, 6)
+            assert np.array_equal(got.view(np.uint64), oc.cov_batch(pb, po, k, 2, 6, True).view(np.uint64))
+        elif after in ("atomic", "merge"):
+            monkeypatch.setenv("KT_BULK", "0" if after == "atomic" else "1")
+            monkeypatch.setenv("KT_BULK_MERGE_DIV", "1000000000")
+            before = xk.clone()
+            ctr.add_reads(bases, offsets, n)                 # (rebuilds the probing image from the arrays first)
+            assert bool((xk == before).all())                # a merge does not write to the export arrays ...
+            xk.fill_(-1)                                     # ... and the table no longer refers to them
+            monkeypatch.setenv("KT_BULK", "1")
+            mult = 2
+        elif after == "retarget":
+            ctr.export_target(None, None, 0)                 # the table takes its own copy before the target goes away
+            xk.fill_(-1)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, mult * wc), after
+        assert ctr.size() == len(wk)
+        ctr.close()
+    # too small: loud, and the arrays are not written past their end
+    small = len(wk) // 2
+    sk = torch.full((len(wk),), -1, dtype=torch.int64, device="cuda")
+    sc = torch.zeros(len(wk), dtype=torch.int32, device="cuda")
+    ctr = device.Counter(ctx, k, 1 << 18)
+    ctr.export_target(sk, sc, small)
+    ctr.add_reads(bases, offsets, n)
+    with pytest.raises(_lib.KmertoolsError) as e:
+        ctr.size()
+    assert e.value.code == _lib.KT_ERR_ARG
+    assert int((sk[small:] != -1).sum()) == 0
+    ctr.clear()
+    ctr.export_target(None, None, 0)
+    ctr.add_reads(bases, offsets, n)
+    gk, gc = ctr.export_host()
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    ctr.close()
+
+
 def test_ctr_range_build_full_table_is_loud(hctx, monkeypatch):
     """more distinct k-mers than slots: the range build must report KT_ERR_FULL, not drop keys or hang"""
     from kmertools_amd import device, _lib
