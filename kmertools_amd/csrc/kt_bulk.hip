@@ -731,11 +731,15 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
                 for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
                 ktd::lds_barrier();
                 if (attempt) counting_only = *sm.flag != 0;  // (written before the barrier above; same for every thread)
-                uint32_t dgp[PER / 2];  // digits, two per register
+                // digits, two per register - unless they are a bit field of the stored hash: then the place pass shifts
+                // them out again (16 K-key chunks of 64-bit keys + the prefetched chunk leave no registers to spare: the
+                // kept digits were what spilled)
+                constexpr bool KEEP_DIG = !stores_hash<K>();
+                uint32_t dgp[KEEP_DIG ? PER / 2 : 1];
 #pragma unroll
                 for (int u = 0; u < PER; u++) {
                     const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
-                    dgp[u / 2] = (u & 1) ? dgp[u / 2] | (d << 16) : d;
+                    if constexpr (KEEP_DIG) dgp[u / 2] = (u & 1) ? dgp[u / 2] | (d << 16) : d;
                     if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[d], 1u);
                 }
                 ktd::lds_barrier();
@@ -748,7 +752,9 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
 #pragma unroll
                     for (int u = 0; u < PER; u++) {
                         if (kcur[u] != EMPTY) {
-                            const uint32_t d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
+                            uint32_t d;
+                            if constexpr (KEEP_DIG) d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
+                            else d = digit2h(hash_of_stored<K>(kcur[u]), p);
                             const uint32_t pos = atomicAdd(&sm.start[d], 1u);
                             sm.sorted[pos] = kcur[u];
                             if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
@@ -881,23 +887,26 @@ struct lds_word<uint32_t> { using type = unsigned int; };
 // EXT (dense only): the packed entries do not go to the range's own slots but straight into the caller's export
 // arrays (kt_ctr_export_target) as (key, occurrences) - the build's output IS the export, and the pass that copied
 // 36 GB of packed ranges into the export arrays (ctr k=31: 12-14 ms of a 65 ms step) is gone.
-// Where a range's entries go cannot be a prefix sum (the number of distinct keys of a range is known only once the range
-// has been built), and one global cursor bumped per range does not work either: a returning atomic on ONE address is
-// served at 83 M/s on this chip (tools/ubench/same_addr_atomic.hip) and waits behind the streaming traffic of its
-// memory channel; a million of them, each holding up a 1024-thread workgroup, took the build from 17.9 to 32.6 ms.
-// So output space is handed out in BLOCKS of XBLK entries, private to a workgroup: one cursor atomic per ~3 ranges,
-// requested a block ahead of need (thread 0 keeps the answer in a register until the current block is full, so its
-// round trip is never waited for), ranges packed back to back inside the blocks - a range that does not fit the rest
-// of its block continues at the front of the next one.  A workgroup that ends leaves the tail of its last block
-// unused (hole[block] says how much), and ext_patch_kernel afterwards moves the entries that lie beyond the packed
-// length n into those holes: 1-2 % of the entries move, the arrays end up holding exactly n entries in [0, n).
+// Where a range's entries go cannot be a prefix sum (how many distinct keys a range has is known only once it has been
+// built), and a global cursor does not work either: a returning atomic on ONE address is served at 83 M/s
+// (tools/ubench/same_addr_atomic.hip), and the compiler waits for it where it is issued, so each one holds a
+// 1024-thread workgroup for a memory round trip under load (one per range: build 17.9 -> 32 ms; one per block of 8192
+// entries, requested ahead: 20.1 ms).  So there is no cursor: output space is cut into BLOCKS of XBLK entries and
+// workgroup b of G owns blocks b, b + G, b + 2 G, ...; it packs its ranges back to back into them (a range that does
+// not fit the rest of a block continues at the front of the workgroup's next one).  The hash spreads the keys, so
+// every workgroup fills about the same number of blocks; what is left are holes - the unused tail of every
+// workgroup's last block, and whole blocks of workgroups that needed one fewer than the others - about 0.5 % of the
+// entries.  ext_scan_kernel / ext_patch_kernel then move the entries that lie beyond the packed length n into the
+// holes below n, and the arrays hold exactly n entries in [0, n).  The order of the entries is deterministic (the
+// contract says unspecified, like the reference's map scan).
 // Positions are "virtual": [0, max) is the caller's arrays, [max, max + ovf_cap) the library's scratch behind them,
-// because blocks + holes may reach past n even when n <= max (the caller's arrays may be exactly n long).
-// Order of the entries: unspecified (kt_ctr_export's contract, like the reference's map scan).  The table keeps no
-// per-range record of where entries went: whatever needs the probing image afterwards re-inserts the exported pairs.
+// because blocks + holes reach past n even when n <= max (the caller's arrays may be exactly n long).  Keys that are
+// NOT spread evenly over the workgroups (an adversarial input) can push the extent past the scratch: ext_scan_kernel
+// raises flag 4 and the host builds the ranges again the ordinary way (finish_typed).
+// The table keeps no per-range record of where entries went: whatever needs the probing image afterwards re-inserts
+// the exported pairs (kt_table_image).
 constexpr uint32_t XBLK = 8192;  // >= the slots of a range: a range spans at most two blocks
 static_assert(XBLK >= (1u << LOG2_S), "a range's entries fit one block");
-constexpr uint64_t XNONE = ~0ull;
 struct ExtOut {
     uint64_t *keys;
     uint32_t *counts;
@@ -905,8 +914,8 @@ struct ExtOut {
     uint64_t *ovf_keys;     // scratch: virtual positions max ... max + ovf_cap
     uint32_t *ovf_counts;
     uint64_t ovf_cap;
-    uint64_t *cursor;       // virtual positions handed out so far (a multiple of XBLK)
-    uint32_t *hole;         // [blocks]: unused entries at the end of a block (0 = full)
+    uint64_t *extent;       // virtual positions in use: max over the workgroups of the end of their last block
+    uint32_t *fill;         // [blocks]: entries at the front of a block (zeroed before the build)
     __device__ __forceinline__ void put(uint64_t pos, uint64_t key, uint32_t occ) const {
         if (pos < max) {
             __builtin_nontemporal_store(key, keys + pos);
@@ -914,7 +923,7 @@ struct ExtOut {
         } else if (pos - max < ovf_cap) {
             ovf_keys[pos - max] = key;
             ovf_counts[pos - max] = occ;
-        }  // (else: far more entries than the arrays hold - ext_scan_kernel reports it)
+        }  // (else: the extent is past the scratch - ext_scan_kernel reports it, the build is redone)
     }
     __device__ __forceinline__ void get(uint64_t pos, uint64_t &key, uint32_t &occ) const {
         if (pos < max) {
@@ -976,31 +985,10 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
     __shared__ uint32_t claimed;             // EXT: distinct keys of the range (slots claimed during the insert)
     __shared__ uint64_t xpiece[2];           // EXT: where the range's entries go: xpiece[0] + i for i < xlen1, then
     __shared__ uint32_t xlen1;               //      xpiece[1] + (i - xlen1)
-    __shared__ unsigned long long xneed;     // EXT: upper bound of the entries this workgroup still has to place
-    // EXT, thread 0 only: the current block [xpos, xend) and the block requested ahead (XNONE: none).  xspare stays in
-    // a register on purpose: it is the result of a returning atomic that nobody waits for until the block is needed.
-    uint64_t xpos = 0, xend = 0, xspare = XNONE;
-#if KT_ABLATION && defined(KT_XA) && KT_XA == 4  // timing experiment: blocks b, b + G, ... - no cursor atomics at all
+    // EXT, thread 0 only: the current block [xpos, xend) and how many blocks this workgroup has taken
+    uint64_t xpos = 0, xend = 0;
     uint32_t xused = 0;
-#define XALLOC() ((uint64_t)(blockIdx.x + (xused++) * gridDim.x) * XBLK)
-#else
-#define XALLOC() atomicAdd(reinterpret_cast<unsigned long long *>(xo.cursor), (unsigned long long)XBLK)
-#endif
-    if (EXT) {
-        if (tid == 0) {
-            claimed = 0;  // (ordered before its first use by the barrier after the image is cleared)
-            xneed = 0;
-        }
-        ktd::lds_barrier();
-        unsigned long long ub = 0;  // keys (with repeats) of all the ranges this workgroup will build
-        for (uint64_t f = blockIdx.x + (uint64_t)tid * gridDim.x; f < n_fine; f += (uint64_t)BUILD_T * gridDim.x)
-            ub += fend[f] - fstart[f];
-        for (int o = 32; o > 0; o >>= 1) ub += __shfl_down(ub, o, 64);
-        if (lane == 0 && ub) atomicAdd(&xneed, ub);
-        ktd::lds_barrier();
-        if (tid == 0 && xneed)
-            xspare = XALLOC();
-    }
+    if (EXT && tid == 0) claimed = 0;  // (ordered before its first use by the barrier after the image is cleared)
     long long placed = 0;  // per thread: occupied slots written - occupied slots found (MERGE)
     // A range starts with two dependent global reads (its bounds, then its first keys): ~4 us during which the
     // workgroup would do nothing, 1500 times over.  Both are taken one range ahead: the next range's bounds are
@@ -1068,9 +1056,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             while (cur != EMPTY) {
                 const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
                 bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
-#if !(KT_ABLATION && defined(KT_XA) && KT_XA == 3)
                 if (EXT) mine += done;
-#endif
                 if (!done && v == cur) {
                     atomicAdd(&scounts[s], 1u);
                     done = true;
@@ -1101,11 +1087,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
         // head loads are issued: a wait for the older operation is a wait for everything issued before the wait)
         if (EXT && tid == 0) {
             // where the range's `claimed` entries go: the rest of the current block, then the front of the spare one
-#if KT_ABLATION && defined(KT_XA) && KT_XA == 3  // timing experiment: no claim counting (an upper bound instead)
-            const uint32_t Dx = (uint32_t)(hi - lo) < RS ? (uint32_t)(hi - lo) : RS;
-#else
             const uint32_t Dx = claimed;
-#endif
             claimed = 0;  // (the next range adds to it two barriers from here)
             xpiece[0] = xpos;
             if (xpos + Dx <= xend) {
@@ -1113,18 +1095,14 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 xpos += Dx;
             } else {
                 const uint32_t l1 = (uint32_t)(xend - xpos);
-                if (xspare == XNONE)  // (only when the bound below was wrong: never, it is an upper bound)
-                    xspare = XALLOC();
+                if (xend) xo.fill[xend / XBLK - 1] = XBLK;  // the block just finished is full
+                const uint64_t nb = ((uint64_t)blockIdx.x + (uint64_t)xused * gridDim.x) * XBLK;
+                xused++;
                 xlen1 = l1;
-                xpiece[1] = xspare;
-                xpos = xspare + (Dx - l1);
-                xend = xspare + XBLK;
-                xspare = XNONE;
+                xpiece[1] = nb;
+                xpos = nb + (Dx - l1);
+                xend = nb + XBLK;
             }
-            const unsigned long long left = xneed - (hi - lo);  // the ranges still to come hold at most this many
-            xneed = left;
-            if (xspare == XNONE && left > xend - xpos)  // they may not fit the current block: ask for the next one now
-                xspare = XALLOC();
         }
         load_head(nlo, nhi, head);  // the next range's first keys travel while this range is written out
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * RS);
@@ -1176,14 +1154,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 for (uint32_t j = lane; j < wc + skew; j += 64) {
                     if (j >= skew) {
                         const uint32_t src = wave * share + (j - skew), i = pre + (j - skew);
-#if KT_ABLATION && defined(KT_XA) && KT_XA == 1  // timing experiment: the range's own slots as the destination
-                        reinterpret_cast<uint64_t *>(dst)[i] = from_stored<K>(skeys[src]);
-                        reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst) + (size_t)RS * 8)[i] = scounts[src] + 1u;
-#elif KT_ABLATION && defined(KT_XA) && KT_XA == 2  // timing experiment: no stores
-                        if (from_stored<K>(skeys[src]) == 12345u && scounts[src] == 77u) xo.put(0, 0, 0);
-#else
                         xo.put(i < l1 ? b1 + i : b2 + (i - l1), from_stored<K>(skeys[src]), scounts[src] + 1u);
-#endif
                     }
                 }
                 if (tid == 0) placed += D;
@@ -1226,9 +1197,9 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
         lo = nlo;
         hi = nhi;
     }
-    if (EXT && tid == 0) {  // what this workgroup leaves unused: the tail of its last block, a spare it never needed
-        if (xend > xpos) xo.hole[xend / XBLK - 1] = (uint32_t)(xend - xpos);
-        if (xspare != XNONE) xo.hole[xspare / XBLK] = XBLK;
+    if (EXT && tid == 0 && xend) {  // the last block is partly filled; the extent of the output is the furthest block's end
+        xo.fill[xend / XBLK - 1] = XBLK - (uint32_t)(xend - xpos);
+        atomicMax(reinterpret_cast<unsigned long long *>(xo.extent), (unsigned long long)xend);
     }
     // the table's distinct counter: one atomic per wave
     for (int o = 32; o > 0; o >>= 1) placed += __shfl_down(placed, o, 64);
@@ -1242,14 +1213,28 @@ __global__ __launch_bounds__(1024) void ext_scan_kernel(ExtOut xo, uint64_t *__r
                                                          uint64_t *__restrict__ info, uint32_t *__restrict__ flags) {
     __shared__ uint64_t wtot[16];
     __shared__ uint64_t carry;
-    const uint64_t T = *xo.cursor;
+    const uint64_t T = *xo.extent;
     uint64_t nb = T / XBLK;
-    if (nb > max_blocks) nb = max_blocks;  // (cannot happen: the hole array is sized for every block the build can take)
+    const bool too_far = nb > max_blocks || (T > xo.max && T - xo.max > xo.ovf_cap);
+    if (too_far) {  // the keys were not spread evenly enough for the scratch: the host builds the ordinary way
+        if (threadIdx.x == 0) {
+            atomicOr(flags, 4u);
+            info[0] = info[1] = info[2] = info[3] = 0;
+        }
+        return;
+    }
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint64_t c0 = 0; c0 < nb; c0 += 1024) {  // hpre[j] = holes of blocks < j
-        const uint64_t i = c0 + threadIdx.x;
-        const uint64_t v = i < nb ? xo.hole[i] : 0;
+    constexpr uint32_t PT = 16;  // blocks per thread and trip (one workgroup scans ~400 K blocks: 25 trips)
+    for (uint64_t c0 = 0; c0 < nb; c0 += 1024 * PT) {  // hpre[j] = holes of blocks < j
+        const uint64_t i0 = c0 + (uint64_t)threadIdx.x * PT;
+        uint32_t h[PT];
+        uint64_t v = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < PT; u++) {
+            h[u] = i0 + u < nb ? XBLK - xo.fill[i0 + u] : 0u;
+            v += h[u];
+        }
         uint64_t inc = v;
         for (int off = 1; off < 64; off <<= 1) {
             const uint64_t u = __shfl_up(inc, off, 64);
@@ -1259,7 +1244,12 @@ __global__ __launch_bounds__(1024) void ext_scan_kernel(ExtOut xo, uint64_t *__r
         __syncthreads();
         uint64_t base = carry;
         for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wtot[w];
-        if (i < nb) hpre[i] = base + inc - v;
+        uint64_t run = base + inc - v;
+#pragma unroll
+        for (uint32_t u = 0; u < PT; u++) {
+            if (i0 + u < nb) hpre[i0 + u] = run;
+            run += h[u];
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry = base + inc;
         __syncthreads();
@@ -1270,14 +1260,14 @@ __global__ __launch_bounds__(1024) void ext_scan_kernel(ExtOut xo, uint64_t *__r
         const uint64_t jn = n / XBLK;
         uint64_t M = htot;  // n == T: no hole below n that is not counted ... (jn == nb)
         if (jn < nb) {
-            const uint64_t fill_end = jn * XBLK + (XBLK - xo.hole[jn]);  // entries of block jn end here
+            const uint64_t fill_end = jn * XBLK + xo.fill[jn];  // entries of block jn end here
             M = hpre[jn] + (n > fill_end ? n - fill_end : 0);
         }
         info[0] = nb * XBLK;
         info[1] = n;
         info[2] = M;
         info[3] = jn;
-        if (n > xo.max || (nb * XBLK > xo.max && nb * XBLK - xo.max > xo.ovf_cap)) atomicOr(flags, 2u);
+        if (n > xo.max) atomicOr(flags, 2u);
     }
 }
 
@@ -1285,12 +1275,12 @@ __global__ __launch_bounds__(1024) void ext_scan_kernel(ExtOut xo, uint64_t *__r
 __global__ __launch_bounds__(256) void ext_patch_kernel(ExtOut xo, const uint64_t *__restrict__ hpre,
                                                         const uint64_t *__restrict__ info,
                                                         const uint32_t *__restrict__ flags) {
-    if (*flags & 2u) return;  // the arrays are too small: nothing can be packed
+    if (*flags & 6u) return;  // the arrays are too small (2) or the build is being redone (4): nothing to pack
     const uint64_t T = info[0], n = info[1], M = info[2], jn = info[3];
     const uint64_t j = jn + blockIdx.x;
     if (j * XBLK >= T) return;
     const uint64_t b0 = j * XBLK;
-    const uint32_t fill = XBLK - xo.hole[j];
+    const uint32_t fill = xo.fill[j];
     const uint32_t e0 = n > b0 ? (uint32_t)(n - b0) : 0u;  // block jn: only what lies at or beyond n
     const uint64_t real_before = b0 - hpre[j], below_n = n - M;  // entries in blocks < j; entries at positions < n
     for (uint32_t e = e0 + threadIdx.x; e < fill; e += 256) {
@@ -1301,7 +1291,7 @@ __global__ __launch_bounds__(256) void ext_patch_kernel(ExtOut xo, const uint64_
             const uint64_t mid = (lo + hi + 1) >> 1;
             if (hpre[mid] <= rho) lo = mid; else hi = mid - 1;
         }
-        const uint64_t dst = lo * XBLK + (XBLK - xo.hole[lo]) + (rho - hpre[lo]);
+        const uint64_t dst = lo * XBLK + xo.fill[lo] + (rho - hpre[lo]);
         uint64_t key;
         uint32_t occ;
         xo.get(b0 + e, key, occ);
@@ -1475,7 +1465,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose;
+        verbose, ext_ovf_blocks;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -1492,6 +1482,7 @@ static BulkKnobs read_knobs() {
     k.build_wgs = env_u64("KT_BUILD_WGS", 64);
     k.dense = env_u64("KT_BULK_DENSE", 1);
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
+    k.ext_ovf_blocks = env_u64("KT_EXT_OVF_BLOCKS", 0);  // tests: n + 1 = blocks of scratch behind the export target
     return k;
 }
 
@@ -1613,49 +1604,68 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     // one's bounds and first keys prefetched, so a few ranges per workgroup are enough - and a smaller static share evens
     // out what the compute units get (k=31: 2 / 4 / 8 / 16 / 32 / 128 per CU = 19.4 / 19.0 / 18.6 / 18.2 / 18.0 / 17.9 ms)
     const bool dense = !j.merge && j.kn.dense != 0;
-    const bool ext = dense && ctr->xt_keys && ctr->xt_counts;  // the packed entries go straight to the export arrays
-    // (ext: every workgroup may leave up to two blocks of the export space unused, and the scratch behind the caller's
-    // arrays is sized for that - 16 per CU there: 18.2 against 17.9 ms)
+    bool ext = dense && ctr->xt_keys && ctr->xt_counts;  // the packed entries go straight to the export arrays
+    // (ext: the scratch behind the caller's arrays is sized by the number of workgroups - 16 per CU there: 18.2 against
+    // 17.9 ms)
     uint64_t gb = (uint64_t)ctx->n_cu * (ext && j.kn.build_wgs > 16 ? 16 : j.kn.build_wgs);
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
     // (ctr k=31: dense build 29.0 ms + dense export 17.4 ms against image build 22-23.5 ms + export 27.5 ms; k=15: 13.8 +
     // 3.2 against 12.5 + 4.7 ms; profiles/r2_build_sweep.txt.  KT_BULK_DENSE=0 builds the probing image at once.)
-    auto build = j.merge ? build_kernel<K, true, false>
-                 : ext   ? build_kernel<K, false, true, true>
-                 : dense ? build_kernel<K, false, true>
-                         : build_kernel<K, false, false>;
-    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)build_lds));
-    ExtOut xo{};
-    uint64_t *hpre = nullptr, *xinfo = nullptr, max_blocks = 0;
+    auto launch_build = [&](bool to_ext, const ExtOut &xo) -> int {
+        auto build = j.merge ? build_kernel<K, true, false>
+                     : to_ext ? build_kernel<K, false, true, true>
+                     : dense  ? build_kernel<K, false, true>
+                              : build_kernel<K, false, false>;
+        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)build_lds));
+        hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart,
+                           m.fend, p, (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_counts, m.spill_cap, ctr->flags,
+                           ctr->distinct, ctr->range_counts, xo);
+        KT_HIP(hipGetLastError());
+        return KT_OK;
+    };
     if (ext) {
-        // scratch behind the caller's arrays (blocks + holes may reach past the packed length), the holes, their prefix
-        const uint64_t ovf_cap = (2 * gb + 2) * XBLK;
-        max_blocks = (ctr->xt_max + ovf_cap) / XBLK + 2;
+        // scratch behind the caller's arrays (blocks + holes reach past the packed length), the blocks' fill, the holes' prefix.
+        // Holes: about half a block per workgroup; the rest of the scratch is the tolerance for workgroups that need more
+        // blocks than the average (KT_EXT_OVF_BLOCKS: tests make it too small on purpose).
+        const uint64_t ovf_cap = (j.kn.ext_ovf_blocks ? j.kn.ext_ovf_blocks - 1 : 2 * gb + 2) * XBLK;
+        const uint64_t max_blocks = (ctr->xt_max + ovf_cap) / XBLK + 2;
         size_t off = 0;
-        const size_t off_hole = off;  off += (max_blocks * 4 + 255) & ~(size_t)255;
+        const size_t off_fill = off;  off += (max_blocks * 4 + 255) & ~(size_t)255;
         const size_t off_hpre = off;  off += ((max_blocks + 1) * 8 + 255) & ~(size_t)255;
         const size_t off_info = off;  off += 256;
         const size_t off_ok = off;    off += (ovf_cap * 8 + 255) & ~(size_t)255;
         const size_t off_oc = off;    off += (ovf_cap * 4 + 255) & ~(size_t)255;
         if (int rc = ctr->b_ext.reserve(off)) return rc;
         char *xb = (char *)ctr->b_ext.p;
-        hpre = (uint64_t *)(xb + off_hpre);
-        xinfo = (uint64_t *)(xb + off_info);
-        xo = ExtOut{ctr->xt_keys, ctr->xt_counts, ctr->xt_max, (uint64_t *)(xb + off_ok), (uint32_t *)(xb + off_oc),
-                    ovf_cap,      ctr->cursor,    (uint32_t *)(xb + off_hole)};
+        uint64_t *hpre = (uint64_t *)(xb + off_hpre), *xinfo = (uint64_t *)(xb + off_info);
+        const ExtOut xo{ctr->xt_keys, ctr->xt_counts, ctr->xt_max, (uint64_t *)(xb + off_ok), (uint32_t *)(xb + off_oc),
+                        ovf_cap,      ctr->cursor,    (uint32_t *)(xb + off_fill)};
         KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
-        KT_HIP(hipMemsetAsync(xo.hole, 0, max_blocks * 4, ctx->stream));
-    }
-    hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart, m.fend,
-                       p, (Slot *)ctr->slots, m.spill_n, m.spill_keys, m.spill_counts, m.spill_cap, ctr->flags,
-                       ctr->distinct, ctr->range_counts, xo);
-    if (ext) {  // close the holes: the entries beyond the packed length move into them
+        KT_HIP(hipMemsetAsync(xo.fill, 0, max_blocks * 4, ctx->stream));
+        if (int rc = launch_build(true, xo)) return rc;
+        // close the holes: the entries beyond the packed length move into them
         hipLaunchKernelGGL(ext_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, xo, hpre, max_blocks, xinfo, ctr->flags);
-        hipLaunchKernelGGL(ext_patch_kernel, dim3((uint32_t)(2 * gb + 3)), dim3(256), 0, ctx->stream, xo,
+        hipLaunchKernelGGL(ext_patch_kernel, dim3((uint32_t)(ovf_cap / XBLK + 3)), dim3(256), 0, ctx->stream, xo,
                            (const uint64_t *)hpre, (const uint64_t *)xinfo, (const uint32_t *)ctr->flags);
+        KT_HIP(hipGetLastError());
+        // did the blocks fit (flag 4: keys spread too unevenly over the workgroups)?  One 4-byte read; the caller's
+        // next step - kt_ctr_size, kt_ctr_export - waits for these kernels anyway.
+        uint32_t fl = 0;
+        KT_HIP(hipMemcpyAsync(&fl, ctr->flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        if (fl & 4u) {  // no: build the ranges the ordinary way (kt_ctr_export will copy them out)
+            fl &= ~4u;
+            KT_HIP(hipMemcpyAsync(ctr->flags, &fl, 4, hipMemcpyHostToDevice, ctx->stream));
+            KT_HIP(hipMemsetAsync(ctr->distinct, 0, 8, ctx->stream));  // (a dense build starts from an empty table)
+            KT_HIP(hipStreamSynchronize(ctx->stream));                 // (fl lives on this stack frame)
+            ext = false;
+            if (j.kn.verbose) fprintf(stderr, "[bulk] export-target build redone into the table (uneven blocks)\n");
+        }
     }
+    if (!ext)
+        if (int rc = launch_build(false, ExtOut{})) return rc;
     ctr->dense = dense;
     ctr->dense_ext = ext;
     if (!dense) {
