@@ -277,10 +277,23 @@ class AsyncWriter {
     ~AsyncWriter() { finish(); }
 };
 
+// Batch limits can be lowered from the environment (KT_CLI_BATCH_READS / KT_CLI_BATCH_BASES): the tests use it to
+// push a small file through many batches (the rotating work items, the ordered writer, several table adds).
+static uint64_t env_cap(const char *name, uint64_t v) {
+    const char *e = getenv(name);
+    if (!e || !*e) return v;
+    const uint64_t c = strtoull(e, nullptr, 10);
+    return c && c < v ? c : v;
+}
+static uint64_t cli_batch_reads(uint64_t v) { return env_cap("KT_CLI_BATCH_READS", v); }
+static uint64_t cli_batch_bases(uint64_t v) { return env_cap("KT_CLI_BATCH_BASES", v); }
+
 // device(w): fills w.rows from w.b, returns "" or an error message.  emit(w): writes the text.
 static std::string run_pipeline(SeqReader &reader, uint64_t max_bases, uint64_t max_reads, PhaseTimer &pt,
                                 const std::function<std::string(Work &)> &device,
                                 const std::function<void(Work &)> &emit, bool keep_ids = false) {
+    max_bases = cli_batch_bases(max_bases);
+    max_reads = cli_batch_reads(max_reads);
     constexpr int DEPTH = 3;
     Work items[DEPTH];
     Channel<Work *> free_q, read_q, done_q;
@@ -693,7 +706,7 @@ std::string CountComputer::count() {
         Batch b;
         Lap lap;
         for (;;) {
-            const bool more = reader.next_batch(b, batch_bases, 1ull << 22);
+            const bool more = reader.next_batch(b, cli_batch_bases(batch_bases), cli_batch_reads(1ull << 22));
             pt.t[0] += lap();
             if (b.n_reads() && !b.bases.empty()) {
                 if (kt_ctr_add_reads_part(ctr_, b.bases.data(), b.offsets.data(), b.n_reads(), KT_MEM_HOST, passes_, pass) != KT_OK)
@@ -841,7 +854,7 @@ std::string CountComputer::count_sharded(uint64_t max_distinct) {
         for (int r = 0; r < N; r++) {
             Batch &b = batches[round & 1][r];
             b.clear();
-            if (more) more = reader.next_batch(b, batch_bases, 1ull << 22);
+            if (more) more = reader.next_batch(b, cli_batch_bases(batch_bases), cli_batch_reads(1ull << 22));
         }
         if (reader.failed() && err.empty()) err = reader.error();
         {

@@ -19,6 +19,8 @@
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
 #include <stdatomic.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -257,16 +259,35 @@ void kto_cgr_coords(uint64_t k, double vecsize, double *xy) {
 
 /* ------------------------------------------------------------------------ */
 /* counter/src/lib.rs:92-170 count_chunk + :172-234 merge, in memory.
- * The reference keeps `n_parts` concurrent maps, owner = min_mer % n_parts
- * (:100,:127), `entry(m).and_modify(+1).or_insert(1)` (:126-130), u32 counts.
- * Here: n_parts open-addressing tables, each behind a mutex (the analogue of
- * scc's bucket locks), worker-pull over reads (the analogue of
- * records.lock().next(), :119). */
-typedef struct {
-    uint64_t *keys; uint32_t *vals; uint64_t cap, used; pthread_mutex_t mu;
-} kto_map;
-
+ * The reference keeps `n_parts` concurrent maps (scc::HashMap), owner = min_mer % n_parts
+ * (:100,:127), `entry(m).and_modify(+1).or_insert(1)` (:126-130), u32 counts.  An scc map locks
+ * one BUCKET (a cache-line sized cell of 32 entries) per operation and grows by rehashing in
+ * steps, so threads that hit different buckets of one map do not wait for each other.
+ * Here: every map is an array of GROUPS of 8 slots - 128 bytes, two adjacent cache lines: lock,
+ * counts, keys - each with its own spin lock; a key hashes to a group and probes inside it only.  A group that is full hands the key to a small
+ * overflow table behind a mutex (so an add never fails and never needs the map to grow while
+ * other threads are in it); the map itself is resized between the threaded phases
+ * (map_reserve: before a batch is added it gets room for the batch's k-mers - what scc does
+ * step by step while adding).  Worker-pull over reads = records.lock().next() (:119). */
 #define KTO_EMPTY 0xFFFFFFFFFFFFFFFFULL   /* canonical k-mers are < 2^62 (kmer.rs:38) */
+#define KTO_G 8                           /* slots per group */
+
+typedef struct {
+    _Atomic uint32_t lock; uint32_t n;     /* n = keys in the group */
+    uint32_t vals[KTO_G];
+    uint64_t keys[KTO_G];
+    char pad[128 - 8 - 4 * KTO_G - 8 * KTO_G];
+} kto_group;                               /* 128 bytes: an aligned pair of cache lines per group */
+
+typedef struct {                           /* open addressing, grows by doubling; callers serialise */
+    uint64_t *keys; uint32_t *vals; uint64_t cap, used;
+} kto_flat;
+
+typedef struct {
+    kto_group *groups; uint64_t n_groups;  /* power of two */
+    kto_flat ov; pthread_mutex_t ov_mu;    /* keys whose group is full */
+    char pad[64];                          /* maps of one counter sit in an array: no shared lines */
+} kto_map;
 
 static inline uint64_t mix64(uint64_t z) {
     z += 0x9e3779b97f4a7c15ULL;
@@ -275,32 +296,144 @@ static inline uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-static void map_init(kto_map *m, uint64_t cap) {
+static void flat_init(kto_flat *m, uint64_t cap) {
     m->cap = cap; m->used = 0;
     m->keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
     m->vals = (uint32_t *)calloc(cap, sizeof(uint32_t));
     memset(m->keys, 0xFF, cap * sizeof(uint64_t));
-    pthread_mutex_init(&m->mu, NULL);
 }
-static void map_free(kto_map *m) { free(m->keys); free(m->vals); pthread_mutex_destroy(&m->mu); }
-
-static void map_add_nolock(kto_map *m, uint64_t key, uint32_t add);
-static void map_grow(kto_map *m) {
-    kto_map n; map_init(&n, m->cap * 2);
+static void flat_add(kto_flat *m, uint64_t key, uint32_t add);
+static void flat_grow(kto_flat *m) {
+    kto_flat n; flat_init(&n, m->cap * 2);
     for (uint64_t i = 0; i < m->cap; i++)
-        if (m->keys[i] != KTO_EMPTY) map_add_nolock(&n, m->keys[i], m->vals[i]);
+        if (m->keys[i] != KTO_EMPTY) flat_add(&n, m->keys[i], m->vals[i]);
     free(m->keys); free(m->vals);
-    m->keys = n.keys; m->vals = n.vals; m->cap = n.cap; m->used = n.used;
-    pthread_mutex_destroy(&n.mu);
+    *m = n;
 }
-static void map_add_nolock(kto_map *m, uint64_t key, uint32_t add) {
-    if ((m->used + 1) * 10 > m->cap * 7) map_grow(m);
+static void flat_add(kto_flat *m, uint64_t key, uint32_t add) {
+    if ((m->used + 1) * 10 > m->cap * 7) flat_grow(m);
     uint64_t h = mix64(key) & (m->cap - 1);
     for (;;) {
         if (m->keys[h] == key) { m->vals[h] += add; return; }        /* and_modify / += (u32 wrap) */
         if (m->keys[h] == KTO_EMPTY) { m->keys[h] = key; m->vals[h] = add; m->used++; return; } /* or_insert */
         h = (h + 1) & (m->cap - 1);
     }
+}
+static int flat_get(const kto_flat *m, uint64_t key, uint32_t *val) {
+    uint64_t h = mix64(key) & (m->cap - 1);
+    for (;;) {
+        if (m->keys[h] == key) { *val = m->vals[h]; return 1; }
+        if (m->keys[h] == KTO_EMPTY) return 0;
+        h = (h + 1) & (m->cap - 1);
+    }
+}
+
+static kto_group *groups_new(uint64_t n_groups) {
+    /* large tables: 2 MB alignment + MADV_HUGEPAGE - every add is a random access, and with 4 KB pages most of
+     * its cost would be the page walk */
+    const size_t bytes = n_groups * sizeof(kto_group);
+    kto_group *g = NULL;
+    if (bytes >= (4u << 20)) {
+        if (posix_memalign((void **)&g, 2u << 20, (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1)) != 0) g = NULL;
+#ifdef MADV_HUGEPAGE
+        if (g) (void)madvise(g, bytes, MADV_HUGEPAGE);
+#endif
+    }
+    if (!g) g = (kto_group *)aligned_alloc(128, bytes);
+    for (uint64_t i = 0; i < n_groups; i++) {
+        atomic_init(&g[i].lock, 0); g[i].n = 0;
+        memset(g[i].keys, 0xFF, sizeof g[i].keys);
+        memset(g[i].vals, 0, sizeof g[i].vals);
+    }
+    return g;
+}
+static void map_init(kto_map *m, uint64_t slots) {
+    uint64_t ng = 1;
+    while (ng * KTO_G < slots) ng <<= 1;
+    m->groups = groups_new(ng); m->n_groups = ng;
+    flat_init(&m->ov, 64);
+    pthread_mutex_init(&m->ov_mu, NULL);
+}
+static void map_free(kto_map *m) {
+    free(m->groups); free(m->ov.keys); free(m->ov.vals); pthread_mutex_destroy(&m->ov_mu);
+}
+
+/* table[key] += add; safe to call from many threads */
+static void map_add(kto_map *m, uint64_t key, uint32_t add) {
+    const uint64_t h = mix64(key);
+    kto_group *g = &m->groups[(h >> 8) & (m->n_groups - 1)];
+    uint32_t s = (uint32_t)h & (KTO_G - 1);
+    while (atomic_exchange_explicit(&g->lock, 1u, memory_order_acquire)) {   /* the bucket's lock */
+        uint32_t spins = 0;
+        while (atomic_load_explicit(&g->lock, memory_order_relaxed)) {
+            if (++spins < 64) __builtin_ia32_pause();
+            else { sched_yield(); spins = 0; }                               /* the holder may have been descheduled */
+        }
+    }
+    for (uint32_t i = 0; i < KTO_G; i++, s = (s + 1) & (KTO_G - 1)) {
+        if (g->keys[s] == key) { g->vals[s] += add; goto done; }             /* and_modify / += (u32 wrap) */
+        if (g->keys[s] == KTO_EMPTY) { g->keys[s] = key; g->vals[s] = add; g->n++; goto done; } /* or_insert */
+    }
+    atomic_store_explicit(&g->lock, 0u, memory_order_release);
+    pthread_mutex_lock(&m->ov_mu);                                           /* a full group: overflow table */
+    flat_add(&m->ov, key, add);
+    pthread_mutex_unlock(&m->ov_mu);
+    return;
+done:
+    atomic_store_explicit(&g->lock, 0u, memory_order_release);
+}
+
+/* no writers around (lookups of cov, exports) */
+static uint32_t map_get(const kto_map *m, uint64_t key) {
+    const uint64_t h = mix64(key);
+    const kto_group *g = &m->groups[(h >> 8) & (m->n_groups - 1)];
+    uint32_t s = (uint32_t)h & (KTO_G - 1);
+    for (uint32_t i = 0; i < KTO_G; i++, s = (s + 1) & (KTO_G - 1)) {
+        if (g->keys[s] == key) return g->vals[s];
+        if (g->keys[s] == KTO_EMPTY) return 0;
+    }
+    uint32_t v = 0;
+    return flat_get(&m->ov, key, &v) ? v : 0;
+}
+
+static uint64_t map_used(const kto_map *m) {
+    uint64_t n = m->ov.used;
+    for (uint64_t i = 0; i < m->n_groups; i++) n += m->groups[i].n;
+    return n;
+}
+
+/* visits every (key, value); no writers around */
+#define KTO_MAP_FOREACH(m, K, V, BODY)                                                   \
+    do {                                                                                 \
+        for (uint64_t gi_ = 0; gi_ < (m)->n_groups; gi_++)                               \
+            for (uint32_t si_ = 0; si_ < KTO_G; si_++) {                                 \
+                if ((m)->groups[gi_].keys[si_] == KTO_EMPTY) continue;                   \
+                const uint64_t K = (m)->groups[gi_].keys[si_];                           \
+                const uint32_t V = (m)->groups[gi_].vals[si_];                           \
+                BODY                                                                     \
+            }                                                                            \
+        for (uint64_t oi_ = 0; oi_ < (m)->ov.cap; oi_++) {                               \
+            if ((m)->ov.keys[oi_] == KTO_EMPTY) continue;                                \
+            const uint64_t K = (m)->ov.keys[oi_];                                        \
+            const uint32_t V = (m)->ov.vals[oi_];                                        \
+            BODY                                                                         \
+        }                                                                                \
+    } while (0)
+
+/* room for `keys` keys in all at load <= 0.5: ~2 % of the groups fill up and use the overflow table
+ * (single-threaded: between the threaded phases) */
+static void map_reserve(kto_map *m, uint64_t keys) {
+    uint64_t want = 1;
+    while (want * KTO_G * 5 < keys * 10) want <<= 1;
+    if (want <= m->n_groups) return;
+    kto_map n;
+    n.groups = groups_new(want); n.n_groups = want;
+    flat_init(&n.ov, 64);
+    pthread_mutex_init(&n.ov_mu, NULL);
+    KTO_MAP_FOREACH(m, key, val, { map_add(&n, key, val); });
+    pthread_mutex_destroy(&n.ov_mu);
+    free(m->groups); free(m->ov.keys); free(m->ov.vals);
+    m->groups = n.groups; m->n_groups = n.n_groups; m->ov = n.ov;
 }
 
 typedef struct {
@@ -337,10 +470,7 @@ static void *count_worker(void *p) {
             uint64_t f, r;
             while (kto_gen_next(&g, &f, &r)) {                /* lib.rs:123 */
                 uint64_t mn = f < r ? f : r;                   /* :124 */
-                kto_map *m = &c->parts[mn % c->n_parts];       /* :127 */
-                pthread_mutex_lock(&m->mu);
-                map_add_nolock(m, mn, 1);                      /* :128-130 */
-                pthread_mutex_unlock(&m->mu);
+                map_add(&c->parts[mn % c->n_parts], mn, 1);    /* :127-130 */
             }
         }
     }
@@ -351,6 +481,16 @@ static void *count_worker(void *p) {
 int kto_counter_add_reads(kto_counter *c, const uint8_t *bases, const uint64_t *offsets,
                           uint64_t n_reads, uint64_t k, int threads) {
     pthread_once(&nt4_once, nt4_init);
+    /* room before the threads start: an empty map gets what this batch can add at most (one k-mer per base,
+     * spread over the maps by `% n_parts`); a map that holds data doubles once it is half full - within a batch
+     * the overflow tables take what the groups cannot */
+    {
+        const uint64_t bound = offsets[n_reads] / c->n_parts + offsets[n_reads] / c->n_parts / 8 + 1024;
+        for (uint64_t i = 0; i < c->n_parts; i++) {
+            const uint64_t used = map_used(&c->parts[i]);
+            map_reserve(&c->parts[i], used ? 2 * used : bound);
+        }
+    }
     _Atomic uint64_t next = 0;
     count_job job = {c, bases, offsets, n_reads, k, &next};
     if (threads <= 1) {
@@ -364,16 +504,22 @@ int kto_counter_add_reads(kto_counter *c, const uint8_t *bases, const uint64_t *
     return 0;
 }
 
+/* room for `keys` distinct keys in all (what scc reaches by growing while it adds) */
+void kto_counter_reserve(kto_counter *c, uint64_t keys) {
+    for (uint64_t i = 0; i < c->n_parts; i++) map_reserve(&c->parts[i], keys / c->n_parts + keys / c->n_parts / 8 + 1024);
+}
+
 /* merge's arithmetic (lib.rs:201-210): `*map.entry(kmer).or_insert(0) += count`. */
 int kto_counter_add_pairs(kto_counter *c, const uint64_t *keys, const uint32_t *counts, uint64_t n) {
+    for (uint64_t i = 0; i < c->n_parts; i++) map_reserve(&c->parts[i], map_used(&c->parts[i]) + n / c->n_parts + 1024);
     for (uint64_t i = 0; i < n; i++)
-        map_add_nolock(&c->parts[keys[i] % c->n_parts], keys[i], counts[i]);
+        map_add(&c->parts[keys[i] % c->n_parts], keys[i], counts[i]);
     return 0;
 }
 
 uint64_t kto_counter_size(const kto_counter *c) {
     uint64_t n = 0;
-    for (uint64_t i = 0; i < c->n_parts; i++) n += c->parts[i].used;
+    for (uint64_t i = 0; i < c->n_parts; i++) n += map_used(&c->parts[i]);
     return n;
 }
 
@@ -390,8 +536,7 @@ uint64_t kto_counter_export(const kto_counter *c, uint64_t *keys, uint32_t *coun
     kv_t *kv = (kv_t *)malloc((n ? n : 1) * sizeof(kv_t));
     for (uint64_t p = 0; p < c->n_parts; p++) {
         const kto_map *m = &c->parts[p];
-        for (uint64_t i = 0; i < m->cap; i++)
-            if (m->keys[i] != KTO_EMPTY) { kv[o].k = m->keys[i]; kv[o].v = m->vals[i]; o++; }
+        KTO_MAP_FOREACH(m, key, val, { kv[o].k = key; kv[o].v = val; o++; });
     }
     if (sorted) qsort(kv, n, sizeof(kv_t), cmp_kv);
     for (uint64_t i = 0; i < n; i++) { keys[i] = kv[i].k; counts[i] = kv[i].v; }
@@ -419,9 +564,7 @@ static void *spill_worker(void *p) {
         FILE *f = fopen(path, "w");
         if (!f) { j->err = 1; continue; }
         const kto_map *m = &j->c->parts[part];
-        for (uint64_t i = 0; i < m->cap; i++)                     /* map.scan :162-165 */
-            if (m->keys[i] != KTO_EMPTY)
-                fprintf(f, "%llu\t%u\n", (unsigned long long)m->keys[i], m->vals[i]);
+        KTO_MAP_FOREACH(m, key, val, { fprintf(f, "%llu\t%u\n", (unsigned long long)key, val); }); /* map.scan :162-165 */
         fclose(f);
     }
     return NULL;
@@ -459,9 +602,7 @@ static void *merge_worker(void *p) {
             unsigned long long kmer = strtoull(line, &tab, 10);   /* parts.next().parse::<Kmer>() :205 */
             if (tab == line || *tab != '\t') continue;
             uint32_t count = (uint32_t)strtoul(tab + 1, NULL, 10);/* :206 */
-            pthread_mutex_lock(&j->map->mu);
-            map_add_nolock(j->map, kmer, count);                  /* *entry(kmer).or_insert(0) += count :207 */
-            pthread_mutex_unlock(&j->map->mu);
+            map_add(j->map, kmer, count);                         /* *entry(kmer).or_insert(0) += count :207 */
         }
         fclose(f);
         if (j->del) remove(path);                                 /* :208-210 */
@@ -480,6 +621,16 @@ uint64_t kto_merge(const char *dir, uint64_t n_parts, uint64_t chunks, int threa
     int err = 0;
     for (uint64_t part = 0; part < n_parts; part++) {             /* for part in 0..n_parts :188 (serial) */
         kto_map map; map_init(&map, 1024);                        /* SccMap::new() :190 */
+        {   /* room for the partition's lines (scc grows while the tasks add): a line is at least 4 bytes */
+            uint64_t bytes = 0;
+            for (uint64_t ch = 0; ch < chunks; ch++) {
+                snprintf(path, sizeof path, "%s/temp_kmers.part_%llu_chunk_%llu", dir, (unsigned long long)part,
+                         (unsigned long long)ch);
+                FILE *pf = fopen(path, "r");
+                if (pf) { fseek(pf, 0, SEEK_END); bytes += (uint64_t)ftell(pf); fclose(pf); }
+            }
+            map_reserve(&map, bytes / 4 + 1024);
+        }
         _Atomic uint64_t next = 0;
         merge_job job = {&map, dir, part, chunks, &next, del, 0};
         int T = threads < 1 ? 1 : threads;
@@ -493,16 +644,15 @@ uint64_t kto_merge(const char *dir, uint64_t n_parts, uint64_t chunks, int threa
             free(t);
         }
         err |= job.err;
-        for (uint64_t i = 0; i < map.cap; i++) {                  /* map_arc.scan :220-230 */
-            if (map.keys[i] == KTO_EMPTY) continue;
+        KTO_MAP_FOREACH(&map, key, val, {                          /* map_arc.scan :220-230 */
             if (acgt) {
-                kto_numeric_to_kmer(map.keys[i], k, mer);
-                fprintf(out, "%s\t%u\n", mer, map.vals[i]);
+                kto_numeric_to_kmer(key, k, mer);
+                fprintf(out, "%s\t%u\n", mer, val);
             } else {
-                fprintf(out, "%llu\t%u\n", (unsigned long long)map.keys[i], map.vals[i]);
+                fprintf(out, "%llu\t%u\n", (unsigned long long)key, val);
             }
             lines++;
-        }
+        });
         map_free(&map);
     }
     fclose(out);
@@ -670,13 +820,7 @@ uint64_t kto_minimisers_batch(const uint8_t *bases, const uint64_t *offsets, uin
  * per k-mer: count = table[min(f,r)] or 0 (:171), bin = min(floor(count / bin_size),
  * bin_count - 1) (:172-173), vec[bin] += 1, total += 1; norm: /= max(1, total) (:180-182). */
 static uint32_t counter_get(const kto_counter *c, uint64_t key) {
-    const kto_map *m = &c->parts[key % c->n_parts];
-    uint64_t h = mix64(key) & (m->cap - 1);
-    for (;;) {
-        if (m->keys[h] == key) return m->vals[h];
-        if (m->keys[h] == KTO_EMPTY) return 0;
-        h = (h + 1) & (m->cap - 1);
-    }
+    return map_get(&c->parts[key % c->n_parts], key);
 }
 
 int kto_cov_batch(const kto_counter *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
@@ -744,4 +888,129 @@ void kto_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint6
             bases[i * read_len + p] = c;
         }
     }
+}
+
+/* ------------------------------------------------------------------------ */
+/* The reference's text formats for whole matrices, written to a file - so that the CLI's
+ * multi-batch outputs (gigabytes of text) can be compared byte for byte without formatting
+ * 10^8 numbers in Python.
+ *   fixed6  : Rust `format!("{:.6}", x)` (composition/src/oligo.rs:132-134) = printf("%.6f")
+ *   display : Rust `Display` for f64 (oligo.rs:136, oligocgr.rs:95): the shortest digit string
+ *             that round-trips, positional notation only, integral values without ".0"
+ * Rows are formatted by `threads` workers (contiguous shares), written in row order. */
+static int fmt_display_c(double x, char *out) {
+    if (x != x) return sprintf(out, "NaN");
+    if (x == 0.0) return sprintf(out, (1.0 / x < 0) ? "-0" : "0");
+    if (x - x != 0.0) return sprintf(out, x > 0 ? "inf" : "-inf");
+    if (x == (double)(long long)x && x > -1e15 && x < 1e15) return sprintf(out, "%lld", (long long)x);
+    char buf[40];
+    int p;
+    for (p = 1; p <= 17; p++) {                       /* shortest precision that round-trips */
+        snprintf(buf, sizeof buf, "%.*e", p - 1, x);
+        if (strtod(buf, NULL) == x) break;
+    }
+    /* buf = [-]d.ddddde[+-]XX  ->  positional */
+    char digits[24]; int nd = 0, neg = 0;
+    const char *s = buf;
+    if (*s == '-') { neg = 1; s++; }
+    for (; *s && *s != 'e'; s++) if (*s != '.') digits[nd++] = *s;
+    int ex = atoi(s + 1);
+    while (nd > 1 && digits[nd - 1] == '0') nd--;     /* trailing zeros of the mantissa */
+    int point = 1 + ex;                               /* digits before the decimal point */
+    char *o = out;
+    if (neg) *o++ = '-';
+    if (point <= 0) {
+        *o++ = '0'; *o++ = '.';
+        for (int i = 0; i < -point; i++) *o++ = '0';
+        for (int i = 0; i < nd; i++) *o++ = digits[i];
+    } else if (point >= nd) {
+        for (int i = 0; i < nd; i++) *o++ = digits[i];
+        for (int i = nd; i < point; i++) *o++ = '0';
+    } else {
+        for (int i = 0; i < point; i++) *o++ = digits[i];
+        *o++ = '.';
+        for (int i = point; i < nd; i++) *o++ = digits[i];
+    }
+    *o = 0;
+    return (int)(o - out);
+}
+
+int kto_fmt_display(double x, char *out) { return fmt_display_c(x, out); }
+
+typedef struct {
+    const double *mat; uint64_t r0, r1, cols; int mode; char delim; const double *xy;
+    char *buf; uint64_t len, cap;
+} text_job;
+
+static void text_put(text_job *j, const char *s, int n) {
+    if (j->len + (uint64_t)n + 1 > j->cap) {
+        j->cap = (j->cap + (uint64_t)n) * 2 + 4096;
+        j->buf = (char *)realloc(j->buf, j->cap);
+    }
+    memcpy(j->buf + j->len, s, (size_t)n);
+    j->len += (uint64_t)n;
+}
+
+/* mode 0 = display, 1 = fixed6, 2 = "(x,y,v)" triples of `comp cgr -k` (oligocgr.rs:93-97, xy = cgr_coords) */
+static void *text_worker(void *p) {
+    text_job *j = (text_job *)p;
+    char t[400];   /* (a denormal in positional notation has ~330 characters) */
+    /* display-mode values repeat (counts / read lengths): a small memo keyed by the bit pattern */
+    enum { MEMO = 1 << 14, MEMO_LEN = 48 };
+    uint64_t *mk = NULL; char (*mv)[MEMO_LEN] = NULL;
+    if (j->mode != 1) { mk = (uint64_t *)malloc(MEMO * 8); mv = malloc(MEMO * MEMO_LEN); memset(mk, 0xFF, MEMO * 8); }
+    for (uint64_t r = j->r0; r < j->r1; r++) {
+        const double *row = j->mat + r * j->cols;
+        for (uint64_t c = 0; c < j->cols; c++) {
+            if (c) text_put(j, &j->delim, 1);
+            if (j->mode == 1) {
+                text_put(j, t, snprintf(t, sizeof t, "%.6f", row[c]));
+                continue;
+            }
+            if (j->mode == 2) {
+                text_put(j, "(", 1);
+                text_put(j, t, fmt_display_c(j->xy[2 * c], t));
+                text_put(j, ",", 1);
+                text_put(j, t, fmt_display_c(j->xy[2 * c + 1], t));
+                text_put(j, ",", 1);
+            }
+            uint64_t bits; memcpy(&bits, &row[c], 8);
+            uint64_t h = (bits * 0x9e3779b97f4a7c15ULL) >> 50;
+            if (mk[h] != bits || bits == ~0ULL) {
+                const int n = fmt_display_c(row[c], t);
+                if (n >= MEMO_LEN) { text_put(j, t, n); if (j->mode == 2) text_put(j, ")", 1); continue; }
+                mk[h] = bits; memcpy(mv[h], t, (size_t)n + 1);
+            }
+            text_put(j, mv[h], (int)strlen(mv[h]));
+            if (j->mode == 2) text_put(j, ")", 1);
+        }
+        text_put(j, "\n", 1);
+    }
+    free(mk); free(mv);
+    return NULL;
+}
+
+/* appends (append != 0) or writes the text of `rows` x `cols` values to `path`; 0 on success */
+int kto_matrix_text_file(const double *mat, uint64_t rows, uint64_t cols, int mode, char delim, const double *xy,
+                         const char *path, int append, int threads) {
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > rows) threads = rows ? (int)rows : 1;
+    text_job *jobs = (text_job *)calloc((size_t)threads, sizeof(text_job));
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    for (int i = 0; i < threads; i++) {
+        jobs[i].mat = mat; jobs[i].cols = cols; jobs[i].mode = mode; jobs[i].delim = delim; jobs[i].xy = xy;
+        jobs[i].r0 = rows * (uint64_t)i / (uint64_t)threads;
+        jobs[i].r1 = rows * (uint64_t)(i + 1) / (uint64_t)threads;
+        pthread_create(&th[i], NULL, text_worker, &jobs[i]);
+    }
+    FILE *f = fopen(path, append ? "ab" : "wb");
+    int err = f == NULL;
+    for (int i = 0; i < threads; i++) {
+        pthread_join(th[i], NULL);
+        if (f && jobs[i].len && fwrite(jobs[i].buf, 1, jobs[i].len, f) != jobs[i].len) err = 1;
+        free(jobs[i].buf);
+    }
+    if (f && fclose(f) != 0) err = 1;
+    free(jobs); free(th);
+    return err;
 }

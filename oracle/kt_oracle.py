@@ -64,6 +64,8 @@ def lib():
         L.kto_counter_free.argtypes = [C.c_void_p]
         L.kto_counter_add_reads.restype = C.c_int
         L.kto_counter_add_reads.argtypes = [C.c_void_p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_int]
+        L.kto_counter_reserve.restype = None
+        L.kto_counter_reserve.argtypes = [C.c_void_p, C.c_uint64]
         L.kto_counter_add_pairs.restype = C.c_int
         L.kto_counter_add_pairs.argtypes = [C.c_void_p, u64p, u32p, C.c_uint64]
         L.kto_counter_size.restype = C.c_uint64
@@ -84,6 +86,11 @@ def lib():
         L.kto_cgr_batch.argtypes = [u8p, u64p, C.c_uint64, C.c_double, f64p]
         L.kto_cov_batch.restype = C.c_int
         L.kto_cov_batch.argtypes = [C.c_void_p, u8p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, f64p]
+        L.kto_matrix_text_file.restype = C.c_int
+        L.kto_matrix_text_file.argtypes = [f64p, C.c_uint64, C.c_uint64, C.c_int, C.c_char, f64p, C.c_char_p, C.c_int,
+                                           C.c_int]
+        L.kto_fmt_display.restype = C.c_int
+        L.kto_fmt_display.argtypes = [C.c_double, C.c_char_p]
         L.kto_synth_reads.restype = None
         L.kto_synth_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
                                       C.c_uint64, u8p]
@@ -271,6 +278,10 @@ class Counter:
         bb = bases if bases.size else np.zeros(1, np.uint8)
         lib().kto_counter_add_reads(self.h, _p(bb, u8p), _p(offsets, u64p), len(offsets) - 1, k, threads)
 
+    def reserve(self, keys):
+        """room for `keys` distinct k-mers (scc grows while it adds; this map is sized between threaded phases)"""
+        lib().kto_counter_reserve(self.h, int(keys))
+
     def add_pairs(self, keys, counts):
         keys = np.ascontiguousarray(keys, np.uint64)
         counts = np.ascontiguousarray(counts, np.uint32)
@@ -378,6 +389,25 @@ def oligo_text(mat, norm, delim=" ", header_line=None):
     for row in mat:
         lines.append(delim.join(f(v) for v in row) + "\n")
     return "".join(lines).encode()
+
+
+def matrix_text_file(mat, path, mode="fixed6", delim=" ", xy=None, append=False, threads=8):
+    """Writes / appends the reference's text of a row matrix to `path` with the C formatter (multi-batch CLI
+    comparisons: too many numbers for the Python formatters above, which it is tested against).
+    mode: "fixed6" ({:.6}), "display" (Rust Display) or "cgr" ("(x,y,v)" triples, xy = cgr_coords)."""
+    mat = np.ascontiguousarray(mat, np.float64)
+    m = {"display": 0, "fixed6": 1, "cgr": 2}[mode]
+    xyp = None if xy is None else _p(np.ascontiguousarray(xy, np.float64), f64p)
+    rc = lib().kto_matrix_text_file(_p(mat, f64p), mat.shape[0], mat.shape[1], m, delim.encode(), xyp,
+                                    str(path).encode(), int(append), threads)
+    if rc:
+        raise OSError("kto_matrix_text_file(%s) failed" % path)
+
+
+def fmt_display_c(x):
+    buf = C.create_string_buffer(400)
+    lib().kto_fmt_display(float(x), buf)
+    return buf.value.decode()
 
 
 def oligocgr_text(mat, xy):

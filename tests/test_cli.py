@@ -320,3 +320,148 @@ def test_parallel_reader_matches_serial(cli, tmp_path):
         assert serial[1] == n
         for threads in (2, 5):
             assert digest(path, threads) == serial
+
+
+# ---- several batches, several threads, repeated: the reference's own end-to-end idiom ----------------------------
+def _write_reads(path, n, seed, fastq=False, genome=0, chunk=100_000):
+    """n ragged reads (40..260 bases; N, lower case; genome > 0: sampled from a random genome of that length so that
+    k-mers repeat) as FASTA or FASTQ with ids r0000000...; -> (bases u8[total], offsets u64[n + 1]).  Some FASTQ
+    quality lines begin with '@' (legal, and the record-boundary finder of the parallel reader has to cope)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    gen = alpha[rng.integers(0, 4, size=genome)] if genome else None
+    all_bases, all_lens = [], []
+    with open(path, "wb") as fh:
+        for c0 in range(0, n, chunk):
+            m = min(chunk, n - c0)
+            lens = rng.integers(40, 261, size=m)
+            lens[rng.random(m) < 0.001] = 0                     # a few empty records
+            off = np.zeros(m + 1, np.int64)
+            np.cumsum(lens, out=off[1:])
+            T = int(off[-1])
+            if genome:
+                start = rng.integers(0, genome - 260, size=m)
+                idx = np.repeat(start - off[:-1], lens) + np.arange(T)
+                b = gen[idx].copy()
+                err = rng.random(T) < 0.01
+                b[err] = alpha[rng.integers(0, 4, size=int(err.sum()))]
+            else:
+                b = alpha[rng.integers(0, 4, size=T)]
+            r = rng.random(T)
+            b[r < 0.002] = ord("N")
+            b[(r > 0.002) & (r < 0.02)] |= 0x20
+            # records: ">r0000000\n" + seq + "\n"   or   "@r0000000\n" + seq + "\n+\n" + qual + "\n"
+            ids = np.arange(c0, c0 + m)
+            hdr = np.empty((m, 10), np.uint8)
+            hdr[:, 0] = ord("@" if fastq else ">")
+            hdr[:, 1] = ord("r")
+            for d in range(7):
+                hdr[:, 8 - d] = ord("0") + (ids // 10 ** d) % 10
+            hdr[:, 9] = ord("\n")
+            per = 10 + lens + 1 + ((2 + lens + 1) if fastq else 0)
+            rs = np.zeros(m + 1, np.int64)
+            np.cumsum(per, out=rs[1:])
+            out = np.full(int(rs[-1]), ord("\n"), np.uint8)
+            out[(rs[:-1, None] + np.arange(10)[None, :]).ravel()] = hdr.ravel()
+            rid = np.repeat(np.arange(m), lens)
+            within = np.arange(T) - off[:-1][rid]
+            out[rs[:-1][rid] + 10 + within] = b
+            if fastq:
+                out[rs[:-1] + 10 + lens + 1] = ord("+")
+                q = np.full(T, ord("I"), np.uint8)
+                first = off[:-1][lens > 0]
+                q[first[rng.random(first.size) < 0.02]] = ord("@")
+                out[rs[:-1][rid] + 10 + lens[rid] + 3 + within] = q
+            fh.write(out.tobytes())
+            all_bases.append(b)
+            all_lens.append(lens)
+    lens = np.concatenate(all_lens)
+    offsets = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    return np.concatenate(all_bases), offsets
+
+
+def _same_file(a, b):
+    import filecmp
+    return filecmp.cmp(str(a), str(b), shallow=False)
+
+
+@pytest.mark.gpu
+def test_cli_many_batches_many_threads_repeated(cli, oracle, tmp_path):
+    """composition/src/oligo.rs:327-368: the reference's tests push a file through several batches with 8 threads and
+    repeat the run, comparing the bytes.  Here: 1.4 M ragged reads (4 batches of 64 Mbases through the rotating work
+    items, the pinned row buffers, the ordered writer), FASTA and FASTQ, -t 1 and -t 8, the parallel reader on and off,
+    `comp oligo -k 4` normalised (three times over) and -c against the oracle's text byte for byte; then `comp cgr
+    -k 5`, `ctr -k 21` and `cov -k 15` over many (forced) batches of reads that share k-mers."""
+    import os
+    import numpy as np
+    n = 1_400_000
+    fa, fq = tmp_path / "big.fa", tmp_path / "big.fq"
+    bases, offsets = _write_reads(fa, n, 21)
+    assert int(offsets[-1]) > 3 * (64 << 20)                      # more than three 64-Mbase batches
+    cores = min(os.cpu_count() or 8, 32)
+    want_n, want_c = tmp_path / "want_norm", tmp_path / "want_counts"
+    for r0 in range(0, n, 120_000):                                # the oracle's rows, a slab at a time
+        r1 = min(n, r0 + 120_000)
+        b, o = bases[int(offsets[r0]):int(offsets[r1])], offsets[r0:r1 + 1] - offsets[r0]
+        oracle.matrix_text_file(oracle.oligo_batch(b, o, 4, True, True, threads=cores), want_n, "fixed6",
+                                append=r0 > 0, threads=cores)
+        oracle.matrix_text_file(oracle.oligo_batch(b, o, 4, True, False, threads=cores), want_c, "display",
+                                append=r0 > 0, threads=cores)
+    out = tmp_path / "out"
+    serial = dict(os.environ, KT_READER_THREADS="1")
+
+    def oligo(src, *extra, env=None):
+        r = run(cli, "comp", "oligo", "-i", src, "-o", out, "-k", 4, *extra, env=env)
+        assert r.returncode == 0 and r.stderr == "", r.stderr
+    for rep in range(3):                                           # the reference's repetition idiom
+        oligo(fa, "-t", 8)
+        assert _same_file(out, want_n), "normalised, -t 8, parallel reader, repeat %d" % rep
+    oligo(fa, "-t", 1, env=serial)
+    assert _same_file(out, want_n), "normalised, -t 1, serial reader"
+    oligo(fa, "-t", 8, "-c", env=serial)
+    assert _same_file(out, want_c), "-c, -t 8, serial reader"
+    _write_reads(fq, n, 21, fastq=True)                            # the same reads as FASTQ
+    oligo(fq, "-t", 1, "-c")
+    assert _same_file(out, want_c), "-c, -t 1, FASTQ, parallel reader"
+    oligo(fq, "-t", 8)
+    assert _same_file(out, want_n), "normalised, -t 8, FASTQ, parallel reader"
+    for p in (out, want_n, want_c, fq, fa):
+        p.unlink()
+
+    # reads that share k-mers (37x over a 3 Mbp genome), pushed through many small batches
+    m = 420_000
+    g = tmp_path / "genome_reads.fa"
+    gb, go = _write_reads(g, m, 22, genome=3_000_000)
+    assert g.stat().st_size > (32 << 20)                           # big enough for the parallel reader
+    import pandas as pd
+    small = dict(os.environ, KT_CLI_BATCH_BASES=str(13 << 20), KT_CLI_BATCH_READS="70000")
+    keys, counts = oracle.count_reads(gb, go, 21, n_parts=cores, threads=cores)
+    oc = oracle.Counter(cores)
+    oc.add_reads(gb, go, 15, threads=cores)
+    want_v = tmp_path / "want_cov"
+    oracle.matrix_text_file(oc.cov_batch(gb, go, 15, 16, 16, True), want_v, "fixed6", threads=cores)
+    del oc
+    for env in (small, dict(small, KT_READER_THREADS="1")):
+        d = tmp_path / "ctr"
+        r = run(cli, "ctr", "-i", g, "-o", d, "-k", 21, "-t", 8, env=env)
+        assert r.returncode == 0, r.stderr
+        got = pd.read_csv(d / "kmers.counts", sep="\t", header=None, dtype=np.uint64).to_numpy()
+        order = np.argsort(got[:, 0], kind="stable")
+        assert np.array_equal(got[order, 0], keys) and np.array_equal(got[order, 1], counts.astype(np.uint64))
+        del got
+        cv = tmp_path / "cov"
+        r = run(cli, "cov", "-i", g, "-o", cv, "-k", 15, "-t", 8, env=env)
+        assert r.returncode == 0, r.stderr
+        assert _same_file(cv / "kmers.vectors", want_v)
+    sub = 60_000
+    s = tmp_path / "sub.fa"
+    sb, so = _write_reads(s, sub, 23, genome=3_000_000)
+    want_g = tmp_path / "want_cgr"
+    oracle.matrix_text_file(oracle.oligo_batch(sb, so, 5, True, True, threads=cores), want_g, "cgr",
+                            xy=oracle.cgr_coords(5, 1), threads=cores)
+    for t in (1, 8):
+        r = run(cli, "comp", "cgr", "-i", s, "-o", out, "-k", 5, "-t", t, env=dict(os.environ, KT_CLI_BATCH_READS="9000"))
+        assert r.returncode == 0 and r.stderr == "", r.stderr
+        assert _same_file(out, want_g), "comp cgr -k 5, -t %d, 7 batches" % t
