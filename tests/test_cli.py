@@ -329,6 +329,7 @@ def _write_reads(path, n, seed, fastq=False, genome=0, chunk=100_000):
     quality lines begin with '@' (legal, and the record-boundary finder of the parallel reader has to cope)."""
     import numpy as np
     rng = np.random.default_rng(seed)
+    qrng = np.random.default_rng(seed + 1000)   # (its own stream: FASTA and FASTQ of one seed hold the same reads)
     alpha = np.frombuffer(b"ACGT", np.uint8)
     gen = alpha[rng.integers(0, 4, size=genome)] if genome else None
     all_bases, all_lens = [], []
@@ -371,7 +372,7 @@ def _write_reads(path, n, seed, fastq=False, genome=0, chunk=100_000):
                 out[rs[:-1] + 10 + lens + 1] = ord("+")
                 q = np.full(T, ord("I"), np.uint8)
                 first = off[:-1][lens > 0]
-                q[first[rng.random(first.size) < 0.02]] = ord("@")
+                q[first[qrng.random(first.size) < 0.02]] = ord("@")
                 out[rs[:-1][rid] + 10 + lens[rid] + 3 + within] = q
             fh.write(out.tobytes())
             all_bases.append(b)
