@@ -461,7 +461,7 @@ def test_cli_many_batches_many_threads_repeated(cli, oracle, tmp_path):
     sb, so = _write_reads(s, sub, 23, genome=3_000_000)
     want_g = tmp_path / "want_cgr"
     oracle.matrix_text_file(oracle.oligo_batch(sb, so, 5, True, True, threads=cores), want_g, "cgr",
-                            xy=oracle.cgr_coords(5, 1), threads=cores)
+                            xy=oracle.cgr_coords(5, 25), threads=cores)   # (vec-size defaults to k^2, args.rs:266-269)
     for t in (1, 8):
         r = run(cli, "comp", "cgr", "-i", s, "-o", out, "-k", 5, "-t", t, env=dict(os.environ, KT_CLI_BATCH_READS="9000"))
         assert r.returncode == 0 and r.stderr == "", r.stderr
