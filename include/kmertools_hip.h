@@ -241,22 +241,27 @@ int kt_ctr_route(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uin
 
 /* ---- one table sharded over the GPUs of a node (hash-prefix ownership) -------------------------------------------
  * replaces: the `n_parts` partitioning of counter/src/lib.rs:100,127,243-247 and the per-partition merge of
- * :188-231 - the partitions are GPUs.  Rank o (one process or thread, one kt_ctx, one GPU) owns every canonical k-mer
- * with kt_owner_of(kmer, n_ranks) == o.  kt_sharded_add_reads and kt_sharded_finalize are COLLECTIVE: every rank
- * calls them the same number of times (a rank without reads passes n_reads = 0).  Each rank routes the canonical
- * k-mers of its reads into per-owner regions, exchanges the regions with every peer (grouped ncclSend / ncclRecv
- * from librccl over xGMI, or the caller's host all-to-all), and counts what it received into its own shard with the
- * same partition + range build as a single-GPU table; the batch is cut into slices so that routing, the exchange
- * and the counting overlap.  Results stay sharded: the union of the ranks' exports is the answer (the reference's
- * output order is unspecified anyway).  With n_ranks == 1 everything degenerates to kt_ctr_add_reads. */
+ * :188-231 - the partitions are GPUs.  The N shards are the pieces of ONE table addressed by the top bits of the
+ * k-mer's hash: rank o (one process or thread, one kt_ctx, one GPU) holds the hash prefixes (level-1 buckets of the
+ * partition passes) [ceil(o B / N), ceil((o + 1) B / N)) of B = 2^b - kt_sharded_owner_of tells which rank owns a
+ * k-mer.  kt_sharded_add_reads and kt_sharded_finalize are COLLECTIVE: every rank calls them the same number of times
+ * (a rank without reads passes n_reads = 0).  Each rank runs the first partition pass over its own reads - its output
+ * regions ARE the messages - exchanges them with every peer (grouped ncclSend / ncclRecv from librccl over xGMI, or
+ * the caller's host all-to-all), and runs the second pass and the range builds over what it owns; the batch is cut
+ * into slices so that the first pass and the exchange overlap.  Results stay sharded: the union of the ranks' exports
+ * is the answer (the reference's output order is unspecified anyway).  With n_ranks == 1 everything degenerates to
+ * kt_ctr_add_reads.  A rank that cannot take part in a collective call (a batch larger than agreed, a pending list
+ * that overflowed) still completes the exchange, and EVERY rank returns an error - none is left waiting. */
 typedef struct kt_sharded kt_sharded;
 
 /* 128-byte RCCL unique id (ncclGetUniqueId): rank 0 makes it, the caller hands it to the other ranks (any channel:
  * MPI, a file, torch.distributed's store) */
 int kt_rccl_unique_id(uint8_t *id128);
 
-/* capacity_slots: slots of THIS rank's shard (kt_ctr_create); max_batch_bases: the largest batch any rank will pass
- * to kt_sharded_add_reads - it fixes the size of the exchanged regions, so it must be the same on every rank. */
+/* capacity_slots: slots per rank's shard (the rank with the fewest hash prefixes gets at least that many; the same
+ * value on every rank - the ranks derive the whole table's geometry from it); max_batch_bases: the largest batch any
+ * rank will pass to kt_sharded_add_reads - it fixes the size of the exchanged regions, so it must be the same on
+ * every rank. */
 int kt_sharded_create_rccl(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t max_batch_bases, int n_ranks, int rank,
                            const uint8_t *id128, kt_sharded **out);
 
@@ -266,6 +271,14 @@ int kt_sharded_create_rccl(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t
 typedef int (*kt_alltoall_fn)(void *user, const void *send, void *recv, uint64_t bytes_per_rank);
 int kt_sharded_create_host(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t max_batch_bases, int n_ranks, int rank,
                            kt_alltoall_fn fn, void *user, kt_sharded **out);
+/* The same in two steps, for callers that want to agree between them: kt_sharded_create_local allocates everything
+ * (the shard, the exchange buffers) and needs no peer; once EVERY rank has succeeded (the caller's own barrier: a
+ * rank whose allocation failed never enters ncclCommInitRank, where its peers would wait for it), kt_sharded_connect_rccl
+ * / kt_sharded_connect_host brings the transport up. */
+int kt_sharded_create_local(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t max_batch_bases, int n_ranks, int rank,
+                            kt_sharded **out);
+int kt_sharded_connect_rccl(kt_sharded *s, const uint8_t *id128);
+int kt_sharded_connect_host(kt_sharded *s, kt_alltoall_fn fn, void *user);
 int kt_sharded_destroy(kt_sharded *s);
 int kt_sharded_clear(kt_sharded *s);
 
@@ -279,13 +292,22 @@ int kt_sharded_finalize(kt_sharded *s);
 /* this rank's shard, an ordinary table: kt_ctr_size / kt_ctr_export / kt_cov_batch work on it (owned by `s`) */
 int kt_sharded_table(kt_sharded *s, kt_ctr **table);
 
-/* bytes this rank has sent to other ranks so far; size of one exchanged region (host helper: lets a caller size
- * its transport buffers) */
+/* bytes this rank has sent to other ranks so far */
 int kt_sharded_exchanged_bytes(kt_sharded *s, uint64_t *bytes);
-uint64_t kt_sharded_message_bytes(uint64_t max_batch_bases, int n_ranks, int n_slices);
 
-/* owner rank of a canonical k-mer among n_owners (host helper, same function the
- * device uses): high bits of a 64-bit mix, independent of the table's slot bits. */
+/* the rank that owns a canonical k-mer in this sharded table (host helper, the function the device uses) */
+int kt_sharded_owner_of(kt_sharded *s, uint64_t kmer, uint32_t *owner);
+
+/* The layout every rank derives from (capacity_slots, n_ranks), without a GPU: the number of hash-prefix bits that
+ * ownership goes by, the prefixes [bucket_lo, bucket_hi) of `rank`, the slots of its shard; and the owner of a k-mer
+ * under such a layout: (top prefix_bits of the k-mer's hash) * n_ranks >> prefix_bits.
+ * replaces: `min_mer % n_parts`, counter/src/lib.rs:127 */
+int kt_shard_layout(uint64_t capacity_slots, int n_ranks, int rank, uint32_t *prefix_bits, uint32_t *bucket_lo,
+                    uint32_t *bucket_hi, uint64_t *local_slots);
+uint32_t kt_shard_owner_of(uint64_t kmer, uint32_t prefix_bits, uint32_t n_ranks);
+
+/* hash partition of a canonical k-mer among n_owners (host helper, same function the device uses): what
+ * kt_ctr_add_reads_part and kt_ctr_route split by - the LOW hash bits, independent of a table's slot bits. */
 uint32_t kt_owner_of(uint64_t kmer, uint32_t n_owners);
 
 /* Synthetic reads for benchmarks/parity, generated in HBM:

@@ -62,7 +62,12 @@ SYMBOLS = {
     "kt_sharded_finalize": (_i, [_vp]),
     "kt_sharded_table": (_i, [_vp, C.POINTER(_vp)]),
     "kt_sharded_exchanged_bytes": (_i, [_vp, C.POINTER(_u64)]),
-    "kt_sharded_message_bytes": (_u64, [_u64, _i, _i]),
+    "kt_sharded_create_local": (_i, [_vp, _i, _u64, _u64, _i, _i, C.POINTER(_vp)]),
+    "kt_sharded_connect_rccl": (_i, [_vp, _vp]),
+    "kt_sharded_connect_host": (_i, [_vp, _vp, _vp]),
+    "kt_sharded_owner_of": (_i, [_vp, _u64, C.POINTER(_u32)]),
+    "kt_shard_layout": (_i, [_u64, _i, _i, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64)]),
+    "kt_shard_owner_of": (_u32, [_u64, _u32, _u32]),
     "kt_synth_reads": (_i, [_vp, _u64, _u64, _u64, _u32, _i, _u64, _vp, _vp]),
 }
 

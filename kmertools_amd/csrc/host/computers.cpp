@@ -776,8 +776,18 @@ std::string CountComputer::count_sharded(uint64_t max_distinct) {
     uint64_t per_rank = max_distinct / N + max_distinct / N / 16 + 4096;
     uint64_t cap = per_rank + per_rank / 10 * 9;
     uint8_t id[128] = {};
-    if (!share && kt_rccl_unique_id(id) != KT_OK) return kt_last_error();
+    if (!share) {
+        // a rank thread whose device does not exist would leave the others waiting in ncclCommInitRank
+        int n_dev = 0;
+        if (kt_device_count(&n_dev) != KT_OK) return kt_last_error();
+        if (dev_.index + N > n_dev)
+            return "--devices " + std::to_string(N) + " from device " + std::to_string(dev_.index) + ": this node has " +
+                   std::to_string(n_dev) + " GPU(s)";
+        if (kt_rccl_unique_id(id) != KT_OK) return kt_last_error();
+    }
     LocalFabric fabric(N);
+    std::atomic<int> created_ok{0};
+    const char *inject = getenv("KT_CLI_FAIL_RANK");  // tests: this rank's bring-up fails
     std::vector<FabricEnd> ends(N);
     shard_keys_.assign(N, {});
     shard_counts_.assign(N, {});
@@ -794,13 +804,26 @@ std::string CountComputer::count_sharded(uint64_t max_distinct) {
         kt_ctx *ctx = nullptr;
         kt_sharded *sh = nullptr;
         auto fail = [&](const std::string &e) { errs[rank] = e.empty() ? "error" : e; };
+        // bring-up in two steps with an agreement in between: everything a rank can fail at on its own (its device, its
+        // allocations) happens first; only when EVERY rank got through does anyone enter a collective - the communicator's
+        // creation, then the counting.  Otherwise all ranks stop here with the error (no rank is left waiting for one
+        // that never comes).
         int rc = kt_ctx_create(share ? dev_.index : dev_.index + rank, nullptr, 1, &ctx);
-        if (rc == KT_OK) {
+        if (rc == KT_OK) rc = kt_sharded_create_local(ctx, ksize_, cap, max_batch, N, rank, &sh);
+        const bool injected = rc == KT_OK && inject && atoi(inject) == rank;
+        if (rc == KT_OK && !injected) created_ok.fetch_add(1);
+        else fail(injected ? "injected bring-up failure (KT_CLI_FAIL_RANK)" : kt_last_error());
+        fabric.barrier();
+        const bool all_up = created_ok.load() == N;
+        if (all_up) {
             ends[rank] = FabricEnd{&fabric, rank};
-            rc = share ? kt_sharded_create_host(ctx, ksize_, cap, max_batch, N, rank, local_alltoall, &ends[rank], &sh)
-                       : kt_sharded_create_rccl(ctx, ksize_, cap, max_batch, N, rank, id, &sh);
+            rc = share ? kt_sharded_connect_host(sh, local_alltoall, &ends[rank]) : kt_sharded_connect_rccl(sh, id);
+            if (rc != KT_OK) fail(kt_last_error());  // (a communicator that fails on one rank fails on its peers too)
+        } else {
+            if (errs[rank].empty()) fail("another device's bring-up failed");
+            if (sh) kt_sharded_destroy(sh);
+            sh = nullptr;
         }
-        if (rc != KT_OK) fail(kt_last_error());
         for (int round = 0;; round++) {
             bool last;
             {

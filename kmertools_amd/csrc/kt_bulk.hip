@@ -39,6 +39,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "kt_launch.hpp"
 #include "kt_segment.hpp"
 #include "kt_table.hpp"
 
@@ -86,8 +87,10 @@ struct Plan {
     uint32_t b1, b2;  // hash bits per level; b1 + b2 + LOG2_S == n
     uint32_t B1, B2;
     uint32_t G;       // persistent workgroups of hist1 / scatter1
-    uint64_t cap1;    // paged level 1: keys of room per level-1 bucket in keys1 / keys2
-    uint64_t cap2;    // ... and per fine bucket in keys2 (cap1 / B2)
+    uint64_t cap1;    // paged level 1: keys of room per level-1 bucket in a level-1 output (keys1: one per slice)
+    uint64_t cap2;    // ... and per fine bucket in keys2 (room1 / B2)
+    uint64_t room1;   // keys of room per level-1 bucket in keys2: cap1 x the number of level-1 outputs that feed it
+    uint32_t d_lo, d_hi;  // the level-1 buckets whose ranges this table holds: all B1 of them, or - a shard - its interval
     uint32_t dbg;     // KT_BUILD_DBG: ablation switches of build_kernel (profiling only)
 };
 
@@ -98,9 +101,10 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *H;        // [G][B1] k-mers of workgroup g in bucket d1
     uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
-    uint64_t *gcur;     // [B1] paged level 1: keys of bucket room handed out so far (page allocator)
+    uint64_t *gcur;     // [slices][B1] paged level 1: keys of bucket room handed out so far (page allocator)
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
-    uint32_t *wcur;     // [G][B1] paged level 1: every workgroup's position in its current page of every bucket
+    uint32_t *wcur;     // [slices][G][B1] paged level 1: every workgroup's position in its current page of every bucket
+    kt_seg_src *srcs;   // [n_src] part2's sources (device copy)
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -536,6 +540,18 @@ __global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, ui
 // of 32-byte ones, a quarter of the rounds per segment, 32 key registers instead of 64, so 16 waves fit a CU (one
 // workgroup, ~150 KB of LDS: the sort buffer takes over the staged segments' space).  Same pages, same allocator, same carried state (wcur) as scatter1p, which stays for comparison
 // (KT_S1_WIDE=0).
+// A sender of the sharded counter (kt_shard.hip) cannot redo its level 1 with exact offsets when a bucket's region
+// overflows - the regions are messages of a fixed size - so there the keys that do not fit are COUNTED in a small
+// table of the sender's own (a batch dominated by a few k-mers: poly-A reads, adapters - few distinct keys, many
+// copies; kt_sharded_finalize delivers its (k-mer, count) pairs to their owners) and the pass carries on.
+// slots == nullptr: no such table (the pass stops, the build is redone with exact offsets).
+struct PendList {
+    Slot *slots;
+    kttab::Geom g;
+    uint32_t *flags;     // the pending table's own flags: bit 0 = it is full
+    uint64_t *distinct;  // its distinct-key counter
+};
+
 constexpr int WIDE_T = 1024, WIDE_GROUPS = WIDE_T / BLOCK;
 #ifndef KT_WIDE_PER64
 #define KT_WIDE_PER64 16
@@ -566,7 +582,7 @@ static_assert(sizeof(Scatter1WShared<uint64_t>) <= 160 * 1024 && sizeof(Scatter1
 template <class Source, class K>
 __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, uint64_t *__restrict__ gcur,
                                                            uint32_t *__restrict__ ovf, uint32_t *__restrict__ wcur,
-                                                           K *__restrict__ keys1) {
+                                                           K *__restrict__ keys1, PendList pend) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Scatter1WShared<K> &sm = *reinterpret_cast<Scatter1WShared<K> *>(smem_raw);
     constexpr int PER = wide_per<K>(), NQ = ktseg::PER_THREAD / PER;
@@ -623,12 +639,14 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                 }
             }
             if (room) {
-                if (got + room > p.cap1) {
+                if (got + room > p.cap1 && !pend.slots) {
                     sm.ovf = 1;
                     atomicOr(ovf, 1u);
                 }
-                sm.to_new[tid] = (uint32_t)got - spl;
-                sm.cur[tid] = (uint32_t)got + nxt;
+                // (a region far past its room - a sender's heavy-hitter bucket - must not wrap back into it)
+                const uint32_t g32 = got > 0xE0000000ull ? 0xE0000000u : (uint32_t)got;
+                sm.to_new[tid] = g32 - spl;
+                sm.cur[tid] = g32 + nxt;
             }
             ktd::lds_barrier();
             stop = sm.ovf != 0;  // the same for every thread
@@ -638,7 +656,13 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                     const uint32_t d = digit1h(hash_of_stored<K>(key), p);  // (one shift of a stored hash; 32-bit
                                                                             // keys are hashed again: no room for digits)
                     const uint32_t at = (i < sm.split[d] ? sm.to_cur[d] : sm.to_new[d]) + i;
-                    keys1[(uint64_t)d * p.cap1 + at] = key;
+                    if (at < p.cap1) {
+                        keys1[(uint64_t)d * p.cap1 + at] = key;
+                    } else if (pend.slots) {  // the bucket's region is full: counted aside, delivered later
+                        const uint32_t st = kttab::table_add(TableRef{pend.slots, pend.g, pend.flags}, from_stored<K>(key), 1u);
+                        if (st == 0u) atomicOr(pend.flags, 1u);
+                        else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(pend.distinct), 1ull);
+                    }
                 }
             }
             ktd::lds_barrier();
@@ -656,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) void page_tails_kernel(Plan p, const uint32_
     for (uint32_t idx = threadIdx.x; idx < p.B1 * PAGE; idx += BLOCK) {
         const uint32_t d = idx / PAGE, q = idx % PAGE;
         const uint32_t cur = wcur[(uint64_t)blockIdx.x * p.B1 + d];
-        if (q < ((0u - cur) & (PAGE - 1u))) keys1[(uint64_t)d * p.cap1 + cur + q] = empty_of<K>();
+        if (q < ((0u - cur) & (PAGE - 1u)) && (uint64_t)cur + q < p.cap1) keys1[(uint64_t)d * p.cap1 + cur + q] = empty_of<K>();
     }
 }
 
@@ -696,10 +720,20 @@ struct Part2Shared {
 // processed so far, and as soon as one is heading past its room it stops placing keys, finishes the pass counting
 // only (which is exactly the histogram), and the bucket is redone with the exact boundaries - the price of a
 // wrong guess is the part of the pass done before it was noticed.
+// Where part2 reads a bucket from.  A bucket's keys arrive in SEGMENTS - one per level-1 output that holds keys of the
+// bucket: one for a table of its own; for a shard of the sharded counter one per (slice, sender), the regions the
+// other GPUs' level-1 passes filled and sent (kt_shard.hip).  Segment s of local bucket jl = srcs[s].keys + jl * cap1,
+// min(srcs[s].counts[jl], cap1) keys, empty keys in the page gaps.  (exact level 1, srcs == nullptr: keys1 is dense,
+// bucket j = [bstart[j], bstart[j + 1]).)
+struct P2In {
+    const void *keys1;
+    const uint64_t *bstart;
+    const kt_seg_src *srcs;
+    uint32_t n_src;
+};
+
 template <class K, bool FIXED, bool BIG>
-__global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void part2_kernel(const K *__restrict__ keys1,
-                                                      const uint64_t *__restrict__ bstart,
-                                                      const uint64_t *__restrict__ gcur, Plan p,
+__global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void part2_kernel(P2In in, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart,
                                                       uint64_t *__restrict__ fend) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -707,94 +741,121 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
     constexpr K EMPTY = empty_of<K>();
     constexpr int P2T = p2t<K, BIG>();
     constexpr int PER = chunk2<K, BIG>() / P2T;  // 16 (32) keys per thread, held in registers
+    constexpr uint32_t CH = chunk2<K, BIG>();
     const uint32_t tid = threadIdx.x;
-    for (uint32_t j = blockIdx.x; j < p.B1; j += gridDim.x) {
-        // exact level 1: keys1 is dense; paged level 1 (cap1 != 0): the bucket's region, empty keys in the gaps
-        const uint64_t lo = p.cap1 ? (uint64_t)j * p.cap1 : bstart[j];
-        const uint64_t hi = p.cap1 ? lo + gcur[j] : bstart[j + 1];
-        auto load_chunk = [&](uint64_t c0, K (&dst)[PER]) {
+    const uint32_t nd = p.d_hi - p.d_lo;
+    for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
+        // the bucket's segments, and where the bucket lives in keys2
+        const uint32_t n_seg = in.srcs ? in.n_src : 1u;
+        auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
+            if (in.srcs) {
+                const kt_seg_src &q = in.srcs[sidx];
+                const uint64_t c = q.counts[jl];
+                base = reinterpret_cast<const K *>(q.keys) + (uint64_t)jl * q.cap1;
+                n = c < q.cap1 ? c : q.cap1;
+            } else {
+                base = reinterpret_cast<const K *>(in.keys1) + in.bstart[jl];
+                n = in.bstart[jl + 1] - in.bstart[jl];
+            }
+        };
+        uint64_t total = 0;
+        for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
+            const K *b;
+            uint64_t n;
+            segment(sidx, b, n);
+            total += n;
+        }
+        const uint64_t lo = in.srcs ? (uint64_t)jl * p.room1 : in.bstart[jl];
+        auto load_chunk = [&](const K *base, uint64_t n, uint64_t c0, K (&dst)[PER]) {
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint64_t i = c0 + (uint64_t)u * P2T + tid;
-                dst[u] = i < hi ? keys1[i] : EMPTY;
+                dst[u] = i < n ? base[i] : EMPTY;
             }
         };
-        // one pass over the bucket in chunks of chunk2<K, BIG>() keys: counting sort in LDS, runs appended at the fine
-        // buckets' cursors.  The next chunk's keys are loaded while the current one is sorted; digits are hashed once.
+        // one pass over the bucket in chunks of chunk2<K, BIG>() keys, segment after segment: counting sort in LDS, runs
+        // appended at the fine buckets' cursors.  The next chunk's keys are loaded while the current one is sorted.
         // attempt = fixed fine regions (cursors may run past their room: then nothing is stored any more)
         auto run_pass = [&](const bool attempt) {
             K kcur[PER], knxt[PER];
             bool counting_only = false;
-            if (lo < hi) load_chunk(lo, kcur);
-            for (uint64_t c0 = lo; c0 < hi; c0 += chunk2<K, BIG>()) {
-                if (c0 + chunk2<K, BIG>() < hi) load_chunk(c0 + chunk2<K, BIG>(), knxt);
-                for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
-                ktd::lds_barrier();
-                if (attempt) counting_only = *sm.flag != 0;  // (written before the barrier above; same for every thread)
-                // digits, two per register - unless they are a bit field of the stored hash: then the place pass shifts
-                // them out again (16 K-key chunks of 64-bit keys + the prefetched chunk leave no registers to spare: the
-                // kept digits were what spilled)
-                constexpr bool KEEP_DIG = !stores_hash<K>();
-                uint32_t dgp[KEEP_DIG ? PER / 2 : 1];
-#pragma unroll
-                for (int u = 0; u < PER; u++) {
-                    const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
-                    if constexpr (KEEP_DIG) dgp[u / 2] = (u & 1) ? dgp[u / 2] | (d << 16) : d;
-                    if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[d], 1u);
-                }
-                ktd::lds_barrier();
-                if (!counting_only) {
-                    const uint32_t nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
-                    // (cnt has been summed: from here to the cursor update it holds cur - start, what the copy-out adds
-                    // to a sorted key's index to get its place in the level-1 bucket)
-                    for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = sm.cur[i] - sm.start[i];
+            uint64_t seen_keys = 0;
+            for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
+                const K *base;
+                uint64_t n;
+                segment(sidx, base, n);
+                if (n) load_chunk(base, n, 0, kcur);
+                for (uint64_t c0 = 0; c0 < n; c0 += CH) {
+                    if (c0 + CH < n) load_chunk(base, n, c0 + CH, knxt);
+                    for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
                     ktd::lds_barrier();
+                    if (attempt) counting_only = *sm.flag != 0;  // (written before the barrier above; same for every thread)
+                    // digits, two per register - unless they are a bit field of the stored hash: then the place pass
+                    // shifts them out again
+                    constexpr bool KEEP_DIG = !stores_hash<K>();
+                    uint32_t dgp[KEEP_DIG ? PER / 2 : 1];
 #pragma unroll
                     for (int u = 0; u < PER; u++) {
-                        if (kcur[u] != EMPTY) {
-                            uint32_t d;
-                            if constexpr (KEEP_DIG) d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
-                            else d = digit2h(hash_of_stored<K>(kcur[u]), p);
-                            const uint32_t pos = atomicAdd(&sm.start[d], 1u);
-                            sm.sorted[pos] = kcur[u];
-                            if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
-                        }
+                        const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
+                        if constexpr (KEEP_DIG) dgp[u / 2] = (u & 1) ? dgp[u / 2] | (d << 16) : d;
+                        if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[d], 1u);
                     }
                     ktd::lds_barrier();
-                    for (uint32_t i = tid; i < nc; i += P2T) {
-                        const K key = sm.sorted[i];
-                        uint32_t d;
-                        if constexpr (p2_sdig<K, BIG>()) d = sm.sdig[i];
-                        else d = digit2h(hash_of_stored<K>(key), p);
-                        const uint64_t pos = lo + (uint32_t)(sm.cnt[d] + i);
-                        if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = key;
-                    }
-                    ktd::lds_barrier();
-                }
-                // cursors move on; during an attempt every fine bucket's fill is held against its room scaled to
-                // the part of the level-1 bucket seen so far (+ 6 sigma): hashed distinct keys never get there
-                float allowed = 0.f;
-                if (attempt) {
-                    const float seen = (float)(c0 + chunk2<K, BIG>() - lo) / (float)(hi - lo);
-                    const float room = (float)p.cap2 * (seen < 1.f ? seen : 1.f);
-                    allowed = 0.93f * room + 6.f * sqrtf(room) + 32.f;
-                }
-                for (uint32_t i = tid; i < p.B2; i += P2T) {
-                    // placed: start[] stands at the runs' ends, so start + (cur - start at their beginnings) = cur + count
-                    const uint32_t c = counting_only ? sm.cur[i] + sm.cnt[i] : sm.start[i] + sm.cnt[i];
-                    sm.cur[i] = c;
-                    if (attempt && !counting_only && (float)(c - i * (uint32_t)p.cap2) > allowed) *sm.flag = 1;
-                }
+                    if (!counting_only) {
+                        const uint32_t nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
+                        // (cnt has been summed: from here to the cursor update it holds cur - start, what the copy-out
+                        // adds to a sorted key's index to get its place in the level-1 bucket)
+                        for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = sm.cur[i] - sm.start[i];
+                        ktd::lds_barrier();
 #pragma unroll
-                for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
-                // (the next iteration's first barrier orders the cursor / flag updates before their use)
+                        for (int u = 0; u < PER; u++) {
+                            if (kcur[u] != EMPTY) {
+                                uint32_t d;
+                                if constexpr (KEEP_DIG) d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
+                                else d = digit2h(hash_of_stored<K>(kcur[u]), p);
+                                const uint32_t pos = atomicAdd(&sm.start[d], 1u);
+                                sm.sorted[pos] = kcur[u];
+                                if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
+                            }
+                        }
+                        ktd::lds_barrier();
+                        for (uint32_t i = tid; i < nc; i += P2T) {
+                            const K key = sm.sorted[i];
+                            uint32_t d;
+                            if constexpr (p2_sdig<K, BIG>()) d = sm.sdig[i];
+                            else d = digit2h(hash_of_stored<K>(key), p);
+                            const uint64_t pos = lo + (uint32_t)(sm.cnt[d] + i);
+                            if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = key;
+                        }
+                        ktd::lds_barrier();
+                    }
+                    // cursors move on; during an attempt every fine bucket's fill is held against its room scaled to
+                    // the part of the level-1 bucket seen so far (+ 6 sigma): hashed distinct keys never get there
+                    float allowed = 0.f;
+                    if (attempt) {
+                        const float seen = (float)(seen_keys + c0 + CH) / (float)total;
+                        // (the bucket may hold fewer keys than its room: what counts is the share of a fine bucket)
+                        const float room = (float)p.cap2 * (seen < 1.f ? seen : 1.f);
+                        allowed = 0.93f * room + 6.f * sqrtf(room) + 32.f;
+                    }
+                    for (uint32_t i = tid; i < p.B2; i += P2T) {
+                        // placed: start[] stands at the runs' ends, so start + (cur - start at their beginnings) = cur + count
+                        const uint32_t c = counting_only ? sm.cur[i] + sm.cnt[i] : sm.start[i] + sm.cnt[i];
+                        sm.cur[i] = c;
+                        if (attempt && !counting_only && (float)(c - i * (uint32_t)p.cap2) > allowed) *sm.flag = 1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
+                    // (the next iteration's first barrier orders the cursor / flag updates before their use)
+                }
+                seen_keys += n;
             }
             ktd::lds_barrier();
         };
 
         bool exact = !FIXED;
         if constexpr (FIXED) {
-            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cur[i] = i * (uint32_t)p.cap2;  // (cap1 = B2 * cap2 < 2^32)
+            for (uint32_t i = tid; i < p.B2; i += P2T) sm.cur[i] = i * (uint32_t)p.cap2;  // (room1 = B2 * cap2 < 2^32)
             if (tid == 0) *sm.flag = 0;
             ktd::lds_barrier();
             run_pass(true);
@@ -804,8 +865,8 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
             ktd::lds_barrier();
             if (*sm.flag == 0) {
                 for (uint32_t i = tid; i < p.B2; i += P2T) {
-                    fstart[(uint64_t)j * p.B2 + i] = lo + (uint64_t)i * p.cap2;
-                    fend[(uint64_t)j * p.B2 + i] = lo + sm.cur[i];
+                    fstart[(uint64_t)jl * p.B2 + i] = lo + (uint64_t)i * p.cap2;
+                    fend[(uint64_t)jl * p.B2 + i] = lo + sm.cur[i];
                 }
             } else {  // no: the cursors hold the exact sizes now
                 for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = sm.cur[i] - i * (uint32_t)p.cap2;
@@ -816,16 +877,21 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
             // whole-bucket histogram of d2
             for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
             ktd::lds_barrier();
-            for (uint64_t i0 = lo + tid; i0 < hi; i0 += (uint64_t)P2T * 8) {  // 8 loads in flight per thread
-                K kk[8];
+            for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
+                const K *base;
+                uint64_t n;
+                segment(sidx, base, n);
+                for (uint64_t i0 = tid; i0 < n; i0 += (uint64_t)P2T * 8) {  // 8 loads in flight per thread
+                    K kk[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint64_t i = i0 + (uint64_t)u * P2T;
-                    kk[u] = i < hi ? keys1[i] : EMPTY;
+                    for (int u = 0; u < 8; u++) {
+                        const uint64_t i = i0 + (uint64_t)u * P2T;
+                        kk[u] = i < n ? base[i] : EMPTY;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2h(hash_of_stored<K>(kk[u]), p)], 1u);
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2h(hash_of_stored<K>(kk[u]), p)], 1u);
             }
             ktd::lds_barrier();
         }
@@ -835,8 +901,8 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
             for (uint32_t i = tid; i < p.B2; i += P2T) {
                 const uint64_t pos = lo + sm.start[i];
                 sm.cur[i] = sm.start[i];
-                fstart[(uint64_t)j * p.B2 + i] = pos;
-                fend[(uint64_t)j * p.B2 + i] = pos + sm.cnt[i];
+                fstart[(uint64_t)jl * p.B2 + i] = pos;
+                fend[(uint64_t)jl * p.B2 + i] = pos + sm.cnt[i];
             }
             ktd::lds_barrier();
             run_pass(false);
@@ -962,7 +1028,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
     K *const skeys = reinterpret_cast<K *>(smem_raw);
     uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)RS * sizeof(K));
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
+    const uint64_t n_fine = (uint64_t)(p.d_hi - p.d_lo) * p.B2;  // the ranges this table holds
     const uint32_t shift = 64 - p.n;
     // (the image in LDS holds keys in their stored form, like the key arrays: to_stored / from_stored)
     auto home = [&](K stored) {  // home position inside the range (kttab::probe_of)
@@ -1494,6 +1560,13 @@ struct kt_bulk_job {
     bool paged = false, merge = false, open = false;
     uint64_t max_keys = 0, added_bound = 0;
     std::vector<SourceRec> srcs;
+    // level 1 in slices (the sharded counter, kt_shard.hip): slice i writes the level-1 output i of b_keys1 (B1 regions of
+    // cap1 keys), with its own page allocator state; a table of its own has one slice
+    uint32_t n_slices = 1, n_src = 1;
+    bool sharded = false;  // regions are messages: level 1 parks what does not fit (pend) instead of being redone
+    PendList pend{};
+    std::vector<kt_seg_src> p2_srcs;  // where part2 reads every local bucket from (set by the caller when sharded)
+    size_t ksz() const { return narrow ? 4 : 8; }
 };
 
 void kt_bulk_job_free(kt_bulk_job *job) { delete job; }
@@ -1501,22 +1574,26 @@ void kt_bulk_job_free(kt_bulk_job *job) { delete job; }
 namespace {
 
 template <class K>
-int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
+int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice = 0) {
     kt_ctx *ctx = ctr->ctx;
-    K *keys1 = (K *)ctr->b_keys1.p;
-    if (j.kn.s1_wide) {
+    K *keys1 = (K *)ctr->b_keys1.p + (size_t)slice * j.p.B1 * j.p.cap1;
+    Meta sm_ = j.m;  // this slice's allocator state
+    sm_.gcur = j.m.gcur + (size_t)slice * j.p.B1;
+    sm_.wcur = j.m.wcur + (size_t)slice * j.p.G * j.p.B1;
+    struct { Meta m; } jj{sm_};
+    if (j.kn.s1_wide || j.sharded) {
         const uint32_t wgs = j.p.G / 2 ? j.p.G / 2 : 1;  // one resident workgroup per CU (its rows of wcur are [0, wgs))
         const size_t lds = sizeof(Scatter1WShared<K>);
         if (r.reads) {
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1w_kernel<ReadsSource, K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((scatter1w_kernel<ReadsSource, K>), dim3(wgs), dim3(WIDE_T), lds, ctx->stream, r.rs, j.p,
-                               j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+                               jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1, j.pend);
         } else {
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1w_kernel<KeysSource, K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((scatter1w_kernel<KeysSource, K>), dim3(wgs), dim3(WIDE_T), lds, ctx->stream, r.ks, j.p,
-                               j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+                               jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1, j.pend);
         }
         KT_HIP(hipGetLastError());
         return KT_OK;
@@ -1525,12 +1602,12 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
         KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<ReadsSource, K>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
         hipLaunchKernelGGL((scatter1p_kernel<ReadsSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>),
-                           ctx->stream, r.rs, j.p, j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+                           ctx->stream, r.rs, j.p, jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1);
     } else {
         KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<KeysSource, K>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
         hipLaunchKernelGGL((scatter1p_kernel<KeysSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>),
-                           ctx->stream, r.ks, j.p, j.m.gcur, j.m.ovf, j.m.wcur, keys1);
+                           ctx->stream, r.ks, j.p, jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1);
     }
     KT_HIP(hipGetLastError());
     return KT_OK;
@@ -1569,7 +1646,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     Plan &p = j.p;
     Meta &m = j.m;
     K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
-    if (j.paged) {
+    if (j.paged && !j.sharded) {
         hipLaunchKernelGGL(page_tails_kernel<K>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, p, m.wcur, keys1);
         // the one host round trip of the build: did every bucket fit its region?
         uint32_t ovf = 0;
@@ -1586,6 +1663,17 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             if (int rc = level1_exact<K>(ctr, j)) return rc;
         }
     }
+    // where part2 finds every bucket: the one level-1 output of a table of its own, or what the sharded counter set
+    P2In in{keys1, m.bstart, nullptr, 0};
+    if (j.paged) {
+        if (!j.sharded) j.p2_srcs.assign(1, kt_seg_src{keys1, m.gcur, p.cap1});
+        if (j.p2_srcs.empty() || j.p2_srcs.size() > j.n_src) return kt::fail(KT_ERR_ARG, "bulk build: level-2 sources not set");
+        KT_HIP(hipMemcpyAsync(m.srcs, j.p2_srcs.data(), j.p2_srcs.size() * sizeof(kt_seg_src), hipMemcpyHostToDevice, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));  // (p2_srcs may be reassigned by the caller right after)
+        in.srcs = m.srcs;
+        in.n_src = (uint32_t)j.p2_srcs.size();
+    }
+    const uint32_t nd = p.d_hi - p.d_lo;
     const bool big2 = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 &&
                       Part2Shared<K, true>::bytes(p.B2) <= 160 * 1024;
     auto run_part2 = [&](auto big) -> int {
@@ -1594,12 +1682,11 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         auto part2 = p.cap2 ? part2_kernel<K, true, BIG> : part2_kernel<K, false, BIG>;
         KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)part2_lds));
-        hipLaunchKernelGGL(part2, dim3(p.B1), dim3(p2t<K, BIG>()), part2_lds, ctx->stream, (const K *)keys1, m.bstart, m.gcur,
-                           p, keys2, m.fstart, m.fend);
+        hipLaunchKernelGGL(part2, dim3(nd), dim3(p2t<K, BIG>()), part2_lds, ctx->stream, in, p, keys2, m.fstart, m.fend);
         return KT_OK;
     };
     if (int rc = big2 ? run_part2(std::true_type{}) : run_part2(std::false_type{})) return rc;
-    const uint64_t n_fine = (uint64_t)p.B1 * p.B2;
+    const uint64_t n_fine = (uint64_t)nd * p.B2;
     // workgroups per CU over the launch; up to two are resident per CU.  Each takes ranges b, b + grid, ... with the next
     // one's bounds and first keys prefetched, so a few ranges per workgroup are enough - and a smaller static share evens
     // out what the compute units get (k=31: 2 / 4 / 8 / 16 / 32 / 128 per CU = 19.4 / 19.0 / 18.6 / 18.2 / 18.0 / 17.9 ms)
@@ -1669,7 +1756,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     ctr->dense = dense;
     ctr->dense_ext = ext;
     if (!dense) {
-        TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+        TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
         hipLaunchKernelGGL(spill_insert_kernel, dim3(ctx->n_cu), dim3(BLOCK), 0, ctx->stream, m.spill_n, m.spill_keys,
                            m.spill_counts, m.spill_cap, t, ctr->distinct);
     }
@@ -1689,18 +1776,30 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
 
 // Plans the partition of at most `max_keys` k-mers into the table's ranges and reserves the buffers.  *eligible = 0:
 // the table shape or the batch does not suit the bulk path (or HBM is short) and the caller uses the probing path.
-int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
+// slice_keys: the most k-mers one level-1 output (slice) takes; n_slices of them; n_src: level-1 outputs that feed one
+// bucket of this table (a table of its own: 1; a shard: slices x senders).  sharded: the sharded counter's job - level 1
+// parks what does not fit its regions in `pend`, the caller sets part2's sources, small batches take the bulk path too.
+static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_t n_src, bool sharded, const PendList *pend,
+                    int *eligible) {
     *eligible = 0;
     kt_ctx *ctx = ctr->ctx;
     const BulkKnobs kn = read_knobs();
-    if (kn.bulk == 0) return KT_OK;
-    if (max_keys < kn.min_bases) return KT_OK;  // small batches: atomics are fine
+    const uint64_t max_keys = slice_keys * n_slices;
+    if (!sharded) {
+        if (kn.bulk == 0) return KT_OK;
+        if (max_keys < kn.min_bases) return KT_OK;  // small batches: atomics are fine
+    }
     if (!ctr->job) ctr->job = new (std::nothrow) kt_bulk_job();
     if (!ctr->job) return kt::fail(KT_ERR_NOMEM, "bulk build: host alloc");
     kt_bulk_job &j = *ctr->job;
     j.kn = kn;
     j.open = false;
     j.srcs.clear();
+    j.p2_srcs.clear();
+    j.sharded = sharded;
+    j.n_slices = n_slices;
+    j.n_src = n_src;
+    j.pend = pend ? *pend : PendList{};
     j.merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
     if (j.merge)
         if (int rc = kt_table_image(ctr)) return rc;  // (a densely packed table gets its probing image first)
@@ -1716,24 +1815,33 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
 #endif
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
     // a rebuild moves the whole table: small batches are cheaper through the atomics
-    if (j.merge && max_keys < ctr->cap / (kn.merge_div ? kn.merge_div : 1)) return KT_OK;
+    if (!sharded && j.merge && max_keys < ctr->cap / (kn.merge_div ? kn.merge_div : 1)) return KT_OK;
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
     if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
+    if (ctr->n_owners > 1) p.b1 = ctr->owner_bits;  // a shard: the level-1 buckets are what the GPUs own (kt_shard.hip)
     p.b2 = fb - p.b1;
     if (p.b2 > 11) return KT_OK;
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
+    p.d_lo = ctr->n_owners > 1 ? ctr->bucket_lo : 0;
+    p.d_hi = ctr->n_owners > 1 ? ctr->bucket_hi : p.B1;
+    const uint32_t nd = p.d_hi - p.d_lo;
     // persistent level-1 workgroups (the same for every source of the job): two per CU for the per-unit kernels; the wide
     // kernel launches G / 2 of them, one resident per CU (KT_BULK_G_MULT > 1: more, shorter-lived workgroups)
     p.G = (uint32_t)ctx->n_cu * 2 * (uint32_t)(kn.g_mult ? kn.g_mult : 1);
     // paged level 1 (no hist1): room per bucket = its share of the most keys there can be + 1/8 + a page per
     // workgroup (every workgroup leaves at most one partly used page per bucket)
-    bool paged = kn.paged != 0 && !ctr->paged_failed;
+    bool paged = (kn.paged != 0 && !ctr->paged_failed) || sharded;
     const uint64_t PAGE = KT_PAGE_BYTES / ksz;
-    uint64_t cap1 = (max_keys / p.B1 + max_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
-    if (cap1 >= (1ull << 32)) paged = false;
-    uint64_t key_room = paged ? cap1 * p.B1 : max_keys;
+    uint64_t cap1 = (slice_keys / p.B1 + slice_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
+    const uint64_t room1 = cap1 * n_src;
+    if (room1 >= (1ull << 32)) {
+        if (sharded) return kt::fail(KT_ERR_ARG, "sharded counter: batch too large for its level-1 regions (lower max_batch_bases)");
+        paged = false;
+    }
+    uint64_t room_in = paged ? cap1 * p.B1 * n_slices : max_keys;  // level-1 outputs
+    uint64_t room_out = paged ? room1 * nd : max_keys;             // keys2: the local buckets, every source's share
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
     // spill list: keys of ranges that hold more distinct keys than slots (they fail in the probing path: table full)
@@ -1741,23 +1849,24 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     size_t meta = 0;
     const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;
-    const size_t off_wc = meta;      meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
+    const size_t off_wc = meta;      meta += ((size_t)n_slices * p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_bs = meta;      meta += ((size_t)(p.B1 + 1) * 8 + 255) & ~(size_t)255;
-    const size_t off_fs = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
-    const size_t off_fe = meta;      meta += (((size_t)p.B1 * p.B2 + 1) * 8 + 255) & ~(size_t)255;
-    const size_t off_gc = meta;      meta += ((size_t)p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_fs = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
+    const size_t off_fe = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
+    const size_t off_gc = meta;      meta += ((size_t)n_slices * p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_sr = meta;      meta += ((size_t)n_src * sizeof(kt_seg_src) + 255) & ~(size_t)255;
     const size_t off_ov = meta;      meta += 256;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
     const size_t off_sc = meta;      meta += (spill_cap * 4 + 255) & ~(size_t)255;
     auto reserve_all = [&]() {
-        return ctr->b_keys1.reserve(key_room * ksz) == KT_OK && ctr->b_keys2.reserve(key_room * ksz) == KT_OK &&
+        return ctr->b_keys1.reserve(room_in * ksz) == KT_OK && ctr->b_keys2.reserve(room_out * ksz) == KT_OK &&
                ctr->b_meta.reserve(meta) == KT_OK;
     };
     bool have = reserve_all();
-    if (!have && paged) {  // the paged layout wants 1/8 more room than the keys: try the exact one before giving up
+    if (!have && paged && !sharded) {  // the paged layout wants 1/8 more room than the keys: try the exact one before giving up
         paged = false;
-        key_room = max_keys;
+        room_in = room_out = max_keys;
         have = reserve_all();
         if (have) kt::set_error("");
     }
@@ -1765,6 +1874,7 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
         ctr->b_keys1.release();
         ctr->b_keys2.release();
         ctr->b_meta.release();
+        if (sharded) return kt::fail(KT_ERR_NOMEM, "sharded counter: not enough HBM for the partition buffers");
         kt::set_error("");
         return KT_OK;  // not enough HBM for the bulk buffers: incremental path
     }
@@ -1777,6 +1887,7 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     m.fstart = (uint64_t *)(mb + off_fs);
     m.fend = (uint64_t *)(mb + off_fe);
     m.gcur = (uint64_t *)(mb + off_gc);
+    m.srcs = (kt_seg_src *)(mb + off_sr);
     m.ovf = (uint32_t *)(mb + off_ov);
     m.spill_n = (uint64_t *)(mb + off_sn);
     m.spill_keys = (uint64_t *)(mb + off_sk);
@@ -1785,16 +1896,88 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
     if (paged) {
         p.cap1 = cap1;
-        p.cap2 = kn.fixed2 ? cap1 / p.B2 : 0;
-        KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)p.B1 * 8, ctx->stream));
+        p.room1 = room1;
+        p.cap2 = kn.fixed2 ? room1 / p.B2 : 0;
+        KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)n_slices * p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
-        KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)p.G * p.B1 * 4, ctx->stream));
+        KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)n_slices * p.G * p.B1 * 4, ctx->stream));
     }
     j.p = p;
     j.m = m;
     j.paged = paged;
     j.open = true;
     *eligible = 1;
+    return KT_OK;
+}
+
+int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
+    return plan_job(ctr, max_keys, 1, 1, false, nullptr, eligible);
+}
+
+// ---- the sharded counter's job (kt_shard.hip): level 1 runs where the reads are, level 2 + build where the keys belong ----
+int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_t n_src, kt_ctr *pend) {
+    if (int rc = ktl::table_ready(pend)) return rc;  // (a deferred clear happens now; a full table is reported)
+    pend->empty = false;
+    const PendList pl{(Slot *)pend->slots, ktl::geom_of(pend), pend->flags, pend->distinct};
+    int eligible = 0;
+    if (int rc = plan_job(ctr, slice_keys, n_slices, n_src, true, &pl, &eligible)) return rc;
+    if (!eligible) return kt::fail(KT_ERR_ARG, "sharded counter: the table's shape does not suit the partition passes");
+    return KT_OK;
+}
+
+// level 1 of slice `slice` over the k-mers that start in segments [seg_lo, seg_hi) of this rank's reads: the slice's
+// B1 regions fill up; finished off by kt_bulk_slice_done (page tails) before the regions are sent
+int kt_bulk_slice_reads(kt_ctr *ctr, uint32_t slice, const uint8_t *d_bases, const uint64_t *d_offsets,
+                        const uint64_t *seg_first, uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->open || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
+    if (seg_hi <= seg_lo) return KT_OK;
+    SourceRec r{};
+    r.reads = true;
+    r.rs.a.bases = d_bases;
+    r.rs.a.offsets = d_offsets;
+    r.rs.a.seg_first = seg_first;
+    r.rs.a.n_reads = n_reads;
+    r.rs.a.n_seg = n_seg;
+    r.rs.a.k = (uint32_t)ctr->k;
+    r.rs.seg_lo = seg_lo;
+    r.rs.seg_hi = seg_hi;
+    r.rs.n_parts = 1;
+    r.rs.part = 0;
+    r.n_units = seg_hi - seg_lo;
+    return job->narrow ? level1_paged<uint32_t>(ctr, *job, r, slice) : level1_paged<uint64_t>(ctr, *job, r, slice);
+}
+
+int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->open || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
+    const Plan &p = job->p;
+    const uint32_t *wcur = job->m.wcur + (size_t)slice * p.G * p.B1;
+    char *keys1 = (char *)ctr->b_keys1.p + (size_t)slice * p.B1 * p.cap1 * job->ksz();
+    if (job->narrow)
+        hipLaunchKernelGGL(page_tails_kernel<uint32_t>, dim3(p.G), dim3(BLOCK), 0, ctr->ctx->stream, p, wcur, (uint32_t *)keys1);
+    else
+        hipLaunchKernelGGL(page_tails_kernel<uint64_t>, dim3(p.G), dim3(BLOCK), 0, ctr->ctx->stream, p, wcur, (uint64_t *)keys1);
+    KT_HIP(hipGetLastError());
+    return KT_OK;
+}
+
+// the job's shape, and where slice `slice` keeps the regions and the key counts of level-1 buckets bucket .. B1
+int kt_bulk_slice_info(kt_ctr *ctr, uint32_t slice, uint32_t bucket, kt_bulk_shape *shape, void **keys, uint64_t **counts) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
+    const Plan &p = job->p;
+    if (shape) *shape = kt_bulk_shape{p.B1, p.d_lo, p.d_hi, p.cap1, (uint32_t)job->ksz()};
+    if (keys) *keys = (char *)ctr->b_keys1.p + ((size_t)slice * p.B1 + bucket) * p.cap1 * job->ksz();
+    if (counts) *counts = job->m.gcur + (size_t)slice * p.B1 + bucket;
+    return KT_OK;
+}
+
+// part2's sources: one per (slice, sender), each the regions of this table's buckets d_lo .. d_hi in bucket order
+int kt_bulk_set_sources(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->open || !job->sharded || n > job->n_src) return kt::fail(KT_ERR_ARG, "bulk build: bad level-2 sources");
+    job->p2_srcs.assign(srcs, srcs + n);
     return KT_OK;
 }
 

@@ -198,7 +198,7 @@ extern "C" int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t 
     if (total) {
         SegArgs a;
         if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, table->k, &a)) return rc;
-        CovArgs c{(const Slot *)table->slots, kttab::Geom{table->cap, table->shift, table->m8},
+        CovArgs c{(const Slot *)table->slots, ktl::geom_of(table),
                   bin_size > 0xFFFFFFFFull ? 0u : (uint32_t)bin_size, (uint32_t)bin_count, d_counts};
         hipLaunchKernelGGL(cov_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, c);
         KT_HIP(hipGetLastError());

@@ -324,12 +324,16 @@ using namespace ktl;
 
 extern "C" {
 
-int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
+}  // extern "C"
+
+// a table with a given geometry: its own (kt_ctr_create), or the ranges of level-1 buckets [bucket_lo, bucket_hi) of a
+// table spread over n_owners GPUs (kt_shard.hip; g.cap = the slots held here, g.range_base = the first range)
+int kt_ctr_create_geom(kt_ctx *ctx, int k, const kttab::Geom &geom, uint32_t n_owners, uint32_t owner, uint32_t owner_bits,
+                       uint32_t bucket_lo, uint32_t bucket_hi, kt_ctr **out) {
     if (!ctx || !out) return kt::fail(KT_ERR_ARG, "kt_ctr_create: null");
     *out = nullptr;
     if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_ctr_create: k must be in 1..31");
     if (int rc = ctx->use()) return rc;
-    const kttab::Geom geom = kttab::make_geom(capacity_slots);
     const uint64_t cap = geom.cap;
     kt_ctr *c = new (std::nothrow) kt_ctr();
     if (!c) return kt::fail(KT_ERR_NOMEM, "kt_ctr_create: host alloc");
@@ -338,6 +342,12 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     c->cap = cap;
     c->shift = geom.shift;
     c->m8 = geom.m8;
+    c->range_base = geom.range_base;
+    c->n_owners = n_owners;
+    c->owner = owner;
+    c->owner_bits = owner_bits;
+    c->bucket_lo = bucket_lo;
+    c->bucket_hi = bucket_hi;
     hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
@@ -349,6 +359,12 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     }
     *out = c;
     return kt_ctr_clear(c);
+}
+
+extern "C" {
+
+int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
+    return kt_ctr_create_geom(ctx, k, kttab::make_geom(capacity_slots), 1, 0, 0, 0, 1, out);
 }
 
 int kt_ctr_destroy(kt_ctr *ctr) {
@@ -450,7 +466,7 @@ int kt_ctr_add_reads_part(kt_ctr *ctr, const uint8_t *bases, const uint64_t *off
     if (int rc = ensure_cleared(ctr)) return rc;
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, ctr->k, &a)) return rc;
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
     hipLaunchKernelGGL(count_reads_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, t, n_parts,
                        part, ctr->distinct);
     KT_HIP(hipGetLastError());
@@ -487,7 +503,7 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
     }
     ctr->empty = false;
     if (int rc = ensure_cleared(ctr)) return rc;
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctx->stream, d_keys, d_counts, n, t, ctr->distinct);
     KT_HIP(hipGetLastError());
@@ -510,7 +526,7 @@ int kt_ctr_reload_pairs(kt_ctr *ctr, const uint64_t *d_keys, const uint32_t *d_c
     if (int rc = ensure_cleared(ctr)) return rc;
     KT_HIP(hipMemsetAsync(ctr->distinct, 0, 8, ctx->stream));
     if (n == 0) return KT_OK;
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0, ctx->stream,
                        d_keys, d_counts, n, t, ctr->distinct);
     KT_HIP(hipGetLastError());
@@ -524,7 +540,7 @@ int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_ke
     if (int rc = ctx->use()) return rc;
     ctr->empty = false;
     if (int rc = ensure_cleared(ctr)) return rc;
-    TableRef t{(Slot *)ctr->slots, kttab::Geom{ctr->cap, ctr->shift, ctr->m8}, ctr->flags};
+    TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
     hipLaunchKernelGGL(add_keys_counted_kernel, dim3(grid_for(ctx, (cap_keys + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
                        ctx->stream, d_keys, cap_keys, d_n, t, ctr->distinct);
     KT_HIP(hipGetLastError());

@@ -34,9 +34,11 @@ static_assert(sizeof(Slot) == 16, "slot layout");
 constexpr uint32_t LOG2_RANGE = KT_LOG2_RANGE, RANGE_FULL = 1u << LOG2_RANGE;
 
 struct Geom {
-    uint64_t cap;
-    uint32_t shift;  // 64 - n
+    uint64_t cap;    // slots held HERE: all of the table, or - a shard of a table spread over several GPUs
+                     // (kt_shard.hip) - the ranges [range_base, range_base + cap / range_slots()) of the whole table
+    uint32_t shift;  // 64 - n, n = hash bits that address the WHOLE table
     uint32_t m8;     // slots per range / 1024
+    uint64_t range_base = 0;
     // slots of one range (the whole table when it is smaller than a range)
     __host__ __device__ uint32_t range_slots() const {
         return shift > 64 - LOG2_RANGE ? (uint32_t)cap : m8 << (LOG2_RANGE - 3);
@@ -53,7 +55,7 @@ inline Geom make_geom(uint64_t cap_request) {
     uint32_t m8 = 8;
     if (n >= LOG2_RANGE + 2)
         while (m8 > 5 && p / 8 * (m8 - 1) >= cap_request) m8--;
-    return Geom{p / 8 * m8, 64 - n, m8};
+    return Geom{p / 8 * m8, 64 - n, m8, 0};
 }
 
 struct TableRef {
@@ -74,10 +76,13 @@ __host__ __device__ __forceinline__ Probe probe_of(uint64_t key, const Geom &g) 
     const uint64_t x = ktd::khash(key) >> g.shift;  // n <= 54 bits
     if (g.shift > 64 - LOG2_RANGE) return Probe{0, (uint32_t)x, (uint32_t)g.cap};  // one small range, home = x
     const uint32_t rs = g.m8 << (LOG2_RANGE - 3);
-    return Probe{(x >> LOG2_RANGE) * rs, (((uint32_t)x & (RANGE_FULL - 1)) * g.m8) >> 3, rs};
+    const uint64_t r = (x >> LOG2_RANGE) - g.range_base;  // (wraps for a key below this shard's ranges)
+    if (r * rs >= g.cap) return Probe{0, 0, 0};           // a key of another shard: a probe sequence of length 0
+    return Probe{r * rs, (((uint32_t)x & (RANGE_FULL - 1)) * g.m8) >> 3, rs};
 }
 
-// table[key] += add; returns 0 = the key's range is full, 1 = the key was there, 2 = the key is new.
+// table[key] += add; returns 0 = the key's range is full (or the key belongs to another shard), 1 = the key was there,
+// 2 = the key is new.
 // A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe can only show EMPTY for a slot that is now
 // taken, and the CAS (device scope, coherent across XCDs) settles that case.  A k-mer seen once costs one probing load
 // + one CAS (claiming the slot is its first count); a repeat costs one load + one 32-bit atomic add.  At most one
@@ -107,6 +112,10 @@ __device__ __forceinline__ uint32_t table_add(const TableRef &t, uint64_t key, u
 
 }  // namespace kttab
 
+// kt_ctr.hip: a table with a given geometry (kt_shard.hip: one GPU's ranges of a table spread over several)
+int kt_ctr_create_geom(kt_ctx *ctx, int k, const kttab::Geom &geom, uint32_t n_owners, uint32_t owner, uint32_t owner_bits,
+                       uint32_t bucket_lo, uint32_t bucket_hi, kt_ctr **out);
+
 // kt_bulk.hip: adds a whole read batch to the table without global atomics (partition by hash prefix, then every
 // range is built - or rebuilt with what it already holds - in LDS).
 // Returns KT_OK, or an error; `*done` = 0 when the batch / table shape is not eligible and
@@ -121,6 +130,17 @@ int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int
 // sources (segments [seg_lo, seg_hi) of a read batch / arrays of canonical k-mers, optionally with a device-side
 // count), finish (level 2 + range builds; one host round trip).  Sources must stay readable until finish.
 int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible);
+// The job of the sharded counter (kt_shard.hip): level 1 runs on the GPU that holds the reads - its B1 regions are the
+// messages, the buckets [bucket_lo, bucket_hi) of owner o go to GPU o - and level 2 + the range builds on the GPU that
+// owns the buckets, over one source per (slice, sender).  begin: n_slices level-1 outputs of at most slice_keys k-mers
+// each, n_src sources per bucket, the (small, local) table that counts what does not fit a region.
+struct kt_bulk_shape { uint32_t B1, d_lo, d_hi; uint64_t cap1; uint32_t key_bytes; };
+int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_t n_src, kt_ctr *pend);
+int kt_bulk_slice_reads(kt_ctr *ctr, uint32_t slice, const uint8_t *d_bases, const uint64_t *d_offsets,
+                        const uint64_t *seg_first, uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi);
+int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice);
+int kt_bulk_slice_info(kt_ctr *ctr, uint32_t slice, uint32_t bucket, kt_bulk_shape *shape, void **keys, uint64_t **counts);
+int kt_bulk_set_sources(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n);
 int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
                       uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_parts, uint32_t part);
 int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n);

@@ -70,7 +70,21 @@ def cgr_coords(k, vecsize):
 
 
 def owner_of(kmer, n_owners):
+    """hash partition of a k-mer among n_owners (out-of-core passes, kt_ctr_route): the LOW hash bits"""
     return int(_lib.lib().kt_owner_of(int(kmer), int(n_owners)))
+
+
+def shard_layout(capacity_slots, n_ranks, rank):
+    """-> (prefix_bits, bucket_lo, bucket_hi, local_slots): what a rank of a sharded table derives for itself"""
+    b, lo, hi, n = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    check(_lib.lib().kt_shard_layout(int(capacity_slots), int(n_ranks), int(rank), C.byref(b), C.byref(lo), C.byref(hi),
+                                     C.byref(n)))
+    return b.value, lo.value, hi.value, n.value
+
+
+def shard_owner_of(kmer, prefix_bits, n_ranks):
+    """the rank that owns a k-mer in a sharded table: its hash PREFIX scaled to the number of ranks"""
+    return int(_lib.lib().kt_shard_owner_of(int(kmer), int(prefix_bits), int(n_ranks)))
 
 
 def to_csr(seqs):
@@ -316,31 +330,61 @@ class Counter:
 class Sharded:
     """This rank's part of a table sharded over n_ranks GPUs by hash prefix (kt_sharded).  add_reads and finalize are
     collective: every rank calls them the same number of times.  `transport`: ("rccl", id128 bytes) or
-    ("host", alltoall) where alltoall(send_addr, recv_addr, bytes_per_rank) moves host memory and returns 0."""
+    ("host", alltoall) where alltoall(send_addr, recv_addr, bytes_per_rank) moves host memory and returns 0.
+    connect=False: allocate only (kt_sharded_create_local); the caller agrees with its peers and calls connect()."""
 
-    def __init__(self, ctx, k, capacity_slots, max_batch_bases, n_ranks=1, rank=0, transport=None):
+    def __init__(self, ctx, k, capacity_slots, max_batch_bases, n_ranks=1, rank=0, transport=None, connect=True):
         self.ctx, self.k, self.n_ranks, self.rank = ctx, k, n_ranks, rank
         self._h = C.c_void_p()
         self._cb = None
+        self._cb_exc = None
+        self._transport = transport
         L = _lib.lib()
         if n_ranks > 1 and transport is None:
             raise ValueError("a sharded counter over several ranks needs a transport")
-        if n_ranks == 1 or transport[0] == "rccl":
-            idb = None if n_ranks == 1 else (C.c_uint8 * 128).from_buffer_copy(bytes(transport[1]))
-            check(L.kt_sharded_create_rccl(ctx._h, k, int(capacity_slots), int(max_batch_bases), n_ranks, rank, idb,
-                                           C.byref(self._h)))
-        elif transport[0] == "host":
-            fn = transport[1]
-            self._cb = _lib.ALLTOALL_FN(lambda user, send, recv, nbytes: int(fn(send, recv, nbytes)))
-            check(L.kt_sharded_create_host(ctx._h, k, int(capacity_slots), int(max_batch_bases), n_ranks, rank,
-                                           C.cast(self._cb, C.c_void_p), None, C.byref(self._h)))
-        else:
+        if transport is not None and transport[0] not in ("rccl", "host"):
             raise ValueError("unknown transport %r" % (transport[0],))
+        check(L.kt_sharded_create_local(ctx._h, k, int(capacity_slots), int(max_batch_bases), n_ranks, rank,
+                                        C.byref(self._h)))
         t = C.c_void_p()
         check(L.kt_sharded_table(self._h, C.byref(t)))
         self.table = Counter.__new__(Counter)   # a view of the shard: owned by the kt_sharded
         self.table.ctx, self.table.k, self.table._h = ctx, k, t
         self.table.close = lambda: None
+        if connect:
+            self.connect()
+
+    def connect(self):
+        """brings the transport up (RCCL: ncclCommInitRank - every rank must get here)"""
+        L = _lib.lib()
+        transport = self._transport
+        if self.n_ranks == 1 or transport[0] == "rccl":
+            idb = None if self.n_ranks == 1 else (C.c_uint8 * 128).from_buffer_copy(bytes(transport[1]))
+            check(L.kt_sharded_connect_rccl(self._h, idb))
+        else:
+            fn = transport[1]
+
+            def cb(user, send, recv, nbytes):
+                # an exception must not be swallowed by ctypes (it would return 0 = success and the library would count
+                # whatever the receive buffer held): report failure, keep the exception for the caller
+                try:
+                    return int(fn(send, recv, nbytes))
+                except BaseException as e:  # noqa: BLE001
+                    self._cb_exc = e
+                    return 1
+            self._cb = _lib.ALLTOALL_FN(cb)
+            check(L.kt_sharded_connect_host(self._h, C.cast(self._cb, C.c_void_p), None))
+
+    def _checked(self, rc):
+        if self._cb_exc is not None:
+            e, self._cb_exc = self._cb_exc, None
+            raise e
+        check(rc)
+
+    def owner_of(self, kmer):
+        o = C.c_uint32()
+        check(_lib.lib().kt_sharded_owner_of(self._h, int(kmer), C.byref(o)))
+        return o.value
 
     @staticmethod
     def unique_id():
@@ -364,7 +408,7 @@ class Sharded:
         check(_lib.lib().kt_sharded_clear(self._h))
 
     def add_reads(self, bases, offsets, n_reads, mem=KT_MEM_DEVICE):
-        check(_lib.lib().kt_sharded_add_reads(self._h, _ptr(bases), _ptr(offsets), n_reads, mem))
+        self._checked(_lib.lib().kt_sharded_add_reads(self._h, _ptr(bases), _ptr(offsets), n_reads, mem))
 
     def add_reads_host(self, bases, offsets):
         bases = np.ascontiguousarray(bases, np.uint8)
@@ -372,7 +416,7 @@ class Sharded:
         self.add_reads(bases if bases.size else np.zeros(1, np.uint8), offsets, len(offsets) - 1, KT_MEM_HOST)
 
     def finalize(self):
-        check(_lib.lib().kt_sharded_finalize(self._h))
+        self._checked(_lib.lib().kt_sharded_finalize(self._h))
 
     def exchanged_bytes(self):
         n = C.c_uint64()

@@ -3,8 +3,9 @@
 
 The reference partitions its table by `min_mer % n_parts` inside one process and merges
 partitions through temp files (counter/src/lib.rs:100,127,188-231).  Here the partitions
-are GPUs: rank `o` owns every canonical k-mer with kt_owner_of(kmer, world) == o, and the library routes, exchanges
-(librccl over xGMI, called from C) and counts.  torch.distributed only does what a launcher does: it carries the
+are GPUs: rank `o` owns the k-mers whose hash prefix falls into its interval (kt_sharded_owner_of), every rank runs the
+first partition pass over its own reads, and the library exchanges the pass's output regions (librccl over xGMI,
+called from C) and counts what each rank owns.  torch.distributed only does what a launcher does: it carries the
 128-byte RCCL id from rank 0 to the others, or - with the gloo backend, i.e. the CPU tests and several ranks sharing
 one GPU - it IS the transport, through the library's host all-to-all callback.
 """
@@ -50,7 +51,11 @@ class ShardedCounter:
                 if self.rank == 0:
                     print("kmertools_amd: librccl communicator unavailable on some rank - sharded counting falls back "
                           "to the host all-to-all transport (gloo)", file=sys.stderr)
+                # (new_group is collective over the DEFAULT group: fine for the whole world - what bench.py passes - and a
+                # caller with a sub-group has to bring its own gloo group instead)
                 ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+                if len(ranks) != dist.get_world_size():
+                    raise RuntimeError("sharded counting over a sub-group needs a working librccl communicator")
                 self._host_group = dist.new_group(ranks=ranks, backend="gloo")
                 self.transport = "host all-to-all over gloo (fallback: librccl communicator unavailable)"
                 self.sharded = device.Sharded(ctx, k, capacity_slots, max_batch_bases, self.world, self.rank,
@@ -73,22 +78,28 @@ class ShardedCounter:
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
             return bool(t.item())
 
+        # step 1, no peer needed: librccl loads and its symbols resolve; the shard and the exchange buffers are allocated
         try:
-            uid = device.Sharded.unique_id()   # every rank: loads librccl and resolves its symbols
+            uid = device.Sharded.unique_id()
+            sh = device.Sharded(ctx, k, capacity_slots, max_batch_bases, self.world, self.rank, ("rccl", b""), connect=False)
             ok = True
         except Exception:
-            uid, ok = None, False
-        if not all_ok(ok):
-            return None
-        box = [uid if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        try:
-            sh = device.Sharded(ctx, k, capacity_slots, max_batch_bases, self.world, self.rank, ("rccl", box[0]))
-        except Exception:
-            sh = None
-        if not all_ok(sh is not None):
+            uid, sh, ok = None, None, False
+        if not all_ok(ok):   # some rank could not: nobody enters ncclCommInitRank
             if sh is not None:
                 sh.close()
+            return None
+        # step 2: rank 0's id reaches the others, every rank joins the communicator
+        box = [uid if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        sh._transport = ("rccl", box[0])
+        try:
+            sh.connect()
+            ok = True
+        except Exception:
+            ok = False
+        if not all_ok(ok):
+            sh.close()
             return None
         return sh
 

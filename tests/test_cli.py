@@ -275,6 +275,17 @@ def test_ctr_out_of_core_passes_and_devices(cli, oracle, tmp_path):
     assert sorted((d2 / "kmers.counts").read_text().splitlines()) == want
     r = run(cli, "ctr", "-i", "-", "-o", tmp_path / "x", "-k", "21", input=fq.read_text())
     assert r.returncode == 101 and "Error" in r.stderr
+    # --devices must fail, not hang: a rank whose bring-up fails makes every rank stop before the first collective
+    # (timeout of run() = the hang detector), and more devices than the node has are refused before any thread starts
+    d3 = tmp_path / "three"
+    r = run(cli, "ctr", "-i", fq, "-o", d3, "-k", "21", "--devices", "3", env=dict(env, KT_CLI_SHARE_GPU="1", KT_CLI_FAIL_RANK="1"))
+    assert r.returncode != 0 and "bring-up" in r.stderr
+    r = run(cli, "ctr", "-i", fq, "-o", d3, "-k", "21", "--devices", "63", env=env)
+    assert r.returncode != 0 and "GPU(s)" in r.stderr
+    # three ranks (the level-1 buckets do not divide evenly) give the oracle's lines too
+    r = run(cli, "ctr", "-i", fq, "-o", d3, "-k", "21", "--devices", "3", env=dict(env, KT_CLI_SHARE_GPU="1"))
+    assert r.returncode == 0, r.stderr
+    assert sorted((d3 / "kmers.counts").read_text().splitlines()) == want
 
 
 def test_parallel_reader_matches_serial(cli, tmp_path):

@@ -1,8 +1,9 @@
-"""world_size-2 CPU (gloo) test of the multi-GPU counting schedule's host side: ownership by hash prefix, the layout
-of the exchanged regions (kt_sharded_message_bytes: a 64-byte header with the key count, then the keys) and the host
-all-to-all transport that kt_sharded_create_host drives (kmertools_amd.dist.host_alltoall over torch.distributed).
-The GPU kernels are replaced here by the oracle (test infrastructure): every rank fills its regions the way
-route_regions_kernel does, the transport moves them, and the received regions are counted."""
+"""world_size-2 CPU (gloo) test of the multi-GPU counting schedule's host side: ownership by hash prefix
+(kt_shard_layout / kt_shard_owner_of: every rank derives the same layout, the owners partition the k-mers, a rank's
+k-mers have hash prefixes inside its bucket interval) and the host all-to-all transport that kt_sharded_connect_host
+drives (kmertools_amd.dist.host_alltoall over torch.distributed: equal blocks, block p to rank p).
+The GPU kernels are replaced here by the oracle (test infrastructure): every rank fills one block per owner - a status
+word, the key count, the keys, like the library's blocks - the transport moves them, and what arrives is counted."""
 import os
 import socket
 
@@ -45,26 +46,32 @@ def _worker(rank, port, q):
         bases, offsets = oracle.synth_reads(SEED, N_PER_RANK, L, noise=True, genome_len=20000,
                                             first_read=rank * N_PER_RANK)
         canon = _canonical_kmers(oracle, bases, offsets, K)
-        owners = np.array([device.owner_of(int(x), WORLD) for x in canon], dtype=np.int64)
-        # one slice: WORLD regions of the size the library would use for a batch of this many bases
-        msg_bytes = int(_lib.lib().kt_sharded_message_bytes(N_PER_RANK * L, WORLD, 1))
-        words = msg_bytes // 8
-        assert msg_bytes % 8 == 0 and words - 8 >= (canon.size // WORLD)
+        cap = 1 << 20
+        bits, lo, hi, slots = device.shard_layout(cap, WORLD, rank)
+        layouts = [device.shard_layout(cap, WORLD, r) for r in range(WORLD)]
+        assert all(x[0] == bits for x in layouts) and slots >= cap          # every rank derives the same prefix bits
+        assert layouts[0][1] == 0 and layouts[-1][2] == 1 << bits           # the intervals tile the buckets
+        assert all(layouts[r][2] == layouts[r + 1][1] for r in range(WORLD - 1))
+        owners = np.array([device.shard_owner_of(int(x), bits, WORLD) for x in canon], dtype=np.int64)
+        # one block per owner: [status, count, keys...], equal sizes (the host transport's contract)
+        words = 8 + N_PER_RANK * (L - K + 1)                  # (the same on every rank: at most this many k-mers)
+        msg_bytes = words * 8
         send = np.zeros(WORLD * words, np.uint64)
         for o in range(WORLD):
             mine = canon[owners == o]
-            send[o * words] = len(mine)                       # header: key count
+            send[o * words + 1] = len(mine)
             send[o * words + 8:o * words + 8 + len(mine)] = mine
         recv = np.full(WORLD * words, 0xDEAD, np.uint64)
-        fn = ktdist.host_alltoall(dist.group.WORLD)          # what kt_sharded_create_host is given
+        fn = ktdist.host_alltoall(dist.group.WORLD)          # what kt_sharded_connect_host is given
         assert fn(send.ctypes.data, recv.ctypes.data, msg_bytes) == 0
         got = []
         for p in range(WORLD):
-            n = int(recv[p * words])
+            assert int(recv[p * words]) == 0                  # the sender's status word
+            n = int(recv[p * words + 1])
             got.append(recv[p * words + 8:p * words + 8 + n])
         got = np.concatenate(got)
         # everything received is owned by this rank
-        assert all(device.owner_of(int(x), WORLD) == rank for x in got[:500])
+        assert all(device.shard_owner_of(int(x), bits, WORLD) == rank for x in got[:500])
         ctr = oracle.Counter(1)
         ctr.add_pairs(got, np.ones(len(got), np.uint32))
         k_, c_ = ctr.export()

@@ -422,7 +422,8 @@ def _two_rank_worker(rank, port, q, case):
         sc.finalize()
         keys, counts = sc.export_local()
         total = sc.size_global()
-        q.put((rank, keys, counts, total, sc.sharded.exchanged_bytes()))
+        mine = all(sc.sharded.owner_of(int(x)) == rank for x in keys[:300])
+        q.put((rank, keys, counts, total, sc.sharded.exchanged_bytes(), mine))
         sc.close()
         ctx.close()
     finally:
@@ -465,9 +466,11 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     wk, wc = ctr.export()
     keys = np.concatenate([r[1] for r in res])
     counts = np.concatenate([r[2] for r in res])
-    for rank, rk, _, total, sent in res:
+    for rank, rk, _, total, sent, mine in res:
         assert total == len(wk) and sent > 0
-        assert all(device.owner_of(int(x), world) == rank for x in rk[:300])
+        assert mine                                      # every k-mer of a shard is owned by its rank (hash prefix)
+        bits, lo, hi, _ = device.shard_layout(1 << 23, world, rank)
+        assert all(device.shard_owner_of(int(x), bits, world) == rank for x in rk[:300])
     order = np.argsort(keys)
     assert np.array_equal(keys[order], wk) and np.array_equal(counts[order], wc)
 

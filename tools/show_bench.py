@@ -4,7 +4,7 @@ import sys
 
 for path in sys.argv[1:]:
     try:
-        j = json.loads(open(path).read().strip().splitlines()[-1])
+        j = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
     except Exception as e:  # noqa: BLE001
         print(path, "unreadable:", e)
         continue
