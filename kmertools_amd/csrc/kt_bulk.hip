@@ -91,6 +91,7 @@ struct Plan {
     uint64_t cap2;    // ... and per fine bucket in keys2 (room1 / B2)
     uint64_t room1;   // keys of room per level-1 bucket in keys2: cap1 x the number of level-1 outputs that feed it
     uint32_t d_lo, d_hi;  // the level-1 buckets whose ranges this table holds: all B1 of them, or - a shard - its interval
+    uint32_t bx;          // hash bits a pre-split pass resolves between level 1 and level 2 (0: none; see finish_typed)
     uint32_t dbg;     // KT_BUILD_DBG: ablation switches of build_kernel (profiling only)
 };
 
@@ -104,7 +105,8 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint64_t *gcur;     // [slices][B1] paged level 1: keys of bucket room handed out so far (page allocator)
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
     uint32_t *wcur;     // [slices][G][B1] paged level 1: every workgroup's position in its current page of every bucket
-    kt_seg_src *srcs;   // [n_src] part2's sources (device copy)
+    kt_seg_src *srcs;   // [n_src + 1] part2's sources (device copy; the last one: the pre-split pass's output)
+    uint64_t *xstart, *xend, *xcount;  // [local buckets << bx] pre-split pass: the sub-buckets' bounds in keys2, their sizes
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -751,7 +753,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
             if (in.srcs) {
                 const kt_seg_src &q = in.srcs[sidx];
                 const uint64_t c = q.counts[jl];
-                base = reinterpret_cast<const K *>(q.keys) + (uint64_t)jl * q.cap1;
+                base = reinterpret_cast<const K *>(q.keys) + (q.starts ? q.starts[jl] : (uint64_t)jl * q.cap1);
                 n = c < q.cap1 ? c : q.cap1;
             } else {
                 base = reinterpret_cast<const K *>(in.keys1) + in.bstart[jl];
@@ -1513,6 +1515,13 @@ __global__ __launch_bounds__(XT) void dense_export_kernel(const Slot *__restrict
     }
 }
 
+// pre-split pass (finish_typed): sizes of the sub-buckets from their bounds
+__global__ void sub_counts_kernel(const uint64_t *__restrict__ fs, const uint64_t *__restrict__ fe, uint32_t n,
+                                  uint64_t *__restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) counts[i] = fe[i] - fs[i];
+}
+
 uint64_t env_u64(const char *name, uint64_t dflt) {
     const char *s = getenv(name);
     if (!s || !*s) return dflt;
@@ -1531,7 +1540,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks;
+        verbose, ext_ovf_blocks, max_b2;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -1548,6 +1557,8 @@ static BulkKnobs read_knobs() {
     k.build_wgs = env_u64("KT_BUILD_WGS", 64);
     k.dense = env_u64("KT_BULK_DENSE", 1);
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
+    k.max_b2 = env_u64("KT_BULK_MAX_B2", 11);  // tests: a smaller level 2, so that small shards need the pre-split pass
+    if (k.max_b2 < 1 || k.max_b2 > 11) k.max_b2 = 11;
     k.ext_ovf_blocks = env_u64("KT_EXT_OVF_BLOCKS", 0);  // tests: n + 1 = blocks of scratch behind the export target
     return k;
 }
@@ -1666,7 +1677,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     // where part2 finds every bucket: the one level-1 output of a table of its own, or what the sharded counter set
     P2In in{keys1, m.bstart, nullptr, 0};
     if (j.paged) {
-        if (!j.sharded) j.p2_srcs.assign(1, kt_seg_src{keys1, m.gcur, p.cap1});
+        if (!j.sharded) j.p2_srcs.assign(1, kt_seg_src{keys1, m.gcur, p.cap1, nullptr});
         if (j.p2_srcs.empty() || j.p2_srcs.size() > j.n_src) return kt::fail(KT_ERR_ARG, "bulk build: level-2 sources not set");
         KT_HIP(hipMemcpyAsync(m.srcs, j.p2_srcs.data(), j.p2_srcs.size() * sizeof(kt_seg_src), hipMemcpyHostToDevice, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));  // (p2_srcs may be reassigned by the caller right after)
@@ -1674,18 +1685,53 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         in.n_src = (uint32_t)j.p2_srcs.size();
     }
     const uint32_t nd = p.d_hi - p.d_lo;
-    const bool big2 = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 &&
-                      Part2Shared<K, true>::bytes(p.B2) <= 160 * 1024;
-    auto run_part2 = [&](auto big) -> int {
-        constexpr bool BIG = decltype(big)::value;
-        const size_t part2_lds = Part2Shared<K, BIG>::bytes(p.B2);
-        auto part2 = p.cap2 ? part2_kernel<K, true, BIG> : part2_kernel<K, false, BIG>;
-        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)part2_lds));
-        hipLaunchKernelGGL(part2, dim3(nd), dim3(p2t<K, BIG>()), part2_lds, ctx->stream, in, p, keys2, m.fstart, m.fend);
-        return KT_OK;
+    // one level-2 launch: `pp` says which hash bits it sorts by and how many buckets it reads, `src` where from
+    auto run_part2 = [&](const Plan &pp, const P2In &src, K *out, uint64_t *fs, uint64_t *fe) -> int {
+        const bool big2 = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 &&
+                          Part2Shared<K, true>::bytes(pp.B2) <= 160 * 1024;
+        auto launch = [&](auto big) -> int {
+            constexpr bool BIG = decltype(big)::value;
+            const size_t part2_lds = Part2Shared<K, BIG>::bytes(pp.B2);
+            auto part2 = pp.cap2 ? part2_kernel<K, true, BIG> : part2_kernel<K, false, BIG>;
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)part2_lds));
+            hipLaunchKernelGGL(part2, dim3(pp.d_hi - pp.d_lo), dim3(p2t<K, BIG>()), part2_lds, ctx->stream, src, pp, out, fs, fe);
+            KT_HIP(hipGetLastError());
+            return KT_OK;
+        };
+        return big2 ? launch(std::true_type{}) : launch(std::false_type{});
     };
-    if (int rc = big2 ? run_part2(std::true_type{}) : run_part2(std::false_type{})) return rc;
+    if (p.bx == 0) {
+        if (int rc = run_part2(p, in, keys2, m.fstart, m.fend)) return rc;
+    } else {
+        // The shard of a table spread over many GPUs: level 2 cannot take all the bits level 1 left (plan_job).  Pass A
+        // splits every bucket 2^bx ways into keys2 (long runs: close to a copy); pass B is the ordinary level 2 over the
+        // sub-buckets - they are its "level-1 buckets" - and writes where the level-1 outputs were (every one of them
+        // has been sent, and read by pass A, by now); the range builds read from there.
+        Plan pa = p;
+        pa.b2 = p.bx;
+        pa.B2 = 1u << p.bx;
+        pa.cap2 = p.room1 / pa.B2;
+        if (int rc = run_part2(pa, in, keys2, m.xstart, m.xend)) return rc;
+        const uint32_t n_sub = nd << p.bx;
+        hipLaunchKernelGGL(sub_counts_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)m.xstart,
+                           (const uint64_t *)m.xend, n_sub, m.xcount);
+        Plan pb = p;
+        pb.b1 = p.b1 + p.bx;
+        pb.B1 = p.B1 << p.bx;
+        pb.b2 = p.b2 - p.bx;
+        pb.B2 = 1u << pb.b2;
+        pb.d_lo = p.d_lo << p.bx;
+        pb.d_hi = p.d_hi << p.bx;
+        pb.room1 = p.room1 >> p.bx;
+        pb.cap2 = pb.room1 / pb.B2;
+        const kt_seg_src from_a{keys2, m.xcount, ~0ull, m.xstart};
+        KT_HIP(hipMemcpyAsync(m.srcs + j.n_src, &from_a, sizeof from_a, hipMemcpyHostToDevice, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));  // (from_a lives on this frame)
+        const P2In inb{nullptr, nullptr, m.srcs + j.n_src, 1};
+        if (int rc = run_part2(pb, inb, keys1, m.fstart, m.fend)) return rc;
+        keys2 = keys1;  // what the builds read
+    }
     const uint64_t n_fine = (uint64_t)nd * p.B2;
     // workgroups per CU over the launch; up to two are resident per CU.  Each takes ranges b, b + grid, ... with the next
     // one's bounds and first keys prefetched, so a few ranges per workgroup are enough - and a smaller static share evens
@@ -1765,9 +1811,9 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         uint64_t spilled = 0;
         KT_HIP(hipMemcpyAsync(&spilled, m.spill_n, 8, hipMemcpyDeviceToHost, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s %s spilled=%llu\n", ctr->k,
+        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s%s %s spilled=%llu\n", ctr->k,
                 (unsigned long long)j.max_keys, j.paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact",
-                j.merge ? "merge" : "build", (unsigned long long)spilled);
+                p.bx ? " +presplit" : "", j.merge ? "merge" : "build", (unsigned long long)spilled);
     }
     return KT_OK;
 }
@@ -1821,7 +1867,12 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
     if (ctr->n_owners > 1) p.b1 = ctr->owner_bits;  // a shard: the level-1 buckets are what the GPUs own (kt_shard.hip)
     p.b2 = fb - p.b1;
-    if (p.b2 > 11) return KT_OK;
+    // a pass resolves at most 10 (level 1) / 11 (level 2) hash bits.  The shards of a table spread over N GPUs are
+    // addressed by log2(N) more bits than a table of the same size on one GPU, and level 1 - run by the senders - spends
+    // its bits on the whole table: what level 2 cannot take is resolved by a pre-split of every bucket (a third trip of the
+    // keys through HBM, a 2^bx-way split with long runs).
+    p.bx = p.b2 > (uint32_t)kn.max_b2 ? p.b2 - (uint32_t)kn.max_b2 : 0;
+    if (p.bx && (!sharded || p.bx > 6)) return KT_OK;
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
     p.d_lo = ctr->n_owners > 1 ? ctr->bucket_lo : 0;
@@ -1841,6 +1892,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
         paged = false;
     }
     uint64_t room_in = paged ? cap1 * p.B1 * n_slices : max_keys;  // level-1 outputs
+    if (p.bx && room_in < room1 * nd) room_in = room1 * nd;        // (the pre-split's second pass writes where they were)
     uint64_t room_out = paged ? room1 * nd : max_keys;             // keys2: the local buckets, every source's share
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
@@ -1854,7 +1906,11 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const size_t off_fs = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fe = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_gc = meta;      meta += ((size_t)n_slices * p.B1 * 8 + 255) & ~(size_t)255;
-    const size_t off_sr = meta;      meta += ((size_t)n_src * sizeof(kt_seg_src) + 255) & ~(size_t)255;
+    const size_t off_sr = meta;      meta += ((size_t)(n_src + 1) * sizeof(kt_seg_src) + 255) & ~(size_t)255;
+    const size_t n_sub = (size_t)nd << p.bx;  // pre-split: sub-bucket bounds and sizes
+    const size_t off_xs = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
+    const size_t off_xe = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
+    const size_t off_xc = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_ov = meta;      meta += 256;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
@@ -1888,6 +1944,9 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.fend = (uint64_t *)(mb + off_fe);
     m.gcur = (uint64_t *)(mb + off_gc);
     m.srcs = (kt_seg_src *)(mb + off_sr);
+    m.xstart = (uint64_t *)(mb + off_xs);
+    m.xend = (uint64_t *)(mb + off_xe);
+    m.xcount = (uint64_t *)(mb + off_xc);
     m.ovf = (uint32_t *)(mb + off_ov);
     m.spill_n = (uint64_t *)(mb + off_sn);
     m.spill_keys = (uint64_t *)(mb + off_sk);
@@ -1897,7 +1956,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     if (paged) {
         p.cap1 = cap1;
         p.room1 = room1;
-        p.cap2 = kn.fixed2 ? room1 / p.B2 : 0;
+        p.cap2 = kn.fixed2 || p.bx ? room1 / p.B2 : 0;
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)n_slices * p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)n_slices * p.G * p.B1 * 4, ctx->stream));

@@ -56,6 +56,7 @@ struct kt_seg_src {
     const void *keys;
     const uint64_t *counts;
     uint64_t cap1;
+    const uint64_t *starts;  // null: bucket jl at keys + jl * cap1; else at keys + starts[jl] (the pre-split pass's output)
 };
 
 struct kt_bulk_job;  // kt_bulk.hip: the plan and buffers of a partition + range build in progress

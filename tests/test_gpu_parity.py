@@ -391,7 +391,7 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 # N > 1 path on one GPU: two ranks share cuda:0, route on the GPU, exchange (gloo, host-staged),
 # count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
 
-_SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15)}   # case -> (ranks, k)
+_SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "presplit": (2, 31), "presplit3": (3, 15)}   # case -> (ranks, k)
 
 
 def _two_rank_worker(rank, port, q, case):
@@ -402,8 +402,11 @@ def _two_rank_worker(rank, port, q, case):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["KT_BULK_MIN_BASES"] = "0"   # the received k-mers take the partition + range build even at this size
-    if case == "narrow3":
+    if case in ("narrow3", "presplit3"):
         os.environ["KT_SHARD_SLICES"] = "3"
+    if case.startswith("presplit"):
+        os.environ["KT_BULK_MAX_B2"] = "3"    # level 2 takes 3 bits only: the shards need the pre-split pass (2 bits)
+        os.environ["KT_BULK_VERBOSE"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from kmertools_amd import device, dist as ktdist
@@ -430,12 +433,14 @@ def _two_rank_worker(rank, port, q, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3"])
+@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3"])
 def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     """the C ABI's sharded counter with two ranks on cuda:0 and the host all-to-all transport over gloo: route on
     the GPU, exchange fixed-size regions, partition + range build of what arrived, finalize; the union of the shards
     is the oracle's table of all reads.  `skewed`: one k-mer floods its owner's regions, so the pending list and
-    several finalize rounds run; `narrow3`: three ranks, three slices, k=15 (32-bit keys through the partition)"""
+    several finalize rounds run; `narrow3`: three ranks, three slices, k=15 (32-bit keys through the partition);
+    `presplit*`: level 2 restricted to 3 hash bits, so that the shards need the pre-split pass that 4- and 8-GPU tables
+    of BASELINE size need (a third trip of the keys: 2^bx-way split, then the ordinary level 2 over the sub-buckets)"""
     import socket
     import torch.multiprocessing as mp
     from kmertools_amd import device
