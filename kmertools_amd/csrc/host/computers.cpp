@@ -619,22 +619,28 @@ CountComputer::~CountComputer() {
 
 // "{kmer}\t{count}\n" (or the ACGT form) for n table entries, appended to `out` (counter/src/lib.rs:220-230)
 static void write_counts(FILE *out, const uint64_t *keys, const uint32_t *counts, uint64_t n, bool acgt, int k, int threads) {
+    // (in slabs: the text of a table of billions of entries is not held in memory at once)
+    constexpr uint64_t SLAB = 16ull << 20;
     std::vector<std::string> pieces;
-    format_rows(n, threads, acgt ? (size_t)k + 4 : 24, pieces, [&](uint64_t i, std::string &s) {
-        char buf[40];
-        if (acgt) {
-            kt_numeric_to_kmer(keys[i], k, buf);  // counter/src/lib.rs:221-226
-            s += buf;
-        } else {
-            const auto r = std::to_chars(buf, buf + sizeof buf, keys[i]);
-            s.append(buf, (size_t)(r.ptr - buf));
-        }
-        s += '\t';
-        const auto r2 = std::to_chars(buf, buf + sizeof buf, counts[i]);
-        s.append(buf, (size_t)(r2.ptr - buf));
-        s += '\n';
-    });
-    for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+    for (uint64_t i0 = 0; i0 < n; i0 += SLAB) {
+        const uint64_t m = n - i0 < SLAB ? n - i0 : SLAB;
+        format_rows(m, threads, acgt ? (size_t)k + 4 : 24, pieces, [&](uint64_t r, std::string &s) {
+            const uint64_t i = i0 + r;
+            char buf[40];
+            if (acgt) {
+                kt_numeric_to_kmer(keys[i], k, buf);  // counter/src/lib.rs:221-226
+                s += buf;
+            } else {
+                const auto rr = std::to_chars(buf, buf + sizeof buf, keys[i]);
+                s.append(buf, (size_t)(rr.ptr - buf));
+            }
+            s += '\t';
+            const auto r2 = std::to_chars(buf, buf + sizeof buf, counts[i]);
+            s.append(buf, (size_t)(r2.ptr - buf));
+            s += '\n';
+        });
+        for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+    }
 }
 
 static uint64_t env_u64_host(const char *name, uint64_t dflt) {
@@ -688,9 +694,15 @@ std::string CountComputer::count() {
     if (fit < 1024) fit = 1024;
     passes_ = (uint32_t)((want + fit - 1) / fit);
     if (passes_ < 1) passes_ = 1;
-    // a partition's share of the keys varies a little: 1 / passes + 5 sigma of room
-    uint64_t cap = passes_ == 1 ? want : want / passes_ + want / passes_ / 16 + 4096;
-    if (kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_) != KT_OK) return kt_last_error();
+    // a partition's share of the keys varies a little: 1 / passes + 5 sigma of room.  The library rounds the request up
+    // (to m * 2^j, at most 1.25x), so a table sized to the edge of the free HBM may not fit after all: more passes then.
+    uint64_t cap = 0;
+    for (;; passes_++) {
+        cap = passes_ == 1 ? want : want / passes_ + want / passes_ / 16 + 4096;
+        const int rc = kt_ctr_create(dev_.ctx, ksize_, cap, &ctr_);
+        if (rc == KT_OK) break;
+        if (rc != KT_ERR_NOMEM || passes_ >= 4096) return kt_last_error();
+    }
     if (getenv("KT_CLI_TIMING")) {
         uint64_t slots = cap;
         (void)kt_ctr_capacity(ctr_, &slots);

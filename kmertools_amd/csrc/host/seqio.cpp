@@ -165,6 +165,38 @@ struct SeqReader::Parallel {
     }
 };
 
+// The piecewise reader finds FASTQ record starts by the 4-line shape of a record (Parallel::boundary).  The serial
+// parser also takes sequences and qualities wrapped over several lines; such a file must stay with it.  Looks at the
+// first records of the file: '@' line, sequence, '+' line, quality of the sequence's length - up to 64 of them.
+static bool fastq_is_four_line(int fd, size_t size) {
+    std::vector<unsigned char> head(size < (1u << 20) ? size : (1u << 20));
+    size_t got = 0;
+    while (got < head.size()) {
+        const ssize_t r = pread(fd, head.data() + got, head.size() - got, (off_t)got);
+        if (r <= 0) return false;
+        got += (size_t)r;
+    }
+    size_t p = 0;
+    auto line = [&](size_t &s0, size_t &len) {  // next line [s0, s0 + len), CR stripped; false at the sample's end
+        if (p >= got) return false;
+        const unsigned char *e = (const unsigned char *)memchr(head.data() + p, '\n', got - p);
+        if (!e) return false;
+        s0 = p;
+        len = (size_t)(e - head.data()) - p;
+        if (len && head[s0 + len - 1] == '\r') len--;
+        p = (size_t)(e - head.data()) + 1;
+        return true;
+    };
+    for (int rec = 0; rec < 64; rec++) {
+        size_t s0, l0, s1, l1, s2, l2, s3, l3;
+        if (!line(s0, l0)) return rec > 0;          // (the sample ended between records: what was seen was regular)
+        if (l0 == 0 || head[s0] != '@') return false;
+        if (!line(s1, l1) || !line(s2, l2) || !line(s3, l3)) return rec > 0;
+        if (l2 == 0 || head[s2] != '+' || l1 != l3) return false;
+    }
+    return true;
+}
+
 static int reader_threads() {
     if (const char *e = getenv("KT_READER_THREADS")) return atoi(e) > 0 ? atoi(e) : 1;
     long n = sysconf(_SC_NPROCESSORS_ONLN);
@@ -203,10 +235,13 @@ bool SeqReader::open(const std::string &path, bool sniff) {
                 P->size = (size_t)st.st_size;
                 SeqFormat f = sniff ? SeqFormat::Unknown : format_from_path(path);
                 if (f == SeqFormat::Unknown) f = magic[0] == '>' ? SeqFormat::Fasta : SeqFormat::Fastq;
-                P->fmt = f;
-                fmt_ = f;
-                par_ = P;
-                return true;
+                if (f != SeqFormat::Fastq || fastq_is_four_line(fd, (size_t)st.st_size)) {
+                    P->fmt = f;
+                    fmt_ = f;
+                    par_ = P;
+                    return true;
+                }
+                P->fd = -1;  // a wrapped FASTQ: the serial parser below (the descriptor is closed just after)
             }
         }
         if (fd >= 0) ::close(fd);

@@ -325,8 +325,22 @@ def test_parallel_reader_matches_serial(cli, tmp_path):
             s = alpha[rng.integers(0, 4, size=L)].tobytes()
             q = qual[rng.integers(0, len(qual), size=L)].tobytes()
             f.write(b"@q%d extra\n%s\n+\n%s\n" % (i, s, q))
-    assert fa.stat().st_size > (32 << 20) and fq.stat().st_size > (32 << 20)
-    for path, n in ((fa, 90_000), (fq, 140_000)):
+    # a FASTQ whose sequences and qualities are wrapped over several lines (quality lines starting with '@'): the serial
+    # parser reads it; the piecewise reader's 4-line boundary rule does not hold, so the file must stay with the former
+    fw = tmp_path / "wrapped.fastq"
+    with open(fw, "wb") as f:
+        for i in range(60_000):
+            L = int(rng.integers(100, 900))
+            s = alpha[rng.integers(0, 4, size=L)].tobytes()
+            q = b"@" + b"I" * (L - 1)
+            f.write(b"@w%d\n" % i)
+            for j in range(0, L, 80):
+                f.write(s[j:j + 80] + b"\n")
+            f.write(b"+\n")
+            for j in range(0, L, 80):
+                f.write(q[j:j + 80] + b"\n")
+    assert fa.stat().st_size > (32 << 20) and fq.stat().st_size > (32 << 20) and fw.stat().st_size > (32 << 20)
+    for path, n in ((fa, 90_000), (fq, 140_000), (fw, 60_000)):
         serial = digest(path, 1)
         assert serial[1] == n
         for threads in (2, 5):
