@@ -230,6 +230,18 @@ int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, u
                  uint64_t bin_size, uint64_t bin_count, int norm, int out_dtype, void *out,
                  int mem);
 
+/* The same lookups against a table that holds only PART of the k-mers - one hash partition of an out-of-core count
+ * (kt_ctr_add_reads_part: n_parts passes, the table refilled for each) or one shard of a sharded table (n_parts = 1;
+ * the shard answers for the k-mers kt_sharded_owner_of gives it).  Only the k-mers this table answers for are binned
+ * (a k-mer of another partition is not "absent": it is skipped), as raw u32 counts ADDED to `counts` (n_reads x
+ * bin_count, zeroed by the caller before the first part; `mem` says where it lives).  Summed over the parts every
+ * k-mer of every read has been binned exactly once - the rows kt_cov_batch gives with KT_U32; normalisation
+ * (count / max(1, sum of the row), coverage/src/lib.rs:180-182) is then one division per cell.
+ * replaces: coverage/src/lib.rs:69-92 + :165-184 for inputs whose k-mers do not fit one table. */
+int kt_cov_batch_part(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                      uint64_t bin_size, uint64_t bin_count, uint32_t *counts, int mem, uint32_t n_parts,
+                      uint32_t part);
+
 /* Multi-GPU routing step (the reference's `min_mer % n_parts` partitioning,
  * counter/src/lib.rs:127, re-expressed as hash-prefix ownership):
  * writes every canonical k-mer of the reads into keys_out grouped by owner

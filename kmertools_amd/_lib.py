@@ -51,6 +51,7 @@ SYMBOLS = {
     "kt_cgr_points": (_i, [_vp, _vp, _vp, _u64, C.c_double, _vp, _vp, _i]),
     "kt_minimisers": (_i, [_vp, _vp, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64), _i]),
     "kt_cov_batch": (_i, [_vp, _vp, _vp, _u64, _u64, _u64, _i, _i, _vp, _i]),
+    "kt_cov_batch_part": (_i, [_vp, _vp, _vp, _u64, _u64, _u64, _vp, _i, _u32, _u32]),
     "kt_ctr_route": (_i, [_vp, _vp, _vp, _u64, _i, _i, _vp, _vp, _i]),
     "kt_owner_of": (_u32, [_u64, _u32]),
     "kt_rccl_unique_id": (_i, [_vp]),

@@ -729,7 +729,10 @@ std::string CountComputer::count() {
         }
         if (reader.failed()) return reader.error();
         if (passes_ == 1) break;  // the table stays resident: merge() (and cov) read it
-        // out of core: this partition is complete - its lines go to kmers.counts now, the table is reused
+        // out of core: this partition is complete - whoever needs to look k-mers up does it now (cov) -
+        if (pass_hook_)
+            if (std::string e = pass_hook_(pass, passes_, ctr_); !e.empty()) return e;
+        // - its lines go to kmers.counts, and the table is reused
         uint64_t n = 0, got = 0;
         if (kt_ctr_size(ctr_, &n) != KT_OK) return kt_last_error();
         std::vector<uint64_t> keys(n ? n : 1);
@@ -944,12 +947,39 @@ CovComputer::CovComputer(std::string in_path, std::string out_dir, int ksize, ui
 
 CovComputer::~CovComputer() { delete ctr_; }
 
+// one pass of an out-of-core table is complete: the raw bin counts of every read's k-mers of this hash partition
+std::string CovComputer::cov_pass(uint32_t pass, uint32_t passes, kt_ctr *table) {
+    SeqReader reader;
+    if (!reader.open(in_path_, false)) return reader.error();
+    Batch b;
+    uint64_t at = 0;
+    for (;;) {
+        const bool more = reader.next_batch(b, cli_batch_bases(256ull << 20), cli_batch_reads(bin_count_ >= 2048 ? 8192 : 1ull << 19));
+        const uint64_t n = b.n_reads();
+        if (n) {
+            if (pass == 0) acc_rows_.resize((at + n) * bin_count_, 0u);
+            else if ((at + n) * bin_count_ > acc_rows_.size()) return "cov: the input changed between the passes";
+            if (kt_cov_batch_part(table, bases_ptr(b), b.offsets.data(), n, bin_size_, bin_count_, acc_rows_.data() + at * bin_count_,
+                                  KT_MEM_HOST, passes, pass) != KT_OK)
+                return kt_last_error();
+            at += n;
+        }
+        if (!more) break;
+    }
+    if (reader.failed()) return reader.error();
+    acc_reads_ = at;
+    return "";
+}
+
 std::string CovComputer::build_table() {
     delete ctr_;
+    acc_rows_.clear();
+    acc_reads_ = 0;
     ctr_ = new CountComputer(in_path_kmer_, out_dir_, ksize_);
     ctr_->set_threads(threads_);
     ctr_->set_max_memory(memory_ceil_gb_);
     ctr_->set_device(device_);
+    ctr_->set_pass_hook([this](uint32_t pass, uint32_t passes, kt_ctr *t) { return cov_pass(pass, passes, t); });
     std::string e = ctr_->count();
     if (e.empty()) e = ctr_->merge(true);  // the reference leaves kmers.counts behind as well
     return e;
@@ -957,6 +987,34 @@ std::string CovComputer::build_table() {
 
 std::string CovComputer::compute_coverages() {
     // the reference parses kmers.counts back into a HashMap (:82-92); the table is still in HBM here
+    if (ctr_ && ctr_->passes() > 1) {
+        // ... unless it took several passes: the rows were summed pass by pass (cov_pass); normalise, format, write
+        const std::string path = out_dir_ + "/kmers.vectors";
+        FILE *out = fopen(path.c_str(), "wb");
+        if (!out) return "Unable to write to file: " + path;
+        PhaseTimer pt("cov (rows summed over the passes)");
+        AsyncWriter writer(out, pt);
+        std::vector<std::string> pieces;
+        const uint64_t bins = bin_count_, slab = bins >= 2048 ? 8192 : 1ull << 19;
+        Work w;
+        for (uint64_t r0 = 0; r0 < acc_reads_; r0 += slab) {
+            const uint64_t n = acc_reads_ - r0 < slab ? acc_reads_ - r0 : slab;
+            w.b.clear();
+            w.b.offsets.assign(n + 1, 0);  // (emit_matrix only needs the number of reads)
+            w.resize_rows(n * bins);
+            for (uint64_t r = 0; r < n; r++) {
+                const uint32_t *row = acc_rows_.data() + (r0 + r) * bins;
+                uint64_t total = 0;
+                for (uint64_t i = 0; i < bins; i++) total += row[i];
+                const double d = total > 1 ? (double)total : 1.0;   // coverage/src/lib.rs:180-182
+                for (uint64_t i = 0; i < bins; i++) w.rows[r * bins + i] = norm_ ? (double)row[i] / d : (double)row[i];
+            }
+            emit_matrix(writer, w, bins, norm_, delim_, threads_, pieces, pt);
+        }
+        writer.finish();
+        fclose(out);
+        return "";
+    }
     if (!ctr_ || !ctr_->table()) return "build_table() has not run";
     SeqReader reader;
     if (!reader.open(in_path_, false)) return reader.error();

@@ -12,6 +12,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -103,6 +104,8 @@ class CountComputer {
     std::string merge(bool del);     // counter/src/lib.rs:172-234: writes {out_dir}/kmers.counts
     uint64_t seq_count() const { return seq_count_; }  // 0 when the sizing pre-pass was skipped (plain files)
     uint32_t passes() const { return passes_; }
+    // out of core (passes() > 1): called with every pass's complete table before it is written out and cleared
+    void set_pass_hook(std::function<std::string(uint32_t pass, uint32_t passes, kt_ctr *table)> h) { pass_hook_ = std::move(h); }
     kt_ctr *table() const { return passes_ == 1 && !sharded_done_ ? ctr_ : nullptr; }  // the resident table (after count())
     kt_ctx *context() const { return dev_.ctx; }
 
@@ -119,6 +122,7 @@ class CountComputer {
     bool sharded_done_ = false;
     std::vector<std::vector<uint64_t>> shard_keys_;
     std::vector<std::vector<uint32_t>> shard_counts_;
+    std::function<std::string(uint32_t, uint32_t, kt_ctr *)> pass_hook_;
     std::string count_sharded(uint64_t max_distinct);
 };
 
@@ -151,6 +155,11 @@ class CovComputer {
     bool norm_ = true;
     double memory_ceil_gb_ = 6.0;
     CountComputer *ctr_ = nullptr;  // owns the HBM table the coverages are looked up in
+    // a table that needed several passes (the k-mers do not fit the HBM): the reads' raw bin counts, summed over the
+    // passes as each pass's table is complete (kt_cov_batch_part), normalised and written at the end
+    std::vector<uint32_t> acc_rows_;
+    uint64_t acc_reads_ = 0;
+    std::string cov_pass(uint32_t pass, uint32_t passes, kt_ctr *table);
 
   public:
     ~CovComputer();

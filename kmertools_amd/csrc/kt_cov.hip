@@ -37,6 +37,8 @@ struct CovArgs {
     uint32_t bin_size;   // 0 = wider than any u32 count: every k-mer falls in bin 0
     uint32_t bin_count;
     uint32_t *counts;    // n_reads x bin_count, zeroed
+    uint32_t n_parts, part;  // n_parts > 1: only the k-mers of hash partition `part` are binned (kt_cov_batch_part)
+    uint32_t shard;          // the table is a shard of a sharded table: only the k-mers it owns are binned
 };
 
 __device__ __forceinline__ uint4 load_slot(const Slot *slots, uint64_t slot) {
@@ -108,6 +110,9 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
 #pragma unroll
                 for (uint32_t u = 0; u < GROUP; u++) {
                     if (!((ok >> (jj + u)) & 1u)) continue;
+                    // (a k-mer that another pass / another shard answers for is not "absent" here: it is skipped)
+                    if (c.n_parts > 1 && ktd::owner_of(key[u], c.n_parts) != c.part) continue;
+                    if (c.shard && kttab::probe_of(key[u], c.g).rs == 0) continue;
                     const uint32_t cnt = resolve_count(c, v[u], key[u]);
                     uint32_t bin = c.bin_size ? cnt / c.bin_size : 0u;  // coverage/src/lib.rs:172
                     bin = bin < last_bin ? bin : last_bin;              // :173
@@ -158,6 +163,58 @@ __global__ __launch_bounds__(BLOCK) void cov_finalize_kernel(const uint32_t *__r
 
 using namespace ktl;
 
+// the lookup pass: u32 bin counts of the reads' k-mers (those of hash partition `part` of n_parts) into d_counts
+static int cov_counts(kt_ctr *table, kt_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                      uint64_t total, uint64_t bin_size, uint64_t bin_count, uint32_t *d_counts, uint32_t n_parts,
+                      uint32_t part) {
+    if (!total) return KT_OK;
+    SegArgs a;
+    if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, table->k, &a)) return rc;
+    CovArgs c{(const Slot *)table->slots, ktl::geom_of(table), bin_size > 0xFFFFFFFFull ? 0u : (uint32_t)bin_size,
+              (uint32_t)bin_count, d_counts, n_parts, part, table->n_owners > 1 ? 1u : 0u};
+    hipLaunchKernelGGL(cov_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, c);
+    KT_HIP(hipGetLastError());
+    return KT_OK;
+}
+
+extern "C" int kt_cov_batch_part(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                                 uint64_t bin_size, uint64_t bin_count, uint32_t *counts, int mem, uint32_t n_parts,
+                                 uint32_t part) {
+    if (!table) return kt::fail(KT_ERR_ARG, "kt_cov_batch_part: null table");
+    if (bin_size == 0) return kt::fail(KT_ERR_ARG, "kt_cov_batch_part: bin_size must be >= 1");
+    if (bin_count == 0 || bin_count > 0xFFFFFFFFull) return kt::fail(KT_ERR_ARG, "kt_cov_batch_part: bin_count must be in 1..2^32-1");
+    if (n_parts < 1 || part >= n_parts) return kt::fail(KT_ERR_ARG, "kt_cov_batch_part: need part < n_parts");
+    if (mem != KT_MEM_HOST && mem != KT_MEM_DEVICE) return kt::fail(KT_ERR_ARG, "kt_cov_batch_part: bad mem");
+    if (n_reads == 0) return KT_OK;
+    if (!offsets || !counts) return kt::fail(KT_ERR_ARG, "kt_cov_batch_part: null buffer");
+    kt_ctx *ctx = table->ctx;
+    if (int rc = ctx->use()) return rc;
+    if (int rc = table_ready(table)) return rc;
+    uint64_t total = 0;
+    if (int rc = total_bases_of(ctx, offsets, n_reads, mem, &total)) return rc;
+    if (total && !bases) return kt::fail(KT_ERR_ARG, "kt_cov_batch_part: null bases");
+    const uint64_t n_cells = n_reads * bin_count;
+    if (mem == KT_MEM_DEVICE) return cov_counts(table, ctx, bases, offsets, n_reads, total, bin_size, bin_count, counts, n_parts, part);
+    // host rows: this call's counts are made on the device from zero and added to the caller's
+    const uint8_t *d_bases = bases;
+    const uint64_t *d_offsets = offsets;
+    if (total)
+        if (int rc = stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) return rc;
+    if (int rc = ctx->s_aux1.reserve(n_cells * 4)) return rc;
+    uint32_t *d_counts = (uint32_t *)ctx->s_aux1.p;
+    KT_HIP(hipMemsetAsync(d_counts, 0, n_cells * 4, ctx->stream));
+    if (int rc = cov_counts(table, ctx, d_bases, d_offsets, n_reads, total, bin_size, bin_count, d_counts, n_parts, part)) return rc;
+    uint32_t *tmp = (uint32_t *)malloc(n_cells * 4);
+    if (!tmp) return kt::fail(KT_ERR_NOMEM, "kt_cov_batch_part: host alloc");
+    hipError_t e = hipMemcpyAsync(tmp, d_counts, n_cells * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+        for (uint64_t i = 0; i < n_cells; i++) counts[i] += tmp[i];
+    free(tmp);
+    if (e != hipSuccess) return kt::fail(KT_ERR_HIP, std::string("kt_cov_batch_part: ") + hipGetErrorString(e));
+    return KT_OK;
+}
+
 extern "C" int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                             uint64_t bin_size, uint64_t bin_count, int norm, int out_dtype, void *out, int mem) {
     if (!table) return kt::fail(KT_ERR_ARG, "kt_cov_batch: null table");
@@ -169,6 +226,8 @@ extern "C" int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t 
     if (mem != KT_MEM_HOST && mem != KT_MEM_DEVICE) return kt::fail(KT_ERR_ARG, "kt_cov_batch: bad mem");
     if (n_reads == 0) return KT_OK;
     if (!offsets || !out) return kt::fail(KT_ERR_ARG, "kt_cov_batch: null buffer");
+    if (table->n_owners > 1)
+        return kt::fail(KT_ERR_ARG, "kt_cov_batch: the table is one shard of a sharded table - kt_cov_batch_part on every shard, summed");
     kt_ctx *ctx = table->ctx;
     if (int rc = ctx->use()) return rc;
     if (int rc = table_ready(table)) return rc;
@@ -195,14 +254,7 @@ extern "C" int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t 
         d_counts = (uint32_t *)ctx->s_aux1.p;
     }
     KT_HIP(hipMemsetAsync(d_counts, 0, n_cells * 4, ctx->stream));
-    if (total) {
-        SegArgs a;
-        if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, table->k, &a)) return rc;
-        CovArgs c{(const Slot *)table->slots, ktl::geom_of(table),
-                  bin_size > 0xFFFFFFFFull ? 0u : (uint32_t)bin_size, (uint32_t)bin_count, d_counts};
-        hipLaunchKernelGGL(cov_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, c);
-        KT_HIP(hipGetLastError());
-    }
+    if (int rc = cov_counts(table, ctx, d_bases, d_offsets, n_reads, total, bin_size, bin_count, d_counts, 1, 0)) return rc;
     const uint32_t fb = (uint32_t)((n_reads + BLOCK - 1) / BLOCK);
     if (out_dtype == KT_F64)
         hipLaunchKernelGGL(cov_finalize_kernel<double>, dim3(fb), dim3(BLOCK), 0, ctx->stream, d_counts, n_reads,

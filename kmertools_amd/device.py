@@ -305,6 +305,13 @@ class Counter:
                                       int(bool(norm)), _DT[dtype], _ptr(out), mem))
         return out
 
+    def cov_part(self, bases, offsets, n_reads, bin_size, bin_count, counts, n_parts=1, part=0, mem=KT_MEM_DEVICE):
+        """adds the u32 bin counts of the k-mers this table answers for (hash partition `part` of n_parts; a shard: the
+        k-mers it owns) to `counts` (n_reads x bin_count)"""
+        check(_lib.lib().kt_cov_batch_part(self._h, _ptr(bases), _ptr(offsets), n_reads, int(bin_size), int(bin_count),
+                                           _ptr(counts), mem, int(n_parts), int(part)))
+        return counts
+
     def cov_host(self, bases, offsets, bin_size, bin_count, norm=True, dtype="f64"):
         bases = np.ascontiguousarray(bases, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)

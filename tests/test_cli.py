@@ -269,6 +269,19 @@ def test_ctr_out_of_core_passes_and_devices(cli, oracle, tmp_path):
     passes = int(r.stderr.split(" pass(es)")[0].split()[-1])
     assert passes >= 4
     assert sorted((d4 / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(keys, counts, k=21, acgt=True)
+    # cov over a table that needs passes (coverage/src/lib.rs:69-184 works for any input its ctr can count): every pass's
+    # table is probed for the k-mers of its hash partition, the raw rows summed, normalised at the end
+    k15, c15 = oracle.count_reads(bases, offsets, 15, n_parts=4, threads=4)
+    oc = oracle.Counter(1)
+    oc.add_pairs(k15, c15)
+    cv = tmp_path / "cov4"
+    small15 = max(1024, int(1.4 * len(k15) / 4))
+    for extra, norm, text in (((), True, None), (("--counts",), False, None)):
+        r = run(cli, "cov", "-i", fq, "-o", cv, "-k", "15", "-s", "5", "-c", "6", *extra, env=dict(env, KT_CTR_MAX_SLOTS=str(small15)))
+        assert r.returncode == 0, r.stderr
+        assert int(r.stderr.split(" pass(es)")[0].split()[-1]) >= 4
+        assert (cv / "kmers.vectors").read_bytes() == oracle.oligo_text(oc.cov_batch(bases, offsets, 15, 5, 6, norm), norm)
+        assert sorted((cv / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(k15, c15)
     d2 = tmp_path / "two"
     r = run(cli, "ctr", "-i", fq, "-o", d2, "-k", "21", "--devices", "2", env=dict(env, KT_CLI_SHARE_GPU="1"))
     assert r.returncode == 0, r.stderr

@@ -984,6 +984,29 @@ def test_cov_vs_oracle(hctx, oracle, k, bin_size, bin_count):
     ctr.close()
 
 
+@pytest.mark.parametrize("k,n_parts", [(15, 4), (31, 3), (9, 5)])
+def test_cov_over_hash_partitions(hctx, oracle, monkeypatch, k, n_parts):
+    """kt_cov_batch_part: a table that holds one hash partition of the k-mers (an out-of-core pass) answers for that
+    partition only; the raw rows summed over the passes are the rows of the whole table (every k-mer binned once -
+    absent k-mers too, by the pass their hash belongs to), host and device rows alike"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    seqs = ragged_reads(40 + k, 500) + _random_reads(k, 200)
+    bases, offsets = device.to_csr(seqs)
+    pb, po = device.to_csr(seqs[::3] + _random_reads(k + 1, 60) + [b"", b"ACG"])
+    oc = oracle.Counter(1)
+    oc.add_reads(bases, offsets, k)
+    want = oc.cov_batch(pb, po, k, 3, 7, False).astype(np.uint32)
+    n = len(po) - 1
+    acc = np.zeros((n, 7), np.uint32)
+    for part in range(n_parts):
+        ctr = device.Counter(hctx, k, 1 << 18)
+        ctr.add_reads_host(bases, offsets, n_parts, part)
+        ctr.cov_part(pb if pb.size else np.zeros(1, np.uint8), po, n, 3, 7, acc, n_parts, part, mem=0)
+        ctr.close()
+    assert np.array_equal(acc, want)
+
+
 def test_cov_tiny_reads_and_empty_table(hctx, oracle):
     """segments holding more bin cells than the LDS image (thousands of k-length reads) take the
     direct path; an empty table puts every k-mer in bin 0"""
