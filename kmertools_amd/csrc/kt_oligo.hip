@@ -299,9 +299,16 @@ __device__ __forceinline__ void halo(uint32_t P, uint32_t V, uint32_t &Whi, uint
 // rem = bases left in that read from base 0 on, len1 = length of the following read (0: none);
 // all clamped to small ranges by the caller.  Branch-free: 16-bit masks over the lane's bases
 // (base i <-> bit 15-i), 16 unconditional LUT reads, 16 unconditional ds_add of 0 or 1.
+#ifndef KT_OLIGO_LUTREG
+#define KT_OLIGO_LUTREG 0  // 1 (k <= 4): the canonical-rank LUT (<= 256 one-byte bins) in ONE register per lane of the wave - lane
+#endif                     // i holds the bins of k-mers 4 i .. 4 i + 3 - looked up with a ds_bpermute (crossbar, no LDS banks) +
+                           // a v_perm byte select instead of a ds_read_u16 at a random LDS address.  Measured round 3, same
+                           // call, twice: 2.15 / 2.18 ms against 2.08 / 2.11 ms for the LDS table - the two extra VALU
+                           // instructions per k-mer cost more than the bank conflicts they remove (the kernel's B phase is
+                           // issue bound).  Off.
 template <int K, bool CANON>
 __device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t V, uint32_t lane, uint32_t rid0,
-                                       int32_t pos0, uint32_t rem, uint32_t len1, const uint16_t *lut,
+                                       int32_t pos0, uint32_t rem, uint32_t len1, const uint16_t *lut, uint32_t lutreg,
                                        uint32_t *hist, uint32_t *tot) {
     constexpr uint32_t KMASK = (1u << (2 * K)) - 1u;
     const uint32_t R = a.R, bins = a.bins;
@@ -332,7 +339,12 @@ __device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t 
         for (int j = 0; j < 8; j++) {
             const int i = h * 8 + j;
             const uint32_t f = __builtin_amdgcn_alignbit(Whi, P, 2 * (15 - i)) & KMASK;
-            bin[j] = CANON ? (uint32_t)lut[f] : f * 4u;  // byte offset of the bin inside its row
+            if constexpr (CANON && K <= 4 && KT_OLIGO_LUTREG) {
+                const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(f & ~3u), (int)lutreg);  // lane f / 4's register
+                bin[j] = __builtin_amdgcn_perm(0u, w, (f & 3u) | 0x0C0C0C00u) << 2;               // its byte f % 4, x 4
+            } else {
+                bin[j] = CANON ? (uint32_t)lut[f] : f * 4u;  // byte offset of the bin inside its row
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -355,8 +367,8 @@ __device__ __forceinline__ void emit16(const OligoArgs &a, uint32_t P, uint32_t 
 // ---- one 1008-base chunk of a tile -> LDS histogram rows ------------------------------------------
 template <int K, bool CANON>
 __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile &t, uint64_t ci, uint4 data,
-                                              uint32_t lane, const uint16_t *lut, uint32_t *hist, uint32_t *tot,
-                                              const uint64_t *roff) {
+                                              uint32_t lane, const uint16_t *lut, uint32_t lutreg, uint32_t *hist,
+                                              uint32_t *tot, const uint64_t *roff) {
     constexpr uint32_t KMASK = (1u << (2 * K)) - 1u;
     const uint32_t bins = a.bins, nr = t.nr;
     uint32_t P, V;
@@ -375,7 +387,7 @@ __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile
         const uint32_t rem = pos0 < 0 ? 255u : (left > 255u ? 255u : left);
         const uint32_t len1 = (rid0 + 1 < nr) ? (Lr > 255u ? 255u : Lr) : 0u;
         if (q < 0 || q >= (int32_t)(uint32_t)t.flat_end || rid0 >= nr) V = 0xFFFFu;
-        emit16<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot);
+        emit16<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, lutreg, hist, tot);
         return;
     }
     // general tile: 64-bit positions, membership by binary search of the tile's offsets
@@ -416,7 +428,7 @@ __device__ __forceinline__ void process_chunk(const OligoArgs &a, const ProdTile
         slow = rem < NB && rid0 + 1 < nr && len1 < NB - rem;
     }
     if (__ballot(slow) == 0) {
-        emit16<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, hist, tot);
+        emit16<K, CANON>(a, P, V, lane, rid0, pos0, rem, len1, lut, lutreg, hist, tot);
         return;
     }
     // per-base path: every base finds its own read (several boundaries in 16 bases)
@@ -564,6 +576,14 @@ __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    uint32_t lutreg = 0;  // k <= 4: bins of k-mers 4 lane .. 4 lane + 3, one byte each (a.lut holds 4 * bin)
+    if constexpr (CANON && K <= 4 && KT_OLIGO_LUTREG) {
+#pragma unroll
+        for (uint32_t jj = 0; jj < 4; jj++) {
+            const uint32_t f = lane * 4 + jj;
+            if (f < (1u << (2 * K))) lutreg |= ((uint32_t)a.lut[f] >> 2) << (8 * jj);
+        }
+    }
     for (uint32_t i = tid; i < R * bins; i += NT) hist[i] = 0;
     for (uint32_t i = tid; i < MAX_R; i += NT) tot[i] = 0;
     for (uint32_t i = tid; i < NLUT; i += NT) reinterpret_cast<uint16_t *>(smem)[i] = a.lut[i];
@@ -606,7 +626,7 @@ __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
                 } else {
                     d = load_chunk(a, t_cur, ci, lane, total_bytes);
                 }
-                process_chunk<K, CANON>(a, t_cur, ci, d, lane, lut, hist, tot, roff);
+                process_chunk<K, CANON>(a, t_cur, ci, d, lane, lut, lutreg, hist, tot, roff);
             }
         }
         TileCtx tc;
