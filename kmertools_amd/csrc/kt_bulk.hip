@@ -590,7 +590,10 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
     constexpr int PER = wide_per<K>(), NQ = ktseg::PER_THREAD / PER;
     constexpr uint32_t PAGE = page_keys<K>();
     const uint32_t tid = threadIdx.x, grp = tid / BLOCK, t = tid % BLOCK;
-    if (tid < p.B1) sm.cur[tid] = wcur[(uint64_t)blockIdx.x * p.B1 + tid];
+    if (tid < p.B1) {
+        sm.cur[tid] = wcur[(uint64_t)blockIdx.x * p.B1 + tid];
+        sm.cnt[tid] = 0;  // (from here on every round leaves cnt zeroed for the next one: see below)
+    }
     if (tid == 0) sm.ovf = 0;
     const uint64_t n_units = src.n_units();
     bool stop = false;
@@ -603,8 +606,8 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
             uint32_t ok;
             src.template take<PER, K>(wk, t, keys, ok);
             if (!valid) ok = 0;
-            if (tid < p.B1) sm.cnt[tid] = 0;
-            ktd::lds_barrier();
+            // (no barrier here: cnt was zeroed by the previous round's layout step, two barriers ago, and nothing a
+            // wave still busy with the previous round's copy-out reads is written before the barrier after the count)
 #pragma unroll
             for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
                 keys[j] = to_stored<K>((uint64_t)keys[j]);
@@ -618,6 +621,7 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
             uint32_t room = 0, spl = 0, nxt = 0;
             if (tid < p.B1) {
                 const uint32_t d = tid, c = sm.cnt[d], rs = sm.start[d], cur = sm.cur[d];
+                sm.cnt[d] = 0;  // for the next round's count
                 const uint32_t left = (0u - cur) & (PAGE - 1u);
                 sm.to_cur[d] = cur - rs;
                 spl = rs + (c < left ? c : left);
@@ -667,7 +671,9 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                     }
                 }
             }
-            ktd::lds_barrier();
+            // the next round's count, scan and layout touch nothing the copy-out reads, and its placement comes three
+            // barriers later: only the staging of a new segment (it shares LDS with the sort buffer) has to wait
+            if (q == NQ - 1) ktd::lds_barrier();
         }
     }
     ktd::lds_barrier();
@@ -727,6 +733,9 @@ struct Part2Shared {
 // other GPUs' level-1 passes filled and sent (kt_shard.hip).  Segment s of local bucket jl = srcs[s].keys + jl * cap1,
 // min(srcs[s].counts[jl], cap1) keys, empty keys in the page gaps.  (exact level 1, srcs == nullptr: keys1 is dense,
 // bucket j = [bstart[j], bstart[j + 1]).)
+#ifndef KT_P2_LOAD16
+#define KT_P2_LOAD16 0  // two keys per 16-byte load in part2: measured 16.0 against 15.5 ms (k=31) - off
+#endif
 struct P2In {
     const void *keys1;
     const uint64_t *bstart;
@@ -734,7 +743,7 @@ struct P2In {
     uint32_t n_src;
 };
 
-template <class K, bool FIXED, bool BIG>
+template <class K, bool FIXED, bool BIG, bool L16 = false>
 __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void part2_kernel(P2In in, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart,
                                                       uint64_t *__restrict__ fend) {
@@ -769,6 +778,19 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
         }
         const uint64_t lo = in.srcs ? (uint64_t)jl * p.room1 : in.bstart[jl];
         auto load_chunk = [&](const K *base, uint64_t n, uint64_t c0, K (&dst)[PER]) {
+            if constexpr (sizeof(K) == 8 && L16) {  // two keys per load (regions are 16-byte aligned: paged level 1)
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int u = 0; u < PER / 2; u++) {
+                    const uint64_t i = c0 + ((uint64_t)u * P2T + tid) * 2;
+                    u64x2 v = {(unsigned long long)EMPTY, (unsigned long long)EMPTY};
+                    if (i + 1 < n) v = *reinterpret_cast<const u64x2 *>(base + i);
+                    else if (i < n) v.x = base[i];
+                    dst[2 * u] = (K)v.x;
+                    dst[2 * u + 1] = (K)v.y;
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < PER; u++) {
                 const uint64_t i = c0 + (uint64_t)u * P2T + tid;
@@ -779,7 +801,10 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
         // appended at the fine buckets' cursors.  The next chunk's keys are loaded while the current one is sorted.
         // attempt = fixed fine regions (cursors may run past their room: then nothing is stored any more)
         auto run_pass = [&](const bool attempt) {
-            K kcur[PER], knxt[PER];
+            // One set of key registers: the next chunk's loads are issued once the current chunk's keys have been placed in
+            // LDS (they are dead then) and travel during the copy-out.  (Holding the prefetched chunk beside the current one
+            // - 64 registers of keys - spilled a quarter of them at the 128 registers a 16-wave workgroup gets.)
+            K kcur[PER];
             bool counting_only = false;
             uint64_t seen_keys = 0;
             for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
@@ -788,23 +813,18 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
                 segment(sidx, base, n);
                 if (n) load_chunk(base, n, 0, kcur);
                 for (uint64_t c0 = 0; c0 < n; c0 += CH) {
-                    if (c0 + CH < n) load_chunk(base, n, c0 + CH, knxt);
                     for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
                     ktd::lds_barrier();
                     if (attempt) counting_only = *sm.flag != 0;  // (written before the barrier above; same for every thread)
-                    // digits, two per register - unless they are a bit field of the stored hash: then the place pass
-                    // shifts them out again
-                    constexpr bool KEEP_DIG = !stores_hash<K>();
-                    uint32_t dgp[KEEP_DIG ? PER / 2 : 1];
 #pragma unroll
                     for (int u = 0; u < PER; u++) {
                         const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
-                        if constexpr (KEEP_DIG) dgp[u / 2] = (u & 1) ? dgp[u / 2] | (d << 16) : d;
                         if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[d], 1u);
                     }
                     ktd::lds_barrier();
+                    uint32_t nc = 0;
                     if (!counting_only) {
-                        const uint32_t nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
+                        nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
                         // (cnt has been summed: from here to the cursor update it holds cur - start, what the copy-out
                         // adds to a sorted key's index to get its place in the level-1 bucket)
                         for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = sm.cur[i] - sm.start[i];
@@ -812,14 +832,15 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
 #pragma unroll
                         for (int u = 0; u < PER; u++) {
                             if (kcur[u] != EMPTY) {
-                                uint32_t d;
-                                if constexpr (KEEP_DIG) d = (u & 1) ? dgp[u / 2] >> 16 : dgp[u / 2] & 0xFFFFu;
-                                else d = digit2h(hash_of_stored<K>(kcur[u]), p);
+                                const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
                                 const uint32_t pos = atomicAdd(&sm.start[d], 1u);
                                 sm.sorted[pos] = kcur[u];
                                 if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
                             }
                         }
+                    }
+                    if (c0 + CH < n) load_chunk(base, n, c0 + CH, kcur);  // the next chunk travels during the copy-out
+                    if (!counting_only) {
                         ktd::lds_barrier();
                         for (uint32_t i = tid; i < nc; i += P2T) {
                             const K key = sm.sorted[i];
@@ -846,8 +867,6 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
                         sm.cur[i] = c;
                         if (attempt && !counting_only && (float)(c - i * (uint32_t)p.cap2) > allowed) *sm.flag = 1;
                     }
-#pragma unroll
-                    for (int u = 0; u < PER; u++) kcur[u] = knxt[u];
                     // (the next iteration's first barrier orders the cursor / flag updates before their use)
                 }
                 seen_keys += n;
@@ -1692,7 +1711,9 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         auto launch = [&](auto big) -> int {
             constexpr bool BIG = decltype(big)::value;
             const size_t part2_lds = Part2Shared<K, BIG>::bytes(pp.B2);
-            auto part2 = pp.cap2 ? part2_kernel<K, true, BIG> : part2_kernel<K, false, BIG>;
+            // (16-byte loads where every region starts on a 16-byte boundary: paged level-1 outputs, not the pre-split's)
+            const bool l16 = KT_P2_LOAD16 && sizeof(K) == 8 && pp.cap2 && src.srcs && src.srcs != m.srcs + j.n_src;
+            auto part2 = !pp.cap2 ? part2_kernel<K, false, BIG> : l16 ? part2_kernel<K, true, BIG, true> : part2_kernel<K, true, BIG>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)part2_lds));
             hipLaunchKernelGGL(part2, dim3(pp.d_hi - pp.d_lo), dim3(p2t<K, BIG>()), part2_lds, ctx->stream, src, pp, out, fs, fe);

@@ -123,24 +123,34 @@ __device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegS
 // 128-bit shift register held in two VGPR pairs: fwd = top 2k bits, rev rolls like the
 // reference's generator (kmer/src/kmer.rs:91-93).
 struct Window {
-    uint64_t hi, lo, iv, bd, mk, mk1, f, r;
-    uint32_t sh, rsh;
+    uint64_t hi, lo, f, r;
+    uint32_t sh, rsh, okm;
+    // OR of x >> i for i in [0, len): log2(len) shift-or steps (len is the same for every lane)
+    static __device__ __forceinline__ uint64_t or_span(uint64_t x, uint32_t len) {
+        uint32_t c = 1;
+        while (2 * c <= len) {
+            x |= x >> c;
+            c *= 2;
+        }
+        if (c < len) x |= x >> (len - c);
+        return x;
+    }
     __device__ __forceinline__ Window(const SegShared &sm, uint32_t tid, uint32_t k) {
         hi = sm.codes[tid];
         lo = sm.codes[tid + 1];
-        iv = (uint64_t)sm.inv[tid] | ((uint64_t)sm.inv[tid + 1] << 32);
-        bd = (uint64_t)sm.bnd[tid] | ((uint64_t)sm.bnd[tid + 1] << 32);
+        const uint64_t iv = (uint64_t)sm.inv[tid] | ((uint64_t)sm.inv[tid + 1] << 32);
+        const uint64_t bd = (uint64_t)sm.bnd[tid] | ((uint64_t)sm.bnd[tid + 1] << 32);
         sh = 64u - 2u * k;
         rsh = 2u * (k - 1);
-        mk = (1ull << k) - 1ull;          // k bases
-        mk1 = (1ull << (k - 1)) - 1ull;   // the k-1 later bases
+        // which of the 32 window starts are k-mers, all at once: start j is one iff none of bases j .. j + k - 1 is
+        // invalid and no read starts at j + 1 .. j + k - 1 (testing every start on its own was 8 instructions x 32)
+        const uint64_t bad = or_span(iv, k) | (k > 1 ? or_span(bd >> 1, k - 1) : 0ull);
+        okm = ~(uint32_t)bad;
         f = hi >> sh;
         r = ktd::rev_comp(f, (int)k);
     }
     // is window start j (0..31) a k-mer: k valid bases, no read start among the k-1 later ones
-    __device__ __forceinline__ bool ok(uint32_t j) const {
-        return (((iv >> j) & mk) == 0) && (((bd >> (j + 1)) & mk1) == 0);
-    }
+    __device__ __forceinline__ bool ok(uint32_t j) const { return (okm >> j) & 1u; }
     // slide one base: the next code enters fwd at the bottom, its complement enters rev at the top
     __device__ __forceinline__ void step() {
         hi = (hi << 2) | (lo >> 62);
