@@ -699,14 +699,15 @@ template <class K, bool BIG>
 struct Part2Shared {
     K *sorted;         // [chunk2<K, BIG>()]
     uint32_t *cur;     // [B2] where the fine bucket's next key goes, relative to the level-1 bucket's first key
-    uint32_t *cnt;     // [B2] keys of the chunk per fine bucket; while a chunk is placed: cur - start (copy-out adds i)
+    uint32_t *cnt;     // [2][B2] keys of the chunk per fine bucket; while a chunk is placed: cur - start (copy-out adds i).
+                       // Two of them, used by alternate chunks: the next chunk counts while this one is copied out.
     uint32_t *start;   // [B2] the chunk's runs in sorted[]; the placement pass moves them to the runs' ends
     uint32_t *tmp;     // [16] block scan scratch
     uint32_t *flag;    // [1] (+1 pad) fixed fine regions: a fine bucket is outgrowing its room
     uint16_t *sdig;    // [chunk2<K, BIG>()]
-    // 12 bytes per fine bucket: with 64-bit keys, 8 K-key chunks and B2 <= 1024 two 512-thread workgroups fit a CU
+    // 16 bytes per fine bucket
     static size_t bytes(uint32_t B2) {
-        return (size_t)chunk2<K, BIG>() * sizeof(K) + (size_t)B2 * 12 + 16 * 4 + 8 +
+        return (size_t)chunk2<K, BIG>() * sizeof(K) + (size_t)B2 * 16 + 16 * 4 + 8 +
                (p2_sdig<K, BIG>() ? (size_t)chunk2<K, BIG>() * 2 : 0);
     }
     __device__ Part2Shared(unsigned char *raw, uint32_t B2) {
@@ -714,7 +715,7 @@ struct Part2Shared {
         raw += (size_t)chunk2<K, BIG>() * sizeof(K);
         cur = reinterpret_cast<uint32_t *>(raw);
         cnt = cur + B2;
-        start = cnt + B2;
+        start = cnt + 2 * B2;
         tmp = start + B2;
         flag = tmp + 16;
         sdig = reinterpret_cast<uint16_t *>(flag + 2);
@@ -807,27 +808,35 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
             K kcur[PER];
             bool counting_only = false;
             uint64_t seen_keys = 0;
+            // Five barriers per chunk (it was seven): the chunks alternate between two count arrays, each zeroed a chunk
+            // ahead, so a wave that has copied its share of the sorted chunk out goes straight on to the cursor update
+            // and the next chunk's count while the others are still copying.
+            uint32_t par = 0;
+            for (uint32_t i = tid; i < 2 * p.B2; i += P2T) sm.cnt[i] = 0;
+            ktd::lds_barrier();
             for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
                 const K *base;
                 uint64_t n;
                 segment(sidx, base, n);
                 if (n) load_chunk(base, n, 0, kcur);
-                for (uint64_t c0 = 0; c0 < n; c0 += CH) {
-                    for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = 0;
-                    ktd::lds_barrier();
-                    if (attempt) counting_only = *sm.flag != 0;  // (written before the barrier above; same for every thread)
+                for (uint64_t c0 = 0; c0 < n; c0 += CH, par ^= 1u) {
+                    uint32_t *const cntc = sm.cnt + par * p.B2, *const cntn = sm.cnt + (par ^ 1u) * p.B2;
 #pragma unroll
                     for (int u = 0; u < PER; u++) {
                         const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
-                        if (kcur[u] != EMPTY) atomicAdd(&sm.cnt[d], 1u);
+                        if (kcur[u] != EMPTY) atomicAdd(&cntc[d], 1u);
                     }
                     ktd::lds_barrier();
-                    uint32_t nc = 0;
+                    if (attempt) counting_only = *sm.flag != 0;  // (raised in a cursor update before the barrier above)
                     if (!counting_only) {
-                        nc = block_excl_scan<P2T>(sm.cnt, sm.start, p.B2, sm.tmp);  // keys in the chunk
-                        // (cnt has been summed: from here to the cursor update it holds cur - start, what the copy-out
-                        // adds to a sorted key's index to get its place in the level-1 bucket)
-                        for (uint32_t i = tid; i < p.B2; i += P2T) sm.cnt[i] = sm.cur[i] - sm.start[i];
+                        const uint32_t nc = block_excl_scan<P2T>(cntc, sm.start, p.B2, sm.tmp);  // keys in the chunk
+                        // (cntc has been summed: from here to the cursor update it holds cur - start, what the copy-out
+                        // adds to a sorted key's index to get its place in the level-1 bucket; the other array - last
+                        // read by the previous chunk's cursor update, before the barrier above - is zeroed for the next)
+                        for (uint32_t i = tid; i < p.B2; i += P2T) {
+                            cntc[i] = sm.cur[i] - sm.start[i];
+                            cntn[i] = 0;
+                        }
                         ktd::lds_barrier();
 #pragma unroll
                         for (int u = 0; u < PER; u++) {
@@ -838,22 +847,23 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
                                 if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
                             }
                         }
-                    }
-                    if (c0 + CH < n) load_chunk(base, n, c0 + CH, kcur);  // the next chunk travels during the copy-out
-                    if (!counting_only) {
+                        if (c0 + CH < n) load_chunk(base, n, c0 + CH, kcur);  // the next chunk travels during the copy-out
                         ktd::lds_barrier();
                         for (uint32_t i = tid; i < nc; i += P2T) {
                             const K key = sm.sorted[i];
                             uint32_t d;
                             if constexpr (p2_sdig<K, BIG>()) d = sm.sdig[i];
                             else d = digit2h(hash_of_stored<K>(key), p);
-                            const uint64_t pos = lo + (uint32_t)(sm.cnt[d] + i);
+                            const uint64_t pos = lo + (uint32_t)(cntc[d] + i);
                             if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = key;
                         }
-                        ktd::lds_barrier();
+                    } else {
+                        if (c0 + CH < n) load_chunk(base, n, c0 + CH, kcur);
+                        for (uint32_t i = tid; i < p.B2; i += P2T) cntn[i] = 0;
                     }
-                    // cursors move on; during an attempt every fine bucket's fill is held against its room scaled to
-                    // the part of the level-1 bucket seen so far (+ 6 sigma): hashed distinct keys never get there
+                    // cursors move on (no barrier: nothing the copy-out of the other waves reads is written here); during
+                    // an attempt every fine bucket's fill is held against its room scaled to the part of the level-1
+                    // bucket seen so far (+ 6 sigma): hashed distinct keys never get there
                     float allowed = 0.f;
                     if (attempt) {
                         const float seen = (float)(seen_keys + c0 + CH) / (float)total;
@@ -863,11 +873,11 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
                     }
                     for (uint32_t i = tid; i < p.B2; i += P2T) {
                         // placed: start[] stands at the runs' ends, so start + (cur - start at their beginnings) = cur + count
-                        const uint32_t c = counting_only ? sm.cur[i] + sm.cnt[i] : sm.start[i] + sm.cnt[i];
+                        const uint32_t c = counting_only ? sm.cur[i] + cntc[i] : sm.start[i] + cntc[i];
                         sm.cur[i] = c;
                         if (attempt && !counting_only && (float)(c - i * (uint32_t)p.cap2) > allowed) *sm.flag = 1;
                     }
-                    // (the next iteration's first barrier orders the cursor / flag updates before their use)
+                    if (counting_only) ktd::lds_barrier();  // (the zeroing above against the next chunk's count)
                 }
                 seen_keys += n;
             }
