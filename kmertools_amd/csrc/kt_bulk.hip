@@ -1569,7 +1569,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -1584,6 +1584,7 @@ static BulkKnobs read_knobs() {
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
     k.build_wgs = env_u64("KT_BUILD_WGS", 64);
+    k.build_wgs_ext = env_u64("KT_BUILD_WGS_EXT", 16);
     k.dense = env_u64("KT_BULK_DENSE", 1);
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
     k.max_b2 = env_u64("KT_BULK_MAX_B2", 11);  // tests: a smaller level 2, so that small shards need the pre-split pass
@@ -1771,7 +1772,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     bool ext = dense && ctr->xt_keys && ctr->xt_counts;  // the packed entries go straight to the export arrays
     // (ext: the scratch behind the caller's arrays is sized by the number of workgroups - 16 per CU there: 18.2 against
     // 17.9 ms)
-    uint64_t gb = (uint64_t)ctx->n_cu * (ext && j.kn.build_wgs > 16 ? 16 : j.kn.build_wgs);
+    uint64_t gb = (uint64_t)ctx->n_cu * (ext ? j.kn.build_wgs_ext : j.kn.build_wgs);
     if (gb > n_fine) gb = n_fine;
     const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
     // (ctr k=31: dense build 29.0 ms + dense export 17.4 ms against image build 22-23.5 ms + export 27.5 ms; k=15: 13.8 +
