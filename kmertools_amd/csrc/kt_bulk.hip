@@ -1247,11 +1247,28 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             if constexpr (EXT) {
                 const uint64_t b1 = xpiece[0], b2 = xpiece[1];
                 const uint32_t l1 = xlen1;
-                const uint32_t skew = (uint32_t)(pre < l1 ? b1 + pre : b2 + (pre - l1)) & 31u;
-                for (uint32_t j = lane; j < wc + skew; j += 64) {
-                    if (j >= skew) {
-                        const uint32_t src = wave * share + (j - skew), i = pre + (j - skew);
-                        xo.put(i < l1 ? b1 + i : b2 + (i - l1), from_stored<K>(skeys[src]), scounts[src] + 1u);
+                // where this wave's run starts (the same for all its lanes), and whether the run is one plain stretch of
+                // the caller's arrays - nearly always: then the copy is the ordinary one, from a wave-uniform base; a run
+                // that straddles two blocks or reaches the scratch takes the entry-by-entry path
+                const uint64_t at0 = ktd::uniform64(pre < l1 ? b1 + pre : b2 + (pre - l1));
+                const uint32_t skew = (uint32_t)at0 & 31u;
+                const bool plain = (pre >= l1 || pre + wc <= l1) && at0 + wc <= xo.max;
+                if (plain) {
+                    uint64_t *const dk = xo.keys + at0;
+                    uint32_t *const dc = xo.counts + at0;
+                    for (uint32_t j = lane; j < wc + skew; j += 64) {
+                        if (j >= skew) {
+                            const uint32_t src = wave * share + (j - skew);
+                            __builtin_nontemporal_store(from_stored<K>(skeys[src]), dk + (j - skew));
+                            __builtin_nontemporal_store(scounts[src] + 1u, dc + (j - skew));
+                        }
+                    }
+                } else {
+                    for (uint32_t j = lane; j < wc + skew; j += 64) {
+                        if (j >= skew) {
+                            const uint32_t src = wave * share + (j - skew), i = pre + (j - skew);
+                            xo.put(i < l1 ? b1 + i : b2 + (i - l1), from_stored<K>(skeys[src]), scounts[src] + 1u);
+                        }
                     }
                 }
                 if (tid == 0) placed += D;
