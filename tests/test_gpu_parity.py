@@ -1275,28 +1275,38 @@ def test_minimiser_python_surface(hctx, oracle):
         kt.MinimiserGenerator(seq, 3, 7)
 
 
-@pytest.mark.parametrize("workload", ["comp_oligo_k4", "ctr_k31"])
-def test_bench_two_rank_launch(workload):
-    """bench.py through torch.distributed.run with two ranks (both on GPU 0, gloo collectives): the launch
-    contract the driver uses for --gpus N - one JSON line from rank 0, whole-job value, n_gpus = 2"""
+@pytest.mark.parametrize("workload,ranks,presplit", [("comp_oligo_k4", 2, False), ("ctr_k31", 2, False), ("ctr_k31", 8, True),
+                                                     ("ctr_k15", 3, False)])
+def test_bench_two_rank_launch(workload, ranks, presplit):
+    """bench.py through torch.distributed.run with several ranks (all on GPU 0, gloo collectives): the launch
+    contract the driver uses for --gpus N - one JSON line from rank 0, whole-job value, n_gpus = N.  Eight ranks:
+    the 8-GPU ownership intervals, 4 slices x 8 senders of sources per bucket and the pre-split pass (forced: at
+    this size level 2 could take all the bits), three ranks: buckets that do not divide evenly; bench.py's own
+    output check (the counts of all ranks sum to reads x (L - k + 1)) is what certifies the result"""
     import json, os, subprocess, sys, pathlib
     root = pathlib.Path(__file__).resolve().parents[1]
     env = dict(os.environ, KT_BENCH_SHARE_GPU="1", KT_BULK_MIN_BASES="0")
+    if presplit:
+        env["KT_BULK_MAX_B2"] = "6"
     import socket
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
            "--workload", workload, "--reads", "200000"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["n_gpus"] == ranks and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
     assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j and j["config"]["reduced"] is True
+    assert j["output_check"]["ok"] is True
+    if workload.startswith("ctr"):
+        k = 31 if workload == "ctr_k31" else 15
+        assert j["output_check"]["sum_of_counts"] == ranks * 200000 * (150 - k + 1)
 
 
 def test_ctr_cfg3_full_size_properties(torch_mod, ctx):
