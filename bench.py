@@ -515,6 +515,8 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
                  "ok": int(tot[0].item()) == want}
     if check is not None:
         extra["output_check"] = check
+        if wl["kind"] == "oligo" and k == 4:   # the launch shape this process measured for itself (kt_oligo_launch_info)
+            extra["oligo_launch"] = {a: (round(b, 4) if isinstance(b, float) else b) for a, b in ctx.oligo_launch_info().items()}
         if not check["ok"]:
             sys.exit("bench.py: %s produced a wrong output: %r" % (name, check))
 

@@ -129,6 +129,14 @@ int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, u
                    int k, int count_min, int norm, int total_step, int out_dtype, void *out,
                    int mem);
 
+/* No counterpart in the reference (a launch detail made visible): the number of workgroups per resident slot the k = 4
+ * histogram launches of this context use.  It is chosen by measurement: a few early large launches (>= ~6 M reads of
+ * 150 bases) alternate between 32 and 96 with events around them, the faster stays.  *decided = 0
+ * while still measuring (then *wgs_per_slot is the default, 96, and the two means are 0); the means are ns per read.
+ * Results never depend on it.  KT_OLIGO_TUNE=0 in the environment keeps the default, KT_OLIGO_OVERSUB=n fixes n. */
+int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read_32,
+                         double *ns_per_read_96);
+
 /* Self-test of the f64 normalisation: the kernels compute `vec[i] /= max(1, total)` (composition/src/oligo.rs:255-257)
  * as a reciprocal + two fused multiply-adds per bin instead of a division.  For every divisor d in [d_lo, d_hi]
  * and every count c in 0..d this runs that exact device code and the IEEE division side by side:

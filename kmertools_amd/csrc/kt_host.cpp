@@ -148,6 +148,7 @@ int kt_ctx_destroy(kt_ctx *ctx) {
         if (p) (void)hipFree(p);
     for (auto &p : ctx->lut32_dev)
         if (p) (void)hipFree(p);
+    ctx->oligo_tune.release();
     ctx->s_bases.release();
     ctx->s_offsets.release();
     ctx->s_out.release();

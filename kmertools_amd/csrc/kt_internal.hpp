@@ -44,7 +44,20 @@ struct kt_ctx {
     struct OligoKnobs {  // KT_OLIGO_* launch tunables, read once per context (kt_oligo.hip)
         bool loaded = false, live = false;
         uint32_t shape = 104, R = 0, oversub = 0, debug = 0;
+        bool tune = true;
     } oligo_knobs;
+    // Workgroups per resident slot of the k = 4 histogram launch, chosen by measurement in this process (kt_oligo.hip,
+    // oligo_launch): a few early large launches alternate between the two candidates with events around them, the
+    // faster one stays.  (Which one is faster goes with the process, not with the code: profiles/r2_box_variance.txt.)
+    struct OligoTune {
+        static constexpr int RING = 8, NEED = 4, WARM = 8, GIVE_UP = 40;
+        bool decided = false;
+        uint32_t pick = 96, trials = 0;
+        struct Trial { hipEvent_t a = nullptr, b = nullptr; uint32_t which = 0; uint64_t reads = 0; bool live = false; } ring[RING];
+        double ns_per_read[2] = {0, 0};  // sums while measuring, means once decided
+        uint32_t kept[2] = {0, 0};
+        void release();
+    } oligo_tune;
     int use();  // hipSetDevice
     int canon_lut(int k, const uint16_t **out);
     int canon_lut32(int k, const uint32_t **out);

@@ -714,12 +714,43 @@ const kt_ctx::OligoKnobs &oligo_knobs(kt_ctx *ctx) {
         kn.shape = env_u32("KT_OLIGO_SHAPE", 104);
         kn.R = env_u32("KT_OLIGO_R", 0);
         kn.oversub = env_u32("KT_OLIGO_OVERSUB", 0);
+        const char *tune = getenv("KT_OLIGO_TUNE");
+        kn.tune = !(tune && tune[0] == '0');
 #if KT_OLIGO_ABLATION
         kn.debug = env_u32("KT_OLIGO_DEBUG", 0);
 #endif
         kn.loaded = true;
     }
     return kn;
+}
+
+constexpr uint32_t TUNE_SETTINGS[2] = {32, 96};
+
+// collects the trials whose launches have finished; decides once both settings have NEED kept samples
+void oligo_tune_poll(kt_ctx::OligoTune &tn) {
+    for (auto &t : tn.ring) {
+        if (!t.live || hipEventQuery(t.b) != hipSuccess) continue;
+        float ms = 0.f;
+        t.live = false;
+        if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess || !(ms > 0.f)) continue;
+        tn.ns_per_read[t.which] += (double)ms * 1e6 / (double)t.reads;
+        tn.kept[t.which]++;
+    }
+    (void)hipGetLastError();  // hipErrorNotReady of a pending event is not an error of ours
+    if (tn.kept[0] >= (uint32_t)tn.NEED && tn.kept[1] >= (uint32_t)tn.NEED) {
+        for (int i = 0; i < 2; i++) tn.ns_per_read[i] /= tn.kept[i];
+        tn.pick = TUNE_SETTINGS[tn.ns_per_read[0] < 0.99 * tn.ns_per_read[1] ? 0 : 1];  // 96 unless 32 is clearly faster
+        tn.decided = true;
+        tn.release();
+    } else if (tn.trials >= (uint32_t)tn.GIVE_UP) {  // events kept failing: the default stays
+        bool pending = false;
+        for (auto &t : tn.ring) pending |= t.live;
+        if (!pending) {
+            tn.ns_per_read[0] = tn.ns_per_read[1] = 0.0;
+            tn.decided = true;
+            tn.release();
+        }
+    }
 }
 
 }  // namespace
@@ -802,11 +833,71 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     // (profiles/r2_box_variance.txt)
     // The big-row shapes (k >= 6: a few reads per tile, one or two workgroups per CU) go the other way: k=7 f32, 1 M
     // reads: 2 / 4 / 8 / 16 / 32 / 64 / 128 per slot = 5.30 / 5.33 / 5.28 / 5.41 / 5.58 / 5.72 / 5.97 ms (two processes alike).
-    uint64_t grid = (uint64_t)ctx->n_cu * per_cu * (kn.oversub ? kn.oversub : k == 4 ? 96 : bins > 1024 ? 8 : 32);
+    // Since neither setting is right for both kinds, k = 4 measures: of the launches that are large enough for the
+    // choice to matter, the first WARM run as before, the next ones alternate between 32 and 96 with a pair of events
+    // around each, and once both have NEED samples the faster one stays for the life of the context
+    // (KT_OLIGO_OVERSUB fixes it, KT_OLIGO_TUNE=0 keeps 96).  The events are polled at later launches, never waited
+    // for - a launch costs what it did before, and a caller that never synchronises between launches keeps 96.
+    uint32_t per_slot = kn.oversub ? kn.oversub : k == 4 ? 96 : bins > 1024 ? 8 : 32;
+    kt_ctx::OligoTune &tn = ctx->oligo_tune;
+    kt_ctx::OligoTune::Trial *trial = nullptr;
+    const uint64_t slots = (uint64_t)ctx->n_cu * per_cu;
+    if (k == 4 && !kn.oversub && kn.tune) {
+        if (!tn.decided) oligo_tune_poll(tn);
+        if (tn.decided) {
+            per_slot = tn.pick;
+        } else if (n_tiles >= slots * TUNE_SETTINGS[1]) {
+            if (tn.trials >= (uint32_t)tn.WARM && tn.trials < (uint32_t)tn.GIVE_UP)
+                for (auto &t : tn.ring)
+                    if (!t.live) { trial = &t; break; }
+            if (trial) {
+                if (!trial->a && (hipEventCreate(&trial->a) != hipSuccess || hipEventCreate(&trial->b) != hipSuccess)) {
+                    (void)hipGetLastError();
+                    trial = nullptr;
+                }
+            }
+            if (trial) {
+                const uint32_t t = tn.trials - tn.WARM;
+                trial->which = (t ^ (t >> 1)) & 1;   // 0 1 1 0 0 1 1 0: a drift over the trials cancels
+                trial->reads = n_reads;
+                per_slot = TUNE_SETTINGS[trial->which];
+            }
+            tn.trials++;
+        }
+    }
+    uint64_t grid = slots * per_slot;
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
+    if (trial) KT_HIP(hipEventRecord(trial->a, ctx->stream));
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(nthreads), lds, ctx->stream, a);
     KT_HIP(hipGetLastError());
+    if (trial) {
+        KT_HIP(hipEventRecord(trial->b, ctx->stream));
+        trial->live = true;
+    }
+    return KT_OK;
+}
+
+void kt_ctx::OligoTune::release() {
+    for (auto &t : ring) {
+        if (t.a) (void)hipEventDestroy(t.a);
+        if (t.b) (void)hipEventDestroy(t.b);
+        t.a = t.b = nullptr;
+        t.live = false;
+    }
+}
+
+extern "C" int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read_32,
+                                    double *ns_per_read_96) {
+    if (!ctx) return kt::fail(KT_ERR_ARG, "kt_oligo_launch_info: null ctx");
+    if (int rc = ctx->use()) return rc;
+    kt_ctx::OligoTune &tn = ctx->oligo_tune;
+    const kt_ctx::OligoKnobs &kn = oligo_knobs(ctx);
+    if (!tn.decided && !kn.oversub && kn.tune) oligo_tune_poll(tn);
+    if (wgs_per_slot) *wgs_per_slot = kn.oversub ? kn.oversub : tn.pick;
+    if (decided) *decided = tn.decided ? 1 : 0;
+    if (ns_per_read_32) *ns_per_read_32 = tn.decided ? tn.ns_per_read[0] : 0.0;
+    if (ns_per_read_96) *ns_per_read_96 = tn.decided ? tn.ns_per_read[1] : 0.0;
     return KT_OK;
 }
 

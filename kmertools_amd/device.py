@@ -141,6 +141,12 @@ class Context:
                        total_step, dtype, KT_MEM_HOST)
         return out
 
+    def oligo_launch_info(self):
+        """-> dict: workgroups per resident slot of the k = 4 launches, whether it has been measured yet, ns per read of both"""
+        w, d, a, b = C.c_uint32(), C.c_int(), C.c_double(), C.c_double()
+        check(_lib.lib().kt_oligo_launch_info(self._h, C.byref(w), C.byref(d), C.byref(a), C.byref(b)))
+        return {"wgs_per_slot": w.value, "measured": bool(d.value), "ns_per_read_32": a.value, "ns_per_read_96": b.value}
+
     def selftest_quotient(self, d_lo, d_hi):
         """-> (pairs checked, mismatches, checksum of the IEEE quotients' bits) for all 0 <= c <= d, d_lo <= d <= d_hi"""
         n, bad, chk = C.c_uint64(), C.c_uint64(), C.c_uint64()
