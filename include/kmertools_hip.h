@@ -130,12 +130,16 @@ int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, u
                    int mem);
 
 /* No counterpart in the reference (a launch detail made visible): the number of workgroups per resident slot the k = 4
- * histogram launches of this context use.  It is chosen by measurement: a few early large launches (>= ~6 M reads of
- * 150 bases) alternate between 32 and 96 with events around them, the faster stays.  *decided = 0
- * while still measuring (then *wgs_per_slot is the default, 96, and the two means are 0); the means are ns per read.
- * Results never depend on it.  KT_OLIGO_TUNE=0 in the environment keeps the default, KT_OLIGO_OVERSUB=n fixes n. */
-int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read_32,
-                         double *ns_per_read_96);
+ * histogram launches into the output array of the latest launch use.  It is chosen by measurement, per output array
+ * (which setting is fastest goes with where the array lies in the memory: DESIGN.md 4.1): a few early large launches
+ * (>= ~6 M reads of 150 bases) into an array cycle through 32 / 96 / 200 with events around them, the fastest stays.
+ * *decided = 0 while still measuring (then *wgs_per_slot is the default, 96, and the means are 0); ns_per_read[3] =
+ * the means for 32, 96, 200 in ns per read.  Results never depend on it.  KT_OLIGO_TUNE=0 in the environment keeps
+ * the default, KT_OLIGO_OVERSUB=n fixes n. */
+int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read);
+/* on = 0: the launches that follow neither count towards nor take part in that measurement (they use what has been
+ * decided for their array, else the default) - for a caller that is timing launches itself; on = 1 resumes. */
+int kt_oligo_tuning(kt_ctx *ctx, int on);
 
 /* Self-test of the f64 normalisation: the kernels compute `vec[i] /= max(1, total)` (composition/src/oligo.rs:255-257)
  * as a reciprocal + two fused multiply-adds per bin instead of a division.  For every divisor d in [d_lo, d_hi]

@@ -37,7 +37,8 @@ SYMBOLS = {
     "kt_cgr_coords": (_i, [_i, C.c_double, _vp]),
     "kt_kmers": (_i, [_vp, _vp, _vp, _u64, _i, _vp, _vp, _vp, _i]),
     "kt_oligo_batch": (_i, [_vp, _vp, _vp, _u64, _i, _i, _i, _i, _i, _vp, _i]),
-    "kt_oligo_launch_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "kt_oligo_tuning": (_i, [_vp, _i]),
+    "kt_oligo_launch_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_i), C.POINTER(C.c_double)]),
     "kt_selftest_quotient": (_i, [_vp, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "kt_ctr_create": (_i, [_vp, _i, _u64, C.POINTER(_vp)]),
     "kt_ctr_destroy": (_i, [_vp]),

@@ -46,16 +46,24 @@ struct kt_ctx {
         uint32_t shape = 104, R = 0, oversub = 0, debug = 0;
         bool tune = true;
     } oligo_knobs;
-    // Workgroups per resident slot of the k = 4 histogram launch, chosen by measurement in this process (kt_oligo.hip,
-    // oligo_launch): a few early large launches alternate between the two candidates with events around them, the
-    // faster one stays.  (Which one is faster goes with the process, not with the code: profiles/r2_box_variance.txt.)
+    // Workgroups per resident slot of the k = 4 histogram launch, chosen by measurement per OUTPUT ARRAY (kt_oligo.hip,
+    // oligo_launch): a few early large launches into an array cycle through the candidates with events around them,
+    // the fastest stays for that array.  Which one is fastest goes with where the array lies in the memory, not with
+    // the code (profiles/r3_oligo_placement.txt): the same process sees 1.90 and 2.40 ms on two of its allocations.
     struct OligoTune {
-        static constexpr int RING = 8, NEED = 4, WARM = 8, GIVE_UP = 40;
-        bool decided = false;
-        uint32_t pick = 96, trials = 0;
-        struct Trial { hipEvent_t a = nullptr, b = nullptr; uint32_t which = 0; uint64_t reads = 0; bool live = false; } ring[RING];
-        double ns_per_read[2] = {0, 0};  // sums while measuring, means once decided
-        uint32_t kept[2] = {0, 0};
+        static constexpr int NSET = 3, RING = 9, NEED = 3, WARM = 24, GIVE_UP = 45, ARRAYS = 8;
+        struct Entry {                  // one output array (keyed by its address)
+            const void *out = nullptr;
+            uint64_t stamp = 0;         // last use (the least recently used entry makes room)
+            bool decided = false;
+            uint32_t pick = 96, launches = 0;
+            double ns_per_read[NSET] = {0, 0, 0};  // sums while measuring, means once decided
+            uint32_t kept[NSET] = {0, 0, 0};
+        } arrays[ARRAYS];
+        struct Trial { hipEvent_t a = nullptr, b = nullptr; const void *out = nullptr; uint32_t which = 0; uint64_t reads = 0; bool live = false; } ring[RING];
+        uint64_t clock = 0;
+        bool paused = false;            // kt_oligo_tuning(ctx, 0): launches neither count nor measure until switched on again
+        const void *last = nullptr;     // the array of the latest launch (kt_oligo_launch_info reports it)
         void release();
     } oligo_tune;
     int use();  // hipSetDevice

@@ -724,31 +724,46 @@ const kt_ctx::OligoKnobs &oligo_knobs(kt_ctx *ctx) {
     return kn;
 }
 
-constexpr uint32_t TUNE_SETTINGS[2] = {32, 96};
+constexpr uint32_t TUNE_SETTINGS[kt_ctx::OligoTune::NSET] = {32, 96, 200};
+constexpr int TUNE_DEFAULT = 1;
 
-// collects the trials whose launches have finished; decides once both settings have NEED kept samples
+kt_ctx::OligoTune::Entry *tune_find(kt_ctx::OligoTune &tn, const void *out) {
+    for (auto &e : tn.arrays)
+        if (e.out == out) return &e;
+    return nullptr;
+}
+
+// collects the trials whose launches have finished; an array is decided once every setting has NEED samples
 void oligo_tune_poll(kt_ctx::OligoTune &tn) {
     for (auto &t : tn.ring) {
         if (!t.live || hipEventQuery(t.b) != hipSuccess) continue;
         float ms = 0.f;
         t.live = false;
+        kt_ctx::OligoTune::Entry *e = tune_find(tn, t.out);
+        if (!e || e->decided) continue;   // the array's entry has made room for another since
         if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess || !(ms > 0.f)) continue;
-        tn.ns_per_read[t.which] += (double)ms * 1e6 / (double)t.reads;
-        tn.kept[t.which]++;
+        e->ns_per_read[t.which] += (double)ms * 1e6 / (double)t.reads;
+        e->kept[t.which]++;
     }
     (void)hipGetLastError();  // hipErrorNotReady of a pending event is not an error of ours
-    if (tn.kept[0] >= (uint32_t)tn.NEED && tn.kept[1] >= (uint32_t)tn.NEED) {
-        for (int i = 0; i < 2; i++) tn.ns_per_read[i] /= tn.kept[i];
-        tn.pick = TUNE_SETTINGS[tn.ns_per_read[0] < 0.99 * tn.ns_per_read[1] ? 0 : 1];  // 96 unless 32 is clearly faster
-        tn.decided = true;
-        tn.release();
-    } else if (tn.trials >= (uint32_t)tn.GIVE_UP) {  // events kept failing: the default stays
-        bool pending = false;
-        for (auto &t : tn.ring) pending |= t.live;
-        if (!pending) {
-            tn.ns_per_read[0] = tn.ns_per_read[1] = 0.0;
-            tn.decided = true;
-            tn.release();
+    for (auto &e : tn.arrays) {
+        if (!e.out || e.decided) continue;
+        bool all = true;
+        for (int i = 0; i < tn.NSET; i++) all &= e.kept[i] >= (uint32_t)tn.NEED;
+        if (all) {
+            int best = TUNE_DEFAULT;
+            for (int i = 0; i < tn.NSET; i++) e.ns_per_read[i] /= e.kept[i];
+            for (int i = 0; i < tn.NSET; i++)   // the default unless another is clearly (1 %) faster
+                if (e.ns_per_read[i] < 0.99 * e.ns_per_read[TUNE_DEFAULT] && e.ns_per_read[i] < e.ns_per_read[best]) best = i;
+            e.pick = TUNE_SETTINGS[best];
+            e.decided = true;
+        } else if (e.launches >= (uint32_t)(tn.WARM + tn.GIVE_UP)) {  // events kept failing: the default stays
+            bool pending = false;
+            for (auto &t : tn.ring) pending |= t.live && t.out == e.out;
+            if (!pending) {
+                for (int i = 0; i < tn.NSET; i++) e.ns_per_read[i] = 0.0;
+                e.decided = true;
+            }
         }
     }
 }
@@ -833,36 +848,51 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     // (profiles/r2_box_variance.txt)
     // The big-row shapes (k >= 6: a few reads per tile, one or two workgroups per CU) go the other way: k=7 f32, 1 M
     // reads: 2 / 4 / 8 / 16 / 32 / 64 / 128 per slot = 5.30 / 5.33 / 5.28 / 5.41 / 5.58 / 5.72 / 5.97 ms (two processes alike).
-    // Since neither setting is right for both kinds, k = 4 measures: of the launches that are large enough for the
-    // choice to matter, the first WARM run as before, the next ones alternate between 32 and 96 with a pair of events
-    // around each, and once both have NEED samples the faster one stays for the life of the context
-    // (KT_OLIGO_OVERSUB fixes it, KT_OLIGO_TUNE=0 keeps 96).  The events are polled at later launches, never waited
-    // for - a launch costs what it did before, and a caller that never synchronises between launches keeps 96.
+    // Since no setting is right everywhere, k = 4 measures, per output array: of the launches into it that are large
+    // enough for the choice to matter, the first WARM run as before, the next ones cycle through 32 / 96 / 200 with a
+    // pair of events around each, and once each has NEED samples the fastest stays for that array (96 unless another
+    // is > 1 % faster; KT_OLIGO_OVERSUB fixes it, KT_OLIGO_TUNE=0 keeps 96).  The events are polled at later launches,
+    // never waited for - a launch costs what it did before, and a caller that never synchronises keeps 96.
+    // (Round 3, tools/r3_kind_all_vram.py: 23 outputs of 10.9 GB allocated by one process ran at 1.90 / 2.00 / 2.29 /
+    // 2.40 ms with 32 per slot, 2.02 / 2.08 / 2.16 / 2.22 with 96 and 2.10 / 2.19 / 2.10 / 2.22 with 200 - four classes
+    // of placement, reproducible per array, the same zero-fill rate on all of them.)
     uint32_t per_slot = kn.oversub ? kn.oversub : k == 4 ? 96 : bins > 1024 ? 8 : 32;
     kt_ctx::OligoTune &tn = ctx->oligo_tune;
     kt_ctx::OligoTune::Trial *trial = nullptr;
     const uint64_t slots = (uint64_t)ctx->n_cu * per_cu;
-    if (k == 4 && !kn.oversub && kn.tune) {
-        if (!tn.decided) oligo_tune_poll(tn);
-        if (tn.decided) {
-            per_slot = tn.pick;
-        } else if (n_tiles >= slots * TUNE_SETTINGS[1]) {
-            if (tn.trials >= (uint32_t)tn.WARM && tn.trials < (uint32_t)tn.GIVE_UP)
+    if (k == 4 && !kn.oversub && kn.tune && tn.paused) {
+        const kt_ctx::OligoTune::Entry *e = tune_find(tn, out);
+        if (e && e->decided) per_slot = e->pick;
+    } else if (k == 4 && !kn.oversub && kn.tune && n_tiles >= slots * TUNE_SETTINGS[TUNE_DEFAULT]) {
+        oligo_tune_poll(tn);
+        kt_ctx::OligoTune::Entry *e = tune_find(tn, out);
+        if (!e) {   // a new array takes the least recently used entry
+            e = &tn.arrays[0];
+            for (auto &x : tn.arrays)
+                if (x.stamp < e->stamp) e = &x;
+            *e = kt_ctx::OligoTune::Entry{};
+            e->out = out;
+        }
+        e->stamp = ++tn.clock;
+        tn.last = out;
+        if (e->decided) {
+            per_slot = e->pick;
+        } else {
+            if (e->launches >= (uint32_t)tn.WARM && e->launches < (uint32_t)(tn.WARM + tn.GIVE_UP))
                 for (auto &t : tn.ring)
                     if (!t.live) { trial = &t; break; }
-            if (trial) {
-                if (!trial->a && (hipEventCreate(&trial->a) != hipSuccess || hipEventCreate(&trial->b) != hipSuccess)) {
-                    (void)hipGetLastError();
-                    trial = nullptr;
-                }
+            if (trial && !trial->a && (hipEventCreate(&trial->a) != hipSuccess || hipEventCreate(&trial->b) != hipSuccess)) {
+                (void)hipGetLastError();
+                trial = nullptr;
             }
             if (trial) {
-                const uint32_t t = tn.trials - tn.WARM;
-                trial->which = (t ^ (t >> 1)) & 1;   // 0 1 1 0 0 1 1 0: a drift over the trials cancels
+                const uint32_t r = (e->launches - tn.WARM) % (2 * tn.NSET);   // 0 1 2 2 1 0: a drift over the trials cancels
+                trial->which = r < (uint32_t)tn.NSET ? r : 2 * tn.NSET - 1 - r;
                 trial->reads = n_reads;
+                trial->out = out;
                 per_slot = TUNE_SETTINGS[trial->which];
             }
-            tn.trials++;
+            e->launches++;
         }
     }
     uint64_t grid = slots * per_slot;
@@ -887,17 +917,24 @@ void kt_ctx::OligoTune::release() {
     }
 }
 
-extern "C" int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read_32,
-                                    double *ns_per_read_96) {
+extern "C" int kt_oligo_tuning(kt_ctx *ctx, int on) {
+    if (!ctx) return kt::fail(KT_ERR_ARG, "kt_oligo_tuning: null ctx");
+    ctx->oligo_tune.paused = !on;
+    return KT_OK;
+}
+
+extern "C" int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read) {
     if (!ctx) return kt::fail(KT_ERR_ARG, "kt_oligo_launch_info: null ctx");
     if (int rc = ctx->use()) return rc;
     kt_ctx::OligoTune &tn = ctx->oligo_tune;
     const kt_ctx::OligoKnobs &kn = oligo_knobs(ctx);
-    if (!tn.decided && !kn.oversub && kn.tune) oligo_tune_poll(tn);
-    if (wgs_per_slot) *wgs_per_slot = kn.oversub ? kn.oversub : tn.pick;
-    if (decided) *decided = tn.decided ? 1 : 0;
-    if (ns_per_read_32) *ns_per_read_32 = tn.decided ? tn.ns_per_read[0] : 0.0;
-    if (ns_per_read_96) *ns_per_read_96 = tn.decided ? tn.ns_per_read[1] : 0.0;
+    if (!kn.oversub && kn.tune) oligo_tune_poll(tn);
+    const kt_ctx::OligoTune::Entry *e = tn.last ? tune_find(tn, tn.last) : nullptr;
+    const bool done = e && e->decided && !kn.oversub && kn.tune;
+    if (wgs_per_slot) *wgs_per_slot = kn.oversub ? kn.oversub : done ? e->pick : TUNE_SETTINGS[TUNE_DEFAULT];
+    if (decided) *decided = done ? 1 : 0;
+    if (ns_per_read)
+        for (int i = 0; i < tn.NSET; i++) ns_per_read[i] = done ? e->ns_per_read[i] : 0.0;
     return KT_OK;
 }
 

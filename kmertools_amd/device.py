@@ -98,6 +98,40 @@ def to_csr(seqs):
     return bases, offsets
 
 
+def place_array(make, run, stream, candidates=8, launches=4, warm=20, memory_fraction=0.6):
+    """Pick where a large device array lies.  A store-bound kernel writes two allocations of the same size at rates up
+    to 20 % apart, reproducibly per allocation and with no difference in their plain fill rate, and its input's
+    allocation moves it by another few per cent: it goes with where an allocation landed in the HBM (DESIGN.md 4.1,
+    profiles/r3_oligo_placement.txt).  This allocates up to `candidates` arrays with make() (all alive together, so
+    they are different memory; fewer if they would take more than `memory_fraction` of the free memory), runs
+    run(array) `warm` times on the first so that nothing is measured cold, then times `launches` calls on each (torch
+    events on `stream`, the first call not counted), keeps the fastest and frees the others.
+    -> (array, {"candidates": n, "ms": [per candidate], "picked": index}); candidate 0 is the plain allocation."""
+    import torch
+    first = make()
+    free, _ = torch.cuda.mem_get_info()
+    size = first.numel() * first.element_size()
+    n = max(1, min(candidates, 1 + int(free * memory_fraction // max(size, 1))))
+    arrays = [first] + [make() for _ in range(n - 1)]
+    for _ in range(warm):
+        run(first)
+    ms = []
+    for arr in arrays:
+        run(arr)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(max(1, launches - 1)):
+            run(arr)
+        b.record(stream)
+        b.synchronize()
+        ms.append(a.elapsed_time(b) / max(1, launches - 1))
+    picked = min(range(n), key=ms.__getitem__)
+    best = arrays[picked]
+    del arrays, first, arr
+    torch.cuda.empty_cache()
+    return best, {"candidates": n, "ms": [round(x, 4) for x in ms], "picked": picked}
+
+
 class Context:
     """One device + one stream (kt_ctx).  `stream` is a raw hipStream_t handle
     (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream) to enqueue on,
@@ -141,11 +175,16 @@ class Context:
                        total_step, dtype, KT_MEM_HOST)
         return out
 
+    def oligo_tuning(self, on):
+        """False: the launches that follow take no part in the k = 4 launch-shape measurement (a caller timing launches itself)"""
+        check(_lib.lib().kt_oligo_tuning(self._h, int(bool(on))))
+
     def oligo_launch_info(self):
-        """-> dict: workgroups per resident slot of the k = 4 launches, whether it has been measured yet, ns per read of both"""
-        w, d, a, b = C.c_uint32(), C.c_int(), C.c_double(), C.c_double()
-        check(_lib.lib().kt_oligo_launch_info(self._h, C.byref(w), C.byref(d), C.byref(a), C.byref(b)))
-        return {"wgs_per_slot": w.value, "measured": bool(d.value), "ns_per_read_32": a.value, "ns_per_read_96": b.value}
+        """-> dict: workgroups per resident slot of the k = 4 launches into the latest output array, whether that has
+        been measured yet, and the measured ns per read of the candidates 32 / 96 / 200"""
+        w, d, ns = C.c_uint32(), C.c_int(), (C.c_double * 3)()
+        check(_lib.lib().kt_oligo_launch_info(self._h, C.byref(w), C.byref(d), ns))
+        return {"wgs_per_slot": w.value, "measured": bool(d.value), "ns_per_read": {32: ns[0], 96: ns[1], 200: ns[2]}}
 
     def selftest_quotient(self, d_lo, d_hi):
         """-> (pairs checked, mismatches, checksum of the IEEE quotients' bits) for all 0 <= c <= d, d_lo <= d <= d_hi"""
