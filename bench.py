@@ -370,17 +370,16 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
             out = make()
         else:
             bb0, oo0, cnt0 = batch_args[0]
-            ctx.oligo_tuning(False)   # the probes time launches themselves
-            out, placed = device.place_array(
-                make, lambda o: ctx.oligo(bb0, oo0, cnt0, k, o, count_min=True, norm=True, total_step=1, dtype=wl["dtype"]),
-                env.stream)
+            def shaped(per_slot, bb, o):   # k = 4: the probes compare the launch shapes themselves (other k: one shape)
+                ctx.oligo_tuning(per_slot)
+                ctx.oligo(bb, oo0, cnt0, k, o, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+            shapes = (32, 96) if k == 4 else (0,)
+            out, placed = device.place_array(make, [lambda o, p=p: shaped(p, bb0, o) for p in shapes], env.stream)
             extra["output_placement"] = placed
             if nb == 1:   # the same for the (much smaller) input: candidate 0 is the array the reads were generated into
                 pool = [bases]
-                bases, placed = device.place_array(
-                    lambda: pool.pop() if pool else bb0.clone(),
-                    lambda b: ctx.oligo(b, oo0, cnt0, k, out, count_min=True, norm=True, total_step=1, dtype=wl["dtype"]),
-                    env.stream, warm=8)
+                bases, placed = device.place_array(lambda: pool.pop() if pool else bb0.clone(),
+                                                   [lambda b, p=p: shaped(p, b, out) for p in shapes], env.stream, warm=8)
                 batch_args[0] = (bases, oo0, cnt0)
                 extra["input_placement"] = placed
             del bb0

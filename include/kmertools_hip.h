@@ -137,9 +137,10 @@ int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, u
  * the means for 32, 96, 200 in ns per read.  Results never depend on it.  KT_OLIGO_TUNE=0 in the environment keeps
  * the default, KT_OLIGO_OVERSUB=n fixes n. */
 int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read);
-/* on = 0: the launches that follow neither count towards nor take part in that measurement (they use what has been
- * decided for their array, else the default) - for a caller that is timing launches itself; on = 1 resumes. */
-int kt_oligo_tuning(kt_ctx *ctx, int on);
+/* mode 0: the launches that follow neither count towards nor take part in that measurement (they use what has been
+ * decided for their array, else the default) - for a caller that is timing launches itself; mode 1 resumes;
+ * mode n >= 2: as 0, and every k = 4 launch uses n workgroups per resident slot (a caller comparing shapes itself). */
+int kt_oligo_tuning(kt_ctx *ctx, int mode);
 
 /* Self-test of the f64 normalisation: the kernels compute `vec[i] /= max(1, total)` (composition/src/oligo.rs:255-257)
  * as a reciprocal + two fused multiply-adds per bin instead of a division.  For every divisor d in [d_lo, d_hi]

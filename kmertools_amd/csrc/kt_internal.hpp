@@ -63,6 +63,7 @@ struct kt_ctx {
         struct Trial { hipEvent_t a = nullptr, b = nullptr; const void *out = nullptr; uint32_t which = 0; uint64_t reads = 0; bool live = false; } ring[RING];
         uint64_t clock = 0;
         bool paused = false;            // kt_oligo_tuning(ctx, 0): launches neither count nor measure until switched on again
+        uint32_t forced = 0;            // kt_oligo_tuning(ctx, n >= 2): paused, and every launch uses n workgroups per slot
         const void *last = nullptr;     // the array of the latest launch (kt_oligo_launch_info reports it)
         void release();
     } oligo_tune;

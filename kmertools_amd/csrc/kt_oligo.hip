@@ -862,7 +862,8 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     const uint64_t slots = (uint64_t)ctx->n_cu * per_cu;
     if (k == 4 && !kn.oversub && kn.tune && tn.paused) {
         const kt_ctx::OligoTune::Entry *e = tune_find(tn, out);
-        if (e && e->decided) per_slot = e->pick;
+        if (tn.forced) per_slot = tn.forced;
+        else if (e && e->decided) per_slot = e->pick;
     } else if (k == 4 && !kn.oversub && kn.tune && n_tiles >= slots * TUNE_SETTINGS[TUNE_DEFAULT]) {
         oligo_tune_poll(tn);
         kt_ctx::OligoTune::Entry *e = tune_find(tn, out);
@@ -919,7 +920,9 @@ void kt_ctx::OligoTune::release() {
 
 extern "C" int kt_oligo_tuning(kt_ctx *ctx, int on) {
     if (!ctx) return kt::fail(KT_ERR_ARG, "kt_oligo_tuning: null ctx");
-    ctx->oligo_tune.paused = !on;
+    if (on < 0) return kt::fail(KT_ERR_ARG, "kt_oligo_tuning: mode must be 0, 1 or a number of workgroups per slot");
+    ctx->oligo_tune.paused = on != 1;
+    ctx->oligo_tune.forced = on >= 2 ? (uint32_t)on : 0u;
     return KT_OK;
 }
 

@@ -105,26 +105,32 @@ def place_array(make, run, stream, candidates=8, launches=4, warm=20, memory_fra
     profiles/r3_oligo_placement.txt).  This allocates up to `candidates` arrays with make() (all alive together, so
     they are different memory; fewer if they would take more than `memory_fraction` of the free memory), runs
     run(array) `warm` times on the first so that nothing is measured cold, then times `launches` calls on each (torch
-    events on `stream`, the first call not counted), keeps the fastest and frees the others.
+    events on `stream`, the first call not counted), keeps the fastest and frees the others.  `run` may be a list of
+    callables (variants of the launch): a candidate's time is that of its best variant.
     -> (array, {"candidates": n, "ms": [per candidate], "picked": index}); candidate 0 is the plain allocation."""
     import torch
+    runs = list(run) if isinstance(run, (list, tuple)) else [run]
     first = make()
     free, _ = torch.cuda.mem_get_info()
     size = first.numel() * first.element_size()
     n = max(1, min(candidates, 1 + int(free * memory_fraction // max(size, 1))))
     arrays = [first] + [make() for _ in range(n - 1)]
     for _ in range(warm):
-        run(first)
+        runs[0](first)
     ms = []
     for arr in arrays:
-        run(arr)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        for _ in range(max(1, launches - 1)):
-            run(arr)
-        b.record(stream)
-        b.synchronize()
-        ms.append(a.elapsed_time(b) / max(1, launches - 1))
+        best = None
+        for fn in runs:
+            fn(arr)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(max(1, launches - 1)):
+                fn(arr)
+            b.record(stream)
+            b.synchronize()
+            t = a.elapsed_time(b) / max(1, launches - 1)
+            best = t if best is None else min(best, t)
+        ms.append(best)
     picked = min(range(n), key=ms.__getitem__)
     best = arrays[picked]
     del arrays, first, arr
@@ -175,9 +181,10 @@ class Context:
                        total_step, dtype, KT_MEM_HOST)
         return out
 
-    def oligo_tuning(self, on):
-        """False: the launches that follow take no part in the k = 4 launch-shape measurement (a caller timing launches itself)"""
-        check(_lib.lib().kt_oligo_tuning(self._h, int(bool(on))))
+    def oligo_tuning(self, mode):
+        """False / 0: the launches that follow take no part in the k = 4 launch-shape measurement (a caller timing
+        launches itself); True / 1: resume; n >= 2: as 0, with n workgroups per resident slot for every launch"""
+        check(_lib.lib().kt_oligo_tuning(self._h, int(mode)))
 
     def oligo_launch_info(self):
         """-> dict: workgroups per resident slot of the k = 4 launches into the latest output array, whether that has

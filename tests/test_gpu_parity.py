@@ -402,6 +402,16 @@ def test_oligo_launch_shape_is_measured_and_results_do_not_depend_on_it(torch_mo
         best = min(ns, key=ns.get)
         want = best if ns[best] < 0.99 * ns[96] else 96
         assert info["wgs_per_slot"] == want, info
+    # a caller comparing shapes itself: forced shapes give the same rows and leave the measurement alone
+    for mode in (32, 200, 0):
+        c.oligo_tuning(mode)
+        outs[1].zero_()
+        torch.cuda.synchronize()
+        c.oligo(bases, offsets, n, k, outs[1], dtype="f32")
+        torch.cuda.synchronize()
+        assert torch.equal(outs[1], ref), mode
+    c.oligo_tuning(1)
+    assert c.oligo_launch_info() == info
     # small launches neither measure nor are affected
     c2 = device.Context()
     for _ in range(30):
