@@ -404,8 +404,12 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         def step():
             ctx.minimisers(bases, offsets, n, w, k, evo, mk, ms, me, n_ev)
     elif wl["kind"] == "cgr":
-        out = torch.empty((n * L, 2), dtype=torch.float64, device="cuda")
         bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+        make = lambda: torch.empty((n * L, 2), dtype=torch.float64, device="cuda")
+        if args.no_place or env.share_gpu:
+            out = make()
+        else:   # the 24 GB of points are a store stream like the oligo rows: the array is chosen the same way
+            out, extra["output_placement"] = device.place_array(make, lambda o: ctx.cgr(bases, offsets, n, 1, o, bad), env.stream)
         alg_bytes_per_launch = n * (L * 17 + 8)
         dominant = "cgr_kernel (128-base chunks per lane, bracketing start, LDS-transposed stores)"
         parallelism = "reads sharded by rank, no data-path collective"

@@ -114,7 +114,13 @@ def place_array(make, run, stream, candidates=8, launches=4, warm=20, memory_fra
     free, _ = torch.cuda.mem_get_info()
     size = first.numel() * first.element_size()
     n = max(1, min(candidates, 1 + int(free * memory_fraction // max(size, 1))))
-    arrays = [first] + [make() for _ in range(n - 1)]
+    arrays = [first]
+    for _ in range(n - 1):
+        try:
+            arrays.append(make())
+        except torch.OutOfMemoryError:   # somebody else's memory: fewer candidates
+            break
+    n = len(arrays)
     for _ in range(warm):
         runs[0](first)
     ms = []
