@@ -1385,6 +1385,31 @@ def test_bench_two_rank_launch(workload, ranks, presplit):
         assert j["output_check"]["sum_of_counts"] == ranks * 200000 * (150 - k + 1)
 
 
+def test_bench_places_its_arrays():
+    """bench.py on one GPU, reduced size: the oligo workload's output and input arrays are chosen among candidate
+    allocations (device.place_array), the line says which, the output check and the oracle's slice check pass; with
+    --no-place the objects are absent"""
+    import json, os, subprocess, sys, pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    for flag in ([], ["--no-place"]):
+        cmd = [sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "comp_oligo_k4",
+               "--reads", "300000", "--cpu-seconds", "1"] + flag
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        j = json.loads(lines[0])
+        assert j["output_check"]["ok"] is True and j["config"]["reduced"] is True
+        assert j["output_check"]["oracle_slice"]["ok"] is True
+        if flag:
+            assert "output_placement" not in j and "input_placement" not in j
+        else:
+            for key in ("output_placement", "input_placement"):
+                p = j[key]
+                assert p["candidates"] == len(p["ms"]) >= 1 and 0 <= p["picked"] < p["candidates"]
+                assert p["ms"][p["picked"]] == min(p["ms"])
+
+
 def test_ctr_cfg3_full_size_properties(torch_mod, ctx):
     """BASELINE cfg3 at full size (50 M x 150 bp, k=15) through the bulk build: every k-mer instance is
     counted exactly once (sum of counts = n * 136), no key is outside the canonical 15-mer space or stored
