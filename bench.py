@@ -21,6 +21,12 @@ work off (ablation builds only) makes bench.py exit non-zero before anything is 
 untimed, the output is checked (`output_check`): oligo rows sum to 1 over the whole output and a 4096-row slice
 is compared with the CPU oracle inside the cpu_baseline leg; ctr's exported counts sum to reads x (L - k + 1).
 
+Array placement (oligo / cgr workloads, untimed, before the ramp): where an array lies in the HBM moves the store-bound
+kernels by up to 20 %, so the output array - and for one-batch workloads the input array - is the
+fastest of up to eight candidate allocations (kmertools_amd.device.place_array).  The line's `output_placement` /
+`input_placement` objects list every candidate's time and which was kept, candidate 0 being the plain allocation;
+`--no-place` takes the plain allocation.  Nothing about the timed steps changes: same kernel, same work, same checks.
+
 ctr's step is what SURVEY.md 8d puts inside it: clear + insert (+ the key exchange at N > 1) +
 kt_ctr_size + kt_ctr_export into device arrays; algorithmic bytes = L + kmers*16 per read + distinct*12.
 
