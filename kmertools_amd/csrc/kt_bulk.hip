@@ -1082,13 +1082,11 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
         }
     };
     __shared__ uint32_t runs[BUILD_T / 64];  // DENSE: entries packed by each wave
-    __shared__ uint32_t claimed;             // EXT: distinct keys of the range (slots claimed during the insert)
-    __shared__ uint64_t xpiece[2];           // EXT: where the range's entries go: xpiece[0] + i for i < xlen1, then
-    __shared__ uint32_t xlen1;               //      xpiece[1] + (i - xlen1)
-    // EXT, thread 0 only: the current block [xpos, xend) and how many blocks this workgroup has taken
+    // EXT: the current block [xpos, xend) and how many blocks this workgroup has taken.  Every thread carries the same
+    // (workgroup-uniform) values: a range's entry count D comes out of the pack's scan in every wave, so where its entries
+    // go - the rest of the current block, then the front of the workgroup's next one - needs no shared state at all.
     uint64_t xpos = 0, xend = 0;
     uint32_t xused = 0;
-    if (EXT && tid == 0) claimed = 0;  // (ordered before its first use by the barrier after the image is cleared)
     long long placed = 0;  // per thread: occupied slots written - occupied slots found (MERGE)
     // A range starts with two dependent global reads (its bounds, then its first keys): ~4 us during which the
     // workgroup would do nothing, 1500 times over.  Both are taken one range ahead: the next range's bounds are
@@ -1161,13 +1159,12 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 // with linear probing and 11.8 with the strides, where k=31's went from 19.2 to 16.9 ms)
                 if (!KT_BUILD_DHASH || !DENSE || sizeof(K) < 8) return 1u;
                 const uint32_t j = (uint32_t)(hash_of_stored<K>(stored) >> (shift >= 3 ? shift - 3 : 0)) & 7u;
-                return (uint32_t)(0x251F1D1713110D0Bull >> (8 * j)) & 0xffu;   // 11 13 17 19 23 29 31 37
+                return 11u + 2u * ((0xDA964310u >> (4u * j)) & 15u);   // 11 13 17 19 23 29 31 37
             };
-            uint32_t s = home(cur), step = stride(cur), probes = 0, mine = 0;
+            uint32_t s = home(cur), step = stride(cur), probes = 0;
             while (cur != EMPTY) {
                 const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
                 bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
-                if (EXT) mine += done;
                 if (!done && v == cur) {
                     atomicAdd(&scounts[s], 1u);
                     done = true;
@@ -1190,33 +1187,8 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                     probes = 0;
                 }
             }
-            if (EXT) {  // the wave's claims, one LDS atomic per wave
-                for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-                if (lane == 0 && mine) atomicAdd(&claimed, mine);
-            }
         }
         ktd::lds_barrier();
-        // (thread 0's look at its spare block - the result of an atomic issued a range ago - comes BEFORE the next range's
-        // head loads are issued: a wait for the older operation is a wait for everything issued before the wait)
-        if (EXT && tid == 0) {
-            // where the range's `claimed` entries go: the rest of the current block, then the front of the spare one
-            const uint32_t Dx = claimed;
-            claimed = 0;  // (the next range adds to it two barriers from here)
-            xpiece[0] = xpos;
-            if (xpos + Dx <= xend) {
-                xlen1 = Dx;
-                xpos += Dx;
-            } else {
-                const uint32_t l1 = (uint32_t)(xend - xpos);
-                if (xend) xo.fill[xend / XBLK - 1] = XBLK;  // the block just finished is full
-                const uint64_t nb = ((uint64_t)blockIdx.x + (uint64_t)xused * gridDim.x) * XBLK;
-                xused++;
-                xlen1 = l1;
-                xpiece[1] = nb;
-                xpos = nb + (Dx - l1);
-                xend = nb + XBLK;
-            }
-        }
         load_head(nlo, nhi, head);  // the next range's first keys travel while this range is written out
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * RS);
         if (DENSE) {
@@ -1261,8 +1233,20 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             // compare chain, so that thread t could write element t, t + 1024, ..., took a third of the kernel's
             // VALU instructions.)
             if constexpr (EXT) {
-                const uint64_t b1 = xpiece[0], b2 = xpiece[1];
-                const uint32_t l1 = xlen1;
+                // where the range's D entries go: b1 + i for i < l1, then b2 + (i - l1)
+                const uint64_t b1 = xpos;
+                uint64_t b2 = 0;
+                uint32_t l1 = D;
+                if (xpos + D <= xend) {
+                    xpos += D;
+                } else {
+                    l1 = (uint32_t)(xend - xpos);
+                    if (tid == 0 && xend) xo.fill[xend / XBLK - 1] = XBLK;  // the block just finished is full
+                    b2 = ((uint64_t)blockIdx.x + (uint64_t)xused * gridDim.x) * XBLK;
+                    xused++;
+                    xpos = b2 + (D - l1);
+                    xend = b2 + XBLK;
+                }
                 // where this wave's run starts (the same for all its lanes), and whether the run is one plain stretch of
                 // the caller's arrays - nearly always: then the copy is the ordinary one, from a wave-uniform base; a run
                 // that straddles two blocks or reaches the scratch takes the entry-by-entry path
