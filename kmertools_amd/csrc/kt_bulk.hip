@@ -72,14 +72,18 @@ constexpr uint32_t MAX_B = 2048;          // digits per level (11 bits)
 #ifndef KT_P2_BIG32_PER
 #define KT_P2_BIG32_PER 16  // keys per thread of the 1024-thread shape with 32-bit keys (KT_P2_BIG32=1; measured at k=15:
 #endif                      // 18.8 ms with 16, 33.2 ms with 32, against 18.3 ms for the 512-thread shape - off by default)
+#ifndef KT_P2_T64
+#define KT_P2_T64 512  // threads of the BIG shape with 64-bit keys (16384-key chunks either way): 512 x 32 keys per thread
+#endif                 // in 256 registers, or 1024 x 16 in 128 (round 3: 1024.  Round 4's batched LDS phases and
+                       // in-flight stores want the registers: at 128 the hot loop spilled, and a scratch reload is a vmcnt(0))
 template <class K, bool BIG>
-constexpr int p2t() { return BIG ? 1024 : 512; }           // threads of a part2 workgroup
+constexpr int p2t() { return BIG ? (sizeof(K) == 8 ? KT_P2_T64 : 1024) : 512; }  // threads of a part2 workgroup
 template <class K, bool BIG>
 constexpr bool p2_sdig() { return !BIG && !(sizeof(K) == 8 && KT_STORE_HASH); }  // digit kept beside every sorted key
                                                            // (not when it is a bit field of the stored hash)
 // keys sorted at a time in part2
 template <class K, bool BIG>
-constexpr uint32_t chunk2() { return (sizeof(K) == 8 ? 16u : BIG ? (uint32_t)KT_P2_BIG32_PER : 32u) * p2t<K, BIG>(); }
+constexpr uint32_t chunk2() { return sizeof(K) == 8 ? (BIG ? 16384u : 8192u) : (BIG ? (uint32_t)KT_P2_BIG32_PER : 32u) * p2t<K, BIG>(); }
 
 struct Plan {
     uint32_t n;       // hash bits that address the table: cap = m8 * 2^(n-3) (kttab::Geom)
@@ -107,6 +111,7 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *wcur;     // [slices][G][B1] paged level 1: every workgroup's position in its current page of every bucket
     kt_seg_src *srcs;   // [n_src + 1] part2's sources (device copy; the last one: the pre-split pass's output)
     uint64_t *xstart, *xend, *xcount;  // [local buckets << bx] pre-split pass: the sub-buckets' bounds in keys2, their sizes
+    uint32_t *fail;     // [local buckets << bx] part2_fast_kernel: the bucket did not fit its fixed fine regions
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -182,6 +187,117 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *cnt, uint32_
     }
     ktd::lds_barrier();
     return total;
+}
+
+// ---- vector memory that the compiler's s_waitcnt bookkeeping does not see ---------------------------------------
+// The partition kernels prefetch the next chunk's keys and then scatter the current chunk's runs; the wave must wait for
+// the loads before the next count, and must NOT wait for the stores - they should drain while the next chunk is counted,
+// scanned and placed.  vmcnt retires in order, so "the loads are in" is vmcnt(number of stores issued after them).  The
+// compiler can only emit that when it can count the stores on every path into the wait; with the first chunk loaded
+// ahead of the loop, stores under exec-mask branches and the odd scratch reload it falls back to vmcnt(0) - every wave
+// drained its stores once per chunk (ablation: part2 13.8 ms, 6.7 ms without its stores).  So the loads and stores of
+// the chunk loops are issued from inline assembly (the compiler inserts no waits for what it does not know about) and
+// waited for by hand: buf_wait<N>() = s_waitcnt vmcnt(N), tied to the loaded registers so that no use is moved above it.
+// Rules that keep this sound: a loaded value is touched by nothing between its load and its buf_wait (same iteration,
+// no loop-carried copy of a value that has not arrived); a store that must not happen gets an offset outside the
+// resource (the hardware drops it), so the number of stores per chunk is fixed; no scratch traffic inside the loops
+// (checked in the ISA: a spill of an in-flight register would save garbage).
+typedef int kt_i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t BUF_DROP = 0x80000000u;  // an offset beyond any resource made here (all are shorter than 2^31 bytes)
+__device__ __forceinline__ kt_i32x4 buf_rsrc(const void *base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    kt_i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xFFFFu));  // (stride 0: raw buffer)
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);                           // num_records = bytes
+    r.w = 0x00020000;                                                           // 32-bit data format, no swizzle
+    return r;
+}
+// eight loads: d[j] = the K at byte offset voff + j * STRIDE of the resource; voff moves on by 8 * STRIDE.  (One offset
+// register bumped between the loads: per-load scalar offsets were thirty-two more scalar registers than the kernels have.)
+template <class K, int STRIDE>
+__device__ __forceinline__ void buf_load8_async(K *d, kt_i32x4 rs, uint32_t &voff) {
+#define KT_LD8(INSN)                                                                                                      \
+    asm volatile(INSN " %0, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8\n\t" INSN " %1, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8\n\t" \
+                 INSN " %2, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8\n\t" INSN " %3, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8\n\t" \
+                 INSN " %4, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8\n\t" INSN " %5, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8\n\t" \
+                 INSN " %6, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8\n\t" INSN " %7, %8, %9, 0 offen\n\tv_add_u32 %8, %10, %8"       \
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]),  \
+                   "+v"(voff)                                                                                            \
+                 : "s"(rs), "n"(STRIDE))
+    if constexpr (sizeof(K) == 8) KT_LD8("buffer_load_dwordx2");
+    else KT_LD8("buffer_load_dword");
+#undef KT_LD8
+}
+template <class K>
+__device__ __forceinline__ void buf_store_async(K v, kt_i32x4 rs, uint32_t off) {
+    if constexpr (sizeof(K) == 8) asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" ::"v"(v), "v"(off), "s"(rs));
+    else asm volatile("buffer_store_dword %0, %1, %2, 0 offen" ::"v"(v), "v"(off), "s"(rs));
+}
+template <int N, class K, int PER>
+__device__ __forceinline__ void buf_wait(K (&v)[PER]) {
+    static_assert(PER % 16 == 0, "sixteen registers per asm statement");
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 : "n"(N));
+    if constexpr (PER == 32)  // (volatile asm statements keep their order: these sixteen are behind the wait as well)
+        asm volatile("" : "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]),
+                          "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]), "+v"(v[28]), "+v"(v[29]), "+v"(v[30]), "+v"(v[31]));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS round trips): row_shr 1 / 2 / 4 / 8 inside the
+// rows of 16 lanes, then row_bcast:15 (lane 15 of rows 0 and 2 into rows 1 and 3) and row_bcast:31 (lane 31 into rows 2, 3)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// block_excl_scan for B <= NT * PB with PB (counters per thread) known at compile time: the same contract - all NT threads
+// call, two barriers, returns the total - in straight-line code: the wave's scan by DPP, the NT / 64 <= 16 wave totals
+// scanned inside one DPP row.  (The general routine's per-thread loops with a run-time trip count cost the partition
+// kernels a few hundred instructions and a dozen spilled registers per call.)
+template <int NT, int PB>
+__device__ __forceinline__ uint32_t block_excl_scan_n(const uint32_t *cnt, uint32_t *out, uint32_t B, uint32_t *tmp) {
+    static_assert(NT % 64 == 0 && NT / 64 <= 16, "wave totals fit one DPP row");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t c[PB], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PB; j++) {
+        c[j] = tid * PB + j < B ? cnt[tid * PB + j] : 0u;
+        sum += c[j];
+    }
+    const uint32_t inc = wave_incl_scan(sum);
+    if (lane == 63) tmp[tid >> 6] = inc;
+    ktd::lds_barrier();
+    uint32_t w = lane < NT / 64 ? tmp[lane] : 0u;
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x111, 0xf, 0xf, true);
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x112, 0xf, 0xf, true);
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x114, 0xf, 0xf, true);
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x118, 0xf, 0xf, true);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)w, NT / 64 - 1);
+    const uint32_t uw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t wbase = uw ? (uint32_t)__builtin_amdgcn_readlane((int)w, (int)uw - 1) : 0u;
+    uint32_t run = wbase + inc - sum;
+#pragma unroll
+    for (int j = 0; j < PB; j++) {
+        if (tid * PB + j < B) out[tid * PB + j] = run;
+        run += c[j];
+    }
+    ktd::lds_barrier();
+    return total;
+}
+// B <= 4 * NT (every caller: B <= 2048, NT >= 512), dispatched on a workgroup-uniform condition
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan_fast(const uint32_t *cnt, uint32_t *out, uint32_t B, uint32_t *tmp) {
+    if (B <= (uint32_t)NT) return block_excl_scan_n<NT, 1>(cnt, out, B, tmp);
+    if (B <= 2u * NT) return block_excl_scan_n<NT, 2>(cnt, out, B, tmp);
+    return block_excl_scan_n<NT, 4>(cnt, out, B, tmp);
 }
 
 // ---- where the level-1 passes get their keys ---------------------------------------------------------------
@@ -697,26 +813,28 @@ __global__ __launch_bounds__(BLOCK) void page_tails_kernel(Plan p, const uint32_
 // B2 <= 1024 two workgroups fit a CU
 template <class K, bool BIG>
 struct Part2Shared {
-    K *sorted;         // [chunk2<K, BIG>()]
+    K *sorted;         // [chunk2<K, BIG>() + 1] (+ a spare slot where the placement drops empty keys)
     uint32_t *cur;     // [B2] where the fine bucket's next key goes, relative to the level-1 bucket's first key
-    uint32_t *cnt;     // [2][B2] keys of the chunk per fine bucket; while a chunk is placed: cur - start (copy-out adds i).
-                       // Two of them, used by alternate chunks: the next chunk counts while this one is copied out.
-    uint32_t *start;   // [B2] the chunk's runs in sorted[]; the placement pass moves them to the runs' ends
+    uint32_t *cnt;     // [2][B2] keys of the chunk per fine bucket.  Two of them, used by alternate chunks: the next chunk
+                       // counts while this one is copied out.
+    uint32_t *start;   // [B2] the chunk's runs in sorted[]
+    uint32_t *delta;   // [B2] cur - start: what the copy-out adds to a sorted key's index to get its place in the bucket
     uint32_t *tmp;     // [16] block scan scratch
     uint32_t *flag;    // [1] (+1 pad) fixed fine regions: a fine bucket is outgrowing its room
-    uint16_t *sdig;    // [chunk2<K, BIG>()]
-    // 16 bytes per fine bucket
+    uint16_t *sdig;    // [chunk2<K, BIG>() + 1]
+    // 20 bytes per fine bucket
     static size_t bytes(uint32_t B2) {
-        return (size_t)chunk2<K, BIG>() * sizeof(K) + (size_t)B2 * 16 + 16 * 4 + 8 +
-               (p2_sdig<K, BIG>() ? (size_t)chunk2<K, BIG>() * 2 : 0);
+        return (size_t)chunk2<K, BIG>() * sizeof(K) + 16 + (size_t)B2 * 20 + 16 * 4 + 8 +
+               (p2_sdig<K, BIG>() ? (size_t)chunk2<K, BIG>() * 2 + 16 : 0);
     }
     __device__ Part2Shared(unsigned char *raw, uint32_t B2) {
         sorted = reinterpret_cast<K *>(raw);
-        raw += (size_t)chunk2<K, BIG>() * sizeof(K);
+        raw += (size_t)chunk2<K, BIG>() * sizeof(K) + 16;
         cur = reinterpret_cast<uint32_t *>(raw);
         cnt = cur + B2;
         start = cnt + 2 * B2;
-        tmp = start + B2;
+        delta = start + B2;
+        tmp = delta + B2;
         flag = tmp + 16;
         sdig = reinterpret_cast<uint16_t *>(flag + 2);
     }
@@ -745,9 +863,9 @@ struct P2In {
 };
 
 template <class K, bool FIXED, bool BIG, bool L16 = false>
-__global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void part2_kernel(P2In in, Plan p,
+__global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) void part2_kernel(P2In in, Plan p,
                                                       K *__restrict__ keys2, uint64_t *__restrict__ fstart,
-                                                      uint64_t *__restrict__ fend) {
+                                                      uint64_t *__restrict__ fend, const uint32_t *__restrict__ only) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Part2Shared<K, BIG> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
@@ -757,6 +875,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
     const uint32_t tid = threadIdx.x;
     const uint32_t nd = p.d_hi - p.d_lo;
     for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
+        if (only && !only[jl]) continue;  // (the redo pass behind part2_fast_kernel: only the buckets whose attempt failed)
         // the bucket's segments, and where the bucket lives in keys2
         const uint32_t n_seg = in.srcs ? in.n_src : 1u;
         auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
@@ -938,6 +1057,218 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (sizeof(K) == 8 ? 4 : 2)) void par
             ktd::lds_barrier();
             run_pass(false);
         }
+    }
+}
+
+// ---- part2, the kernel the bulk path runs (round 4): fixed fine regions, nothing else --------------------------------
+// part2_kernel<.., FIXED> with everything that is not the common case taken out: one attempt with fixed fine regions
+// per bucket; a bucket whose keys do not spread like hashed distinct keys raises fail[jl] and is left to a second launch of
+// the general kernel (exact boundaries from a histogram pass), which skips every other bucket.  What round 3's ISA and
+// ablations showed about the old loop, and what this one does about it:
+//  * the wave waited for every LDS round trip on its own: sixteen times "ds_add_rtn, s_waitcnt lgkmcnt(0), ds_write_b64"
+//    in the placement, a rolled "ds_read_b64, wait, ds_read_b32, wait, store" in the copy-out - with 4 waves per SIMD
+//    nothing hid those ~50 round trips per chunk.  Now ONE LDS atomic per key: the count's atomic returns the key's rank
+//    inside its run, so its place is start[d] + rank - a plain read, identical for the keys of a run - and every phase
+//    issues its LDS operations for a batch of keys before it waits once.
+//  * the stores were the other half (13.8 ms -> 6.7 ms with the stores ablated): they sat inside exec-mask branches behind
+//    the next chunk's loads, so the wait for those loads at the top of the next chunk had to be vmcnt(0) - every wave
+//    drained its stores once per chunk, and the one workgroup of a CU does nothing else meanwhile.  Now loads and stores
+//    are issued out of the compiler's sight (buf_load8_async / buf_store_async) and the wait is vmcnt(PER): the loads are in,
+//    this chunk's stores drain while the next chunk is counted, scanned and placed.
+//  * registers: 512 threads x 32 keys (64-bit keys) in a 256-register budget, the general kernel's other paths gone, the
+//    scan with a compile-time number of counters per thread (PB), the thread index made opaque per chunk - the hot loop
+//    must not touch scratch: a reload is a vmcnt(0).
+template <class K, bool BIG, int PB>
+__global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) void part2_fast_kernel(
+    P2In in, Plan p, K *__restrict__ keys2, uint64_t *__restrict__ fstart, uint64_t *__restrict__ fend,
+    uint32_t *__restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Part2Shared<K, BIG> sm(smem_raw, p.B2);
+    constexpr K EMPTY = empty_of<K>();
+    constexpr int P2T = p2t<K, BIG>();
+    constexpr int PER = chunk2<K, BIG>() / P2T;
+    constexpr uint32_t CH = chunk2<K, BIG>();
+    constexpr bool RKD = p2_sdig<K, BIG>();  // the digit is kept beside the rank (32-bit keys: it would cost a second hash)
+    static_assert(PER % 16 == 0, "buf_wait takes sixteen registers per statement");
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nd = p.d_hi - p.d_lo;
+    const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 64 - p.b1 - p.b2;
+    auto digit = [&](K stored) -> uint32_t { return (uint32_t)(hash_of_stored<K>(stored) >> dshift) & (B2 - 1u); };
+    for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
+        const uint32_t n_seg = in.n_src;
+        auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
+            const kt_seg_src &q = in.srcs[sidx];
+            const uint64_t c = q.counts[jl];
+            base = reinterpret_cast<const K *>(q.keys) + (q.starts ? q.starts[jl] : (uint64_t)jl * q.cap1);
+            n = c < q.cap1 ? c : q.cap1;
+        };
+        uint64_t total = 0;
+        for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
+            const K *b;
+            uint64_t n;
+            segment(sidx, b, n);
+            total += n;
+        }
+        const uint64_t lo = (uint64_t)jl * p.room1;
+        for (uint32_t i = tid; i < B2; i += P2T) {
+            sm.cur[i] = i * cap2;  // (room1 = B2 * cap2 < 2^32)
+            sm.cnt[i] = 0;
+            sm.cnt[B2 + i] = 0;
+        }
+        if (tid == 0) *sm.flag = 0;
+        ktd::lds_barrier();
+        const kt_i32x4 outrs = buf_rsrc(keys2 + lo, (uint32_t)(p.room1 * sizeof(K)));
+        // the running check of an attempt: a fine bucket's fill against its room scaled to the keys seen so far, 7 % off,
+        // + 6 sigma of a full fine bucket + 32 (bit patterns in scalar registers: a float living across the loop in a
+        // vector register is one more candidate for a spill)
+        const uint32_t allow_a = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)__float_as_uint(0.93f * (float)cap2 / (float)(total ? total : 1)));
+        const uint32_t allow_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(6.f * sqrtf((float)cap2) + 32.f));
+        uint64_t seen = 0;
+        uint32_t par = 0;
+        bool failed = false;
+        K kcur[PER];
+        uint32_t rk[RKD ? PER : PER / 2];  // ranks: two to a register, or rank | digit << 16
+        for (uint32_t sidx = 0; sidx < n_seg && !failed; sidx++) {
+            const K *base;
+            uint64_t n;
+            segment(sidx, base, n);
+            if (n == 0) continue;
+            auto load_chunk = [&](uint64_t c0) {  // thread t takes keys c0 + u * P2T + t; in flight until buf_wait
+                const uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n - c0 > CH ? CH : (uint32_t)(n - c0)));
+                const kt_i32x4 rs = buf_rsrc(base + c0, left * (uint32_t)sizeof(K));
+                uint32_t voff = tid * (uint32_t)sizeof(K);
+#pragma unroll
+                for (int u = 0; u < PER; u += 8) buf_load8_async<K, P2T * (int)sizeof(K)>(&kcur[u], rs, voff);
+            };
+            load_chunk(0);
+            buf_wait<0>(kcur);
+            for (uint64_t c0 = 0; c0 < n; c0 += CH, par ^= 1u) {
+                uint32_t *const cntc = sm.cnt + par * B2, *const cntn = sm.cnt + (par ^ 1u) * B2;
+                uint32_t tl = tid;  // (opaque per chunk: nothing derived from the thread index is carried across the loop)
+                asm volatile("" : "+v"(tl));
+                const uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n - c0 > CH ? CH : (uint32_t)(n - c0)));
+                if (left != CH) {  // the segment's last chunk: what lies past its end was read as 0
+#pragma unroll
+                    for (int u = 0; u < PER; u++) kcur[u] = (uint32_t)u * P2T + tl < left ? kcur[u] : EMPTY;
+                }
+                // count: the atomic's answer is the key's rank in its fine bucket's run (an empty key - a page gap - adds 0)
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t d = digit(kcur[u]);
+                    const uint32_t r = atomicAdd(&cntc[d], kcur[u] != EMPTY ? 1u : 0u);
+                    if constexpr (RKD) rk[u] = r | (d << 16);
+                    else if (u & 1) rk[u / 2] |= r << 16;
+                    else rk[u / 2] = r;
+                }
+                ktd::lds_barrier();
+                if (*sm.flag != 0) {  // (raised by a cursor update before the barrier above: the same for every thread)
+                    failed = true;
+                    break;
+                }
+                const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)block_excl_scan_n<P2T, PB>(cntc, sm.start, B2, sm.tmp));  // keys in the chunk; start[] = the runs
+                // (delta is read by the copy-out, behind the barrier after the placement; the other count array - last read
+                // by the previous chunk's cursor update - is zeroed for the next chunk)
+#pragma unroll
+                for (int j = 0; j < PB; j++) {
+                    const uint32_t i = tl * PB + j;
+                    if (i < B2) {
+                        sm.delta[i] = sm.cur[i] - sm.start[i];
+                        cntn[i] = 0;
+                    }
+                }
+                constexpr int PLB = 8;  // keys placed at a time: their start[] reads together, then their writes
+#pragma unroll
+                for (int u0 = 0; u0 < PER; u0 += PLB) {
+                    uint32_t at[PLB];
+#pragma unroll
+                    for (int b = 0; b < PLB; b++) at[b] = sm.start[RKD ? rk[u0 + b] >> 16 : digit(kcur[u0 + b])];
+#pragma unroll
+                    for (int b = 0; b < PLB; b++) {  // (an empty key goes to the spare slot behind the chunk: no branches)
+                        const int u = u0 + b;
+                        const uint32_t r = RKD ? rk[u] & 0xFFFFu : (u & 1 ? rk[u / 2] >> 16 : rk[u / 2] & 0xFFFFu);
+                        const uint32_t pos = kcur[u] != EMPTY ? at[b] + r : CH;
+                        sm.sorted[pos] = kcur[u];
+                        if constexpr (RKD) sm.sdig[pos] = (uint16_t)(rk[u] >> 16);
+                    }
+                }
+                bool more = c0 + CH < n;
+#if KT_ABLATION
+                if (p.dbg & 0x400u) {  // (no loads: synthetic keys)
+#pragma unroll
+                    for (int u = 0; u < PER; u++) kcur[u] = (K)ktd::mix64(c0 + (uint64_t)u * P2T + tl + ((uint64_t)jl << 40));
+                    more = false;
+                }
+#endif
+                if (more) load_chunk(c0 + CH);  // (kcur is dead: placed) the next chunk travels during the copy-out
+                ktd::lds_barrier();
+                // copy-out, COB keys at a time: LDS reads together, then the stores.  A key past the end of the chunk, or
+                // one that finds its fine bucket's room full (the bucket is failing), gets an offset the hardware drops.
+                constexpr int COB = 8;
+#pragma unroll
+                for (int u0 = 0; u0 < PER; u0 += COB) {
+                    K kk[COB];
+                    uint32_t dd[COB], dl[COB];
+                    uint32_t i0 = tl + (uint32_t)u0 * P2T;
+                    asm volatile("" : "+v"(i0));
+#pragma unroll
+                    for (int b = 0; b < COB; b++) {  // (beyond nc: stale keys of an earlier chunk, never stored)
+                        kk[b] = sm.sorted[i0 + (uint32_t)b * P2T];
+                        if constexpr (RKD) dd[b] = sm.sdig[i0 + (uint32_t)b * P2T];
+                    }
+#pragma unroll
+                    for (int b = 0; b < COB; b++) {
+                        if constexpr (!RKD) dd[b] = digit(kk[b]);
+                        dl[b] = sm.delta[dd[b] & (B2 - 1u)];
+                    }
+#pragma unroll
+                    for (int b = 0; b < COB; b++) {
+                        const uint32_t i = i0 + (uint32_t)b * P2T;
+                        const uint32_t rel = dl[b] + i;
+                        bool yes = i < nc && rel < (dd[b] + 1u) * cap2;
+#if KT_ABLATION
+                        if (p.dbg & 0x100u) yes = false;  // (every store dropped by the hardware)
+                        if (p.dbg & 0x200u) continue;     // (no store instructions at all)
+#endif
+                        buf_store_async<K>(kk[b], outrs, yes ? rel * (uint32_t)sizeof(K) : BUF_DROP);
+                    }
+                }
+                // cursors move on (no barrier: nothing the copy-out of the other waves reads is written here)
+                {
+                    const uint64_t sn = seen + c0 + CH;
+                    const float allowed = (float)(uint32_t)(sn < total ? sn : total) * __uint_as_float(allow_a) + __uint_as_float(allow_b);
+#pragma unroll
+                    for (int j = 0; j < PB; j++) {
+                        const uint32_t i = tl * PB + j;
+                        if (i < B2) {
+                            const uint32_t c = sm.cur[i] + cntc[i];
+                            sm.cur[i] = c;
+                            if ((float)(c - i * cap2) > allowed) *sm.flag = 1;
+                        }
+                    }
+                }
+                // the next chunk's keys are in; this chunk's PER stores stay in flight through the next count / scan / place
+                if (more) buf_wait<PER>(kcur);
+            }
+            seen += n;
+        }
+        ktd::lds_barrier();
+        // did every fine bucket stay inside its room?  (the running check is a prediction; this is the fact)
+        if (!failed) {
+            for (uint32_t i = tid; i < B2; i += P2T)
+                if (sm.cur[i] - i * cap2 > cap2) *sm.flag = 1;
+        }
+        ktd::lds_barrier();
+        if (!failed && *sm.flag == 0) {
+            for (uint32_t i = tid; i < B2; i += P2T) {
+                fstart[(uint64_t)jl * B2 + i] = lo + (uint64_t)i * cap2;
+                fend[(uint64_t)jl * B2 + i] = lo + sm.cur[i];
+            }
+        } else if (tid == 0) {
+            fail[jl] = 1u;  // redone by part2_kernel<K, false, BIG> (exact fine boundaries) in the launch behind this one
+        }
+        ktd::lds_barrier();
     }
 }
 
@@ -1586,7 +1917,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -1600,6 +1931,8 @@ static BulkKnobs read_knobs() {
     k.s1_wide = env_u64("KT_S1_WIDE", 1);
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
+    k.p2_grid = env_u64("KT_P2_GRID", 0);  // workgroups of the level-2 launch (0: one per bucket)
+    k.p2_fast = env_u64("KT_P2_FAST", 1);  // 0: the general level-2 kernel also for fixed fine regions (A/B, tests)
     k.build_wgs = env_u64("KT_BUILD_WGS", 64);
     k.build_wgs_ext = env_u64("KT_BUILD_WGS_EXT", 16);
     k.dense = env_u64("KT_BULK_DENSE", 1);
@@ -1739,12 +2072,41 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         auto launch = [&](auto big) -> int {
             constexpr bool BIG = decltype(big)::value;
             const size_t part2_lds = Part2Shared<K, BIG>::bytes(pp.B2);
+            constexpr uint32_t P2T = (uint32_t)p2t<K, BIG>();
+            if (pp.cap2 && src.srcs && j.kn.p2_fast && pp.B2 <= 4 * P2T) {
+                // fixed fine regions: the lean kernel, then the general one over the buckets that did not fit (none, normally)
+                uint32_t *fail = m.fail;
+                KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
+                auto go = [&](auto pb) -> int {
+                    constexpr int PB = decltype(pb)::value;
+                    auto fast = part2_fast_kernel<K, BIG, PB>;
+                    KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)part2_lds));
+                    uint32_t grid = pp.d_hi - pp.d_lo;
+                    if (j.kn.p2_grid && grid > j.kn.p2_grid) grid = (uint32_t)j.kn.p2_grid;
+                    hipLaunchKernelGGL(fast, dim3(grid), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe, fail);
+                    KT_HIP(hipGetLastError());
+                    return KT_OK;
+                };
+                const int rc = pp.B2 <= P2T       ? go(std::integral_constant<int, 1>{})
+                               : pp.B2 <= 2 * P2T ? go(std::integral_constant<int, 2>{})
+                                                  : go(std::integral_constant<int, 4>{});
+                if (rc) return rc;
+                auto redo = part2_kernel<K, false, BIG>;
+                KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)part2_lds));
+                hipLaunchKernelGGL(redo, dim3(pp.d_hi - pp.d_lo), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe,
+                                   (const uint32_t *)fail);
+                KT_HIP(hipGetLastError());
+                return KT_OK;
+            }
             // (16-byte loads where every region starts on a 16-byte boundary: paged level-1 outputs, not the pre-split's)
             const bool l16 = KT_P2_LOAD16 && sizeof(K) == 8 && pp.cap2 && src.srcs && src.srcs != m.srcs + j.n_src;
             auto part2 = !pp.cap2 ? part2_kernel<K, false, BIG> : l16 ? part2_kernel<K, true, BIG, true> : part2_kernel<K, true, BIG>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)part2_lds));
-            hipLaunchKernelGGL(part2, dim3(pp.d_hi - pp.d_lo), dim3(p2t<K, BIG>()), part2_lds, ctx->stream, src, pp, out, fs, fe);
+            hipLaunchKernelGGL(part2, dim3(pp.d_hi - pp.d_lo), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe,
+                               (const uint32_t *)nullptr);
             KT_HIP(hipGetLastError());
             return KT_OK;
         };
@@ -1906,7 +2268,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     p.n = 64 - ctr->shift;
     p.m8 = ctr->m8;
 #if KT_ABLATION
-    p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);
+    p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);  // bits 0-7: build_kernel, 8-11: part2, 12-15: scatter1w
 #endif
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
     // a rebuild moves the whole table: small batches are cheaper through the atomics
@@ -1936,7 +2298,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const uint64_t PAGE = KT_PAGE_BYTES / ksz;
     uint64_t cap1 = (slice_keys / p.B1 + slice_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + PAGE - 1) / PAGE * PAGE;
     const uint64_t room1 = cap1 * n_src;
-    if (room1 >= (1ull << 32)) {
+    if (room1 * ksz >= (1ull << 31)) {  // (part2 addresses a bucket's fixed regions through 32-bit buffer offsets)
         if (sharded) return kt::fail(KT_ERR_ARG, "sharded counter: batch too large for its level-1 regions (lower max_batch_bases)");
         paged = false;
     }
@@ -1961,6 +2323,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const size_t off_xe = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_xc = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_ov = meta;      meta += 256;
+    const size_t off_fl = meta;      meta += ((n_sub + 1) * 4 + 255) & ~(size_t)255;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
     const size_t off_sc = meta;      meta += (spill_cap * 4 + 255) & ~(size_t)255;
@@ -1997,6 +2360,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.xend = (uint64_t *)(mb + off_xe);
     m.xcount = (uint64_t *)(mb + off_xc);
     m.ovf = (uint32_t *)(mb + off_ov);
+    m.fail = (uint32_t *)(mb + off_fl);
     m.spill_n = (uint64_t *)(mb + off_sn);
     m.spill_keys = (uint64_t *)(mb + off_sk);
     m.spill_counts = (uint32_t *)(mb + off_sc);
