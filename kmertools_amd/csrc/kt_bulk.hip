@@ -1272,6 +1272,215 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
     }
 }
 
+// ---- part2 with write combining in LDS: whole, aligned cache lines only (round 4) -----------------------------------
+// tools/ubench/scatter_runs.hip: 1024 output streams per workgroup, 8 GB of 8-byte keys appended in 128-byte runs - lines
+// that are aligned are written at 4.1 TB/s, runs that start anywhere at 1.5 TB/s (64-byte aligned: 2.6; any alignment
+// below 64 bytes: the same 1.5), and with half the compute units masked off level 2 ran as fast as with all of them: the
+// pass was never bound by its LDS work but by the partial 64-byte granules at both ends of every run it wrote.  So here
+// nothing but whole lines is written.  There is no sort buffer: the LDS holds ONE LINE PER FINE BUCKET (B2 x 128 bytes), a
+// key's place in its bucket's stream comes from one returning LDS atomic (q = fill[d]++), and the chunk is emitted in
+// GENERATIONS: generation g = the keys with q / LK == g (LK = keys per line) are written to their slots of the bucket's
+// line, barrier, every bucket whose stream has reached (g + 1) * LK writes its line - 8 lanes x 16 bytes, so a wave's store
+// instruction is eight whole lines - barrier.  A chunk of 16 K keys over 1024 buckets takes two flushing generations and
+// a last one that only writes (what is left in the lines is carried into the next chunk), 5 barriers.  What a bucket
+// still holds when its input ends goes out as one partial line.
+// Same contract as part2_fast_kernel: fixed fine regions (cap2 keys each, a multiple of LK so that every region starts on
+// a line), a bucket that outgrows one raises fail[jl] and is redone by the general kernel.
+template <class K>
+struct SwwcShared {
+    K *buf;             // [B2][LK] the buckets' lines
+    uint32_t *fc;       // [B2][2] {fill: keys in the bucket's stream since its last line boundary; cur: keys written out}
+    uint32_t *flags;    // [0], [1]: some bucket has a line to write in generation g (g & 1); [2]: a bucket is outgrowing its room
+    static size_t bytes(uint32_t B2) { return (size_t)B2 * 128 + (size_t)B2 * 8 + 64; }
+    __device__ SwwcShared(unsigned char *raw, uint32_t B2) {
+        buf = reinterpret_cast<K *>(raw);
+        fc = reinterpret_cast<uint32_t *>(raw + (size_t)B2 * 128);
+        flags = fc + 2 * B2;
+    }
+};
+constexpr int SWWC_T = 512;
+
+template <class K>
+__global__ __launch_bounds__(SWWC_T, 2) void part2_swwc_kernel(P2In in, Plan p, K *__restrict__ keys2,
+                                                              uint64_t *__restrict__ fstart, uint64_t *__restrict__ fend,
+                                                              uint32_t *__restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const SwwcShared<K> sm(smem_raw, p.B2);
+    constexpr K EMPTY = empty_of<K>();
+    constexpr int P2T = SWWC_T, PER = 32;
+    constexpr uint32_t CH = (uint32_t)P2T * PER;       // 16384 keys per chunk, held in registers
+    constexpr uint32_t LK = 128 / sizeof(K), LSH = sizeof(K) == 8 ? 4 : 5;  // keys per line
+    constexpr uint32_t GL = 8;                          // lanes that write one line (16 bytes each)
+    constexpr uint32_t KPL = LK / GL;                   // keys per lane of a line: 2 (4)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nd = p.d_hi - p.d_lo;
+    const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 64 - p.b1 - p.b2;
+    auto digit = [&](K stored) -> uint32_t { return (uint32_t)(hash_of_stored<K>(stored) >> dshift) & (B2 - 1u); };
+    const uint32_t grp = tid / GL, gl = tid % GL;       // the line group this thread belongs to, its lane in it
+    for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
+        const uint32_t n_seg = in.n_src;
+        auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
+            const kt_seg_src &q = in.srcs[sidx];
+            const uint64_t c = q.counts[jl];
+            base = reinterpret_cast<const K *>(q.keys) + (q.starts ? q.starts[jl] : (uint64_t)jl * q.cap1);
+            n = c < q.cap1 ? c : q.cap1;
+        };
+        uint64_t total = 0;
+        for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
+            const K *b;
+            uint64_t n;
+            segment(sidx, b, n);
+            total += n;
+        }
+        const uint64_t lo = (uint64_t)jl * p.room1;
+        for (uint32_t i = tid; i < 2 * B2; i += P2T) sm.fc[i] = 0;
+        if (tid < 4) sm.flags[tid] = 0;
+        ktd::lds_barrier();
+        const kt_i32x4 outrs = buf_rsrc(keys2 + lo, (uint32_t)(p.room1 * sizeof(K)));
+        // the running check: a fine bucket's fill against its room scaled to the keys seen so far, 7 % off, + 6 sigma + 32
+        const uint32_t allow_a = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)__float_as_uint(0.93f * (float)cap2 / (float)(total ? total : 1)));
+        const uint32_t allow_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(6.f * sqrtf((float)cap2) + 32.f));
+        uint64_t seen = 0;
+        bool failed = false;
+        K kcur[PER], knext[PER];
+        uint32_t qa[PER];  // generation << 16 | slot of the key in buf (d * LK + q % LK); ~0: no key
+        // one line per group per trip: generation g's lines.  Returns nothing; raises flags[(g + 1) & 1] when some bucket
+        // has yet another line, flags[2] when a bucket is outgrowing its room.
+        auto flush = [&](uint32_t g, float allowed) {
+            for (uint32_t d0 = 0; d0 < B2; d0 += P2T / GL) {
+                const uint32_t d = d0 + grp;
+                uint32_t fill = 0, cur = 0;
+                if (d < B2) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(&sm.fc[2 * d]);
+                    fill = v.x;
+                    cur = v.y;
+                }
+                const uint32_t lines = fill >> LSH;  // (a bucket whose last line of this chunk went out holds < LK again)
+                const bool go = lines != 0;
+                // (every trip issues its store - one that has nothing to write is dropped by the hardware - so that the number
+                // of stores per generation is fixed: the wait for the next chunk's loads counts them.  Only the LDS read is
+                // skipped when none of the wave's eight buckets has a line.)
+                typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+                raw4 v = {0u, 0u, 0u, 0u};
+                if (__builtin_amdgcn_ballot_w64(go) != 0)
+                    v = *reinterpret_cast<const raw4 *>(&sm.buf[(size_t)(d < B2 ? d : 0) * LK + gl * KPL]);
+                const uint32_t pos = cur;  // keys of the bucket written so far = where this line goes
+                const bool fits = pos + LK <= cap2;
+                const uint32_t off = go && fits ? (d * cap2 + pos + gl * KPL) * (uint32_t)sizeof(K) : BUF_DROP;
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(off), "s"(outrs));
+                if (go && gl == 0) {
+                    // the bucket's stream moves on by a line: fill counts from the new boundary (the keys of the later
+                    // generations have their places already: they were taken from fill before the first barrier)
+                    *reinterpret_cast<uint2 *>(&sm.fc[2 * d]) = make_uint2(fill - LK, cur + LK);
+                    if (lines > 1) sm.flags[(g + 1) & 1] = 1;
+                    if (!fits || (float)(cur + fill) > allowed) sm.flags[2] = 1;
+                }
+            }
+        };
+        for (uint32_t sidx = 0; sidx < n_seg && !failed; sidx++) {
+            const K *base;
+            uint64_t n;
+            segment(sidx, base, n);
+            if (n == 0) continue;
+            auto load_chunk = [&](uint64_t c0, K (&dst)[PER]) {  // thread t takes keys c0 + u * P2T + t; in flight until buf_wait
+                const uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n - c0 > CH ? CH : (uint32_t)(n - c0)));
+                const kt_i32x4 rs = buf_rsrc(base + c0, left * (uint32_t)sizeof(K));
+                uint32_t voff = tid * (uint32_t)sizeof(K);
+#pragma unroll
+                for (int u = 0; u < PER; u += 8) buf_load8_async<K, P2T * (int)sizeof(K)>(&dst[u], rs, voff);
+            };
+            load_chunk(0, kcur);
+            buf_wait<0>(kcur);
+            for (uint64_t c0 = 0; c0 < n; c0 += CH) {
+                uint32_t tl = tid;  // (opaque per chunk: nothing derived from the thread index is carried across the loop)
+                asm volatile("" : "+v"(tl));
+                const uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n - c0 > CH ? CH : (uint32_t)(n - c0)));
+                if (left != CH) {  // the segment's last chunk: what lies past its end was read as 0
+#pragma unroll
+                    for (int u = 0; u < PER; u++) kcur[u] = (uint32_t)u * P2T + tl < left ? kcur[u] : EMPTY;
+                }
+                const bool more = c0 + CH < n;
+                if (more) load_chunk(c0 + CH, knext);  // the next chunk travels while this one is emitted
+                // every key takes its place in its bucket's stream (an empty key - a page gap - takes none)
+                if (tl == 0) sm.flags[0] = 0;  // (read last behind a barrier of the previous chunk, or as 0; set again in generation 0)
+#pragma unroll
+                for (int u = 0; u < PER; u++) {
+                    const uint32_t d = digit(kcur[u]);
+                    const bool valid = kcur[u] != EMPTY;
+                    const uint32_t q = atomicAdd(&sm.fc[2 * d], valid ? 1u : 0u);
+                    qa[u] = valid ? ((q >> LSH) << 16) | (d * LK + (q & (LK - 1u))) : ~0u;
+                }
+                ktd::lds_barrier();
+                if (sm.flags[2] != 0) {  // (raised by a flush before the barrier above: the same for every thread)
+                    failed = true;
+                    break;
+                }
+                const uint64_t sn = seen + c0 + CH;
+                const float allowed = (float)(uint32_t)(sn < total ? sn : total) * __uint_as_float(allow_a) + __uint_as_float(allow_b);
+                // generation 0: the keys that fit the lines as they stand; does any bucket reach a line?
+#pragma unroll
+                for (int u = 0; u < PER; u++)
+                    if ((qa[u] >> 16) == 0u) sm.buf[qa[u] & 0xFFFFu] = kcur[u];
+                for (uint32_t i = tl; i < B2; i += P2T)
+                    if ((sm.fc[2 * i] >> LSH) != 0) sm.flags[0] = 1;
+                if (tl == 0) sm.flags[1] = 0;  // (flush(0) raises it; its last readers are a barrier behind)
+                ktd::lds_barrier();
+                bool any = sm.flags[0] != 0;
+                uint32_t gens = 0;  // flushing generations of this chunk: P2T / GL... B2 / (P2T / GL) stores each
+                for (uint32_t g = 0; any; g++) {
+                    flush(g, allowed);
+                    gens++;
+                    ktd::lds_barrier();
+                    any = sm.flags[(g + 1) & 1] != 0;
+                    // generation g + 1: into the lines that have just gone out.  (flags[g & 1], which flush(g + 1) raises, was
+                    // read by everybody before flush(g): cleared here, behind the barrier that followed it)
+                    if (tl == 0) sm.flags[g & 1] = 0;
+#pragma unroll
+                    for (int u = 0; u < PER; u++)
+                        if ((qa[u] >> 16) == g + 1u) sm.buf[qa[u] & 0xFFFFu] = kcur[u];
+                    if (any) ktd::lds_barrier();  // (the last generation only writes: the next chunk's count may follow at once)
+                }
+                if (more) {
+                    // the next chunk's keys are in (they were requested before the count); the line stores issued since - a
+                    // fixed number per generation - stay in flight
+                    constexpr int SPG = 1024 / (P2T / GL);  // stores per generation at B2 = 1024
+                    const uint32_t issued = gens * ((B2 + P2T / GL - 1) / (P2T / GL));
+                    if (issued == SPG) buf_wait<SPG>(knext);
+                    else if (issued == 2 * SPG) buf_wait<2 * SPG>(knext);
+                    else if (issued == 3 * SPG) buf_wait<3 * SPG>(knext);
+                    else buf_wait<0>(knext);
+#pragma unroll
+                    for (int u = 0; u < PER; u++) kcur[u] = knext[u];
+                }
+            }
+            seen += n;
+        }
+        ktd::lds_barrier();
+        // what the lines still hold goes out as partial lines; the fine buckets' extents
+        if (!failed) {
+            for (uint32_t d0 = 0; d0 < B2; d0 += P2T / GL) {
+                const uint32_t d = d0 + grp;
+                if (d >= B2) continue;
+                const uint32_t fill = sm.fc[2 * d], cur = sm.fc[2 * d + 1];
+                if (cur + fill > cap2) {
+                    sm.flags[2] = 1;
+                    continue;
+                }
+                for (uint32_t e = gl * KPL; e < gl * KPL + KPL; e++)
+                    if (e < fill) keys2[lo + (uint64_t)d * cap2 + cur + e] = sm.buf[(size_t)d * LK + e];
+                if (gl == 0) {
+                    fstart[(uint64_t)jl * B2 + d] = lo + (uint64_t)d * cap2;
+                    fend[(uint64_t)jl * B2 + d] = lo + (uint64_t)d * cap2 + cur + fill;
+                }
+            }
+        }
+        ktd::lds_barrier();
+        if ((failed || sm.flags[2] != 0) && tid == 0) fail[jl] = 1u;  // redone by part2_kernel<K, false, BIG> in the launch behind this one
+        ktd::lds_barrier();
+    }
+}
+
 // ---- build: one workgroup per fine bucket = one range of the table ---------------------------------------
 // A range (kt_table.hpp) is a closed, circular linear-probing table of RS = 1024 * m8 slots, so its image fits LDS
 // (<= 96 KB of keys + counts): the bucket's keys - on top of the range's current image when the table already holds
@@ -1917,7 +2126,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -1932,6 +2141,7 @@ static BulkKnobs read_knobs() {
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
     k.p2_grid = env_u64("KT_P2_GRID", 0);  // workgroups of the level-2 launch (0: one per bucket)
+    k.p2_swwc = env_u64("KT_P2_SWWC", 1);  // level 2 with one line per fine bucket in LDS, whole lines written (0: sort buffer)
     k.p2_fast = env_u64("KT_P2_FAST", 1);  // 0: the general level-2 kernel also for fixed fine regions (A/B, tests)
     k.build_wgs = env_u64("KT_BUILD_WGS", 64);
     k.build_wgs_ext = env_u64("KT_BUILD_WGS_EXT", 16);
@@ -2067,6 +2277,31 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     const uint32_t nd = p.d_hi - p.d_lo;
     // one level-2 launch: `pp` says which hash bits it sorts by and how many buckets it reads, `src` where from
     auto run_part2 = [&](const Plan &pp, const P2In &src, K *out, uint64_t *fs, uint64_t *fe) -> int {
+        if (pp.cap2 && src.srcs && j.kn.p2_swwc && SwwcShared<K>::bytes(pp.B2) <= 160 * 1024) {
+            // fixed fine regions, whole lines only (part2_swwc_kernel); then the general kernel over the buckets that did not
+            // fit their regions (none, normally)
+            const size_t lds = SwwcShared<K>::bytes(pp.B2);
+            uint32_t *fail = m.fail;
+            KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
+            auto swwc = part2_swwc_kernel<K>;
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(swwc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            uint32_t grid = pp.d_hi - pp.d_lo;
+            if (j.kn.p2_grid && grid > j.kn.p2_grid) grid = (uint32_t)j.kn.p2_grid;
+            hipLaunchKernelGGL(swwc, dim3(grid), dim3(SWWC_T), lds, ctx->stream, src, pp, out, fs, fe, fail);
+            KT_HIP(hipGetLastError());
+            const bool bigr = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 && Part2Shared<K, true>::bytes(pp.B2) <= 160 * 1024;
+            auto redo_launch = [&](auto big) -> int {
+                constexpr bool BIG = decltype(big)::value;
+                const size_t rl = Part2Shared<K, BIG>::bytes(pp.B2);
+                auto redo = part2_kernel<K, false, BIG>;
+                KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+                hipLaunchKernelGGL(redo, dim3(pp.d_hi - pp.d_lo), dim3(p2t<K, BIG>()), rl, ctx->stream, src, pp, out, fs, fe,
+                                   (const uint32_t *)fail);
+                KT_HIP(hipGetLastError());
+                return KT_OK;
+            };
+            return bigr ? redo_launch(std::true_type{}) : redo_launch(std::false_type{});
+        }
         const bool big2 = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 &&
                           Part2Shared<K, true>::bytes(pp.B2) <= 160 * 1024;
         auto launch = [&](auto big) -> int {
@@ -2122,7 +2357,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         Plan pa = p;
         pa.b2 = p.bx;
         pa.B2 = 1u << p.bx;
-        pa.cap2 = p.room1 / pa.B2;
+        pa.cap2 = p.room1 / pa.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
         if (int rc = run_part2(pa, in, keys2, m.xstart, m.xend)) return rc;
         const uint32_t n_sub = nd << p.bx;
         hipLaunchKernelGGL(sub_counts_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)m.xstart,
@@ -2135,7 +2370,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         pb.d_lo = p.d_lo << p.bx;
         pb.d_hi = p.d_hi << p.bx;
         pb.room1 = p.room1 >> p.bx;
-        pb.cap2 = pb.room1 / pb.B2;
+        pb.cap2 = pb.room1 / pb.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
         const kt_seg_src from_a{keys2, m.xcount, ~0ull, m.xstart};
         KT_HIP(hipMemcpyAsync(m.srcs + j.n_src, &from_a, sizeof from_a, hipMemcpyHostToDevice, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));  // (from_a lives on this frame)
@@ -2369,7 +2604,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     if (paged) {
         p.cap1 = cap1;
         p.room1 = room1;
-        p.cap2 = kn.fixed2 || p.bx ? room1 / p.B2 : 0;
+        p.cap2 = kn.fixed2 || p.bx ? room1 / p.B2 / (128 / ksz) * (128 / ksz) : 0;  // (whole cache lines: every fine region starts on one)
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)n_slices * p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)n_slices * p.G * p.B1 * 4, ctx->stream));
