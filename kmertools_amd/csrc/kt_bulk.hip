@@ -329,9 +329,6 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
         ktseg::stage_segment(a, seg_lo + g, sm, t);
         return Walk{ktseg::Window(sm, t, a.k), 0u};
     }
-    // open() in two steps (scatter1c stages the next unit while the current one is being emitted)
-    __device__ void stage(uint64_t g, SegShared &sm, uint32_t t) const { ktseg::stage_segment(a, seg_lo + g, sm, t); }
-    __device__ Walk walk(uint64_t, SegShared &sm, uint32_t t) const { return Walk{ktseg::Window(sm, t, a.k), 0u}; }
     template <int N, class KR>  // KR = uint32_t when k <= 16: half the registers
     __device__ void take(Walk &wk, uint32_t, KR (&keys)[N], uint32_t &ok) const {
         ok = 0;
@@ -380,8 +377,6 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
         uint32_t at;
     };
     __device__ Walk open(uint64_t g, SegShared &, uint32_t) const { return Walk{g * ktseg::SEG, count(), 0u}; }
-    __device__ void stage(uint64_t, SegShared &, uint32_t) const {}
-    __device__ Walk walk(uint64_t g, SegShared &, uint32_t) const { return Walk{g * ktseg::SEG, count(), 0u}; }
     template <int N, class KR>
     __device__ void take(Walk &wk, uint32_t t, KR (&out)[N], uint32_t &ok) const {
         ok = 0;
@@ -803,247 +798,6 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
     ktd::lds_barrier();
     if (sm.ovf) return;
     if (tid < p.B1) wcur[(uint64_t)blockIdx.x * p.B1 + tid] = sm.cur[tid];
-}
-
-// ---- level 1 with write combining in LDS (round 4): whole, aligned cache lines only ------------------------------------
-// scatter1w's output pattern - 128-byte runs appended inside private pages, starting wherever the last run ended - is the
-// one tools/ubench/scatter_runs.hip prices at 1.5 TB/s against 4.1 TB/s for aligned lines (see part2_swwc_kernel).  Same
-// cure: no sort buffer, ONE LINE PER LEVEL-1 BUCKET in LDS (1024 x 128 bytes), a key's place in its bucket's stream from one
-// returning LDS atomic, the round's 16 K keys (512 threads x the 32 window starts of a thread, held in registers) emitted in
-// generations of whole lines, 8 lanes x 16 bytes per line.  Lines go to the workgroup's private PAGE of the bucket's region
-// (C1_PAGE_BYTES = 8 lines; one global atomic per page, as before): the page a bucket moves on to is asked for a round
-// ahead by the bucket's owner thread - when the lines left after this round's are fewer than four - so that the allocator's
-// round trip is never waited for; a bucket that runs dry inside a round all the same (a burst of one k-mer) allocates on the
-// spot.  When the launch ends, the partial lines go out padded with the empty key (which level 2 skips), and so do the
-// unused lines of the pages in hand: nothing is carried from launch to launch (at most two pages per workgroup and bucket
-// stay partly used: plan_job's room).  The next unit's segment is staged right behind the count's barrier - before any
-// of the round's stores is issued, so the loads of the stage wait for nothing but the previous round's stores.
-#ifndef KT_C1_PAGE_BYTES
-#define KT_C1_PAGE_BYTES 1024
-#endif
-constexpr int C1_T = 512, C1_GROUPS = C1_T / BLOCK;
-constexpr uint32_t C1_NONE = 0xFFFFFFFFu;
-template <class K>
-struct Scatter1CShared {
-    K buf[MAX_B1 * (128 / sizeof(K))];  // the buckets' lines
-    uint2 fc[MAX_B1];                   // {fill: keys in the bucket's stream since its last line boundary; cur: where its next line goes}
-    uint32_t nxt[MAX_B1];               // the page the bucket moves on to when the current one is full (C1_NONE: not in hand)
-    SegShared seg[C1_GROUPS];
-    uint32_t flags[4];                  // [0], [1]: some bucket has a line to write in generation g (g & 1)
-    uint32_t ovf;
-};
-static_assert(sizeof(Scatter1CShared<uint64_t>) <= 160 * 1024 && sizeof(Scatter1CShared<uint32_t>) <= 160 * 1024, "LDS of a CU");
-
-template <class Source, class K>
-__global__ __launch_bounds__(C1_T, 2) void scatter1c_kernel(Source src, Plan p, uint64_t *__restrict__ gcur,
-                                                           uint32_t *__restrict__ ovf, K *__restrict__ keys1, PendList pend) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Scatter1CShared<K> &sm = *reinterpret_cast<Scatter1CShared<K> *>(smem_raw);
-    constexpr K EMPTY = empty_of<K>();
-    constexpr int PER = (int)ktseg::PER_THREAD;  // 32: a thread's whole walk
-    constexpr uint32_t LK = 128 / sizeof(K), LSH = sizeof(K) == 8 ? 4 : 5;  // keys per line
-    constexpr uint32_t GL = 8, KPL = LK / GL;                                // lanes per line, keys per lane
-    constexpr uint32_t PAGE = KT_C1_PAGE_BYTES / sizeof(K);                   // keys per page (8 lines)
-    constexpr uint32_t NG = C1_T / GL;                                       // lines written per trip of the flush
-    constexpr int OWN = MAX_B1 / C1_T;                                       // buckets an owner thread looks after
-    const uint32_t tid = threadIdx.x, grp = tid / BLOCK, t = tid % BLOCK;
-    const uint32_t fg = tid / GL, gl = tid % GL;
-    const uint32_t B1 = p.B1;
-    const uint32_t cap1 = (uint32_t)(p.cap1 < 0xFFFF0000ull ? p.cap1 : 0xFFFF0000ull);  // (regions are shorter than 2^32 keys)
-    for (uint32_t i = tid; i < MAX_B1; i += C1_T) {
-        sm.fc[i] = make_uint2(0u, 0u);  // cur on a page boundary: "no room in hand"
-        sm.nxt[i] = C1_NONE;
-    }
-    if (tid < 4) sm.flags[tid] = 0;
-    if (tid == 0) sm.ovf = 0;
-    // every bucket's first page, asked for now (in hand at the first flush)
-    uint32_t got[OWN];
-    bool asked[OWN];
-#pragma unroll
-    for (int j = 0; j < OWN; j++) {
-        const uint32_t i = tid + (uint32_t)j * C1_T;
-        asked[j] = i < B1;
-        got[j] = C1_NONE;
-        if (asked[j]) {
-            const unsigned long long a = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[i]), (unsigned long long)PAGE);
-            got[j] = a > 0xE0000000ull ? 0xE0000000u : (uint32_t)a;  // (far past its room - a heavy bucket - must not wrap back into it)
-        }
-    }
-    const kt_i32x4 outrs = buf_rsrc(keys1, 0x7FFFFFFFu);  // (offsets below 2^31 only: see `wide` below)
-    // a level-1 output of 2 GB or more (B1 * cap1 keys): flat stores, addressed with 64 bits
-    const bool wide = (uint64_t)B1 * p.cap1 * sizeof(K) >= (1ull << 31);
-    // where the next line of bucket d goes, and the bookkeeping that moves the bucket on (all lanes of the line's group
-    // compute the same; lane 0 of the group writes it back).  Returns C1_NONE when the line has no room in the region.
-    auto line_pos = [&](uint32_t d, uint32_t fill, uint32_t cur, bool go) -> uint32_t {
-        // the current page is full (or there never was one): move on to the page in hand, or get one on the spot
-        const bool hop = go && (cur & (PAGE - 1u)) == 0u;
-        uint32_t nx = hop ? sm.nxt[d] : 0u;
-        const bool dry = hop && nx == C1_NONE;
-        if (__builtin_amdgcn_ballot_w64(dry) != 0) {  // (rare: a bucket that used up a page within a round or two)
-            uint32_t a32 = 0;
-            if (dry && gl == 0) {
-                const unsigned long long a = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[d]), (unsigned long long)PAGE);
-                a32 = a > 0xE0000000ull ? 0xE0000000u : (uint32_t)a;
-            }
-            a32 = (uint32_t)__shfl((int)a32, (int)(ktd::lane_id() & ~(GL - 1u)), 64);
-            if (dry) nx = a32;
-        }
-        const uint32_t pos = hop ? nx : cur;
-        if (go && gl == 0) {
-            sm.fc[d] = make_uint2(fill >= LK ? fill - LK : 0u, pos + LK);
-            if (hop) sm.nxt[d] = C1_NONE;
-        }
-        return pos;
-    };
-    auto put_line = [&](uint32_t d, uint32_t pos, bool go, const uint32_t (&v)[4], bool filler = false) {
-        // (a line beyond the region's room: counted aside in the sender's table - kt_shard.hip - or the build is redone)
-        const bool fits = pos <= cap1 - LK && pos != C1_NONE;
-        if (!wide) {
-            typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
-            const raw4 r = {v[0], v[1], v[2], v[3]};
-            const uint64_t at = ((uint64_t)d * p.cap1 + pos + gl * KPL) * sizeof(K);
-            const uint32_t off = go && fits ? (uint32_t)at : BUF_DROP;
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(r), "v"(off), "s"(outrs));  // (s_nop: see buf_store_async)
-        } else if (go && fits) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(keys1 + (uint64_t)d * p.cap1 + pos + gl * KPL);
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
-        }
-        if (go && !fits && !filler) {  // (a line of padding that has no room is simply not written)
-            if (pend.slots) {
-#pragma unroll
-                for (uint32_t e = 0; e < KPL; e++) {
-                    K key;
-                    if constexpr (sizeof(K) == 8) key = (K)(((uint64_t)v[2 * e + 1] << 32) | v[2 * e]);
-                    else key = (K)v[e];
-                    if (key == EMPTY) continue;
-                    const uint32_t st = kttab::table_add(TableRef{pend.slots, pend.g, pend.flags}, from_stored<K>(key), 1u);
-                    if (st == 0u) atomicOr(pend.flags, 1u);
-                    else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(pend.distinct), 1ull);
-                }
-            } else if (gl == 0) {
-                sm.ovf = 1;
-                atomicOr(ovf, 1u);
-            }
-        }
-    };
-    auto flush = [&](uint32_t g) {
-        for (uint32_t d0 = 0; d0 < B1; d0 += NG) {
-            const uint32_t d = d0 + fg;
-            uint2 st = make_uint2(0u, 0u);
-            if (d < B1) st = sm.fc[d];
-            const bool go = (st.x >> LSH) != 0;
-            if (__builtin_amdgcn_ballot_w64(go) == 0) continue;  // (no line in this wave's eight buckets)
-            const uint4 q = *reinterpret_cast<const uint4 *>(&sm.buf[(size_t)(d < B1 ? d : 0) * LK + gl * KPL]);
-            const uint32_t pos = line_pos(d, st.x, st.y, go);
-            const uint32_t v[4] = {q.x, q.y, q.z, q.w};
-            put_line(d, pos, go, v);
-            if (go && gl == 0 && (st.x >> LSH) > 1) sm.flags[(g + 1) & 1] = 1;
-        }
-    };
-    ktd::lds_barrier();
-    const uint64_t n_units = src.n_units();
-    const uint64_t stride = (uint64_t)gridDim.x * C1_GROUPS;
-    uint64_t g0 = (uint64_t)blockIdx.x * C1_GROUPS;
-    if (g0 < n_units) src.stage(g0 + grp < n_units ? g0 + grp : n_units - 1, sm.seg[grp], t);
-    bool stop = false;
-    for (; g0 < n_units && !stop; g0 += stride) {
-        const bool valid = g0 + grp < n_units;  // (a group past the end walks the last unit and keeps nothing)
-        auto wk = src.walk(valid ? g0 + grp : n_units - 1, sm.seg[grp], t);
-        K keys[PER];
-        uint32_t ok;
-        src.template take<PER, K>(wk, t, keys, ok);
-        if (!valid) ok = 0;
-        uint32_t qa[PER];  // generation << 16 | slot of the key in buf (d * LK + place % LK); ~0: no key
-        if (tid == 0) sm.flags[0] = 0;  // (read last behind a barrier of the round before, or as 0; raised again in generation 0)
-#pragma unroll
-        for (int u = 0; u < PER; u++) {  // (the keys take their stored form here, where the digit is needed)
-            keys[u] = to_stored<K>((uint64_t)keys[u]);
-            const uint32_t d = digit1h(hash_of_stored<K>(keys[u]), p);
-            const bool has = (ok >> u) & 1u;
-            const uint32_t q = atomicAdd(&sm.fc[d].x, has ? 1u : 0u);
-            qa[u] = has ? ((q >> LSH) << 16) | (d * LK + (q & (LK - 1u))) : ~0u;
-        }
-        ktd::lds_barrier();
-        stop = sm.ovf != 0;  // (raised by a flush of the round before: the same for every thread)
-        if (stop) break;
-        // the next unit's segment, staged now: none of this round's stores has been issued yet (two barriers inside)
-        if (g0 + stride < n_units) src.stage(g0 + stride + grp < n_units ? g0 + stride + grp : n_units - 1, sm.seg[grp], t);
-        // generation 0: the keys that fit the lines as they stand.  The buckets' owners: the page asked for a round ago is in
-        // hand now; does the bucket reach a line this round; will it need another page soon?
-#pragma unroll
-        for (int u = 0; u < PER; u++)
-            if ((qa[u] >> 16) == 0u) sm.buf[qa[u] & 0xFFFFu] = keys[u];
-#pragma unroll
-        for (int j = 0; j < OWN; j++) {
-            const uint32_t i = tid + (uint32_t)j * C1_T;
-            if (i < B1) {
-                if (asked[j]) {
-                    sm.nxt[i] = got[j];
-                    asked[j] = false;
-                }
-                const uint2 st = sm.fc[i];
-                const uint32_t lines = st.x >> LSH;
-                if (lines) sm.flags[0] = 1;
-                const uint32_t left = (st.y & (PAGE - 1u)) ? (PAGE - (st.y & (PAGE - 1u))) / LK : 0u;
-                if (sm.nxt[i] == C1_NONE && left < lines + 4u) {
-                    const unsigned long long a = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[i]), (unsigned long long)PAGE);
-                    got[j] = a > 0xE0000000ull ? 0xE0000000u : (uint32_t)a;
-                    asked[j] = true;
-                }
-            }
-        }
-        if (tid == 0) sm.flags[1] = 0;  // (flush(0) raises it; its last readers are a barrier behind)
-        ktd::lds_barrier();
-        bool any = sm.flags[0] != 0;
-        for (uint32_t g = 0; any; g++) {
-            flush(g);
-            ktd::lds_barrier();
-            any = sm.flags[(g + 1) & 1] != 0;
-            // generation g + 1: into the lines that have just gone out.  (flags[g & 1], which flush(g + 1) raises, was read by
-            // everybody before flush(g): cleared here, behind the barrier that followed it)
-            if (tid == 0) sm.flags[g & 1] = 0;
-#pragma unroll
-            for (int u = 0; u < PER; u++)
-                if ((qa[u] >> 16) == g + 1u) sm.buf[qa[u] & 0xFFFFu] = keys[u];
-            if (any) ktd::lds_barrier();  // (the last generation only writes: the next round's count may follow at once)
-        }
-    }
-    ktd::lds_barrier();
-    if (sm.ovf) return;
-    // the launch ends: pages asked for and not yet noted, then every bucket's partial line and the unused lines of its
-    // pages, padded with the empty key - whole lines as well
-#pragma unroll
-    for (int j = 0; j < OWN; j++) {
-        const uint32_t i = tid + (uint32_t)j * C1_T;
-        if (i < B1 && asked[j]) sm.nxt[i] = got[j];
-    }
-    ktd::lds_barrier();
-    for (uint32_t d0 = 0; d0 < B1; d0 += NG) {
-        const uint32_t d = d0 + fg;
-        uint2 st = make_uint2(0u, 0u);
-        if (d < B1) st = sm.fc[d];
-        const uint32_t e[4] = {(uint32_t)EMPTY, (uint32_t)((uint64_t)EMPTY >> (sizeof(K) == 8 ? 32 : 0)), (uint32_t)EMPTY,
-                               (uint32_t)((uint64_t)EMPTY >> (sizeof(K) == 8 ? 32 : 0))};
-        // the partial line
-        const bool part = d < B1 && st.x != 0;
-        if (__builtin_amdgcn_ballot_w64(part) != 0) {
-            uint4 q = *reinterpret_cast<const uint4 *>(&sm.buf[(size_t)(d < B1 ? d : 0) * LK + gl * KPL]);
-            uint32_t v[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (uint32_t w = 0; w < 4; w++)
-                if ((gl * KPL * (uint32_t)sizeof(K) / 4u + w) * 4u >= st.x * (uint32_t)sizeof(K)) v[w] = e[w];  // (past the bucket's keys)
-            const uint32_t pos = line_pos(d, st.x, st.y, part);
-            put_line(d, pos, part, v);
-        }
-        // what is left of the page in use, and the page in hand that was never used
-        if (d < B1) {
-            st = sm.fc[d];
-            for (uint32_t c = st.y; (c & (PAGE - 1u)) != 0u; c += LK) put_line(d, c, true, e, true);
-            const uint32_t nx = sm.nxt[d];
-            if (nx != C1_NONE)
-                for (uint32_t c = 0; c < PAGE; c += LK) put_line(d, nx + c, true, e, true);
-        }
-    }
 }
 
 // after the last source of a job: the unused tail of every workgroup's last page of every bucket gets the empty key
@@ -2375,7 +2129,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, s1_comb;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2387,7 +2141,6 @@ static BulkKnobs read_knobs() {
     k.paged = env_u64("KT_BULK_PAGED", 1);
     k.fixed2 = env_u64("KT_BULK_FIXED2", 1);
     k.s1_wide = env_u64("KT_S1_WIDE", 1);
-    k.s1_comb = env_u64("KT_S1_COMB", 1);  // level 1 with one line per bucket in LDS, whole lines written (0: scatter1w's sort buffer)
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
     k.p2_grid = env_u64("KT_P2_GRID", 0);  // workgroups of the level-2 launch (0: one per bucket)
@@ -2432,23 +2185,6 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice
     sm_.gcur = j.m.gcur + (size_t)slice * j.p.B1;
     sm_.wcur = j.m.wcur + (size_t)slice * j.p.G * j.p.B1;
     struct { Meta m; } jj{sm_};
-    if (j.kn.s1_comb) {  // write combining in LDS: whole lines only (scatter1c_kernel), one resident workgroup per CU
-        const uint32_t wgs = j.p.G / 2 ? j.p.G / 2 : 1;
-        const size_t lds = sizeof(Scatter1CShared<K>);
-        if (r.reads) {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1c_kernel<ReadsSource, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1c_kernel<ReadsSource, K>), dim3(wgs), dim3(C1_T), lds, ctx->stream, r.rs, j.p, jj.m.gcur,
-                               jj.m.ovf, keys1, j.pend);
-        } else {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1c_kernel<KeysSource, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1c_kernel<KeysSource, K>), dim3(wgs), dim3(C1_T), lds, ctx->stream, r.ks, j.p, jj.m.gcur,
-                               jj.m.ovf, keys1, j.pend);
-        }
-        KT_HIP(hipGetLastError());
-        return KT_OK;
-    }
     if (j.kn.s1_wide || j.sharded) {
         const uint32_t wgs = j.p.G / 2 ? j.p.G / 2 : 1;  // one resident workgroup per CU (its rows of wcur are [0, wgs))
         const size_t lds = sizeof(Scatter1WShared<K>);
@@ -2798,9 +2534,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     // workgroup (every workgroup leaves at most one partly used page per bucket)
     bool paged = (kn.paged != 0 && !ctr->paged_failed) || sharded;
     const uint64_t PAGE = KT_PAGE_BYTES / ksz;
-    // (scatter1c: up to two pages of KT_C1_PAGE_BYTES per workgroup - G / 2 of them - stay partly used per bucket and launch)
-    const uint64_t CPAGE = KT_C1_PAGE_BYTES / ksz;
-    uint64_t cap1 = (slice_keys / p.B1 + slice_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * (kn.s1_comb ? CPAGE : PAGE) + CPAGE - 1) / CPAGE * CPAGE;
+    // (rounded to a multiple of 128 keys: every region starts on a cache line, whatever the key size)
+    uint64_t cap1 = (slice_keys / p.B1 + slice_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + 127) / 128 * 128;
     const uint64_t room1 = cap1 * n_src;
     if (room1 * ksz >= (1ull << 31)) {  // (part2 addresses a bucket's fixed regions through 32-bit buffer offsets)
         if (sharded) return kt::fail(KT_ERR_ARG, "sharded counter: batch too large for its level-1 regions (lower max_batch_bases)");
