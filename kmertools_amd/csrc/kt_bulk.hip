@@ -733,7 +733,7 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                 if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>(keys[j]), p)], 1u);
             }
             ktd::lds_barrier();
-            const uint32_t nk = block_excl_scan<WIDE_T>(sm.cnt, sm.start, p.B1, sm.tmp);
+            const uint32_t nk = block_excl_scan_n<WIDE_T, 1>(sm.cnt, sm.start, p.B1, sm.tmp);  // (B1 <= 1024: one counter per thread)
             // every bucket's run is laid out: what fits goes to the current page, the rest to new pages.  The
             // allocator's answer is only looked at after the placement pass, which hides its round trip.
             uint64_t got = 0;
