@@ -199,8 +199,9 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
  * only report the number of entries - no second pass over the table.  The table keeps referring to the arrays
  * (entries [0, size) in unspecified order; what lies beyond them in the arrays is unspecified) until the next call that changes or probes it (a further add, kt_cov_batch,
  * an export elsewhere, a new target), which first rebuilds its own probing copy from them: leave them untouched
- * until then, or call kt_ctr_clear.  If the arrays turn out too small the next kt_ctr_size / kt_ctr_export returns
- * KT_ERR_ARG and the table's contents are lost (clear, count again). */
+ * until then, or call kt_ctr_clear.  If the arrays turn out too small, the call that counted returns KT_ERR_ARG AFTER
+ * having built the table in its own slots: nothing is lost - kt_ctr_size, kt_ctr_export into arrays of that size, further
+ * adds all work - and the target arrays hold nothing usable (they are never written past max_out). */
 int kt_ctr_export_target(kt_ctr *ctr, uint64_t *keys_dev, uint32_t *counts_dev, uint64_t max_out);
 
 /* replaces: CgrComputer::vectorise_one, composition/src/cgr.rs:127-144 (corners from cgr_maps,

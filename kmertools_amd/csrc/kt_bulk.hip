@@ -1350,34 +1350,55 @@ __global__ __launch_bounds__(SWWC_T, 2) void part2_swwc_kernel(P2In in, Plan p, 
         uint32_t qa[PER];  // generation << 16 | slot of the key in buf (d * LK + q % LK); ~0: no key
         // one line per group per trip: generation g's lines.  Returns nothing; raises flags[(g + 1) & 1] when some bucket
         // has yet another line, flags[2] when a bucket is outgrowing its room.
+#ifndef KT_SWWC_FB
+#define KT_SWWC_FB 2
+#endif
         auto flush = [&](uint32_t g, float allowed) {
-            for (uint32_t d0 = 0; d0 < B2; d0 += P2T / GL) {
-                const uint32_t d = d0 + grp;
-                uint32_t fill = 0, cur = 0;
-                if (d < B2) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(&sm.fc[2 * d]);
-                    fill = v.x;
-                    cur = v.y;
+            // FB trips at a time: the buckets' states are read together, then the lines, then the stores go out (FB = 2: 10.4 ->
+            // 9.5 ms at k=31; FB = 4 needs more than the 256 registers - and a spill in this kernel is not a slowdown but
+            // a fault: see csrc/Makefile's check of the resource remarks)
+            constexpr uint32_t FB = KT_SWWC_FB, NGR = P2T / GL;
+            for (uint32_t d0 = 0; d0 < B2; d0 += NGR * FB) {
+                uint32_t fl[FB], cu[FB];
+                bool some = false;
+#pragma unroll
+                for (uint32_t b = 0; b < FB; b++) {
+                    const uint32_t d = d0 + b * NGR + grp;
+                    fl[b] = d < B2 ? sm.fc[2 * d] : 0u;
+                    cu[b] = d < B2 ? sm.fc[2 * d + 1] : 0u;
                 }
-                const uint32_t lines = fill >> LSH;  // (a bucket whose last line of this chunk went out holds < LK again)
-                const bool go = lines != 0;
-                // (every trip issues its store - one that has nothing to write is dropped by the hardware - so that the number
-                // of stores per generation is fixed: the wait for the next chunk's loads counts them.  Only the LDS read is
-                // skipped when none of the wave's eight buckets has a line.)
+#pragma unroll
+                for (uint32_t b = 0; b < FB; b++) some |= (fl[b] >> LSH) != 0;
                 typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
-                raw4 v = {0u, 0u, 0u, 0u};
-                if (__builtin_amdgcn_ballot_w64(go) != 0)
-                    v = *reinterpret_cast<const raw4 *>(&sm.buf[(size_t)(d < B2 ? d : 0) * LK + gl * KPL]);
-                const uint32_t pos = cur;  // keys of the bucket written so far = where this line goes
-                const bool fits = pos + LK <= cap2;
-                const uint32_t off = go && fits ? (d * cap2 + pos + gl * KPL) * (uint32_t)sizeof(K) : BUF_DROP;
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(outrs));  // (s_nop: see buf_store_async)
-                if (go && gl == 0) {
-                    // the bucket's stream moves on by a line: fill counts from the new boundary (the keys of the later
-                    // generations have their places already: they were taken from fill before the first barrier)
-                    *reinterpret_cast<uint2 *>(&sm.fc[2 * d]) = make_uint2(fill - LK, cur + LK);
-                    if (lines > 1) sm.flags[(g + 1) & 1] = 1;
-                    if (!fits || (float)(cur + fill) > allowed) sm.flags[2] = 1;
+                raw4 v[FB];
+#pragma unroll
+                for (uint32_t b = 0; b < FB; b++) v[b] = raw4{0u, 0u, 0u, 0u};
+                if (__builtin_amdgcn_ballot_w64(some) != 0) {
+#pragma unroll
+                    for (uint32_t b = 0; b < FB; b++) {
+                        const uint32_t d = d0 + b * NGR + grp;
+                        v[b] = *reinterpret_cast<const raw4 *>(&sm.buf[(size_t)(d < B2 ? d : 0) * LK + gl * KPL]);
+                    }
+                }
+#pragma unroll
+                for (uint32_t b = 0; b < FB; b++) {
+                    const uint32_t d = d0 + b * NGR + grp;
+                    if (d0 + b * NGR >= B2) break;  // (uniform: B2 is not a multiple of the batch)
+                    const uint32_t fill = fl[b], cur = cu[b];
+                    const bool go = (fill >> LSH) != 0;
+                    const bool fits = cur + LK <= cap2;
+                    const uint32_t off = go && fits ? (d * cap2 + cur + gl * KPL) * (uint32_t)sizeof(K) : BUF_DROP;
+                    // (every trip issues its store - one that has nothing to write is dropped by the hardware - so that the number
+                    // of stores per generation is fixed: the wait for the next chunk's loads counts them)
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v[b]), "v"(off), "s"(outrs));  // (s_nop: see buf_store_async)
+                    if (go && gl == 0) {
+                        // the bucket's stream moves on by a line: fill counts from the new boundary (the keys of the later
+                        // generations have their places already: they were taken from fill before the first barrier)
+                        sm.fc[2 * d] = fill - LK;
+                        sm.fc[2 * d + 1] = cur + LK;
+                        if ((fill >> LSH) > 1) sm.flags[(g + 1) & 1] = 1;
+                        if (!fits || (float)(cur + fill) > allowed) sm.flags[2] = 1;
+                    }
                 }
             }
         };
@@ -1555,7 +1576,8 @@ struct ExtOut {
     uint32_t *ovf_counts;
     uint64_t ovf_cap;
     uint64_t *extent;       // virtual positions in use: max over the workgroups of the end of their last block
-    uint32_t *fill;         // [blocks]: entries at the front of a block (zeroed before the build)
+    uint32_t *fill;         // [max_blocks]: entries at the front of a block (zeroed before the build)
+    uint64_t max_blocks;    // blocks fill[] has room for (an extent that runs away is cut off there: ext_scan_kernel reports it)
     __device__ __forceinline__ void put(uint64_t pos, uint64_t key, uint32_t occ) const {
         if (pos < max) {
             __builtin_nontemporal_store(key, keys + pos);
@@ -1784,7 +1806,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                     xpos += D;
                 } else {
                     l1 = (uint32_t)(xend - xpos);
-                    if (tid == 0 && xend) xo.fill[xend / XBLK - 1] = XBLK;  // the block just finished is full
+                    if (tid == 0 && xend && xend / XBLK - 1 < xo.max_blocks) xo.fill[xend / XBLK - 1] = XBLK;  // the block just finished is full
                     b2 = ((uint64_t)blockIdx.x + (uint64_t)xused * gridDim.x) * XBLK;
                     xused++;
                     xpos = b2 + (D - l1);
@@ -1855,7 +1877,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
         hi = nhi;
     }
     if (EXT && tid == 0 && xend) {  // the last block is partly filled; the extent of the output is the furthest block's end
-        xo.fill[xend / XBLK - 1] = XBLK - (uint32_t)(xend - xpos);
+        if (xend / XBLK - 1 < xo.max_blocks) xo.fill[xend / XBLK - 1] = XBLK - (uint32_t)(xend - xpos);
         atomicMax(reinterpret_cast<unsigned long long *>(xo.extent), (unsigned long long)xend);
     }
     // the table's distinct counter: one atomic per wave
@@ -1867,7 +1889,8 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
 // info[0] = T (virtual positions handed out), [1] = n (entries = packed length), [2] = M (hole slots below n = entries
 // at or beyond n), [3] = jn (block that holds position n)
 __global__ __launch_bounds__(1024) void ext_scan_kernel(ExtOut xo, uint64_t *__restrict__ hpre, uint64_t max_blocks,
-                                                         uint64_t *__restrict__ info, uint32_t *__restrict__ flags) {
+                                                         uint64_t patch_grid, uint64_t *__restrict__ info,
+                                                         uint32_t *__restrict__ flags) {
     __shared__ uint64_t wtot[16];
     __shared__ uint64_t carry;
     const uint64_t T = *xo.extent;
@@ -1925,6 +1948,10 @@ __global__ __launch_bounds__(1024) void ext_scan_kernel(ExtOut xo, uint64_t *__r
         info[2] = M;
         info[3] = jn;
         if (n > xo.max) atomicOr(flags, 2u);
+        // ext_patch_kernel moves the entries of blocks jn .. nb - 1, one workgroup each: more blocks than it was launched
+        // with (keys spread unevenly over the build's workgroups while the caller's arrays had slack - ADVICE r3) would
+        // leave entries beyond n where they are: the build is redone the ordinary way instead
+        if (nb - jn > patch_grid) atomicOr(flags, 4u);
     }
 }
 
@@ -2423,13 +2450,14 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         char *xb = (char *)ctr->b_ext.p;
         uint64_t *hpre = (uint64_t *)(xb + off_hpre), *xinfo = (uint64_t *)(xb + off_info);
         const ExtOut xo{ctr->xt_keys, ctr->xt_counts, ctr->xt_max, (uint64_t *)(xb + off_ok), (uint32_t *)(xb + off_oc),
-                        ovf_cap,      ctr->cursor,    (uint32_t *)(xb + off_fill)};
+                        ovf_cap,      ctr->cursor,    (uint32_t *)(xb + off_fill), max_blocks};
         KT_HIP(hipMemsetAsync(ctr->cursor, 0, 8, ctx->stream));
         KT_HIP(hipMemsetAsync(xo.fill, 0, max_blocks * 4, ctx->stream));
         if (int rc = launch_build(true, xo)) return rc;
         // close the holes: the entries beyond the packed length move into them
-        hipLaunchKernelGGL(ext_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, xo, hpre, max_blocks, xinfo, ctr->flags);
-        hipLaunchKernelGGL(ext_patch_kernel, dim3((uint32_t)(ovf_cap / XBLK + 3)), dim3(256), 0, ctx->stream, xo,
+        const uint64_t patch_grid = ovf_cap / XBLK + 3;
+        hipLaunchKernelGGL(ext_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, xo, hpre, max_blocks, patch_grid, xinfo, ctr->flags);
+        hipLaunchKernelGGL(ext_patch_kernel, dim3((uint32_t)patch_grid), dim3(256), 0, ctx->stream, xo,
                            (const uint64_t *)hpre, (const uint64_t *)xinfo, (const uint32_t *)ctr->flags);
         KT_HIP(hipGetLastError());
         // did the blocks fit (flag 4: keys spread too unevenly over the workgroups)?  One 4-byte read; the caller's
@@ -2437,13 +2465,20 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         uint32_t fl = 0;
         KT_HIP(hipMemcpyAsync(&fl, ctr->flags, 4, hipMemcpyDeviceToHost, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));
-        if (fl & 4u) {  // no: build the ranges the ordinary way (kt_ctr_export will copy them out)
-            fl &= ~4u;
+        if (fl & 6u) {
+            // 4: the blocks did not fit (or could not all be patched): the ranges are built the ordinary way and
+            //    kt_ctr_export copies them out.
+            // 2: the caller's arrays are smaller than the table: the same, so that the table is NOT lost - the counts
+            //    stay in the table's own slots, kt_ctr_size / kt_ctr_export into large enough arrays work - and the
+            //    call that counted reports KT_ERR_ARG once the build is done.
+            if (fl & 2u) ctr->xt_too_small = true;
+            fl &= ~6u;
             KT_HIP(hipMemcpyAsync(ctr->flags, &fl, 4, hipMemcpyHostToDevice, ctx->stream));
             KT_HIP(hipMemsetAsync(ctr->distinct, 0, 8, ctx->stream));  // (a dense build starts from an empty table)
             KT_HIP(hipStreamSynchronize(ctx->stream));                 // (fl lives on this stack frame)
             ext = false;
-            if (j.kn.verbose) fprintf(stderr, "[bulk] export-target build redone into the table (uneven blocks)\n");
+            if (j.kn.verbose) fprintf(stderr, "[bulk] export-target build redone into the table (%s)\n",
+                                      ctr->xt_too_small ? "arrays too small" : "uneven blocks");
         }
     }
     if (!ext)
@@ -2738,11 +2773,16 @@ int kt_bulk_finish(kt_ctr *ctr) {
     if (!job->paged) {
         if (int rc = job->narrow ? level1_exact<uint32_t>(ctr, *job) : level1_exact<uint64_t>(ctr, *job)) return rc;
     }
-    const int rc = job->narrow ? finish_typed<uint32_t>(ctr, *job) : finish_typed<uint64_t>(ctr, *job);
+    int rc = job->narrow ? finish_typed<uint32_t>(ctr, *job) : finish_typed<uint64_t>(ctr, *job);
     job->srcs.clear();
     if (rc == KT_OK) {
         ctr->empty = false;
         ctr->needs_clear = false;  // every slot was written
+        if (ctr->xt_too_small) {   // (the table is complete and usable; the caller's export arrays hold nothing)
+            ctr->xt_too_small = false;
+            rc = kt::fail(KT_ERR_ARG, "kt_ctr_export_target: the arrays are smaller than the table - the counts are in the table "
+                                      "(kt_ctr_size, then kt_ctr_export into arrays of that size), the target arrays hold nothing");
+        }
     }
     return rc;
 }

@@ -170,6 +170,7 @@ struct kt_sharded {
     void *h_send = nullptr, *h_recv = nullptr;  // pinned staging for the host transport
     size_t h_bytes = 0;
     uint64_t exchanged_bytes = 0;  // sent to other ranks so far (statistics)
+    uint64_t add_calls = 0;        // kt_sharded_add_reads calls so far (tests: KT_SHARD_FAIL_LOCAL)
     uint32_t nb(int o) const { return blo[(size_t)o + 1] - blo[(size_t)o]; }
 };
 
@@ -226,12 +227,18 @@ int exchange_v(kt_sharded *s, const std::vector<Piece> &pc) {
         KT_HIP(hipStreamSynchronize(s->comm_stream));  // the staging buffers are reused by the next exchange
     } else {
         KT_NCCL(s->rccl, s->rccl->GroupStart());
-        for (int p = 0; p < s->n_ranks; p++) {
+        // (a call that fails inside the group must not leave it open - VERDICT r3: the group is closed, then the first
+        // failure is reported)
+        ncclResult_t first = ncclSuccess;
+        for (int p = 0; p < s->n_ranks && first == ncclSuccess; p++) {
             if (p == s->rank) continue;
-            if (pc[p].src_bytes) KT_NCCL(s->rccl, s->rccl->Send(pc[p].src, pc[p].src_bytes, ncclUint8, p, s->comm, s->comm_stream));
-            if (pc[p].dst_bytes) KT_NCCL(s->rccl, s->rccl->Recv(pc[p].dst, pc[p].dst_bytes, ncclUint8, p, s->comm, s->comm_stream));
+            if (pc[p].src_bytes) first = s->rccl->Send(pc[p].src, pc[p].src_bytes, ncclUint8, p, s->comm, s->comm_stream);
+            if (first == ncclSuccess && pc[p].dst_bytes)
+                first = s->rccl->Recv(pc[p].dst, pc[p].dst_bytes, ncclUint8, p, s->comm, s->comm_stream);
         }
-        KT_NCCL(s->rccl, s->rccl->GroupEnd());
+        const ncclResult_t closed = s->rccl->GroupEnd();
+        if (first != ncclSuccess) KT_NCCL(s->rccl, first);
+        KT_NCCL(s->rccl, closed);
     }
     for (int p = 0; p < s->n_ranks; p++)
         if (p != s->rank) s->exchanged_bytes += pc[p].src_bytes;
@@ -517,33 +524,91 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
     if (!s->routed) return kt_ctr_add_reads(s->table, bases, offsets, n_reads, mem);
     kt_ctx *ctx = s->ctx;
     if (int rc = ctx->use()) return rc;
-    // What this rank finds wrong with its own arguments is not returned at once: a rank that left now would leave its
-    // peers waiting in the exchange.  It takes part with no reads and a status word that makes every rank return the error.
+    // What this rank finds wrong - with its arguments, or while it sets the batch up: a pending table that filled up in an
+    // earlier batch, no memory for the partition buffers, a failed copy - is not returned at once: a rank that left now
+    // would leave its peers waiting in the exchange.  Every fallible local step comes first; then the ranks
+    // tell each other in one 8-byte exchange whether they can go on, and either all of them move data or none does.
     std::string my_error;
+    int my_code = KT_OK;
     uint64_t total = 0;
-    if (mem != KT_MEM_HOST && mem != KT_MEM_DEVICE) my_error = "kt_sharded_add_reads: bad mem flag";
-    if (my_error.empty() && n_reads) {
-        if (!offsets) my_error = "kt_sharded_add_reads: null offsets";
-        else if (int rc = ktl::total_bases_of(ctx, offsets, n_reads, mem, &total)) return rc;
+    auto local_fail = [&](int rc) {
+        if (my_code == KT_OK) {
+            my_code = rc;
+            my_error = kt_last_error();
+        }
+        total = 0;
+    };
+    auto arg_fail = [&](const char *what) {
+        if (my_code == KT_OK) {
+            my_code = KT_ERR_ARG;
+            my_error = what;
+        }
+        total = 0;
+    };
+    if (mem != KT_MEM_HOST && mem != KT_MEM_DEVICE) arg_fail("kt_sharded_add_reads: bad mem flag");
+    if (my_code == KT_OK && n_reads) {
+        if (!offsets) arg_fail("kt_sharded_add_reads: null offsets");
+        else if (int rc = ktl::total_bases_of(ctx, offsets, n_reads, mem, &total)) local_fail(rc);
     }
-    if (my_error.empty() && total > s->max_batch_bases) my_error = "kt_sharded_add_reads: batch larger than max_batch_bases (split it)";
-    if (my_error.empty() && total && !bases) my_error = "kt_sharded_add_reads: null bases";
-    if (!my_error.empty()) total = 0;
+    if (my_code == KT_OK && total > s->max_batch_bases) arg_fail("kt_sharded_add_reads: batch larger than max_batch_bases (split it)");
+    if (my_code == KT_OK && total && !bases) arg_fail("kt_sharded_add_reads: null bases");
+    {
+        // tests: KT_SHARD_FAIL_LOCAL=<rank>:<call> - that rank's call number <call> (0-based, per counter) fails locally here
+        const char *inj = getenv("KT_SHARD_FAIL_LOCAL");
+        int r = -1, c = -1;
+        if (inj && sscanf(inj, "%d:%d", &r, &c) == 2 && r == s->rank && (uint64_t)c == s->add_calls) {
+            kt::set_error("kt_sharded_add_reads: injected local failure (KT_SHARD_FAIL_LOCAL)");
+            local_fail(KT_ERR_FULL);
+        }
+        s->add_calls++;
+    }
     const uint8_t *d_bases = bases;
     const uint64_t *d_offsets = offsets;
-    if (mem == KT_MEM_HOST && total) {
-        if (int rc = ktl::stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) return rc;
+    if (my_code == KT_OK && mem == KT_MEM_HOST && total) {
+        if (int rc = ktl::stage_batch(ctx, bases, offsets, n_reads, &d_bases, &d_offsets)) local_fail(rc);
     }
     SegArgs a{};
-    if (total) {
-        if (int rc = ktl::make_seg_args(ctx, d_bases, d_offsets, n_reads, total, s->k, &a)) return rc;
+    if (my_code == KT_OK && total) {
+        if (int rc = ktl::make_seg_args(ctx, d_bases, d_offsets, n_reads, total, s->k, &a)) local_fail(rc);
     }
     const int P = s->n_slices, N = s->n_ranks, me = s->rank;
-    if (int rc = kt_bulk_begin_sharded(s->table, s->slice_keys, (uint32_t)P, (uint32_t)(P * N), s->pend)) return rc;
     kt_bulk_shape sh{};
-    if (int rc = kt_bulk_slice_info(s->table, 0, 0, &sh, nullptr, nullptr)) return rc;
-    if (int rc = sharded_recv_alloc(s, sh)) return rc;
-    const uint64_t status_word = my_error.empty() ? 0 : 1;
+    if (my_code == KT_OK) {
+        if (int rc = kt_bulk_begin_sharded(s->table, s->slice_keys, (uint32_t)P, (uint32_t)(P * N), s->pend)) local_fail(rc);
+    }
+    if (my_code == KT_OK) {
+        if (int rc = kt_bulk_slice_info(s->table, 0, 0, &sh, nullptr, nullptr)) local_fail(rc);
+    }
+    if (my_code == KT_OK) {
+        if (int rc = sharded_recv_alloc(s, sh)) local_fail(rc);
+    }
+    // can everybody go on?  (the finalize buffers serve as the messages: they exist since creation and are idle here)
+    if (N > 1) {
+        const uint64_t words = HDR_U64 + FIN_CAP + FIN_CAP / 2;
+        std::vector<uint64_t> h((size_t)N, my_code != KT_OK ? 1u : 0u);
+        for (int p = 0; p < N; p++)
+            KT_HIP(hipMemcpyAsync(s->fin_send + (uint64_t)p * words, &h[(size_t)p], 8, hipMemcpyHostToDevice, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));  // (h lives on this frame; the comm stream must see the words)
+        std::vector<Piece> pc((size_t)N);
+        for (int p = 0; p < N; p++)
+            if (p != me) pc[p] = Piece{s->fin_send + (uint64_t)p * words, 8, s->fin_recv + (uint64_t)p * words, 8};
+        if (int rc = exchange_v(s, pc)) return rc;  // (a transport that fails fails for everybody)
+        KT_HIP(hipStreamSynchronize(s->comm_stream));
+        bool peer = false;
+        for (int p = 0; p < N; p++) {
+            if (p == me) continue;
+            uint64_t v = 0;
+            KT_HIP(hipMemcpy(&v, s->fin_recv + (uint64_t)p * words, 8, hipMemcpyDeviceToHost));
+            peer |= v != 0;
+        }
+        if (my_code != KT_OK) return kt::fail(my_code, my_error);
+        if (peer)
+            return kt::fail(KT_ERR_ARG, "kt_sharded_add_reads: another rank could not take part (its batch was refused or its "
+                                        "set-up failed); nothing was counted");
+    } else if (my_code != KT_OK) {
+        return kt::fail(my_code, my_error);
+    }
+    const uint64_t status_word = 0;
     std::vector<uint64_t> h_status((size_t)P * 2, status_word);
     KT_HIP(hipMemcpyAsync(s->send_status, h_status.data(), h_status.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     KT_HIP(hipStreamSynchronize(ctx->stream));  // (h_status lives on this frame)
@@ -601,7 +666,6 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
         KT_HIP(hipStreamSynchronize(ctx->stream));
         for (uint64_t v : st) peer_failed |= v != 0;
     }
-    if (!my_error.empty()) return kt::fail(KT_ERR_ARG, my_error);
     if (peer_failed) return kt::fail(KT_ERR_ARG, "kt_sharded_add_reads: another rank could not take part (its batch was refused); nothing was counted");
     // level 2 over every source, then the range builds
     if (int rc = kt_bulk_set_sources(s->table, srcs.data(), (uint32_t)srcs.size())) return rc;

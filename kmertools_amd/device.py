@@ -354,8 +354,10 @@ class Counter:
 
     def export_target(self, keys, counts, max_out):
         """device arrays that the next whole-batch count into the empty table writes its (key, count) pairs to
-        (sticky; None, None switches it off): export(keys, counts, ...) afterwards copies nothing"""
+        (sticky; None, None switches it off): export(keys, counts, ...) afterwards copies nothing.  The library keeps the
+        raw pointers until the target is switched off or the counter closed, so the tensors are kept alive here."""
         check(_lib.lib().kt_ctr_export_target(self._h, _ptr(keys), _ptr(counts), int(max_out) if keys is not None else 0))
+        self._xt = (keys, counts) if keys is not None else None
 
     # -- cov: per-read coverage histograms against this table ---------------------------------
     def cov(self, bases, offsets, n_reads, bin_size, bin_count, out, norm=True, dtype="f64", mem=KT_MEM_DEVICE):

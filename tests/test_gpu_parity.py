@@ -467,7 +467,8 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 # N > 1 path on one GPU: two ranks share cuda:0, route on the GPU, exchange (gloo, host-staged),
 # count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
 
-_SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "presplit": (2, 31), "presplit3": (3, 15)}   # case -> (ranks, k)
+_SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "presplit": (2, 31), "presplit3": (3, 15),
+                "localfail": (2, 31)}   # case -> (ranks, k)
 
 
 def _two_rank_worker(rank, port, q, case):
@@ -483,6 +484,8 @@ def _two_rank_worker(rank, port, q, case):
     if case.startswith("presplit"):
         os.environ["KT_BULK_MAX_B2"] = "3"    # level 2 takes 3 bits only: the shards need the pre-split pass (2 bits)
         os.environ["KT_BULK_VERBOSE"] = "1"
+    if case == "localfail":
+        os.environ["KT_SHARD_FAIL_LOCAL"] = "1:1"   # rank 1's second call fails while it sets the batch up
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from kmertools_amd import device, dist as ktdist
@@ -497,6 +500,15 @@ def _two_rank_worker(rank, port, q, case):
         sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD, max_batch_bases=n * L)
         sc.add_reads(bases, offsets, n)
         m = 100 if rank == 0 else 0                 # a second "chunk" that only rank 0 has reads for
+        if case == "localfail":
+            # one rank cannot take part (a local failure ahead of the exchange): EVERY rank must come back with an error -
+            # none may be left waiting in the exchange - nothing of the batch is counted, and the counter goes on working
+            from kmertools_amd import _lib
+            try:
+                sc.add_reads(bases[: 100 * L], offsets[:101], m)
+                raise AssertionError("the injected failure was not reported on rank %d" % rank)
+            except _lib.KmertoolsError as e:
+                assert e.code == (_lib.KT_ERR_FULL if rank == 1 else _lib.KT_ERR_ARG), (rank, e.code, str(e))
         sc.add_reads(bases[: 100 * L], offsets[:101], m)
         sc.finalize()
         keys, counts = sc.export_local()
@@ -509,14 +521,15 @@ def _two_rank_worker(rank, port, q, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3"])
+@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3", "localfail"])
 def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     """the C ABI's sharded counter with two ranks on cuda:0 and the host all-to-all transport over gloo: route on
     the GPU, exchange fixed-size regions, partition + range build of what arrived, finalize; the union of the shards
     is the oracle's table of all reads.  `skewed`: one k-mer floods its owner's regions, so the pending list and
     several finalize rounds run; `narrow3`: three ranks, three slices, k=15 (32-bit keys through the partition);
     `presplit*`: level 2 restricted to 3 hash bits, so that the shards need the pre-split pass that 4- and 8-GPU tables
-    of BASELINE size need (a third trip of the keys: 2^bx-way split, then the ordinary level 2 over the sub-buckets)"""
+    of BASELINE size need (a third trip of the keys: 2^bx-way split, then the ordinary level 2 over the sub-buckets);
+    `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call works"""
     import socket
     import torch.multiprocessing as mp
     from kmertools_amd import device
@@ -968,23 +981,41 @@ def test_ctr_export_target(torch_mod, ctx, oracle, monkeypatch, k):
         assert ctr.size() == len(wk)
         ctr.close()
     monkeypatch.delenv("KT_EXT_OVF_BLOCKS")
-    # too small: loud, and the arrays are not written past their end
-    small = len(wk) // 2
-    sk = torch.full((len(wk),), -1, dtype=torch.int64, device="cuda")
-    sc = torch.zeros(len(wk), dtype=torch.int32, device="cuda")
+    # too small: loud - the call that counted says so - the arrays are not written past their end, and the table is NOT
+    # lost: its counts are in its own slots, size and an export into large enough arrays work
+    for small in (len(wk) // 2, len(wk) - 1):
+        sk = torch.full((len(wk),), -1, dtype=torch.int64, device="cuda")
+        sc = torch.zeros(len(wk), dtype=torch.int32, device="cuda")
+        ctr = device.Counter(ctx, k, 1 << 18)
+        ctr.export_target(sk, sc, small)
+        with pytest.raises(_lib.KmertoolsError) as e:
+            ctr.add_reads(bases, offsets, n)
+        assert e.value.code == _lib.KT_ERR_ARG
+        assert int((sk[small:] != -1).sum()) == 0
+        assert ctr.size() == len(wk)
+        ctr.export_target(None, None, 0)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        ctr.add_reads(bases, offsets, n)                     # ... and it is a table like any other afterwards
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+        ctr.close()
+    # arrays with slack and a scratch too small for the blocks of unevenly filled workgroups: the build must notice that
+    # the patch pass cannot reach every block and fall back, not drop entries
+    monkeypatch.setenv("KT_EXT_OVF_BLOCKS", "2")
+    monkeypatch.setenv("KT_BUILD_WGS_EXT", "1")
+    big = 8 * len(wk)
+    bk = torch.full((big,), -1, dtype=torch.int64, device="cuda")
+    bc = torch.zeros(big, dtype=torch.int32, device="cuda")
     ctr = device.Counter(ctx, k, 1 << 18)
-    ctr.export_target(sk, sc, small)
+    ctr.export_target(bk, bc, big)
     ctr.add_reads(bases, offsets, n)
-    with pytest.raises(_lib.KmertoolsError) as e:
-        ctr.size()
-    assert e.value.code == _lib.KT_ERR_ARG
-    assert int((sk[small:] != -1).sum()) == 0
-    ctr.clear()
-    ctr.export_target(None, None, 0)
-    ctr.add_reads(bases, offsets, n)
+    assert ctr.size() == len(wk)
     gk, gc = ctr.export_host()
     assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
     ctr.close()
+    monkeypatch.delenv("KT_EXT_OVF_BLOCKS")
+    monkeypatch.delenv("KT_BUILD_WGS_EXT")
 
 
 def test_ctr_range_build_full_table_is_loud(hctx, monkeypatch):
