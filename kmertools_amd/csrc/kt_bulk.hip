@@ -239,14 +239,20 @@ __device__ __forceinline__ void buf_store_async(K v, kt_i32x4 rs, uint32_t off) 
 }
 template <int N, class K, int PER>
 __device__ __forceinline__ void buf_wait(K (&v)[PER]) {
-    static_assert(PER % 16 == 0, "sixteen registers per asm statement");
+    static_assert(PER == 16 || PER == 32 || PER == 48 || PER == 64, "sixteen registers per asm statement");
     asm volatile("s_waitcnt vmcnt(%16)"
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
                    "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
                  : "n"(N));
-    if constexpr (PER == 32)  // (volatile asm statements keep their order: these sixteen are behind the wait as well)
+    if constexpr (PER >= 32)  // (volatile asm statements keep their order: these sixteen are behind the wait as well)
         asm volatile("" : "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]),
                           "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]), "+v"(v[28]), "+v"(v[29]), "+v"(v[30]), "+v"(v[31]));
+    if constexpr (PER >= 48)
+        asm volatile("" : "+v"(v[32]), "+v"(v[33]), "+v"(v[34]), "+v"(v[35]), "+v"(v[36]), "+v"(v[37]), "+v"(v[38]), "+v"(v[39]),
+                          "+v"(v[40]), "+v"(v[41]), "+v"(v[42]), "+v"(v[43]), "+v"(v[44]), "+v"(v[45]), "+v"(v[46]), "+v"(v[47]));
+    if constexpr (PER == 64)
+        asm volatile("" : "+v"(v[48]), "+v"(v[49]), "+v"(v[50]), "+v"(v[51]), "+v"(v[52]), "+v"(v[53]), "+v"(v[54]), "+v"(v[55]),
+                          "+v"(v[56]), "+v"(v[57]), "+v"(v[58]), "+v"(v[59]), "+v"(v[60]), "+v"(v[61]), "+v"(v[62]), "+v"(v[63]));
 }
 
 // inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS round trips): row_shr 1 / 2 / 4 / 8 inside the
@@ -1310,8 +1316,11 @@ __global__ __launch_bounds__(SWWC_T, 2) void part2_swwc_kernel(P2In in, Plan p, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const SwwcShared<K> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
-    constexpr int P2T = SWWC_T, PER = 32;
-    constexpr uint32_t CH = (uint32_t)P2T * PER;       // 16384 keys per chunk, held in registers
+#ifndef KT_SWWC_PER32
+#define KT_SWWC_PER32 32  // keys of a thread per chunk with 32-bit keys: 16 K keys = half a line per fine bucket and chunk.  (48:
+#endif                    // 16.2 against 14.2 ms at k=15; 64 - a whole line per chunk, like the 64-bit keys - does not fit 256 registers)
+    constexpr int P2T = SWWC_T, PER = sizeof(K) == 8 ? 32 : KT_SWWC_PER32;
+    constexpr uint32_t CH = (uint32_t)P2T * PER;       // 16384 (32768) keys per chunk, held in registers
     constexpr uint32_t LK = 128 / sizeof(K), LSH = sizeof(K) == 8 ? 4 : 5;  // keys per line
     constexpr uint32_t GL = 8;                          // lanes that write one line (16 bytes each)
     constexpr uint32_t KPL = LK / GL;                   // keys per lane of a line: 2 (4)
