@@ -23,8 +23,10 @@ is compared with the CPU oracle inside the cpu_baseline leg; ctr's exported coun
 
 Array placement (oligo / cgr workloads, untimed, before the ramp): where an array lies in the HBM moves the store-bound
 kernels by up to 20 %, so the output array - and for one-batch workloads the input array - is the
-fastest of up to eight candidate allocations (kmertools_amd.device.place_array).  The line's `output_placement` /
-`input_placement` objects list every candidate's time and which was kept, candidate 0 being the plain allocation;
+fastest of up to eight candidate allocations, chosen BY THE LIBRARY (kt_device_alloc_placed in include/kmertools_hip.h:
+any caller that links libkmertools_hip.so gets the same array).  The line's `output_placement` / `input_placement`
+objects list every candidate's time and which was kept, candidate 0 being the plain allocation, and
+`roofline.frac_plain_allocation` is the fraction a plain allocation would have given (candidate 0's probe time);
 `--no-place` takes the plain allocation.  Nothing about the timed steps changes: same kernel, same work, same checks.
 
 ctr's step is what SURVEY.md 8d puts inside it: clear + insert (+ the key exchange at N > 1) +
@@ -344,6 +346,7 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
 
     launches_per_step = 1
     extra = {}
+    keep_alive = []   # library-owned arrays (kt_device_alloc_placed) the workload's tensors are views of
     finish = lambda: None
     alg_extra = lambda: 0
     if wl["kind"] == "oligo":
@@ -371,22 +374,32 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         # allocations of one process), so - untimed - up to eight candidate allocations are tried with the
         # first batch and the fastest is kept (`output_placement` in the line lists them all; candidate 0 is what a
         # plain allocation would have got; --no-place switches this off)
-        make = lambda: torch.empty((B, bins), dtype=tdt, device="cuda")
+        out_bytes = B * bins * esz
         if args.no_place or env.share_gpu:
-            out = make()
+            out = torch.empty((B, bins), dtype=tdt, device="cuda")
         else:
             bb0, oo0, cnt0 = batch_args[0]
-            def shaped(per_slot, bb, o):   # k = 4: the probes compare the launch shapes themselves (other k: one shape)
-                ctx.oligo_tuning(per_slot)
-                ctx.oligo(bb, oo0, cnt0, k, o, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+            # k = 4: a probe runs both launch shapes (a candidate is ranked by what it takes with either); afterwards the
+            # library measures the shape for the array that was kept by itself (kt_oligo_tuning on)
             shapes = (32, 96) if k == 4 else (0,)
-            out, placed = device.place_array(make, [lambda o, p=p: shaped(p, bb0, o) for p in shapes], env.stream)
+
+            def run_into(bases_addr, out_addr):
+                for sh in shapes:
+                    ctx.oligo_tuning(sh)
+                    ctx.oligo(bases_addr, oo0, cnt0, k, out_addr, count_min=True, norm=True, total_step=1, dtype=wl["dtype"])
+            out_arr, placed = ctx.alloc_placed(out_bytes, lambda addr: run_into(bb0, addr), candidates=8, launches=4)
+            out = out_arr.tensor((B, bins), tdt)
+            keep_alive.append(out_arr)
             extra["output_placement"] = placed
-            if nb == 1:   # the same for the (much smaller) input: candidate 0 is the array the reads were generated into
-                pool = [bases]
-                bases, placed = device.place_array(lambda: pool.pop() if pool else bb0.clone(),
-                                                   [lambda b, p=p: shaped(p, b, out) for p in shapes], env.stream, warm=8)
-                batch_args[0] = (bases, oo0, cnt0)
+            if nb == 1:   # the same for the (much smaller) input: the reads are copied into every candidate
+                def probe_in(addr):
+                    device.view_tensor(addr, (bb0.numel(),), torch.uint8).copy_(bb0)
+                    run_into(addr, out)
+                in_arr, placed = ctx.alloc_placed(bb0.numel(), probe_in, candidates=8, launches=4)
+                bases_p = in_arr.tensor((bb0.numel(),), torch.uint8)
+                bases_p.copy_(bb0)
+                keep_alive.append(in_arr)
+                batch_args[0] = (bases_p, oo0, cnt0)
                 extra["input_placement"] = placed
             del bb0
             ctx.oligo_tuning(True)
@@ -411,11 +424,12 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
             ctx.minimisers(bases, offsets, n, w, k, evo, mk, ms, me, n_ev)
     elif wl["kind"] == "cgr":
         bad = torch.zeros(1, dtype=torch.int64, device="cuda")
-        make = lambda: torch.empty((n * L, 2), dtype=torch.float64, device="cuda")
         if args.no_place or env.share_gpu:
-            out = make()
+            out = torch.empty((n * L, 2), dtype=torch.float64, device="cuda")
         else:   # the 24 GB of points are a store stream like the oligo rows: the array is chosen the same way
-            out, extra["output_placement"] = device.place_array(make, lambda o: ctx.cgr(bases, offsets, n, 1, o, bad), env.stream)
+            out_arr, extra["output_placement"] = ctx.alloc_placed(n * L * 16, lambda a: ctx.cgr(bases, offsets, n, 1, a, bad))
+            out = out_arr.tensor((n * L, 2), torch.float64)
+            keep_alive.append(out_arr)
         alg_bytes_per_launch = n * (L * 17 + 8)
         dominant = "cgr_kernel (128-base chunks per lane, bracketing start, LDS-transposed stores)"
         parallelism = "reads sharded by rank, no data-path collective"
@@ -489,8 +503,15 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     # --steps 10 --warmup 3, 2.03 with 20 / 5, 2.00 with 100 / 20 and with 10 / 60, same box, same minute.  The count
     # is fixed per workload so that every rank of a collective step runs it the same number of times.
     ramp = 1 if wl["kind"] == "ctr" else 60
-    for _ in range(ramp):
+    # (the first 20 launches of the ramp are timed as well - `ms_first_20_unramped` in the line - so that what the ramp is
+    # worth stays on record: VERDICT r3)
+    rev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(20, ramp))]
+    for i in range(ramp):
+        if i < len(rev):
+            rev[i][0].record(env.stream)
         step()
+        if i < len(rev):
+            rev[i][1].record(env.stream)
     for _ in range(warmup):
         step()
     env.barrier()
@@ -512,6 +533,8 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
 
     # HBM bytes per launch from PMC counters (collected in separate rocprofv3 --pmc passes and
     # committed under profiles/; see profiles/traffic.json) - null when not collected
+    torch.cuda.synchronize()
+    first_ms = [a.elapsed_time(b) for a, b in rev]
     traffic = None
     try:
         tj = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(name + ("_genome" if genome else ""))
@@ -575,9 +598,18 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
                    "reads_per_gpu": n, "read_len": L, "k": k, "parallelism": parallelism, "reduced": reduced},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     # (nothing in this run measures HBM traffic: the figure is read from a committed file)
+                     "traffic_source": ("profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc "
+                                        "passes of this command, committed; not measured in this run") if traffic else None,
                      "kernel": dominant, "kernel_ms": round(kern_ms, 4),
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
+    if len(first_ms) > 1:
+        res["ms_first_20_unramped"] = round(sum(first_ms) / len(first_ms) / launches_per_step, 4)
+    pl = extra.get("output_placement")
+    if pl and pl.get("ms") and pl["ms"][pl["picked"]] > 0:
+        # what a plain allocation (candidate 0 of the placement probes) would have given, by the probes' own ratio
+        res["roofline"]["frac_plain_allocation"] = round(achieved / HBM_PEAK_GBS * pl["ms"][pl["picked"]] / pl["ms"][0], 4)
     res.update(extra)
     finish()
     del bases, offsets

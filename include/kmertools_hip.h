@@ -68,6 +68,21 @@ int kt_ctx_sync(kt_ctx *ctx);
 /* free / total HBM of the context's device in bytes (hipMemGetInfo): lets a caller size a table to what fits */
 int kt_device_memory(kt_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 
+/* A device array that is fast to write.  Where a large allocation lands in the HBM moves the store-bound kernels by up
+ * to 20 % - reproducibly per allocation, with no difference in plain fill rate - so a caller that keeps
+ * an output (or input) array for many launches can have the library choose among `candidates` allocations of `bytes`:
+ * all are allocated (fewer if they would take more than 60 % of the free memory), `probe(user, array)` - the caller's
+ * function, which enqueues the work the array is meant for on the context's stream, e.g. kt_oligo_batch into it - runs
+ * 20 times on the first one and then `launches` times on each between two events (its first call into an array is not
+ * counted), the fastest array is returned in *out and the others are freed.  ms[i] (may be NULL; room for `candidates`
+ * values) = milliseconds per probe on candidate i; candidate 0 is what a plain allocation would have been; *n_tried,
+ * *picked may be NULL.  probe == NULL or candidates <= 1: a plain allocation.  Release with kt_device_free.
+ * No reference counterpart: the Rust side allocates its Vecs where the allocator puts them (composition/src/oligo.rs:147). */
+typedef int (*kt_probe_fn)(void *user, void *candidate_dev);
+int kt_device_alloc_placed(kt_ctx *ctx, uint64_t bytes, int candidates, int launches, kt_probe_fn probe, void *user,
+                           void **out, double *ms, int *n_tried, int *picked);
+int kt_device_free(kt_ctx *ctx, void *ptr);
+
 /* Page-locks / releases a host buffer of the caller (hipHostRegister) so that KT_MEM_HOST calls move it
  * by DMA at full PCIe rate instead of through the driver's pageable staging.  Optional: every entry point
  * accepts ordinary pageable memory.  Worth it for buffers that are reused over many batches (the

@@ -26,6 +26,9 @@ SYMBOLS = {
     "kt_ctx_create": (_i, [_i, _vp, _i, C.POINTER(_vp)]),
     "kt_ctx_destroy": (_i, [_vp]),
     "kt_device_memory": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "kt_device_alloc_placed": (_i, [_vp, _u64, _i, _i, _vp, _vp, C.POINTER(_vp), C.POINTER(C.c_double), C.POINTER(_i),
+                               C.POINTER(_i)]),
+    "kt_device_free": (_i, [_vp, _vp]),
     "kt_host_register": (_i, [_vp, _vp, C.c_size_t]),
     "kt_host_unregister": (_i, [_vp, _vp]),
     "kt_ctx_sync": (_i, [_vp]),
@@ -76,6 +79,7 @@ SYMBOLS = {
 
 
 ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)  # kt_alltoall_fn
+PROBE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)                              # kt_probe_fn
 
 
 class KmertoolsError(RuntimeError):

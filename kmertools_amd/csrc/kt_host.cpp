@@ -177,6 +177,77 @@ int kt_device_memory(kt_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
     return KT_OK;
 }
 
+// Where a large device array lies in the HBM decides how fast the store-bound kernels can write it (DESIGN.md 4.1,
+// profiles/r3_oligo_placement.txt: the same oligo launch ran at 1.90-2.40 ms on 23 equal allocations of one process,
+// reproducibly per allocation).  A caller that keeps an output array for many launches can ask for a good one.
+int kt_device_alloc_placed(kt_ctx *ctx, uint64_t bytes, int candidates, int launches, kt_probe_fn probe, void *user,
+                           void **out, double *ms, int *n_tried, int *picked) {
+    if (!ctx || !out || !bytes) return kt::fail(KT_ERR_ARG, "kt_device_alloc_placed: null");
+    if (int rc = ctx->use()) return rc;
+    *out = nullptr;
+    if (candidates < 1 || !probe) candidates = 1;
+    if (candidates > 16) candidates = 16;
+    if (launches < 2) launches = 2;
+    // all candidates alive together (so that they are different memory) - as long as they take at most 60 % of what is free
+    size_t free_b = 0, total_b = 0;
+    KT_HIP(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t fit = (uint64_t)((double)free_b * 0.6) / bytes;
+    if ((uint64_t)candidates > fit) candidates = fit < 1 ? 1 : (int)fit;
+    void *arr[16] = {};
+    int n = 0;
+    for (; n < candidates; n++) {
+        if (hipMalloc(&arr[n], bytes) != hipSuccess) {
+            (void)hipGetLastError();  // (somebody else's memory: fewer candidates)
+            arr[n] = nullptr;
+            break;
+        }
+    }
+    if (n == 0) return kt::fail(KT_ERR_NOMEM, "kt_device_alloc_placed: out of device memory");
+    int best = 0;
+    int rc = KT_OK;
+    if (n > 1) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) rc = kt::fail(KT_ERR_HIP, "kt_device_alloc_placed: events");
+        double best_ms = 0;
+        for (int w = 0; rc == KT_OK && w < 20; w++) rc = probe(user, arr[0]);  // (nothing is measured cold)
+        for (int i = 0; rc == KT_OK && i < n; i++) {
+            rc = probe(user, arr[i]);  // (the first call into an array is not counted)
+            if (rc == KT_OK && hipEventRecord(a, ctx->stream) != hipSuccess) rc = kt::fail(KT_ERR_HIP, "kt_device_alloc_placed: event");
+            for (int l = 1; rc == KT_OK && l < launches; l++) rc = probe(user, arr[i]);
+            if (rc == KT_OK && (hipEventRecord(b, ctx->stream) != hipSuccess || hipEventSynchronize(b) != hipSuccess))
+                rc = kt::fail(KT_ERR_HIP, "kt_device_alloc_placed: event");
+            float t = 0;
+            if (rc == KT_OK && hipEventElapsedTime(&t, a, b) != hipSuccess) rc = kt::fail(KT_ERR_HIP, "kt_device_alloc_placed: event");
+            const double per = (double)t / (launches - 1);
+            if (ms) ms[i] = per;
+            if (i == 0 || per < best_ms) {
+                best_ms = per;
+                best = i;
+            }
+        }
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (rc != KT_OK && rc > 0 && rc != KT_ERR_HIP) kt::set_error("kt_device_alloc_placed: the probe failed");
+    } else if (ms) {
+        ms[0] = 0;
+    }
+    for (int i = 0; i < n; i++)
+        if (i != best || rc != KT_OK) (void)hipFree(arr[i]);
+    if (rc != KT_OK) return rc;
+    *out = arr[best];
+    if (n_tried) *n_tried = n;
+    if (picked) *picked = best;
+    return KT_OK;
+}
+
+int kt_device_free(kt_ctx *ctx, void *ptr) {
+    if (!ctx) return kt::fail(KT_ERR_ARG, "kt_device_free: null ctx");
+    if (!ptr) return KT_OK;
+    if (int rc = ctx->use()) return rc;
+    KT_HIP(hipFree(ptr));
+    return KT_OK;
+}
+
 int kt_host_register(kt_ctx *ctx, void *ptr, size_t bytes) {
     if (!ctx || !ptr || !bytes) return kt::fail(KT_ERR_ARG, "kt_host_register: null");
     if (int rc = ctx->use()) return rc;

@@ -98,50 +98,44 @@ def to_csr(seqs):
     return bases, offsets
 
 
-def place_array(make, run, stream, candidates=8, launches=4, warm=20, memory_fraction=0.6):
-    """Pick where a large device array lies.  A store-bound kernel writes two allocations of the same size at rates up
-    to 20 % apart, reproducibly per allocation and with no difference in their plain fill rate, and its input's
-    allocation moves it by another few per cent: it goes with where an allocation landed in the HBM (DESIGN.md 4.1,
-    profiles/r3_oligo_placement.txt).  This allocates up to `candidates` arrays with make() (all alive together, so
-    they are different memory; fewer if they would take more than `memory_fraction` of the free memory), runs
-    run(array) `warm` times on the first so that nothing is measured cold, then times `launches` calls on each (torch
-    events on `stream`, the first call not counted), keeps the fastest and frees the others.  `run` may be a list of
-    callables (variants of the launch): a candidate's time is that of its best variant.
-    -> (array, {"candidates": n, "ms": [per candidate], "picked": index}); candidate 0 is the plain allocation."""
+def view_tensor(addr, shape, dtype, owner=None):
+    """a torch tensor over device memory that somebody else owns (no copy, through __cuda_array_interface__); `owner` is
+    kept alive by the tensor"""
     import torch
-    runs = list(run) if isinstance(run, (list, tuple)) else [run]
-    first = make()
-    free, _ = torch.cuda.mem_get_info()
-    size = first.numel() * first.element_size()
-    n = max(1, min(candidates, 1 + int(free * memory_fraction // max(size, 1))))
-    arrays = [first]
-    for _ in range(n - 1):
+    typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.uint8: "|u1", torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(addr), False),
+                                  "version": 2, "strides": None}
+    v._owner = owner
+    t = torch.as_tensor(v, device="cuda")
+    t._kt_owner = owner
+    return t
+
+
+class DeviceArray:
+    """Device memory handed out by the library (kt_device_alloc_placed), released by close() / garbage collection.
+    `tensor(shape, dtype)` views it as a torch tensor (no copy; the view keeps this object alive); `ptr` is the raw
+    address for the C-ABI wrappers here, which accept an int where they accept a tensor."""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self._ctx, self.ptr, self.nbytes = ctx, int(ptr), int(nbytes)
+
+    def tensor(self, shape, dtype):
+        return view_tensor(self.ptr, shape, dtype, owner=self)
+
+    def close(self):
+        if self.ptr and self._ctx._h.value:
+            _lib.lib().kt_device_free(self._ctx._h, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
         try:
-            arrays.append(make())
-        except torch.OutOfMemoryError:   # somebody else's memory: fewer candidates
-            break
-    n = len(arrays)
-    for _ in range(warm):
-        runs[0](first)
-    ms = []
-    for arr in arrays:
-        best = None
-        for fn in runs:
-            fn(arr)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            for _ in range(max(1, launches - 1)):
-                fn(arr)
-            b.record(stream)
-            b.synchronize()
-            t = a.elapsed_time(b) / max(1, launches - 1)
-            best = t if best is None else min(best, t)
-        ms.append(best)
-    picked = min(range(n), key=ms.__getitem__)
-    best = arrays[picked]
-    del arrays, first, arr
-    torch.cuda.empty_cache()
-    return best, {"candidates": n, "ms": [round(x, 4) for x in ms], "picked": picked}
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -155,6 +149,33 @@ class Context:
         own = stream is None
         check(_lib.lib().kt_ctx_create(device, None if own else C.c_void_p(int(stream)), int(own),
                                        C.byref(self._h)))
+
+    def alloc_placed(self, nbytes, probe=None, candidates=8, launches=4):
+        """kt_device_alloc_placed: a device array of nbytes, the fastest of up to `candidates` allocations under
+        probe(address) - a callable that enqueues the work the array is meant for on this context's stream (None: a plain
+        allocation).  -> (DeviceArray, {"candidates": n, "ms": [per candidate], "picked": index}); candidate 0 is the
+        plain allocation.  An exception in the probe is re-raised here."""
+        exc = []
+
+        def cb(_user, ptr):
+            try:
+                probe(int(ptr))
+                return 0
+            except BaseException as e:  # noqa: BLE001 (ctypes would swallow it)
+                exc.append(e)
+                return 1
+        fn = _lib.PROBE_FN(cb) if probe is not None else None
+        out = C.c_void_p()
+        ms = (C.c_double * 16)()
+        n, picked = C.c_int(0), C.c_int(0)
+        rc = _lib.lib().kt_device_alloc_placed(self._h, int(nbytes), int(candidates), int(launches),
+                                               C.cast(fn, C.c_void_p) if fn is not None else None, None, C.byref(out), ms,
+                                               C.byref(n), C.byref(picked))
+        if exc:
+            raise exc[0]
+        check(rc)
+        info = {"candidates": n.value, "ms": [round(ms[i], 4) for i in range(n.value)], "picked": picked.value}
+        return DeviceArray(self, out.value, nbytes), info
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

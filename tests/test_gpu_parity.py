@@ -1416,10 +1416,48 @@ def test_bench_two_rank_launch(workload, ranks, presplit):
         assert j["output_check"]["sum_of_counts"] == ranks * 200000 * (150 - k + 1)
 
 
+def test_alloc_placed_c_abi(torch_mod, ctx):
+    """kt_device_alloc_placed / kt_device_free: the array the library keeps is the fastest of its candidates under the
+    caller's probe - never slower than candidate 0, the plain allocation -, the probe sees every candidate, results
+    written into the kept array are the kernel's, a probe that raises is reported, no probe = a plain allocation"""
+    torch = torch_mod
+    from kmertools_amd import device
+    n, L, k = 200000, 150, 4
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(77, n, L, bases, offsets)
+    bins = device.bins(k, True)
+    seen = []
+
+    def probe(addr):
+        seen.append(addr)
+        ctx.oligo(bases, offsets, n, k, addr, count_min=True, norm=True, total_step=1, dtype="f64")
+    arr, info = ctx.alloc_placed(n * bins * 8, probe, candidates=4, launches=3)
+    assert 1 <= info["candidates"] <= 4 and len(info["ms"]) == info["candidates"]
+    assert info["ms"][info["picked"]] <= info["ms"][0] and arr.ptr in seen
+    assert len(set(seen)) == info["candidates"]
+    out = arr.tensor((n, bins), torch.float64)
+    want = torch.empty((n, bins), dtype=torch.float64, device="cuda")
+    ctx.oligo(bases, offsets, n, k, out, count_min=True, norm=True, total_step=1, dtype="f64")
+    ctx.oligo(bases, offsets, n, k, want, count_min=True, norm=True, total_step=1, dtype="f64")
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    del out
+    arr.close()
+    plain, info = ctx.alloc_placed(1 << 20)
+    assert info["candidates"] == 1 and info["picked"] == 0 and plain.ptr
+    plain.close()
+
+    def bad(addr):
+        raise RuntimeError("probe failed")
+    with pytest.raises(RuntimeError):
+        ctx.alloc_placed(1 << 20, bad, candidates=3)
+
+
 def test_bench_places_its_arrays():
     """bench.py on one GPU, reduced size: the oligo workload's output and input arrays are chosen among candidate
-    allocations (device.place_array), the line says which, the output check and the oracle's slice check pass; with
-    --no-place the objects are absent"""
+    allocations by the library (kt_device_alloc_placed), the line says which and what the plain allocation would have
+    given, the output check and the oracle's slice check pass; with --no-place the objects are absent"""
     import json, os, subprocess, sys, pathlib
     root = pathlib.Path(__file__).resolve().parents[1]
     for flag in ([], ["--no-place"]):
@@ -1439,6 +1477,7 @@ def test_bench_places_its_arrays():
                 p = j[key]
                 assert p["candidates"] == len(p["ms"]) >= 1 and 0 <= p["picked"] < p["candidates"]
                 assert p["ms"][p["picked"]] == min(p["ms"])
+            assert 0 < j["roofline"]["frac_plain_allocation"] <= j["roofline"]["frac"] + 1e-9
 
 
 def test_ctr_cfg3_full_size_properties(torch_mod, ctx):
