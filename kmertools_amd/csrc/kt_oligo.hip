@@ -595,22 +595,43 @@ __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
     const uint64_t nt = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     auto tile_of = [&](uint64_t j) { return (uint64_t)blockIdx.x + j * gridDim.x; };
 
-    OffRegs o_cur = load_offsets(a, tile_of(0), lane);
-    OffRegs o_nxt = nt > 1 ? load_offsets(a, tile_of(1), lane) : OffRegs{0, 0};
-    ProdTile t_cur = make_tile(a, tile_of(0), o_cur, lane, total_bytes);
-    uint4 c_cur[PF];
+    // How far ahead the input travels.  Small rows (k <= 5): the next tile's chunks are requested while this tile's rows
+    // are stored.  Big rows (k >= 6: 4-read tiles of 16 / 32 KB rows, one 600-byte chunk per tile): TWO tiles ahead - a
+    // request issued behind a saturated store queue took longer than one tile's store phase whenever the reads did not
+    // happen to sit in the Infinity Cache (1 M reads of k=7: 6.05 ms against 5.5 ms with the batch resident);
+    // with two tiles of slack the kernel no longer cares where its 0.5 % of input bytes come from.
+#ifndef KT_OLIGO_DEEP
+#define KT_OLIGO_DEEP 2  // (tiles ahead for k >= 6; 1 M reads of k=7, f32: 1 -> 6.04 ms, 2 -> 5.72, 3 -> 5.82, 4 -> 5.85)
+#endif
+    constexpr int AHEAD = K >= 6 ? KT_OLIGO_DEEP : 1;  // tiles of input in flight ahead of the one being counted
+    // q[0] = the tile being counted, q[i] = tile j + i with its chunks in flight; o[i] = offsets of tile j + i (one further)
+    OffRegs o[AHEAD + 1];
+    ProdTile tq[AHEAD];
+    uint4 cq[AHEAD][PF];
 #pragma unroll
-    for (int it = 0; it < PF; it++) {
-        c_cur[it] = make_uint4(0, 0, 0, 0);
-        const uint64_t ci = wave + (uint64_t)NW * it;
-        if (ci < t_cur.n_chunks) c_cur[it] = load_chunk(a, t_cur, ci, lane, total_bytes);
+    for (int i = 0; i <= AHEAD; i++) o[i] = (uint64_t)i < nt ? load_offsets(a, tile_of(i), lane) : OffRegs{0, 0};
+#pragma unroll
+    for (int i = 0; i < AHEAD; i++) {
+#pragma unroll
+        for (int it = 0; it < PF; it++) cq[i][it] = make_uint4(0, 0, 0, 0);
+        if (i == 0 || (uint64_t)i < nt) {
+            tq[i] = make_tile(a, tile_of(i), o[i], lane, total_bytes);
+#pragma unroll
+            for (int it = 0; it < PF; it++) {
+                const uint64_t ci = wave + (uint64_t)NW * it;
+                if (ci < tq[i].n_chunks) cq[i][it] = load_chunk(a, tq[i], ci, lane, total_bytes);
+            }
+        } else {
+            tq[i] = tq[0];
+        }
     }
     for (uint64_t j = 0; j < nt; j++) {
+        ProdTile &t_cur = tq[0];
         // ---- B: positions ------------------------------------------------------------------
         if (!(KT_DBG(a) & 1u)) {
             if (lane < t_cur.nr) {
-                roff[lane] = o_cur.o;
-                roff[lane + 1] = o_cur.on;
+                roff[lane] = o[0].o;
+                roff[lane + 1] = o[0].on;
             }
             // one rolled loop = one copy of the chunk body in the binary (the unrolled form was
             // 37 KB of code and 100 VGPRs); the prefetched registers are picked by a select chain
@@ -619,10 +640,10 @@ __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
             for (uint64_t ci = wave; ci < t_cur.n_chunks; ci += NW, it++) {
                 uint4 d;
                 if (it < (uint32_t)PF) {
-                    d = c_cur[0];
+                    d = cq[0][0];
 #pragma unroll
                     for (int u = 1; u < PF; u++)
-                        if (it == (uint32_t)u) d = c_cur[u];
+                        if (it == (uint32_t)u) d = cq[0][u];
                 } else {
                     d = load_chunk(a, t_cur, ci, lane, total_bytes);
                 }
@@ -635,16 +656,25 @@ __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
         tc.off0 = 0;
         tc.TL = 0;
         lds_barrier();
-        // ---- prefetch the next tile while this one is stored -------------------------------------
+        // ---- prefetch while this tile is stored: the queue moves up, tile j + AHEAD is requested -------------------
         if (j + 1 < nt) {
-            t_cur = make_tile(a, tile_of(j + 1), o_nxt, lane, total_bytes);
-            o_cur = o_nxt;
 #pragma unroll
-            for (int it = 0; it < PF; it++) {
-                const uint64_t ci = wave + (uint64_t)NW * it;
-                if (ci < t_cur.n_chunks) c_cur[it] = load_chunk(a, t_cur, ci, lane, total_bytes);
+            for (int i = 0; i + 1 < AHEAD; i++) {
+                tq[i] = tq[i + 1];
+#pragma unroll
+                for (int it = 0; it < PF; it++) cq[i][it] = cq[i + 1][it];
             }
-            if (j + 2 < nt) o_nxt = load_offsets(a, tile_of(j + 2), lane);
+#pragma unroll
+            for (int i = 0; i < AHEAD; i++) o[i] = o[i + 1];
+            if (j + AHEAD < nt) {
+                tq[AHEAD - 1] = make_tile(a, tile_of(j + AHEAD), o[AHEAD - 1], lane, total_bytes);
+#pragma unroll
+                for (int it = 0; it < PF; it++) {
+                    const uint64_t ci = wave + (uint64_t)NW * it;
+                    if (ci < tq[AHEAD - 1].n_chunks) cq[AHEAD - 1][it] = load_chunk(a, tq[AHEAD - 1], ci, lane, total_bytes);
+                }
+            }
+            if (j + AHEAD + 1 < nt) o[AHEAD] = load_offsets(a, tile_of(j + AHEAD + 1), lane);
         }
         // ---- D: rows out, histogram cleared behind ---------------------------------------------------
         // the store stream is what must never starve: waves in this phase outrank the waves of
