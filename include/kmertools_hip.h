@@ -205,6 +205,15 @@ int kt_ctr_size(kt_ctr *ctr, uint64_t *distinct);
 int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_out,
                   uint64_t *n_out, int mem);
 
+/* The same map.scan (counter/src/lib.rs:162-165, :220-230) in pieces, for callers that must not hold a table of billions
+ * of entries in host memory at once - the reference streams its scan straight into the output file (:220-230).
+ * kt_ctr_export_stage gathers the entries on the DEVICE (a staging area of the library; a table counted into an export
+ * target has them there already) and returns their number; kt_ctr_export_fetch then copies entries
+ * [first, first + count) to host arrays, any number of times, in any order.  The staged entries stay valid until the table
+ * is changed (kt_ctr_clear, adds) or another export / cov call uses the context's scratch. */
+int kt_ctr_export_stage(kt_ctr *ctr, uint64_t *n_out);
+int kt_ctr_export_fetch(kt_ctr *ctr, uint64_t first, uint64_t count, uint64_t *keys_host, uint32_t *counts_host);
+
 /* Where the table's entries are wanted - told BEFORE counting, so that counting can deliver them there.
  * replaces: the same map.scan as kt_ctr_export (counter/src/lib.rs:162-165, :220-230), for the usual life of a
  * table: filled once, written out once.  keys_dev / counts_dev are DEVICE arrays of max_out entries owned by the

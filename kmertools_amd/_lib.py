@@ -53,6 +53,8 @@ SYMBOLS = {
     "kt_ctr_capacity": (_i, [_vp, C.POINTER(_u64)]),
     "kt_ctr_export": (_i, [_vp, _vp, _vp, _u64, C.POINTER(_u64), _i]),
     "kt_ctr_export_target": (_i, [_vp, _vp, _vp, _u64]),
+    "kt_ctr_export_stage": (_i, [_vp, C.POINTER(_u64)]),
+    "kt_ctr_export_fetch": (_i, [_vp, _u64, _u64, _vp, _vp]),
     "kt_cgr_points": (_i, [_vp, _vp, _vp, _u64, C.c_double, _vp, _vp, _i]),
     "kt_minimisers": (_i, [_vp, _vp, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64), _i]),
     "kt_cov_batch": (_i, [_vp, _vp, _vp, _u64, _u64, _u64, _i, _i, _vp, _i]),

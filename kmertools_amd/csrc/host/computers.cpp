@@ -643,6 +643,39 @@ static void write_counts(FILE *out, const uint64_t *keys, const uint32_t *counts
     }
 }
 
+// The table's lines, a slab at a time: the entries are staged on the device and fetched SLAB entries at a time, so the host
+// holds one slab of (key, count) pairs and its text whatever the table's size - the reference's map.scan streams into
+// the file the same way (counter/src/lib.rs:220-230).  `ceil_gb` (-m): the slab shrinks with the ceiling.
+static std::string write_table(FILE *out, kt_ctr *ctr, bool acgt, int k, int threads, double ceil_gb, uint64_t *n_out) {
+    uint64_t n = 0;
+    if (kt_ctr_export_stage(ctr, &n) != KT_OK) return kt_last_error();
+    // ~64 bytes of host memory per entry of a slab (12 of pairs, the rest text in flight): a million entries at a time -
+    // 64 MB, far below any ceiling -m accepts (6 .. 128 GB); a sixteenth of the ceiling if that were ever smaller
+    uint64_t slab = (uint64_t)(ceil_gb * (double)(1ull << 30) / 16.0 / 64.0);
+    if (slab > (1ull << 20)) slab = 1ull << 20;
+    if (slab < (1ull << 16)) slab = 1ull << 16;
+    std::vector<uint64_t> keys((size_t)(n < slab ? (n ? n : 1) : slab));
+    std::vector<uint32_t> counts(keys.size());
+    for (uint64_t i0 = 0; i0 < n; i0 += slab) {
+        const uint64_t m = n - i0 < slab ? n - i0 : slab;
+        if (kt_ctr_export_fetch(ctr, i0, m, keys.data(), counts.data()) != KT_OK) return kt_last_error();
+        write_counts(out, keys.data(), counts.data(), m, acgt, k, threads);
+    }
+    if (n_out) *n_out = n;
+    return "";
+}
+
+static uint64_t peak_rss_kb() {  // VmHWM of this process (KT_CLI_TIMING)
+    FILE *f = fopen("/proc/self/status", "r");
+    if (!f) return 0;
+    char line[256];
+    uint64_t kb = 0;
+    while (fgets(line, sizeof line, f))
+        if (strncmp(line, "VmHWM:", 6) == 0) kb = strtoull(line + 6, nullptr, 10);
+    fclose(f);
+    return kb;
+}
+
 static uint64_t env_u64_host(const char *name, uint64_t dflt) {
     const char *v = getenv(name);
     return v && *v ? strtoull(v, nullptr, 10) : dflt;
@@ -733,19 +766,18 @@ std::string CountComputer::count() {
         if (pass_hook_)
             if (std::string e = pass_hook_(pass, passes_, ctr_); !e.empty()) return e;
         // - its lines go to kmers.counts, and the table is reused
-        uint64_t n = 0, got = 0;
-        if (kt_ctr_size(ctr_, &n) != KT_OK) return kt_last_error();
-        std::vector<uint64_t> keys(n ? n : 1);
-        std::vector<uint32_t> counts(n ? n : 1);
-        if (n && kt_ctr_export(ctr_, keys.data(), counts.data(), n, &got, KT_MEM_HOST) != KT_OK) return kt_last_error();
-        pt.t[1] += lap();
         if (!out) out = fopen(path.c_str(), "wb");
         if (!out) return "Unable to write to file: " + path;
-        write_counts(out, keys.data(), counts.data(), got, acgt_, ksize_, threads_);
+        if (getenv("KT_CLI_TIMING")) fprintf(stderr, "[timing] pass %u counted: VmHWM %llu kB\n", pass, (unsigned long long)peak_rss_kb());
+        if (std::string e = write_table(out, ctr_, acgt_, ksize_, threads_, memory_ceil_gb_, nullptr); !e.empty()) return e;
+        if (getenv("KT_CLI_TIMING")) fprintf(stderr, "[timing] pass %u written: VmHWM %llu kB\n", pass, (unsigned long long)peak_rss_kb());
         pt.t[3] += lap();
         if (kt_ctr_clear(ctr_) != KT_OK) return kt_last_error();
     }
     if (out) fclose(out);
+    if (getenv("KT_CLI_TIMING") && passes_ > 1)
+        fprintf(stderr, "[timing] ctr out of core: %u passes, peak host memory (VmHWM) %llu kB\n", passes_,
+                (unsigned long long)peak_rss_kb());
     return "";
 }
 
@@ -924,20 +956,14 @@ std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
     if (!ctr_) return "count() has not run";
     PhaseTimer pt("ctr merge");
     Lap lap;
-    uint64_t n = 0;
-    if (kt_ctr_size(ctr_, &n) != KT_OK) return kt_last_error();
-    std::vector<uint64_t> keys(n ? n : 1);
-    std::vector<uint32_t> counts(n ? n : 1);
-    uint64_t got = 0;
-    if (n && kt_ctr_export(ctr_, keys.data(), counts.data(), n, &got, KT_MEM_HOST) != KT_OK) return kt_last_error();
-    pt.t[1] += lap();
     FILE *out = fopen(path.c_str(), "wb");
     if (!out) return "Unable to write to file: " + path;
-    write_counts(out, keys.data(), counts.data(), got, acgt_, ksize_, threads_);
+    const std::string e = write_table(out, ctr_, acgt_, ksize_, threads_, memory_ceil_gb_, nullptr);
     pt.t[2] += lap();
     fclose(out);
     pt.t[3] += lap();
-    return "";
+    if (getenv("KT_CLI_TIMING")) fprintf(stderr, "[timing] ctr merge: peak host memory (VmHWM) %llu kB\n", (unsigned long long)peak_rss_kb());
+    return e;
 }
 
 // ---------------------------------------------------------------------------------------------

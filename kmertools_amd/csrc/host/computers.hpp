@@ -94,7 +94,7 @@ class CountComputer {
     CountComputer(std::string in_path, std::string out_dir, int ksize);
     ~CountComputer();
     void set_threads(int t) { threads_ = t; }
-    void set_max_memory(double gb) { memory_ceil_gb_ = gb; }  // accepted; the table is HBM-resident
+    void set_max_memory(double gb) { memory_ceil_gb_ = gb; }  // the host ceiling: the table is written out in slabs sized by it
     void set_acgt_output(bool a) { acgt_ = a; }
     void set_device(int d) { dev_.index = d; }
     void set_devices(int n) { n_devices_ = n < 1 ? 1 : n; }  // --devices N: the table sharded over N GPUs (kt_sharded_*)

@@ -414,6 +414,7 @@ int kt_ctr_clear(kt_ctr *ctr) {
     ctr->empty = true;
     ctr->dense = false;
     ctr->dense_ext = false;
+    ctr->stage_n = 0;  // (what kt_ctr_export_stage staged is gone with the table's contents)
     return KT_OK;
 }
 
@@ -612,6 +613,51 @@ int kt_ctr_export(kt_ctr *ctr, uint64_t *keys, uint32_t *counts, uint64_t max_ou
     }
     *n_out = written;
     if (n > max_out) return kt::fail(KT_ERR_ARG, "kt_ctr_export: max_out smaller than the table's size");
+    return KT_OK;
+}
+
+// The table's entries in pieces (out-of-core callers: the host never holds more than one piece).  kt_ctr_export_stage
+// puts all of them into a device-side staging area of the library (for a table counted into an export target: they are
+// there already) and reports how many; kt_ctr_export_fetch copies entries [first, first + count) to host arrays.
+int kt_ctr_export_stage(kt_ctr *ctr, uint64_t *n_out) {
+    if (!ctr || !n_out) return kt::fail(KT_ERR_ARG, "kt_ctr_export_stage: null");
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    uint64_t n = 0;
+    if (int rc = kt_ctr_size(ctr, &n)) return rc;
+    ctr->stage_keys = nullptr;
+    ctr->stage_counts = nullptr;
+    ctr->stage_n = 0;
+    if (n) {
+        if (ctr->dense && ctr->dense_ext) {
+            ctr->stage_keys = ctr->xt_keys;
+            ctr->stage_counts = ctr->xt_counts;
+        } else {
+            if (int rc = ctx->s_aux1.reserve(n * 8)) return rc;
+            if (int rc = ctx->s_aux2.reserve(n * 4)) return rc;
+            uint64_t got = 0;
+            if (int rc = kt_ctr_export(ctr, (uint64_t *)ctx->s_aux1.p, (uint32_t *)ctx->s_aux2.p, n, &got, KT_MEM_DEVICE)) return rc;
+            n = got;
+            ctr->stage_keys = (const uint64_t *)ctx->s_aux1.p;
+            ctr->stage_counts = (const uint32_t *)ctx->s_aux2.p;
+        }
+    }
+    ctr->stage_n = n;
+    *n_out = n;
+    return KT_OK;
+}
+
+int kt_ctr_export_fetch(kt_ctr *ctr, uint64_t first, uint64_t count, uint64_t *keys_host, uint32_t *counts_host) {
+    if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_export_fetch: null");
+    if (first > ctr->stage_n || count > ctr->stage_n - first)
+        return kt::fail(KT_ERR_ARG, "kt_ctr_export_fetch: beyond the staged entries (call kt_ctr_export_stage first)");
+    if (!count) return KT_OK;
+    if (!keys_host || !counts_host) return kt::fail(KT_ERR_ARG, "kt_ctr_export_fetch: null output");
+    kt_ctx *ctx = ctr->ctx;
+    if (int rc = ctx->use()) return rc;
+    KT_HIP(hipMemcpyAsync(keys_host, ctr->stage_keys + first, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipMemcpyAsync(counts_host, ctr->stage_counts + first, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));
     return KT_OK;
 }
 

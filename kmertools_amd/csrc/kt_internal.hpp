@@ -106,6 +106,9 @@ struct kt_ctr {
     uint32_t *xt_counts = nullptr;
     uint64_t xt_max = 0;
     bool dense_ext = false;            // the table's entries ARE xt_keys / xt_counts [0, *distinct): (key, occurrences)
+    const uint64_t *stage_keys = nullptr;  // kt_ctr_export_stage: where the staged entries are (device), how many
+    const uint32_t *stage_counts = nullptr;
+    uint64_t stage_n = 0;
     bool xt_too_small = false;         // the last build found the export target smaller than the table (reported by kt_bulk_finish)
     kt::Scratch b_ext;                 // the export-target build's holes and the scratch behind the caller's arrays
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls

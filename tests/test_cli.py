@@ -301,6 +301,44 @@ def test_ctr_out_of_core_passes_and_devices(cli, oracle, tmp_path):
     assert sorted((d3 / "kmers.counts").read_text().splitlines()) == want
 
 
+@pytest.mark.gpu
+def test_ctr_out_of_core_bounded_host_memory(cli, oracle, tmp_path):
+    """the reference's whole design for `ctr` is a memory ceiling (chunks sized by -m, counter/src/lib.rs:114-118; the
+    merged map streamed straight into the file, :220-230).  Here a pass's table is staged on the device and fetched a slab
+    of a million entries at a time (kt_ctr_export_stage / _fetch), so the host's peak memory does not depend on how many
+    distinct k-mers a pass holds: ~84 M distinct 31-mers counted in >= 4 passes (>= 21 M entries = 250 MB of (key, count)
+    pairs per pass, were they held whole) peak within 64 MB of the same input counted in >= 16 passes (a quarter of
+    that per pass), and the lines are the oracle's"""
+    import os
+    import re
+    import numpy as np
+    n, L, k = 700_000, 150, 31
+    hb, ho = oracle.synth_reads(31337, n, L, noise=False)
+    fa = tmp_path / "big.fa"
+    with open(fa, "wb") as f:
+        for i in range(n):
+            f.write(b">r%d\n" % i)
+            f.write(hb[int(ho[i]):int(ho[i + 1])].tobytes())
+            f.write(b"\n")
+    keys, counts = oracle.count_reads(hb, ho, k, n_parts=8, threads=8)
+    assert len(keys) > 80_000_000
+    env = dict(os.environ, KT_CLI_TIMING="1", KT_CLI_BATCH_BASES=str(8 << 20))
+    peaks = {}
+    for passes in (4, 16):
+        small = max(1024, int(1.4 * len(keys) / passes))
+        out = tmp_path / ("p%d" % passes)
+        r = run(cli, "ctr", "-i", fa, "-o", out, "-k", str(k), "-m", "6", env=dict(env, KT_CTR_MAX_SLOTS=str(small)))
+        assert r.returncode == 0, r.stderr
+        assert int(r.stderr.split(" pass(es)")[0].split()[-1]) >= passes
+        peaks[passes] = int(re.search(r"peak host memory \(VmHWM\) (\d+) kB", r.stderr).group(1))
+        if passes == 4:
+            got = np.loadtxt(out / "kmers.counts", dtype=np.uint64, delimiter="\t")
+            order = np.argsort(got[:, 0])
+            assert np.array_equal(got[order, 0], keys) and np.array_equal(got[order, 1], counts.astype(np.uint64))
+            del got, order
+    assert abs(peaks[4] - peaks[16]) < 64 * 1024, peaks
+
+
 def test_parallel_reader_matches_serial(cli, tmp_path):
     """plain files of >= 32 MB are mapped and parsed piecewise by several threads: the records must be exactly the
     serial reader's (KT_READER_THREADS=1), in order, with their ordinals - multi-line FASTA with CRLF and blank
