@@ -2186,7 +2186,9 @@ static BulkKnobs read_knobs() {
     k.build_wgs_ext = env_u64("KT_BUILD_WGS_EXT", 16);
     k.dense = env_u64("KT_BULK_DENSE", 1);
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
-    k.max_b2 = env_u64("KT_BULK_MAX_B2", 11);  // tests: a smaller level 2, so that small shards need the pre-split pass
+    // hash bits level 2 takes: 10 - what part2_swwc_kernel's one line per fine bucket fits into the LDS (the sort-buffer
+    // kernels take 11); shards that need more get the pre-split pass.  (tests: smaller, so that small shards need it too)
+    k.max_b2 = env_u64("KT_BULK_MAX_B2", 10);
     if (k.max_b2 < 1 || k.max_b2 > 11) k.max_b2 = 11;
     k.ext_ovf_blocks = env_u64("KT_EXT_OVF_BLOCKS", 0);  // tests: n + 1 = blocks of scratch behind the export target
     return k;
@@ -2316,7 +2318,10 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     const uint32_t nd = p.d_hi - p.d_lo;
     // one level-2 launch: `pp` says which hash bits it sorts by and how many buckets it reads, `src` where from
     auto run_part2 = [&](const Plan &pp, const P2In &src, K *out, uint64_t *fs, uint64_t *fe) -> int {
-        if (pp.cap2 && src.srcs && j.kn.p2_swwc && SwwcShared<K>::bytes(pp.B2) <= 160 * 1024) {
+        // (one line per fine bucket wants about a line's worth of keys per bucket and chunk: with few, large fine buckets -
+        // the pre-split's 2^bx-way pass - a chunk would be hundreds of generations, and its runs are long anyway: that
+        // pass keeps the sort buffer)
+        if (pp.cap2 && src.srcs && j.kn.p2_swwc && pp.B2 >= 512 && SwwcShared<K>::bytes(pp.B2) <= 160 * 1024) {
             // fixed fine regions, whole lines only (part2_swwc_kernel); then the general kernel over the buckets that did not
             // fit their regions (none, normally)
             const size_t lds = SwwcShared<K>::bytes(pp.B2);
@@ -2564,7 +2569,9 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     // addressed by log2(N) more bits than a table of the same size on one GPU, and level 1 - run by the senders - spends
     // its bits on the whole table: what level 2 cannot take is resolved by a pre-split of every bucket (a third trip of the
     // keys through HBM, a 2^bx-way split with long runs).
-    p.bx = p.b2 > (uint32_t)kn.max_b2 ? p.b2 - (uint32_t)kn.max_b2 : 0;
+    // (a table of its own has no pre-split: its level 2 takes up to 11 bits, with the sort-buffer kernel for the 11th)
+    const uint32_t lim2 = sharded ? (uint32_t)kn.max_b2 : 11u;
+    p.bx = p.b2 > lim2 ? p.b2 - lim2 : 0;
     if (p.bx && (!sharded || p.bx > 6)) return KT_OK;
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
