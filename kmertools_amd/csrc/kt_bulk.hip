@@ -335,6 +335,13 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
         ktseg::stage_segment(a, seg_lo + g, sm, t);
         return Walk{ktseg::Window(sm, t, a.k), 0u};
     }
+    // open() with the unit's bytes requested ahead (scatter1w: while the previous unit is still being written out)
+    using Pre = ktseg::SegPrefetch;
+    __device__ Pre prefetch(uint64_t g, uint32_t t) const { return ktseg::prefetch_segment(a, seg_lo + g, t); }
+    __device__ Walk open_pre(uint64_t g, SegShared &sm, uint32_t t, const Pre &pf) const {
+        ktseg::stage_prefetched(a, seg_lo + g, sm, t, pf);
+        return Walk{ktseg::Window(sm, t, a.k), 0u};
+    }
     template <int N, class KR>  // KR = uint32_t when k <= 16: half the registers
     __device__ void take(Walk &wk, uint32_t, KR (&keys)[N], uint32_t &ok) const {
         ok = 0;
@@ -383,6 +390,9 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
         uint32_t at;
     };
     __device__ Walk open(uint64_t g, SegShared &, uint32_t) const { return Walk{g * ktseg::SEG, count(), 0u}; }
+    struct Pre {};
+    __device__ Pre prefetch(uint64_t, uint32_t) const { return Pre{}; }
+    __device__ Walk open_pre(uint64_t g, SegShared &sm, uint32_t t, const Pre &) const { return open(g, sm, t); }
     template <int N, class KR>
     __device__ void take(Walk &wk, uint32_t t, KR (&out)[N], uint32_t &ok) const {
         ok = 0;
@@ -722,9 +732,18 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
     if (tid == 0) sm.ovf = 0;
     const uint64_t n_units = src.n_units();
     bool stop = false;
-    for (uint64_t g0 = (uint64_t)blockIdx.x * WIDE_GROUPS; g0 < n_units && !stop; g0 += (uint64_t)gridDim.x * WIDE_GROUPS) {
+    // the next unit's bytes are asked for while the current one's last round is copied out (round 4: the two dependent
+    // global reads of a unit's staging were waited for with nothing else to do - a fifth of the kernel)
+    const uint64_t stride = (uint64_t)gridDim.x * WIDE_GROUPS;
+    auto unit_of = [&](uint64_t g0) { return g0 + grp < n_units ? g0 + grp : n_units - 1; };
+    typename Source::Pre pre{};
+    {
+        const uint64_t gfirst = (uint64_t)blockIdx.x * WIDE_GROUPS;
+        if (gfirst < n_units) pre = src.prefetch(unit_of(gfirst), t);
+    }
+    for (uint64_t g0 = (uint64_t)blockIdx.x * WIDE_GROUPS; g0 < n_units && !stop; g0 += stride) {
         const bool valid = g0 + grp < n_units;  // (a group past the end walks the last unit and keeps nothing)
-        auto wk = src.open(valid ? g0 + grp : n_units - 1, sm.seg[grp], t);
+        auto wk = src.open_pre(unit_of(g0), sm.seg[grp], t, pre);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {  // (no early exit in here: the loop must stay unrolled)
             K keys[PER];
@@ -781,6 +800,7 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
             }
             ktd::lds_barrier();
             stop = sm.ovf != 0;  // the same for every thread
+            if (q == NQ - 1 && g0 + stride < n_units) pre = src.prefetch(unit_of(g0 + stride), t);  // (the keys are placed: their registers are free)
             if (!stop) {
                 for (uint32_t i = tid; i < nk; i += WIDE_T) {
                     const K key = sm.sorted[i];
@@ -1824,7 +1844,10 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 // where this wave's run starts (the same for all its lanes), and whether the run is one plain stretch of
                 // the caller's arrays - nearly always: then the copy is the ordinary one, from a wave-uniform base; a run
                 // that straddles two blocks or reaches the scratch takes the entry-by-entry path
-                const uint64_t at0 = ktd::uniform64(pre < l1 ? b1 + pre : b2 + (pre - l1));
+                uint64_t at0 = ktd::uniform64(pre < l1 ? b1 + pre : b2 + (pre - l1));
+#if KT_ABLATION
+                if (p.dbg & 0x40u) at0 &= ~31ull;  // (timing only: every wave's run starts on a line - overlapping its neighbour's)
+#endif
                 const uint32_t skew = (uint32_t)at0 & 31u;
                 const bool plain = (pre >= l1 || pre + wc <= l1) && at0 + wc <= xo.max;
                 if (plain) {
