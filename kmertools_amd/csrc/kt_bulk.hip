@@ -2188,7 +2188,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2203,6 +2203,7 @@ static BulkKnobs read_knobs() {
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
     k.p2_grid = env_u64("KT_P2_GRID", 0);  // workgroups of the level-2 launch (0: one per bucket)
+    k.b1 = env_u64("KT_BULK_B1", 0);
     k.p2_swwc = env_u64("KT_P2_SWWC", 1);  // level 2 with one line per fine bucket in LDS, whole lines written (0: sort buffer)
     k.p2_fast = env_u64("KT_P2_FAST", 1);  // 0: the general level-2 kernel also for fixed fine regions (A/B, tests)
     k.build_wgs = env_u64("KT_BUILD_WGS", 64);
@@ -2586,6 +2587,11 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
     if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
+    // level 2's write-combining kernel wants a fan-out of 512 or 1024 (one line per fine bucket; below that the sort-buffer
+    // kernel runs): tables of 2^16 .. 2^17 ranges give level 2 nine bits instead of eight (ctr k=15, 2^17 ranges: level 1 with
+    // 256 instead of 512 buckets 23.7 -> 23.3 ms, level 2 14.4 -> 13.8 ms)
+    if (fb >= 16 && fb - p.b1 < 9) p.b1 = fb - 9;
+    if (kn.b1 && kn.b1 <= 10 && kn.b1 < fb && fb - kn.b1 <= 11) p.b1 = (uint32_t)kn.b1;  // (KT_BULK_B1: the split between the levels, experiments)
     if (ctr->n_owners > 1) p.b1 = ctr->owner_bits;  // a shard: the level-1 buckets are what the GPUs own (kt_shard.hip)
     p.b2 = fb - p.b1;
     // a pass resolves at most 10 (level 1) / 11 (level 2) hash bits.  The shards of a table spread over N GPUs are
