@@ -1327,10 +1327,20 @@ struct SwwcShared {
         flags = fc + 2 * B2;
     }
 };
-constexpr int SWWC_T = 512;
+// threads of a workgroup: 512 x 32 keys with 64-bit keys (at 1024 x 16 the kernel ran 10.0 against 10.7 ms - with 64-80
+// bytes of scratch, which this kernel must not have: see csrc/Makefile), 1024 x 16 with 32-bit keys (no scratch; ctr k=15:
+// 13.9 -> 11.7 ms)
+#ifndef KT_SWWC_T64
+#define KT_SWWC_T64 512
+#endif
+#ifndef KT_SWWC_T32
+#define KT_SWWC_T32 1024
+#endif
+template <class K>
+constexpr int swwc_t() { return sizeof(K) == 8 ? KT_SWWC_T64 : KT_SWWC_T32; }
 
 template <class K>
-__global__ __launch_bounds__(SWWC_T, 2) void part2_swwc_kernel(P2In in, Plan p, K *__restrict__ keys2,
+__global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() == 1024 ? 4 : 2)) void part2_swwc_kernel(P2In in, Plan p, K *__restrict__ keys2,
                                                               uint64_t *__restrict__ fstart, uint64_t *__restrict__ fend,
                                                               uint32_t *__restrict__ fail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1339,7 +1349,7 @@ __global__ __launch_bounds__(SWWC_T, 2) void part2_swwc_kernel(P2In in, Plan p, 
 #ifndef KT_SWWC_PER32
 #define KT_SWWC_PER32 32  // keys of a thread per chunk with 32-bit keys: 16 K keys = half a line per fine bucket and chunk.  (48:
 #endif                    // 16.2 against 14.2 ms at k=15; 64 - a whole line per chunk, like the 64-bit keys - does not fit 256 registers)
-    constexpr int P2T = SWWC_T, PER = sizeof(K) == 8 ? 32 : KT_SWWC_PER32;
+    constexpr int P2T = swwc_t<K>(), PER = (sizeof(K) == 8 ? 32 : KT_SWWC_PER32) * 512 / P2T;
     constexpr uint32_t CH = (uint32_t)P2T * PER;       // 16384 (32768) keys per chunk, held in registers
     constexpr uint32_t LK = 128 / sizeof(K), LSH = sizeof(K) == 8 ? 4 : 5;  // keys per line
     constexpr uint32_t GL = 8;                          // lanes that write one line (16 bytes each)
@@ -2355,7 +2365,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(swwc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             uint32_t grid = pp.d_hi - pp.d_lo;
             if (j.kn.p2_grid && grid > j.kn.p2_grid) grid = (uint32_t)j.kn.p2_grid;
-            hipLaunchKernelGGL(swwc, dim3(grid), dim3(SWWC_T), lds, ctx->stream, src, pp, out, fs, fe, fail);
+            hipLaunchKernelGGL(swwc, dim3(grid), dim3(swwc_t<K>()), lds, ctx->stream, src, pp, out, fs, fe, fail);
             KT_HIP(hipGetLastError());
             const bool bigr = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 && Part2Shared<K, true>::bytes(pp.B2) <= 160 * 1024;
             auto redo_launch = [&](auto big) -> int {
