@@ -3,7 +3,7 @@
 # --kernel-trace --stats, its JSON line, and FETCH_SIZE / WRITE_SIZE of the oligo kernel from separate --pmc passes
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/prof_r3_headline; rm -rf $out; mkdir -p $out
+out=gpurun_out/prof_r4_headline; rm -rf $out; mkdir -p $out
 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats -d $out -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu > $out/bench_under_trace.json 2> $out/kt.err
 {

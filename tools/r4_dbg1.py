@@ -1,4 +1,5 @@
-"""bisect: which level-1 / level-2 combination miscounts (genome-sampled reads, as test_ctr_k31_large_checksums)"""
+"""bisect: which level-2 kernel miscounts (genome-sampled reads, as test_ctr_k31_large_checksums; how the missing s_nop
+behind the 16-byte inline-assembly stores and the spill of an in-flight register were found)"""
 import os, sys, pathlib, subprocess
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
@@ -17,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     ctr.export(keys, counts, d)
     print("n", n, "slots", sys.argv[4], "distinct", d, "sum", int(counts.to(torch.int64).sum()), "want", n * (L - k + 1), flush=True)
     os._exit(0)
-for env in ({"KT_S1_COMB": "0"}, {"KT_S1_COMB": "1", "KT_P2_SWWC": "0"}, {"KT_S1_COMB": "1"}):
+for env in ({"KT_P2_SWWC": "0", "KT_P2_FAST": "0"}, {"KT_P2_SWWC": "0"}, {}):
     for n, G, slots in ((500000, 1000000, 1 << 27), (100000, 1000000, 1 << 25), (20000, 200000, 1 << 23), (500000, 1 << 30, 1 << 27)):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, __file__, "child", str(n), str(G), str(slots)], env=e, capture_output=True, text=True)
