@@ -239,20 +239,40 @@ __device__ __forceinline__ void buf_store_async(K v, kt_i32x4 rs, uint32_t off) 
 }
 template <int N, class K, int PER>
 __device__ __forceinline__ void buf_wait(K (&v)[PER]) {
-    static_assert(PER == 16 || PER == 32 || PER == 48 || PER == 64, "sixteen registers per asm statement");
-    asm volatile("s_waitcnt vmcnt(%16)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+    static_assert(PER % 8 == 0, "eight registers per asm statement");
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
                  : "n"(N));
-    if constexpr (PER >= 32)  // (volatile asm statements keep their order: these sixteen are behind the wait as well)
-        asm volatile("" : "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]),
-                          "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]), "+v"(v[28]), "+v"(v[29]), "+v"(v[30]), "+v"(v[31]));
-    if constexpr (PER >= 48)
-        asm volatile("" : "+v"(v[32]), "+v"(v[33]), "+v"(v[34]), "+v"(v[35]), "+v"(v[36]), "+v"(v[37]), "+v"(v[38]), "+v"(v[39]),
-                          "+v"(v[40]), "+v"(v[41]), "+v"(v[42]), "+v"(v[43]), "+v"(v[44]), "+v"(v[45]), "+v"(v[46]), "+v"(v[47]));
-    if constexpr (PER == 64)
-        asm volatile("" : "+v"(v[48]), "+v"(v[49]), "+v"(v[50]), "+v"(v[51]), "+v"(v[52]), "+v"(v[53]), "+v"(v[54]), "+v"(v[55]),
-                          "+v"(v[56]), "+v"(v[57]), "+v"(v[58]), "+v"(v[59]), "+v"(v[60]), "+v"(v[61]), "+v"(v[62]), "+v"(v[63]));
+#pragma unroll
+    for (int u = 8; u < PER; u += 8)  // (volatile asm statements keep their order: these are behind the wait as well)
+        asm volatile("" : "+v"(v[u]), "+v"(v[u + 1]), "+v"(v[u + 2]), "+v"(v[u + 3]), "+v"(v[u + 4]), "+v"(v[u + 5]), "+v"(v[u + 6]),
+                          "+v"(v[u + 7]));
+}
+
+// the same wait for loads that went into a second set of registers: dst = src behind s_waitcnt vmcnt(N), the copy made
+// inside the statement.  src is an input only: with the in-place form above on a second array the register allocator
+// was free to tie the statement to dst's registers and copy src -> dst IN FRONT of the wait - registers whose loads had
+// not landed (seen with 8 keys per thread: a few hundred wrong keys per run).  tools/check_inflight.py reads the
+// kernel's assembly at build time: no instruction outside these statements may name a register between the asm load
+// that targets it and the asm wait behind it.
+template <int N, class K, int PER>
+__device__ __forceinline__ void buf_take(K (&dst)[PER], K (&src)[PER]) {
+    static_assert(PER % 8 == 0, "eight registers per asm statement");
+#define KT_TAKE8(PRE, MOV, u)                                                                                              \
+    asm volatile(PRE MOV " %0, %8\n\t" MOV " %1, %9\n\t" MOV " %2, %10\n\t" MOV " %3, %11\n\t" MOV " %4, %12\n\t" MOV             \
+                 " %5, %13\n\t" MOV " %6, %14\n\t" MOV " %7, %15"                                                          \
+                 : "=&v"(dst[u]), "=&v"(dst[u + 1]), "=&v"(dst[u + 2]), "=&v"(dst[u + 3]), "=&v"(dst[u + 4]),               \
+                   "=&v"(dst[u + 5]), "=&v"(dst[u + 6]), "=&v"(dst[u + 7])                                                 \
+                 : "v"(src[u]), "v"(src[u + 1]), "v"(src[u + 2]), "v"(src[u + 3]), "v"(src[u + 4]), "v"(src[u + 5]),         \
+                   "v"(src[u + 6]), "v"(src[u + 7]), "n"(N))
+    if constexpr (sizeof(K) == 8) KT_TAKE8("s_waitcnt vmcnt(%16)\n\t", "v_mov_b64", 0);
+    else KT_TAKE8("s_waitcnt vmcnt(%16)\n\t", "v_mov_b32", 0);
+#pragma unroll
+    for (int u = 8; u < PER; u += 8) {  // (volatile asm statements keep their order: these are behind the wait as well)
+        if constexpr (sizeof(K) == 8) KT_TAKE8("", "v_mov_b64", u);
+        else KT_TAKE8("", "v_mov_b32", u);
+    }
+#undef KT_TAKE8
 }
 
 // inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS round trips): row_shr 1 / 2 / 4 / 8 inside the
@@ -1118,7 +1138,6 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
     constexpr int PER = chunk2<K, BIG>() / P2T;
     constexpr uint32_t CH = chunk2<K, BIG>();
     constexpr bool RKD = p2_sdig<K, BIG>();  // the digit is kept beside the rank (32-bit keys: it would cost a second hash)
-    static_assert(PER % 16 == 0, "buf_wait takes sixteen registers per statement");
     const uint32_t tid = threadIdx.x;
     const uint32_t nd = p.d_hi - p.d_lo;
     const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 64 - p.b1 - p.b2;
@@ -1327,11 +1346,11 @@ struct SwwcShared {
         flags = fc + 2 * B2;
     }
 };
-// threads of a workgroup: 512 x 32 keys with 64-bit keys (at 1024 x 16 the kernel ran 10.0 against 10.7 ms - with 64-80
-// bytes of scratch, which this kernel must not have: see csrc/Makefile), 1024 x 16 with 32-bit keys (no scratch; ctr k=15:
-// 13.9 -> 11.7 ms)
+// threads of a workgroup and keys of a thread per chunk: 1024 x 8 with 64-bit keys (half a line per fine bucket and
+// chunk; 512 x 32: 10.6 ms, 768 x 16: 10.0 ms, 1024 x 8: 9.5 ms at ctr k=31 - 1024 x 16 does not fit the 128 registers
+// of a 16-wave workgroup), 1024 x 16 with 32-bit keys (ctr k=15: 512 x 32 13.9 ms, 1024 x 16 11.7 ms)
 #ifndef KT_SWWC_T64
-#define KT_SWWC_T64 512
+#define KT_SWWC_T64 1024
 #endif
 #ifndef KT_SWWC_T32
 #define KT_SWWC_T32 1024
@@ -1340,7 +1359,7 @@ template <class K>
 constexpr int swwc_t() { return sizeof(K) == 8 ? KT_SWWC_T64 : KT_SWWC_T32; }
 
 template <class K>
-__global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() == 1024 ? 4 : 2)) void part2_swwc_kernel(P2In in, Plan p, K *__restrict__ keys2,
+__global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc_kernel(P2In in, Plan p, K *__restrict__ keys2,
                                                               uint64_t *__restrict__ fstart, uint64_t *__restrict__ fend,
                                                               uint32_t *__restrict__ fail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1349,7 +1368,10 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() == 1024 ? 4 : 2)) void 
 #ifndef KT_SWWC_PER32
 #define KT_SWWC_PER32 32  // keys of a thread per chunk with 32-bit keys: 16 K keys = half a line per fine bucket and chunk.  (48:
 #endif                    // 16.2 against 14.2 ms at k=15; 64 - a whole line per chunk, like the 64-bit keys - does not fit 256 registers)
-    constexpr int P2T = swwc_t<K>(), PER = (sizeof(K) == 8 ? 32 : KT_SWWC_PER32) * 512 / P2T;
+#ifndef KT_SWWC_PER64
+#define KT_SWWC_PER64 8
+#endif
+    constexpr int P2T = swwc_t<K>(), PER = sizeof(K) == 8 ? KT_SWWC_PER64 : KT_SWWC_PER32 * 512 / P2T;
     constexpr uint32_t CH = (uint32_t)P2T * PER;       // 16384 (32768) keys per chunk, held in registers
     constexpr uint32_t LK = 128 / sizeof(K), LSH = sizeof(K) == 8 ? 4 : 5;  // keys per line
     constexpr uint32_t GL = 8;                          // lanes that write one line (16 bytes each)
@@ -1453,8 +1475,8 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() == 1024 ? 4 : 2)) void 
 #pragma unroll
                 for (int u = 0; u < PER; u += 8) buf_load8_async<K, P2T * (int)sizeof(K)>(&dst[u], rs, voff);
             };
-            load_chunk(0, kcur);
-            buf_wait<0>(kcur);
+            load_chunk(0, knext);
+            buf_take<0>(kcur, knext);
             for (uint64_t c0 = 0; c0 < n; c0 += CH) {
                 uint32_t tl = tid;  // (opaque per chunk: nothing derived from the thread index is carried across the loop)
                 asm volatile("" : "+v"(tl));
@@ -1507,14 +1529,12 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() == 1024 ? 4 : 2)) void 
                 if (more) {
                     // the next chunk's keys are in (they were requested before the count); the line stores issued since - a
                     // fixed number per generation - stay in flight
-                    constexpr int SPG = 1024 / (P2T / GL);  // stores per generation at B2 = 1024
+                    constexpr int SPG = (1024 + P2T / GL - 1) / (P2T / GL);  // stores per generation at B2 = 1024
                     const uint32_t issued = gens * ((B2 + P2T / GL - 1) / (P2T / GL));
-                    if (issued == SPG) buf_wait<SPG>(knext);
-                    else if (issued == 2 * SPG) buf_wait<2 * SPG>(knext);
-                    else if (issued == 3 * SPG) buf_wait<3 * SPG>(knext);
-                    else buf_wait<0>(knext);
-#pragma unroll
-                    for (int u = 0; u < PER; u++) kcur[u] = knext[u];
+                    if (issued == SPG) buf_take<SPG>(kcur, knext);
+                    else if (issued == 2 * SPG) buf_take<2 * SPG>(kcur, knext);
+                    else if (issued == 3 * SPG) buf_take<3 * SPG>(kcur, knext);
+                    else buf_take<0>(kcur, knext);
                 }
             }
             seen += n;

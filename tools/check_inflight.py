@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Build-time check of the kernels that issue loads from inline assembly (kt_bulk.hip: buf_load8_async / buf_wait /
+buf_take): between an asm load into a register and the asm s_waitcnt behind it, no instruction of the compiler's
+own may name that register - a copy or a spill made there would move a value that has not arrived.
+
+usage: check_inflight.py <device assembly .s> <kernel name regex>
+
+The walk is in layout order, which is the order of execution for these loops (the load block lies in front of the
+wait block in the chunk loop's body; code the compiler placed out of line is not followed).  Exit status 1 and a
+listing when something is found."""
+import re
+import sys
+
+
+def regs_of(text):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(x) for x in re.findall(r"\bv(\d+)\b", text))
+    return out
+
+
+def check(path, pattern):
+    bad = []
+    fn = None
+    in_asm = False
+    inflight = set()
+    pending_clear = False
+    n_loads = n_waits = 0
+    for ln, line in enumerate(open(path), 1):
+        s = line.strip()
+        m = re.match(r"^(\S+):\s*(;.*)?$", line)
+        if m and not m.group(1).startswith(".L"):
+            fn = m.group(1) if re.search(pattern, m.group(1)) else None
+            inflight.clear()
+            in_asm = False
+            continue
+        if fn is None:
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            if pending_clear:
+                inflight.clear()
+                pending_clear = False
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        code = s.split(";")[0]
+        if in_asm:
+            m = re.match(r"buffer_load_dword(x\d)?\s+(v\[\d+:\d+\]|v\d+)\s*,", code)
+            if m:
+                inflight |= regs_of(m.group(2))
+                n_loads += 1
+            elif re.match(r"s_waitcnt\s+vmcnt", code):
+                pending_clear = True
+                n_waits += 1
+            continue
+        if re.match(r"s_waitcnt\s+vmcnt\(0\)", code):  # (one of the compiler's own: everything has landed)
+            inflight.clear()
+            continue
+        hit = regs_of(code) & inflight
+        if hit:
+            bad.append((fn, ln, code.strip(), sorted(hit)))
+    return bad, n_loads, n_waits
+
+
+if __name__ == "__main__":
+    bad, n_loads, n_waits = check(sys.argv[1], sys.argv[2])
+    if n_loads == 0 or n_waits == 0:
+        print("check_inflight: no asm loads / waits found in kernels matching %r - the check is not looking at anything" % sys.argv[2])
+        sys.exit(1)
+    for fn, ln, code, hit in bad:
+        print("register in flight touched: %s line %d: %s   (v%s)" % (fn, ln, code, ", v".join(map(str, hit))))
+    if bad:
+        sys.exit(1)
+    print("check_inflight: %d asm loads, %d asm waits, no in-flight register touched" % (n_loads, n_waits))
