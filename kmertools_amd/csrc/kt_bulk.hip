@@ -1592,6 +1592,12 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
 static_assert(LOG2_S == kttab::LOG2_RANGE, "a fine bucket is a range of the table");
 
 constexpr int BUILD_T = KT_BUILD_T;
+#if KT_ABLATION
+__device__ unsigned long long kt_dbg_phase[16];  // (timing builds: cycles of workgroup thread 0 per phase of build_kernel)
+#define KT_PH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phs[i] += (uint32_t)(t_ - tph); tph = t_; } while (0)
+#else
+#define KT_PH(i) do { } while (0)
+#endif
 
 template <class K>
 struct lds_word;
@@ -1729,6 +1735,10 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
         hi = fend[blockIdx.x];
         load_head(lo, hi, head);
     }
+#if KT_ABLATION
+    unsigned long long tph = __builtin_readcyclecounter();
+    uint32_t phs[8] = {};
+#endif
     for (uint64_t fb = blockIdx.x; fb < n_fine;) {
         const uint64_t nfb = fb + gridDim.x;
         uint64_t nlo = 0, nhi = 0;
@@ -1758,61 +1768,96 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 scounts[i] = 0;
             }
         }
+        KT_PH(0);
         ktd::lds_barrier();
+        KT_PH(1);
         {
             // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
             // trip (the CAS itself reports what the slot holds), and a lane that has placed its key moves on to its
-            // next one at once; four keys are kept prefetched so the loads are never waited for.  ("For each key:
-            // probe until placed" makes the wave wait for its longest probe chain on every key.)
-            uint64_t idx = lo + tid + 4ull * BUILD_T;
-            auto fetch = [&]() {
-                const K k = idx < hi ? keys2[idx] : EMPTY;
-                idx += BUILD_T;
-                return k;
-            };
-            K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
-#if KT_ABLATION
-            if (p.dbg & 1u) cur = EMPTY;
-#endif
+            // next one at once.  ("For each key: probe until placed" makes the wave wait for its longest probe chain on
+            // every key.)  The keys come in BATCHES of four per lane, loaded together: a range of hashed distinct keys is
+            // one batch (~2900 keys for 1024 lanes) and its keys are the ones requested a range ahead; a longer range (a
+            // repeat of the genome, a skewed batch) takes further batches, each requested before the one in front of it
+            // is inserted.  (Round 3's loop refilled a four-deep queue one key at a time: a compare, a branch, an
+            // address and - because the load sat in the loop - a wait for ALL the workgroup's stores in flight on every
+            // key placed, for a refill that hashed keys never need.)
             // A dense build's image is scratch - only the packed entries leave the kernel - so it need not be the
             // table's probing layout: its collisions step by a key-dependent prime (coprime to every range size 1024 * m8)
             // instead of 1.  The insert phase ends when the slowest of the 1024 lanes has placed its keys, i.e. after the
             // LONGEST probe chain of the range, and linear probing's clusters make that chain ~3x longer at 0.47 load.
-            auto stride = [&](K stored) -> uint32_t {
-                // (64-bit keys only: the 32-bit keys of k <= 16 hash nearly collision-free - ctr k=15's build measured 11.5 ms
-                // with linear probing and 11.8 with the strides, where k=31's went from 19.2 to 16.9 ms)
-                if (!KT_BUILD_DHASH || !DENSE || sizeof(K) < 8) return 1u;
-                const uint32_t j = (uint32_t)(hash_of_stored<K>(stored) >> (shift >= 3 ? shift - 3 : 0)) & 7u;
-                return 11u + 2u * ((0xDA964310u >> (4u * j)) & 15u);   // 11 13 17 19 23 29 31 37
+            // (64-bit keys only: the 32-bit keys of k <= 16 hash nearly collision-free - ctr k=15's build measured 11.5 ms
+            // with linear probing and 11.8 with the strides, where k=31's went from 19.2 to 16.9 ms)
+            constexpr bool STRIDES = KT_BUILD_DHASH && DENSE && sizeof(K) == 8;
+            // the hash bits the insert looks at, in one 32-bit word: bits 3.. = position among the range's S homes, bits
+            // 0..2 = which stride (one v_alignbit; the 64-bit shifts are not full-rate instructions)
+            const uint32_t sh3 = shift - 3;  // (the bulk path takes tables of 2^15 .. 2^34 hash positions: shift is 30 .. 49)
+            auto hword = [&](K stored) -> uint32_t {
+                const uint64_t h = hash_of_stored<K>(stored);
+                const uint32_t hi32 = (uint32_t)(h >> 32), lo32 = (uint32_t)h;
+                return sh3 >= 32 ? hi32 >> (sh3 - 32) : __builtin_amdgcn_alignbit(hi32, lo32, sh3);
             };
-            uint32_t s = home(cur), step = stride(cur), probes = 0;
-            while (cur != EMPTY) {
-                const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
-                bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
-                if (!done && v == cur) {
-                    atomicAdd(&scounts[s], 1u);
-                    done = true;
-                }
-                if (!done) {
-                    s += step;                     // round the range (step 1: kttab::Probe)
-                    if (s >= RS) s -= RS;
-                    if (++probes >= RS) {          // the range is full: the table is too small
-                        spill(from_stored<K>(cur), 1u);
+            auto home_w = [&](uint32_t w) -> uint32_t { return __umul24((w >> 3) & (S - 1), p.m8) >> 3; };
+            auto stride_w = [&](uint32_t w) -> uint32_t {
+                if (!STRIDES) return 1u;
+                // 11 13 17 19 23 29 31 37, picked by the word's low three bits: one byte permute of the table
+                return __builtin_amdgcn_perm(0x251f1d17u, 0x13110d0bu, (w & 7u) | 0x0c0c0c00u);
+            };
+            // CHECK: a walk that has come round the whole range reports it as full.  A fresh range that receives no more keys
+            // than it has slots cannot fill up, and its loop goes without the walk's counter - two vector and five scalar
+            // instructions of a trip that issues ~45, in a loop bound by instruction issue (eight waves per SIMD going
+            // round it: 17.2 against 19.2 ms for the kernel).
+            auto insert_batch = [&](auto chk) {
+                constexpr bool CHECK = decltype(chk)::value;
+                K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
+#if KT_ABLATION
+                if (p.dbg & 1u) cur = EMPTY;
+#endif
+                uint32_t w = hword(cur);
+                uint32_t s = home_w(w), step = stride_w(w), probes = 0;
+                while (cur != EMPTY) {
+                    const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
+                    bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
+                    if (!done && v == cur) {
+                        atomicAdd(&scounts[s], 1u);
                         done = true;
                     }
+                    if (!done) {
+                        s += step;                     // round the range (step 1: kttab::Probe)
+                        if (s >= RS) s -= RS;
+                        if (CHECK && ++probes >= RS) {  // the range is full: the table is too small
+                            spill(from_stored<K>(cur), 1u);
+                            done = true;
+                        }
+                    }
+                    if (done) {
+                        cur = q0;
+                        q0 = q1;
+                        q1 = q2;
+                        q2 = EMPTY;
+                        w = hword(cur);
+                        s = home_w(w);
+                        step = stride_w(w);
+                        if (CHECK) probes = 0;
+                    }
                 }
-                if (done) {
-                    cur = q0;
-                    q0 = q1;
-                    q1 = q2;
-                    q2 = fetch();
-                    s = home(cur);
-                    step = stride(cur);
-                    probes = 0;
-                }
+            };
+            const bool roomy = !MERGE && hi - lo <= RS;  // (workgroup uniform)
+            uint64_t bbase = lo;
+            for (;;) {
+                const bool more = bbase + 4ull * BUILD_T < hi;  // (workgroup uniform; false for hashed distinct keys)
+                K nxt[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
+                if (more) load_head(bbase + 4ull * BUILD_T, hi, nxt);
+                if (roomy) insert_batch(std::false_type{});
+                else insert_batch(std::true_type{});
+                if (!more) break;
+                bbase += 4ull * BUILD_T;
+#pragma unroll
+                for (int u = 0; u < 4; u++) head[u] = nxt[u];
             }
         }
+        KT_PH(2);
         ktd::lds_barrier();
+        KT_PH(3);
         load_head(nlo, nhi, head);  // the next range's first keys travel while this range is written out
         uint4 *dst = reinterpret_cast<uint4 *>(slots + fb * RS);
         if (DENSE) {
@@ -1837,7 +1882,9 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 wc += (uint32_t)__popcll(bal);
             }
             if (lane == 0) runs[wave] = wc;
+            KT_PH(4);
             ktd::lds_barrier();
+            KT_PH(5);
             // where this wave's run goes = the runs before it: an inclusive scan of the sixteen counts in lanes 0..15
             // (row_shr inside one DPP row)
             static_assert(NW == 16, "the wave counts are scanned inside one DPP row");
@@ -1884,6 +1931,9 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                     uint64_t *const dk = xo.keys + at0;
                     uint32_t *const dc = xo.counts + at0;
                     for (uint32_t j = lane; j < wc + skew; j += 64) {
+#if KT_ABLATION
+                        if ((p.dbg & 2u) && skeys[0] != (K)0x1234567u) continue;  // (timing only: the build without its stores)
+#endif
                         if (j >= skew) {
                             const uint32_t src = wave * share + (j - skew);
                             __builtin_nontemporal_store(from_stored<K>(skeys[src]), dk + (j - skew));
@@ -1933,11 +1983,17 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
 #endif
             }
         }
+        KT_PH(6);
         ktd::lds_barrier();
+        KT_PH(7);
         fb = nfb;
         lo = nlo;
         hi = nhi;
     }
+#if KT_ABLATION
+    if (tid == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&kt_dbg_phase[i], (unsigned long long)phs[i]);
+#endif
     if (EXT && tid == 0 && xend) {  // the last block is partly filled; the extent of the output is the furthest block's end
         if (xend / XBLK - 1 < xo.max_blocks) xo.fill[xend / XBLK - 1] = XBLK - (uint32_t)(xend - xpos);
         atomicMax(reinterpret_cast<unsigned long long *>(xo.extent), (unsigned long long)xend);
@@ -2945,3 +3001,12 @@ int kt_table_dense_export(kt_ctr *ctr, uint64_t *d_keys, uint32_t *d_counts, uin
     KT_HIP(hipStreamSynchronize(ctx->stream));
     return KT_OK;
 }
+
+#if KT_ABLATION
+extern "C" int kt_dbg_phases(unsigned long long *out) {  // (timing builds) reads and zeroes the phase counters
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(kt_dbg_phase), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(kt_dbg_phase), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -39,4 +39,14 @@ for i in range(a.steps + 1):
         d = -1
     torch.cuda.synchronize()
     ms.append((time.perf_counter() - t0) * 1e3)
+try:  # a timing build (KT_ABLATION): cycles of thread 0 per phase of build_kernel, summed over workgroups and steps
+    import ctypes
+    from kmertools_amd import _lib
+    f = _lib.lib().kt_dbg_phases
+    buf = (ctypes.c_ulonglong * 16)()
+    if f(buf) == 0 and sum(buf):
+        tot = float(sum(buf))
+        print("build phases (share of thread 0's cycles): " + " ".join("%d:%.1f%%" % (i, 100 * buf[i] / tot) for i in range(8)))
+except AttributeError:
+    pass
 print("k=%d reads=%d distinct=%d ms/step %s" % (a.k, n, d, " ".join("%.2f" % x for x in ms[1:])))
