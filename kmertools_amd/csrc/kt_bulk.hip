@@ -1694,10 +1694,8 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint64_t n_fine = (uint64_t)(p.d_hi - p.d_lo) * p.B2;  // the ranges this table holds
     const uint32_t shift = 64 - p.n;
-    // (the image in LDS holds keys in their stored form, like the key arrays: to_stored / from_stored)
-    auto home = [&](K stored) {  // home position inside the range (kttab::probe_of)
-        return __umul24((uint32_t)(hash_of_stored<K>(stored) >> shift) & (S - 1), p.m8) >> 3;
-    };
+    // (the image in LDS holds keys in their stored form, like the key arrays: to_stored / from_stored; a key's home
+    // position inside the range is kttab::probe_of's: home_w below)
     auto spill = [&](uint64_t key, uint32_t occurrences) {
         if (DENSE) {  // (no image to probe afterwards: a full range is reported at once)
             atomicOr(spill_ovf, 1u);

@@ -43,7 +43,7 @@ struct kt_ctx {
     kt::Scratch s_bases, s_offsets, s_out, s_aux0, s_aux1, s_aux2;
     struct OligoKnobs {  // KT_OLIGO_* launch tunables, read once per context (kt_oligo.hip)
         bool loaded = false, live = false;
-        uint32_t shape = 104, R = 0, oversub = 0, debug = 0;
+        uint32_t shape = 104, R = 0, oversub = 0, debug = 0, pw = 7;
         bool tune = true;
     } oligo_knobs;
     // Workgroups per resident slot of the k = 4 histogram launch, chosen by measurement per OUTPUT ARRAY (kt_oligo.hip,

@@ -550,14 +550,26 @@ __device__ __forceinline__ void consume_tile(const OligoArgs &a, const TileCtx &
 // streams out its rows of the same tile (D), barrier.  Half the LDS of the double-buffered
 // kernel, so twice the resident workgroups; loads for the next tile are issued between the
 // phases so they are in flight while the rows are being stored.
-template <int K, bool CANON, int DT, int NW>
+// PW ("producer wave", the big-row shapes): NW + 1 waves; wave 0 reads the input and never stores, waves 1 .. NW write the
+// rows and - as long as a tile is a single chunk - never load.  Why: a wave's loads and stores complete in issue order
+// on one counter, so a wave that has stored a tile's rows and then needs a loaded value waits for ALL of its stores to
+// land before it may go on - with four waves per CU writing 128 KB per tile, every tile boundary emptied the CU's store
+// queue (comp cgr k=7, 1 M reads: 5.84 ms; 5.24 ms with the chunk loads replaced by constants, for 0.5 % of the bytes).
+// With the roles split the store waves stream from tile to tile behind nothing but the two barriers.  The producer
+// publishes each tile's description (and its read offsets) in LDS a tile ahead; a tile of several chunks (long reads) has
+// the store waves count chunks as well, loaded on the spot.
+#ifndef KT_OLIGO_PW_AHEAD
+#define KT_OLIGO_PW_AHEAD 2
+#endif
+template <int K, bool CANON, int DT, int NW, bool PW = false>
 __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // k <= 5: the canonical-rank LUT (<= 2 KB) lives in LDS; k >= 6 (8 / 32 KB) it is read through
     // L2 instead, because there the LDS is better spent on resident tiles (rows are 8-64 KB)
     constexpr bool LUT_LDS = CANON && K <= 5;
     constexpr uint32_t NLUT = LUT_LDS ? (1u << (2 * K)) : 0u;
-    constexpr uint32_t NT = NW * 64;
+    constexpr uint32_t NWT = PW ? NW + 1 : NW;  // waves of the workgroup
+    constexpr uint32_t NT = NWT * 64;
     constexpr int PF = 2;  // chunk loads kept in flight per wave (R=52 x 150 bp = 8 chunks / 4 waves)
 
     const uint32_t R = a.R, bins = a.bins;
@@ -572,6 +584,8 @@ __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
     double *rcp = reinterpret_cast<double *>(smem + off);
     off += MAX_R * 8;
     uint64_t *roff = reinterpret_cast<uint64_t *>(smem + off);
+    off += (MAX_R + 1) * 8;
+    ProdTile *pub = reinterpret_cast<ProdTile *>(smem + off);  // (PW) the tile the store waves meet next
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -595,6 +609,105 @@ __device__ __forceinline__ void oligo_sb_body(const OligoArgs &a) {
     const uint64_t nt = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     auto tile_of = [&](uint64_t j) { return (uint64_t)blockIdx.x + j * gridDim.x; };
 
+    if constexpr (PW) {
+        constexpr int AH = KT_OLIGO_PW_AHEAD;  // tiles of input in flight ahead of the one being counted (producer wave only)
+        const bool producer = wave == 0;
+        OffRegs o[AH + 1];
+        ProdTile tq[AH];
+        uint4 cq[AH][PF];
+        auto publish = [&]() {  // tq[0] / o[0] = the tile every wave meets behind the next barrier
+            if (lane == 0) *pub = tq[0];
+            if (lane < tq[0].nr) {
+                roff[lane] = o[0].o;
+                roff[lane + 1] = o[0].on;
+            }
+        };
+        if (producer) {
+#pragma unroll
+            for (int i = 0; i <= AH; i++) o[i] = (uint64_t)i < nt ? load_offsets(a, tile_of(i), lane) : OffRegs{0, 0};
+#pragma unroll
+            for (int i = 0; i < AH; i++) {
+#pragma unroll
+                for (int it = 0; it < PF; it++) cq[i][it] = make_uint4(0, 0, 0, 0);
+                if (i == 0 || (uint64_t)i < nt) {
+                    tq[i] = make_tile(a, tile_of(i), o[i], lane, total_bytes);
+#pragma unroll
+                    for (int it = 0; it < PF; it++) {
+                        const uint64_t ci = (uint64_t)NWT * it;
+                        if (ci < tq[i].n_chunks) cq[i][it] = load_chunk(a, tq[i], ci, lane, total_bytes);
+                    }
+                } else {
+                    tq[i] = tq[0];
+                }
+            }
+            publish();
+        }
+        lds_barrier();
+        for (uint64_t j = 0; j < nt; j++) {
+            TileCtx tc;
+            tc.r0 = tile_of(j) * R;
+            tc.nr = (uint32_t)((a.n_reads - tc.r0) < R ? (a.n_reads - tc.r0) : R);
+            tc.off0 = 0;
+            tc.TL = 0;
+            // ---- B: positions.  Chunk ci of the tile belongs to wave ci % NWT: the producer has its chunks in registers;
+            // a store wave has work here only when the tile is longer than one chunk, and loads it on the spot
+            if (!(KT_DBG(a) & 1u)) {
+                if (producer) {
+                    const ProdTile &t_cur = tq[0];
+                    uint32_t it = 0;
+#pragma unroll 1
+                    for (uint64_t ci = 0; ci < t_cur.n_chunks; ci += NWT, it++) {
+                        uint4 d;
+                        if (it < (uint32_t)PF) {
+                            d = cq[0][0];
+#pragma unroll
+                            for (int u = 1; u < PF; u++)
+                                if (it == (uint32_t)u) d = cq[0][u];
+                        } else {
+                            d = load_chunk(a, t_cur, ci, lane, total_bytes);
+                        }
+                        process_chunk<K, CANON>(a, t_cur, ci, d, lane, lut, lutreg, hist, tot, roff);
+                    }
+                } else if ((uint64_t)wave < pub->n_chunks) {
+                    const ProdTile t_cur = *pub;
+#pragma unroll 1
+                    for (uint64_t ci = wave; ci < t_cur.n_chunks; ci += NWT)
+                        process_chunk<K, CANON>(a, t_cur, ci, load_chunk(a, t_cur, ci, lane, total_bytes), lane, lut, lutreg, hist, tot, roff);
+                }
+            }
+            lds_barrier();
+            // ---- D: the store waves write the rows out; the producer moves its queue up, requests tile j + AH and
+            // publishes tile j + 1
+            if (producer) {
+                if (j + 1 < nt) {
+#pragma unroll
+                    for (int i = 0; i + 1 < AH; i++) {
+                        tq[i] = tq[i + 1];
+#pragma unroll
+                        for (int it = 0; it < PF; it++) cq[i][it] = cq[i + 1][it];
+                    }
+#pragma unroll
+                    for (int i = 0; i < AH; i++) o[i] = o[i + 1];
+                    if (j + AH < nt) {
+                        tq[AH - 1] = make_tile(a, tile_of(j + AH), o[AH - 1], lane, total_bytes);
+#pragma unroll
+                        for (int it = 0; it < PF; it++) {
+                            const uint64_t ci = (uint64_t)NWT * it;
+                            if (ci < tq[AH - 1].n_chunks) cq[AH - 1][it] = load_chunk(a, tq[AH - 1], ci, lane, total_bytes);
+                        }
+                    }
+                    if (j + AH + 1 < nt) o[AH] = load_offsets(a, tile_of(j + AH + 1), lane);
+                    publish();
+                }
+            } else {
+                if (!(KT_DBG(a) & 16u)) __builtin_amdgcn_s_setprio(3);
+                consume_tile<DT, NW>(a, tc, wave - 1, lane, hist, tot, dnm, rcp);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            lds_barrier();
+        }
+        return;
+    }
     // How far ahead the input travels.  Small rows (k <= 5): the next tile's chunks are requested while this tile's rows
     // are stored.  Big rows (k >= 6: 4-read tiles of 16 / 32 KB rows, one 600-byte chunk per tile): TWO tiles ahead - a
     // request issued behind a saturated store queue took longer than one tile's store phase whenever the reads did not
@@ -696,7 +809,29 @@ __global__ __launch_bounds__(NW * 64) KT_OLIGO_WPE_ATTR void oligo_sb_kernel_den
     oligo_sb_body<K, CANON, DT, NW>(a);
 }
 
+// the big-row shapes with a producer wave: NW store waves + 1
+template <int K, bool CANON, int DT, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void oligo_pw_kernel(OligoArgs a) {
+    oligo_sb_body<K, CANON, DT, NW, true>(a);
+}
+
 using kern_t = void (*)(OligoArgs);
+
+template <int K>
+kern_t pick_pw(int count_min, int dt) {
+    if (count_min) {
+        switch (dt) {
+            case KT_F64: return (kern_t)oligo_pw_kernel<K, true, KT_F64, 4>;
+            case KT_F32: return (kern_t)oligo_pw_kernel<K, true, KT_F32, 4>;
+            default: return (kern_t)oligo_pw_kernel<K, true, KT_U32, 4>;
+        }
+    }
+    switch (dt) {
+        case KT_F64: return (kern_t)oligo_pw_kernel<K, false, KT_F64, 4>;
+        case KT_F32: return (kern_t)oligo_pw_kernel<K, false, KT_F32, 4>;
+        default: return (kern_t)oligo_pw_kernel<K, false, KT_U32, 4>;
+    }
+}
 
 template <int K, int NW>
 kern_t pick_sb(int count_min, int dt) {
@@ -742,6 +877,7 @@ const kt_ctx::OligoKnobs &oligo_knobs(kt_ctx *ctx) {
     if (!kn.loaded || kn.live) {
         kn.live = env_u32("KT_KNOBS_LIVE", 0) != 0;
         kn.shape = env_u32("KT_OLIGO_SHAPE", 104);
+        kn.pw = env_u32("KT_OLIGO_PW", 7);  // smallest k whose kernel runs with a producer wave (8: none)
         kn.R = env_u32("KT_OLIGO_R", 0);
         kn.oversub = env_u32("KT_OLIGO_OVERSUB", 0);
         const char *tune = getenv("KT_OLIGO_TUNE");
@@ -847,7 +983,7 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
 
     size_t lds = (count_min && k <= 5) ? ((((size_t)1 << (2 * k)) * 2 + 15) & ~(size_t)15) : 0;
     lds += nbuf * (size_t)R * bins * 4;
-    lds += 2 * MAX_R * 4 + 2 * MAX_R * 8 + (MAX_R + 1) * 8 + 8;
+    lds += 2 * MAX_R * 4 + 2 * MAX_R * 8 + (MAX_R + 1) * 8 + 8 + 128;  // (+ the published tile of the producer-wave kernels)
     if (lds > 160 * 1024) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: tile does not fit in LDS");
 
     // wave specialisation: small rows are producer-heavy, big rows (k >= 6) are all output
@@ -857,6 +993,10 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
         case 104: kern = pick_sb_k<4>(k, count_min, dt); nthreads = 256; break;
         case 108: kern = pick_sb_k<8>(k, count_min, dt); nthreads = 512; break;
         default: return kt::fail(KT_ERR_ARG, "kt_oligo_batch: unknown KT_OLIGO_SHAPE");
+    }
+    if (k >= 6 && (uint32_t)k >= kn.pw && shape == 104) {  // the big-row shapes: four store waves + a producer wave
+        kern = k == 6 ? pick_pw<6>(count_min, dt) : pick_pw<7>(count_min, dt);
+        nthreads = 320;
     }
     if (!kern) return kt::fail(KT_ERR_ARG, "kt_oligo_batch: k must be in 3..7");
     if (lds > 64 * 1024)

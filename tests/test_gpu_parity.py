@@ -209,6 +209,38 @@ def test_oligo_device_tensors_many_tiles(torch_mod, ctx, oracle):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("count_min", [True, False])
+def test_oligo_k7_producer_wave_many_tiles_per_workgroup(hctx, oracle, monkeypatch, count_min):
+    """comp cgr k=7 runs with a producer wave (four store waves that never load + one wave that reads the input and
+    publishes each tile a tile ahead).  One workgroup per CU (KT_OLIGO_OVERSUB=1) walks dozens of tiles: 150-bp tiles of
+    one chunk, ragged ones, tiles of several chunks (long reads: the store waves count too, from the published tile), empty
+    reads, a last tile that is not full - all rows against the oracle, and against the kernel without the producer wave"""
+    from kmertools_amd import device
+    rng = np.random.default_rng(77 + count_min)
+    alpha = np.frombuffer(b"ACGTN", np.uint8)
+    lens = np.full(12_001, 150)
+    lens[1000:1400] = rng.integers(0, 400, size=400)          # ragged tiles, empty reads
+    lens[5000:5040] = rng.integers(900, 6000, size=40)        # tiles of many chunks
+    lens[5040:5048] = 0
+    lens[9_000:9_016] = 1008                                  # exactly a chunk per read
+    seqs = [alpha[rng.choice(5, size=L, p=[.2475, .2475, .2475, .2475, .01])].tobytes() for L in lens]
+    bases, offsets = device.to_csr(seqs)
+    want = oracle.oligo_batch(bases, offsets, 7, count_min, False, 1.0, threads=8)
+    got = {}
+    for pw in ("7", "8"):
+        monkeypatch.setenv("KT_OLIGO_OVERSUB", "1")
+        monkeypatch.setenv("KT_OLIGO_PW", pw)
+        c = device.Context()
+        got[pw] = c.oligo_host(bases, offsets, 7, count_min, False, 1, "u32")
+        if pw == "7":
+            f64 = c.oligo_host(bases, offsets, 7, count_min, True, 1, "f64")
+        c.close()
+        assert np.array_equal(got[pw].astype(np.float64), want), pw
+    assert np.array_equal(got["7"], got["8"])
+    wantn = oracle.oligo_batch(bases, offsets, 7, count_min, True, 1.0, threads=8)
+    assert np.array_equal(f64.view(np.uint64), wantn.view(np.uint64))
+
+
 def test_pykmertools_surface(oracle, golden, kat):
     """the reference's own python tests (tests/test_oligo.py, test_kmers.py, test_utils.py)"""
     from kmertools_amd import pykmertools as kt
