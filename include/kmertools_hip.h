@@ -150,8 +150,10 @@ int kt_oligo_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, u
  * (>= ~6 M reads of 150 bases) into an array cycle through 32 / 96 / 200 with events around them, the fastest stays.
  * *decided = 0 while still measuring (then *wgs_per_slot is the default, 96, and the means are 0); ns_per_read[3] =
  * the means for 32, 96, 200 in ns per read.  Results never depend on it.  KT_OLIGO_TUNE=0 in the environment keeps
- * the default, KT_OLIGO_OVERSUB=n fixes n.  (The trial launches record a pair of events on the context's stream: a
- * caller that captures its launches into a graph switches the measurement off first - kt_oligo_tuning(ctx, 0).) */
+ * the default, KT_OLIGO_OVERSUB=n fixes n.  (The trial launches record a pair of events on the context's stream.  A
+ * launch made while that stream is being captured into a graph records and queries nothing - it runs with what has
+ * been decided for its array, or the default, like a launch after kt_oligo_tuning(ctx, 0) - and an event that cannot be
+ * created or recorded drops the trial, never the call.) */
 int kt_oligo_launch_info(kt_ctx *ctx, uint32_t *wgs_per_slot, int *decided, double *ns_per_read);
 /* mode 0: the launches that follow neither count towards nor take part in that measurement (they use what has been
  * decided for their array, else the default) - for a caller that is timing launches itself; mode 1 resumes;

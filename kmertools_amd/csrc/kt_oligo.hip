@@ -1030,11 +1030,15 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     kt_ctx::OligoTune &tn = ctx->oligo_tune;
     kt_ctx::OligoTune::Trial *trial = nullptr;
     const uint64_t slots = (uint64_t)ctx->n_cu * per_cu;
-    if (k == 4 && !kn.oversub && kn.tune && tn.paused) {
+    // a stream that is being captured into a graph takes no event records and no event queries: such launches run with
+    // what has been decided for the array so far (or the default) and take no part in the measurement
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    if (k == 4 && !kn.oversub && kn.tune && (tn.paused || capturing)) {
         const kt_ctx::OligoTune::Entry *e = tune_find(tn, out);
         if (tn.forced) per_slot = tn.forced;
         else if (e && e->decided) per_slot = e->pick;
-    } else if (k == 4 && !kn.oversub && kn.tune && n_tiles >= slots * TUNE_SETTINGS[TUNE_DEFAULT]) {
+    } else if (k == 4 && !kn.oversub && kn.tune && n_tiles >= slots * TUNE_SETTINGS[TUNE_DEFAULT] && !capturing) {
         oligo_tune_poll(tn);
         kt_ctx::OligoTune::Entry *e = tune_find(tn, out);
         if (!e) {   // a new array takes the least recently used entry
@@ -1052,9 +1056,14 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
             if (e->launches >= (uint32_t)tn.WARM && e->launches < (uint32_t)(tn.WARM + tn.GIVE_UP))
                 for (auto &t : tn.ring)
                     if (!t.live) { trial = &t; break; }
-            if (trial && !trial->a && (hipEventCreate(&trial->a) != hipSuccess || hipEventCreate(&trial->b) != hipSuccess)) {
-                (void)hipGetLastError();
-                trial = nullptr;
+            if (trial && !trial->a) {  // (both events or none: a slot with one of them would be taken for a usable one)
+                if (hipEventCreate(&trial->a) != hipSuccess) trial->a = nullptr;
+                if (!trial->a || hipEventCreate(&trial->b) != hipSuccess) {
+                    if (trial->a) (void)hipEventDestroy(trial->a);
+                    trial->a = trial->b = nullptr;
+                    (void)hipGetLastError();
+                    trial = nullptr;
+                }
             }
             if (trial) {
                 const uint32_t r = (e->launches - tn.WARM) % (2 * tn.NSET);   // 0 1 2 2 1 0: a drift over the trials cancels
@@ -1069,12 +1078,16 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     uint64_t grid = slots * per_slot;
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) return KT_OK;
-    if (trial) KT_HIP(hipEventRecord(trial->a, ctx->stream));
+    // the trial's events are best effort: a record that fails drops the trial, never the call
+    if (trial && hipEventRecord(trial->a, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        trial = nullptr;
+    }
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(nthreads), lds, ctx->stream, a);
     KT_HIP(hipGetLastError());
     if (trial) {
-        KT_HIP(hipEventRecord(trial->b, ctx->stream));
-        trial->live = true;
+        if (hipEventRecord(trial->b, ctx->stream) == hipSuccess) trial->live = true;
+        else (void)hipGetLastError();
     }
     return KT_OK;
 }
