@@ -614,7 +614,15 @@ CountComputer::CountComputer(std::string in_path, std::string out_dir, int ksize
     : in_path_(std::move(in_path)), out_dir_(std::move(out_dir)), ksize_(ksize) {}
 
 CountComputer::~CountComputer() {
+    release_shards();
     if (ctr_) kt_ctr_destroy(ctr_);
+}
+
+void CountComputer::release_shards() {
+    for (auto *&sh : shards_)
+        if (sh) kt_sharded_destroy(sh), sh = nullptr;
+    for (auto *&c : shard_ctx_)
+        if (c) kt_ctx_destroy(c), c = nullptr;
 }
 
 // "{kmer}\t{count}\n" (or the ACGT form) for n table entries, appended to `out` (counter/src/lib.rs:220-230)
@@ -836,8 +844,9 @@ std::string CountComputer::count_sharded(uint64_t max_distinct) {
     std::atomic<int> created_ok{0};
     const char *inject = getenv("KT_CLI_FAIL_RANK");  // tests: this rank's bring-up fails
     std::vector<FabricEnd> ends(N);
-    shard_keys_.assign(N, {});
-    shard_counts_.assign(N, {});
+    release_shards();
+    shards_.assign(N, nullptr);
+    shard_ctx_.assign(N, nullptr);
     // rounds: the reader fills one batch per rank, the ranks add them collectively (a rank without a batch adds 0 reads)
     std::vector<Batch> batches[2];
     batches[0].resize(N);
@@ -895,19 +904,13 @@ std::string CountComputer::count_sharded(uint64_t max_distinct) {
         if (sh) {
             if (kt_sharded_finalize(sh) != KT_OK && errs[rank].empty()) fail(kt_last_error());
             kt_ctr *t = nullptr;
-            uint64_t n = 0, got = 0;
+            uint64_t n = 0;
             if (errs[rank].empty() && (kt_sharded_table(sh, &t) != KT_OK || kt_ctr_size(t, &n) != KT_OK)) fail(kt_last_error());
-            if (errs[rank].empty()) {
-                shard_keys_[rank].resize(n ? n : 1);
-                shard_counts_[rank].resize(n ? n : 1);
-                if (n && kt_ctr_export(t, shard_keys_[rank].data(), shard_counts_[rank].data(), n, &got, KT_MEM_HOST) != KT_OK)
-                    fail(kt_last_error());
-                shard_keys_[rank].resize(got);
-                shard_counts_[rank].resize(got);
-            }
-            kt_sharded_destroy(sh);
         }
-        if (ctx) kt_ctx_destroy(ctx);
+        // the shard stays where it is: merge() writes it out in slabs (the reference streams its partitions into the file
+        // the same way, counter/src/lib.rs:220-230) - no rank's export is ever held in host memory as a whole
+        shards_[rank] = sh;
+        shard_ctx_[rank] = ctx;
     };
     std::vector<std::thread> threads;
     for (int r = 0; r < N; r++) threads.emplace_back(worker, r);
@@ -945,13 +948,20 @@ std::string CountComputer::count_sharded(uint64_t max_distinct) {
 std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
     if (passes_ > 1) return "";  // out of core: count() wrote every partition's lines as it completed
     const std::string path = out_dir_ + "/kmers.counts";
-    if (sharded_done_) {  // the shards' exports, one after the other (the reference's line order is unspecified)
+    if (sharded_done_) {  // the shards, one after the other, each in slabs (the reference's line order is unspecified)
         FILE *out = fopen(path.c_str(), "wb");
         if (!out) return "Unable to write to file: " + path;
-        for (size_t r = 0; r < shard_keys_.size(); r++)
-            write_counts(out, shard_keys_[r].data(), shard_counts_[r].data(), shard_keys_[r].size(), acgt_, ksize_, threads_);
+        std::string err;
+        for (size_t r = 0; r < shards_.size() && err.empty(); r++) {
+            kt_ctr *t = nullptr;
+            if (kt_sharded_table(shards_[r], &t) != KT_OK) err = kt_last_error();
+            else err = write_table(out, t, acgt_, ksize_, threads_, memory_ceil_gb_, nullptr);
+        }
         fclose(out);
-        return "";
+        if (getenv("KT_CLI_TIMING"))
+            fprintf(stderr, "[timing] ctr --devices %d written: VmHWM %llu kB\n", n_devices_, (unsigned long long)peak_rss_kb());
+        release_shards();
+        return err;
     }
     if (!ctr_) return "count() has not run";
     PhaseTimer pt("ctr merge");

@@ -120,8 +120,10 @@ class CountComputer {
     int n_devices_ = 1;
     uint32_t passes_ = 1;
     bool sharded_done_ = false;
-    std::vector<std::vector<uint64_t>> shard_keys_;
-    std::vector<std::vector<uint32_t>> shard_counts_;
+    // --devices N: the shards stay on their GPUs after count(); merge() writes them out one after the other, in slabs
+    std::vector<kt_sharded *> shards_;
+    std::vector<kt_ctx *> shard_ctx_;
+    void release_shards();
     std::function<std::string(uint32_t, uint32_t, kt_ctr *)> pass_hook_;
     std::string count_sharded(uint64_t max_distinct);
 };
