@@ -97,6 +97,7 @@ struct Plan {
     uint32_t d_lo, d_hi;  // the level-1 buckets whose ranges this table holds: all B1 of them, or - a shard - its interval
     uint32_t bx;          // hash bits a pre-split pass resolves between level 1 and level 2 (0: none; see finish_typed)
     uint32_t dbg;     // KT_BUILD_DBG: ablation switches of build_kernel (profiling only)
+    uint32_t lists;   // the dense build's LDS has room for the claim lists behind the image (build_kernel)
 };
 
 template <class K>
@@ -1592,6 +1593,9 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
 static_assert(LOG2_S == kttab::LOG2_RANGE, "a fine bucket is a range of the table");
 
 constexpr int BUILD_T = KT_BUILD_T;
+// claim lists of a dense build: the slot of every key a wave has placed first, in the order it placed them - three keys per
+// lane at most (a range of up to 3072 keys; ranges of hashed distinct keys hold ~2900)
+constexpr uint32_t LIST_CAP = 192, LIST_KEYS = LIST_CAP * (BUILD_T / 64);
 #if KT_ABLATION
 __device__ unsigned long long kt_dbg_phase[16];  // (timing builds: cycles of workgroup thread 0 per phase of build_kernel)
 #define KT_PH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phs[i] += (uint32_t)(t_ - tph); tph = t_; } while (0)
@@ -1710,6 +1714,12 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
         }
     };
     __shared__ uint32_t runs[BUILD_T / 64];  // DENSE: entries packed by each wave
+    // DENSE with claim lists (p.lists: the launch gave the room): a wave notes the slot of every key it places first, so
+    // the occupied slots need not be looked for afterwards - no pack pass over the whole image, no clearing pass either
+    // (the copy-out empties the slots it has read), one barrier fewer.  All three were proportional to the range's SLOTS
+    // (6144 at load 0.47), the list is proportional to its keys.  A range of more than LIST_KEYS keys takes the pack path.
+    uint16_t *const mylist = reinterpret_cast<uint16_t *>(smem_raw + (size_t)RS * (sizeof(K) + 4)) + (threadIdx.x >> 6) * LIST_CAP;
+    bool dirty = true;  // the image holds something: cleared whole before the next insert (workgroup uniform)
     // EXT: the current block [xpos, xend) and how many blocks this workgroup has taken.  Every thread carries the same
     // (workgroup-uniform) values: a range's entry count D comes out of the pack's scan in every wave, so where its entries
     // go - the rest of the current block, then the front of the workgroup's next one - needs no shared state at all.
@@ -1760,15 +1770,17 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 scounts[i] = v.z;
                 placed -= occ;
             }
-        } else {
+        } else if (dirty) {
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
                 skeys[i] = EMPTY;
                 scounts[i] = 0;
             }
         }
+        const bool listed = DENSE && p.lists != 0 && hi - lo <= LIST_KEYS && hi - lo <= RS;  // (workgroup uniform)
         KT_PH(0);
-        ktd::lds_barrier();
+        if (MERGE || dirty) ktd::lds_barrier();  // (a listed range leaves the image empty behind its end barrier)
         KT_PH(1);
+        uint32_t wc = 0;  // DENSE: entries of this wave - listed: counted as they are claimed; else: by the pack pass
         {
             // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
             // trip (the CAS itself reports what the slot holds), and a lane that has placed its key moves on to its
@@ -1804,8 +1816,8 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             // than it has slots cannot fill up, and its loop goes without the walk's counter - two vector and five scalar
             // instructions of a trip that issues ~45, in a loop bound by instruction issue (eight waves per SIMD going
             // round it: 17.2 against 19.2 ms for the kernel).
-            auto insert_batch = [&](auto chk) {
-                constexpr bool CHECK = decltype(chk)::value;
+            auto insert_batch = [&](auto chk, auto lst) {
+                constexpr bool CHECK = decltype(chk)::value, LISTED = decltype(lst)::value;
                 K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
 #if KT_ABLATION
                 if (p.dbg & 1u) cur = EMPTY;
@@ -1815,6 +1827,11 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 while (cur != EMPTY) {
                     const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
                     bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
+                    if constexpr (LISTED) {  // the claimed slots go to the wave's list (the lanes still in the loop vote)
+                        const uint64_t bal = __ballot(done);
+                        if (done) mylist[wc + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)s;
+                        wc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc + (uint32_t)__popcll(bal)));
+                    }
                     if (!done && v == cur) {
                         atomicAdd(&scounts[s], 1u);
                         done = true;
@@ -1845,13 +1862,25 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 const bool more = bbase + 4ull * BUILD_T < hi;  // (workgroup uniform; false for hashed distinct keys)
                 K nxt[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
                 if (more) load_head(bbase + 4ull * BUILD_T, hi, nxt);
-                if (roomy) insert_batch(std::false_type{});
-                else insert_batch(std::true_type{});
+                if (listed) insert_batch(std::false_type{}, std::true_type{});
+                else if (roomy) insert_batch(std::false_type{}, std::false_type{});
+                else insert_batch(std::true_type{}, std::false_type{});
                 if (!more) break;
                 bbase += 4ull * BUILD_T;
 #pragma unroll
                 for (int u = 0; u < 4; u++) head[u] = nxt[u];
             }
+        }
+        if (DENSE && listed) {
+            // wc was the same in every lane still in the loop; a lane that left it earlier holds the value of its last
+            // trip (the loop's exit is divergent): the wave's count is the largest of them
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)wc, o, 64);
+                wc = other > wc ? other : wc;
+            }
+            wc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wc);
+            if (lane == 0) runs[tid >> 6] = wc;  // (known here: no pack pass, no barrier of its own)
         }
         KT_PH(2);
         ktd::lds_barrier();
@@ -1866,23 +1895,36 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             // every store starting and ending inside cache lines: 36 GB took 14 ms.)
             constexpr uint32_t NW = BUILD_T / 64;
             const uint32_t wave = tid >> 6, share = RS / NW;  // RS = 1024 * m8: a multiple of 64 per wave
-            uint32_t wc = 0;                                  // entries this wave has packed so far (wave uniform)
-            for (uint32_t i0 = 0; i0 < share; i0 += 64) {
-                const uint32_t i = wave * share + i0 + lane;
-                const K kk = skeys[i];
-                const uint32_t cc = scounts[i];
-                const uint64_t bal = __ballot(kk != EMPTY);
-                if (kk != EMPTY) {
-                    const uint32_t at = wave * share + wc + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                    skeys[at] = kk;      // at <= i: behind or at what this wave has read (LDS executes a wave's
-                    scounts[at] = cc;    // accesses in order)
+            // (with claim lists there is nothing to pack: the wave's entries are the slots on its list, wc of them)
+            if (!listed) {
+                for (uint32_t i0 = 0; i0 < share; i0 += 64) {
+                    const uint32_t i = wave * share + i0 + lane;
+                    const K kk = skeys[i];
+                    const uint32_t cc = scounts[i];
+                    const uint64_t bal = __ballot(kk != EMPTY);
+                    if (kk != EMPTY) {
+                        const uint32_t at = wave * share + wc + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                        skeys[at] = kk;      // at <= i: behind or at what this wave has read (LDS executes a wave's
+                        scounts[at] = cc;    // accesses in order)
+                    }
+                    wc += (uint32_t)__popcll(bal);
                 }
-                wc += (uint32_t)__popcll(bal);
+                if (lane == 0) runs[wave] = wc;
+                KT_PH(4);
+                ktd::lds_barrier();
+                KT_PH(5);
             }
-            if (lane == 0) runs[wave] = wc;
-            KT_PH(4);
-            ktd::lds_barrier();
-            KT_PH(5);
+            // entry e of this wave's run: from its packed share of the image, or from the slot its list names - which is
+            // emptied behind the read (the next range finds the image clean)
+            auto take = [&](uint32_t e, K &kk, uint32_t &cc) {
+                const uint32_t src = listed ? (uint32_t)mylist[e] : wave * share + e;
+                kk = skeys[src];
+                cc = scounts[src];
+                if (listed) {
+                    skeys[src] = EMPTY;
+                    scounts[src] = 0;
+                }
+            };
             // where this wave's run goes = the runs before it: an inclusive scan of the sixteen counts in lanes 0..15
             // (row_shr inside one DPP row)
             static_assert(NW == 16, "the wave counts are scanned inside one DPP row");
@@ -1933,16 +1975,21 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                         if ((p.dbg & 2u) && skeys[0] != (K)0x1234567u) continue;  // (timing only: the build without its stores)
 #endif
                         if (j >= skew) {
-                            const uint32_t src = wave * share + (j - skew);
-                            __builtin_nontemporal_store(from_stored<K>(skeys[src]), dk + (j - skew));
-                            __builtin_nontemporal_store(scounts[src] + 1u, dc + (j - skew));
+                            K kk;
+                            uint32_t cc;
+                            take(j - skew, kk, cc);
+                            __builtin_nontemporal_store(from_stored<K>(kk), dk + (j - skew));
+                            __builtin_nontemporal_store(cc + 1u, dc + (j - skew));
                         }
                     }
                 } else {
                     for (uint32_t j = lane; j < wc + skew; j += 64) {
                         if (j >= skew) {
-                            const uint32_t src = wave * share + (j - skew), i = pre + (j - skew);
-                            xo.put(i < l1 ? b1 + i : b2 + (i - l1), from_stored<K>(skeys[src]), scounts[src] + 1u);
+                            const uint32_t i = pre + (j - skew);
+                            K kk;
+                            uint32_t cc;
+                            take(j - skew, kk, cc);
+                            xo.put(i < l1 ? b1 + i : b2 + (i - l1), from_stored<K>(kk), cc + 1u);
                         }
                     }
                 }
@@ -1953,9 +2000,11 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 const uint32_t skew = pre & 31u;
                 for (uint32_t j = lane; j < wc + skew; j += 64) {
                     if (j >= skew) {
-                        const uint32_t src = wave * share + (j - skew);
-                        __builtin_nontemporal_store(from_stored<K>(skeys[src]), dkeys + pre + (j - skew));
-                        __builtin_nontemporal_store(scounts[src], dcounts + pre + (j - skew));
+                        K kk;
+                        uint32_t cc;
+                        take(j - skew, kk, cc);
+                        __builtin_nontemporal_store(from_stored<K>(kk), dkeys + pre + (j - skew));
+                        __builtin_nontemporal_store(cc, dcounts + pre + (j - skew));
                     }
                 }
                 if (tid == 0) {
@@ -1981,6 +2030,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
 #endif
             }
         }
+        dirty = !listed;
         KT_PH(6);
         ktd::lds_barrier();
         KT_PH(7);
@@ -2272,7 +2322,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2292,6 +2342,7 @@ static BulkKnobs read_knobs() {
     k.p2_fast = env_u64("KT_P2_FAST", 1);  // 0: the general level-2 kernel also for fixed fine regions (A/B, tests)
     k.build_wgs = env_u64("KT_BUILD_WGS", 64);
     k.build_wgs_ext = env_u64("KT_BUILD_WGS_EXT", 16);
+    k.build_lists = env_u64("KT_BUILD_LISTS", 1);  // 0: the dense build packs the image instead of keeping claim lists (A/B)
     k.dense = env_u64("KT_BULK_DENSE", 1);
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
     // hash bits level 2 takes: 10 - what part2_swwc_kernel's one line per fine bucket fits into the LDS (the sort-buffer
@@ -2540,7 +2591,10 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     // 17.9 ms)
     uint64_t gb = (uint64_t)ctx->n_cu * (ext ? j.kn.build_wgs_ext : j.kn.build_wgs);
     if (gb > n_fine) gb = n_fine;
-    const size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
+    size_t build_lds = (size_t)(p.m8 << (LOG2_S - 3)) * (sizeof(K) + 4);
+    // the dense build's claim lists ride behind the image where that does not cost the CU its second workgroup
+    p.lists = dense && j.kn.build_lists && build_lds + LIST_KEYS * 2 + 256 <= 80 * 1024 ? 1u : 0u;
+    if (p.lists) build_lds += LIST_KEYS * 2;
     // (ctr k=31: dense build 29.0 ms + dense export 17.4 ms against image build 22-23.5 ms + export 27.5 ms; k=15: 13.8 +
     // 3.2 against 12.5 + 4.7 ms; profiles/r2_build_sweep.txt.  KT_BULK_DENSE=0 builds the probing image at once.)
     auto launch_build = [&](bool to_ext, const ExtOut &xo) -> int {
