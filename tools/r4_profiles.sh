@@ -2,6 +2,7 @@
 # round 4: the rocprofv3 summaries that go to profiles/ (kernel stats + FETCH/WRITE passes per workload, the headline run)
 cd "$GRAFT_REPO_ROOT" || exit 1
 tools/profile_bench.sh r4_ctr_k31 --workload ctr_k31 --steps 5 --warmup 2 > /dev/null 2>&1
+tools/profile_bench.sh r4_ctr_k31_genome --workload ctr_k31 --genome 1000000000 --steps 3 --warmup 1 > /dev/null 2>&1
 tools/profile_bench.sh r4_ctr_k15 --workload ctr_k15 --steps 5 --warmup 2 > /dev/null 2>&1
 tools/profile_bench.sh r4_comp_cgr_k7 --workload comp_cgr_k7 --steps 5 --warmup 2 > /dev/null 2>&1
 tools/profile_bench.sh r4_comp_oligo_k4 --workload comp_oligo_k4 --steps 20 --warmup 5 > /dev/null 2>&1
