@@ -20,6 +20,35 @@ def regs_of(text):
     return out
 
 
+def dead_high_addend(lines, i, code, inflight):
+    """v_mad_u64_u32 D, sdst, a, b, v[lo:hi] with only `hi` in flight: the compiler's way to write lo32(a * b) + x - the
+    addend pair is {x, whatever lies beside it}, and that half reaches only D's high half.  Accepted when D's high half is
+    written again before anything reads it."""
+    m = re.match(r"v_mad_u64_u32\s+v\[(\d+):(\d+)\],\s*[^,]+,\s*[^,]+,\s*[^,]+,\s*v\[(\d+):(\d+)\]\s*$", code.strip())
+    if not m:
+        return False
+    dhi, alo, ahi = int(m.group(2)), int(m.group(3)), int(m.group(4))
+    others = regs_of(code.rsplit(",", 1)[0])  # everything but the addend pair
+    if ahi not in inflight or alo in inflight or (others & inflight):
+        return False
+    for nxt in lines[i + 1:i + 200]:
+        t = nxt.strip()
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        c = t.split(";")[0]
+        if re.match(r"\S+:", c):      # a label: give up looking, refuse
+            return False
+        ops = c.split(None, 1)
+        if len(ops) < 2:
+            continue
+        first, _, rest = ops[1].partition(",")
+        if dhi in regs_of(rest):      # read before being written again
+            return False
+        if dhi in regs_of(first):     # (destination operand comes first) written again: dead
+            return True
+    return False
+
+
 def check(path, pattern):
     bad = []
     fn = None
@@ -27,7 +56,8 @@ def check(path, pattern):
     inflight = set()
     pending_clear = False
     n_loads = n_waits = 0
-    for ln, line in enumerate(open(path), 1):
+    lines = open(path).read().split("\n")
+    for ln, line in enumerate(lines, 1):
         s = line.strip()
         m = re.match(r"^(\S+):\s*(;.*)?$", line)
         if m and not m.group(1).startswith(".L"):
@@ -62,6 +92,8 @@ def check(path, pattern):
             inflight.clear()
             continue
         hit = regs_of(code) & inflight
+        if hit and dead_high_addend(lines, ln - 1, code, inflight):
+            hit = set()
         if hit:
             bad.append((fn, ln, code.strip(), sorted(hit)))
     return bad, n_loads, n_waits
