@@ -974,6 +974,9 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     const uint32_t small_budget = k <= 4 ? 26624u - 2560u - (count_min ? (2u << (2 * k)) : 0u) : 28672u;
     uint32_t R = (bins <= 1024 ? small_budget : 131072u) / (bins * 4u);
     if (R >= 8) R &= ~3u;  // k=4: 40 reads = 6 wave-chunks (1008 B) of 150-bp reads, 6 workgroups per CU
+    // k=6 (8 KB rows): 6-read tiles - one wave-chunk of 150-bp reads, three workgroups per CU - instead of 12-read ones:
+    // 1.70 -> 1.48 ms per 1 M reads (tools/r4_k6_sweep.py: R = 3 .. 9 -> 2.13 / 1.72 / 1.72 / 1.49 / 1.95 / 1.55 / 1.62)
+    if (bins > 1024 && bins * 4u <= 8704u && R > 6) R = 6;
     if (R < 1) R = 1;
     if (R > MAX_R) R = MAX_R;
     if (kn.R) R = kn.R;
