@@ -1367,13 +1367,14 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
     const SwwcShared<K> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
 #ifndef KT_SWWC_PER32
-#define KT_SWWC_PER32 32  // keys of a thread per chunk with 32-bit keys: 16 K keys = half a line per fine bucket and chunk.  (48:
-#endif                    // 16.2 against 14.2 ms at k=15; 64 - a whole line per chunk, like the 64-bit keys - does not fit 256 registers)
+#define KT_SWWC_PER32 16  // keys of a 512-thread lane per chunk with 32-bit keys (1024 threads: half of it): 8 K keys = a quarter of
+#endif                    // a line per fine bucket and chunk.  (At 512 threads: 32 -> 14.2 ms at k=15, 48 -> 16.2, 64 does not fit 256
+                          // registers; at 1024 threads 32 -> 11.5 ms, 16 with four buckets per flush trip -> 11.1-11.2)
 #ifndef KT_SWWC_PER64
 #define KT_SWWC_PER64 8
 #endif
     constexpr int P2T = swwc_t<K>(), PER = sizeof(K) == 8 ? KT_SWWC_PER64 : KT_SWWC_PER32 * 512 / P2T;
-    constexpr uint32_t CH = (uint32_t)P2T * PER;       // 16384 (32768) keys per chunk, held in registers
+    constexpr uint32_t CH = (uint32_t)P2T * PER;       // 8192 keys per chunk, held in registers
     constexpr uint32_t LK = 128 / sizeof(K), LSH = sizeof(K) == 8 ? 4 : 5;  // keys per line
     constexpr uint32_t GL = 8;                          // lanes that write one line (16 bytes each)
     constexpr uint32_t KPL = LK / GL;                   // keys per lane of a line: 2 (4)
@@ -1413,12 +1414,13 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
         // one line per group per trip: generation g's lines.  Returns nothing; raises flags[(g + 1) & 1] when some bucket
         // has yet another line, flags[2] when a bucket is outgrowing its room.
 #ifndef KT_SWWC_FB
-#define KT_SWWC_FB 2
+#define KT_SWWC_FB 4
 #endif
         auto flush = [&](uint32_t g, float allowed) {
-            // FB trips at a time: the buckets' states are read together, then the lines, then the stores go out (FB = 2: 10.4 ->
-            // 9.5 ms at k=31; FB = 4 needs more than the 256 registers - and a spill in this kernel is not a slowdown but
-            // a fault: see csrc/Makefile's check of the resource remarks)
+            // FB trips at a time: the buckets' states are read together, then the lines, then the stores go out (512 threads x 32
+            // keys: FB = 2 10.4 -> 9.5 ms at k=31, FB = 4 did not fit the registers - and a spill in this kernel is not a
+            // slowdown but a fault: see csrc/Makefile's checks.  At 1024 x 8 keys four fit: nothing at k=31 (9.3-9.6 either
+            // way), 11.5 -> 11.1-11.2 ms at k=15 together with the shorter chunk)
             constexpr uint32_t FB = KT_SWWC_FB, NGR = P2T / GL;
             for (uint32_t d0 = 0; d0 < B2; d0 += NGR * FB) {
                 uint32_t fl[FB], cu[FB];
