@@ -209,34 +209,47 @@ def test_oligo_device_tensors_many_tiles(torch_mod, ctx, oracle):
     assert torch.equal(out, out2)
 
 
+_CAPTURE_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from kmertools_amd import device
+n, L, k = 7_000_000, 150, 4
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    c = device.Context(0, stream=side.cuda_stream)
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    c.synth_reads(0x6b6d6572 + 21, n, L, bases, offsets)
+    ref = torch.empty((n, 136), dtype=torch.float32, device="cuda")
+    for _ in range(26):   # past the warm-up launches: the next one would be a trial with events around it
+        c.oligo(bases, offsets, n, k, ref, dtype="f32")
+    side.synchronize()
+    out = torch.zeros((n, 136), dtype=torch.float32, device="cuda")
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        c.oligo(bases, offsets, n, k, out, dtype="f32")
+    assert not c.oligo_launch_info()["measured"]
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    c.close()
+print("captured ok")
+"""
+
+
 def test_oligo_launches_can_be_captured_into_a_graph(torch_mod):
     """a k = 4 launch large enough to take part in the launch-shape measurement, made while its stream is being captured:
-    no event is recorded or queried (that would invalidate the capture), the graph replays, the rows are the plain launch's"""
-    torch = torch_mod
-    from kmertools_amd import device
-    n, L, k = 7_000_000, 150, 4
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        c = device.Context(0, stream=side.cuda_stream)
-        bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
-        offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-        c.synth_reads(0x6b6d6572 + 21, n, L, bases, offsets)
-        ref = torch.empty((n, 136), dtype=torch.float32, device="cuda")
-        for _ in range(26):   # past the warm-up launches: the next one would be a trial with events around it
-            c.oligo(bases, offsets, n, k, ref, dtype="f32")
-        side.synchronize()
-        out = torch.zeros((n, 136), dtype=torch.float32, device="cuda")
-        side.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
-            c.oligo(bases, offsets, n, k, out, dtype="f32")
-        assert not c.oligo_launch_info()["measured"]
-        for _ in range(2):
-            out.zero_()
-            g.replay()
-            torch.cuda.synchronize()
-            assert torch.equal(out, ref)
-        c.close()
+    no event is recorded or queried (that would invalidate the capture), the graph replays, the rows are the plain launch's.
+    In a process of its own: a torch graph capture in the test process left the device-wide synchronize of a later test
+    (the launch-shape one) waiting for ever - torch's capture state, not the library's: the same suite without this test,
+    and this test alone, are both green."""
+    import subprocess, sys, pathlib
+    root = str(pathlib.Path(__file__).resolve().parent.parent)
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "captured ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 @pytest.mark.parametrize("count_min", [True, False])
