@@ -1330,8 +1330,9 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
 // key's place in its bucket's stream comes from one returning LDS atomic (q = fill[d]++), and the chunk is emitted in
 // GENERATIONS: generation g = the keys with q / LK == g (LK = keys per line) are written to their slots of the bucket's
 // line, barrier, every bucket whose stream has reached (g + 1) * LK writes its line - 8 lanes x 16 bytes, so a wave's store
-// instruction is eight whole lines - barrier.  A chunk of 16 K keys over 1024 buckets takes two flushing generations and
-// a last one that only writes (what is left in the lines is carried into the next chunk), 5 barriers.  What a bucket
+// instruction is eight whole lines - barrier.  A chunk of 8 K keys over 1024 buckets (half a line per bucket with 64-bit
+// keys, a quarter with 32-bit ones) takes one or two flushing generations and a last one that only writes (what is left in
+// the lines is carried into the next chunk).  What a bucket
 // still holds when its input ends goes out as one partial line.
 // Same contract as part2_fast_kernel: fixed fine regions (cap2 keys each, a multiple of LK so that every region starts on
 // a line), a bucket that outgrows one raises fail[jl] and is redone by the general kernel.
@@ -1349,7 +1350,8 @@ struct SwwcShared {
 };
 // threads of a workgroup and keys of a thread per chunk: 1024 x 8 with 64-bit keys (half a line per fine bucket and
 // chunk; 512 x 32: 10.6 ms, 768 x 16: 10.0 ms, 1024 x 8: 9.5 ms at ctr k=31 - 1024 x 16 does not fit the 128 registers
-// of a 16-wave workgroup), 1024 x 16 with 32-bit keys (ctr k=15: 512 x 32 13.9 ms, 1024 x 16 11.7 ms)
+// of a 16-wave workgroup), 1024 x 8 with 32-bit keys too (ctr k=15: 512 x 32 13.9 ms, 1024 x 16 11.5-11.7, 1024 x 8 with four
+// buckets per flush trip 11.1-11.3)
 #ifndef KT_SWWC_T64
 #define KT_SWWC_T64 1024
 #endif
