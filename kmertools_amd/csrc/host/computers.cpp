@@ -1,5 +1,6 @@
 #include "computers.hpp"
 
+#include <malloc.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -141,7 +142,9 @@ static void format_rows(uint64_t n, int threads, size_t bytes_per_row, std::vect
     const uint64_t min_rows = 2048;  // a thread is not worth starting for less
     if ((uint64_t)t > (n + min_rows - 1) / min_rows) t = (int)((n + min_rows - 1) / min_rows);
     if (t < 1) t = 1;
-    pieces.resize((size_t)t);
+    // (never fewer pieces than before: a short last batch must not free the text buffers the next full one needs)
+    if (pieces.size() < (size_t)t) pieces.resize((size_t)t);
+    for (size_t w = (size_t)t; w < pieces.size(); w++) pieces[w].clear();
     auto work = [&](int w) {
         const uint64_t lo = n * (uint64_t)w / (uint64_t)t, hi = n * (uint64_t)(w + 1) / (uint64_t)t;
         // build in a thread-local object: the string headers in `pieces` share cache lines, and every
@@ -625,64 +628,107 @@ void CountComputer::release_shards() {
         if (c) kt_ctx_destroy(c), c = nullptr;
 }
 
-// "{kmer}\t{count}\n" (or the ACGT form) for n table entries, appended to `out` (counter/src/lib.rs:220-230)
-static void write_counts(FILE *out, const uint64_t *keys, const uint32_t *counts, uint64_t n, bool acgt, int k, int threads) {
-    // (in slabs: the text of a table of billions of entries is not held in memory at once)
-    constexpr uint64_t SLAB = 16ull << 20;
-    std::vector<std::string> pieces;
-    for (uint64_t i0 = 0; i0 < n; i0 += SLAB) {
-        const uint64_t m = n - i0 < SLAB ? n - i0 : SLAB;
-        format_rows(m, threads, acgt ? (size_t)k + 4 : 24, pieces, [&](uint64_t r, std::string &s) {
-            const uint64_t i = i0 + r;
-            char buf[40];
-            if (acgt) {
-                kt_numeric_to_kmer(keys[i], k, buf);  // counter/src/lib.rs:221-226
-                s += buf;
-            } else {
-                const auto rr = std::to_chars(buf, buf + sizeof buf, keys[i]);
-                s.append(buf, (size_t)(rr.ptr - buf));
-            }
-            s += '\t';
-            const auto r2 = std::to_chars(buf, buf + sizeof buf, counts[i]);
-            s.append(buf, (size_t)(r2.ptr - buf));
-            s += '\n';
-        });
-        for (const auto &p : pieces) fwrite(p.data(), 1, p.size(), out);
+// What the process holds, from the kernel's and the allocator's books (KT_CLI_TIMING): VmHWM is the peak of the resident
+// set - anonymous + file + shared pages, the HIP runtime's mappings among them -, `heap` is what malloc has handed out and
+// not got back (mallinfo2: uordblks of the arenas + hblkhd of its own mmaps), which is what this program's buffers are.
+struct MemReport {
+    uint64_t hwm_kb = 0, rss_kb = 0, anon_kb = 0, file_kb = 0, shmem_kb = 0, heap_kb = 0, heap_free_kb = 0;
+};
+static uint64_t heap_in_use_kb() {
+    const struct mallinfo2 mi = mallinfo2();
+    return (uint64_t)(mi.uordblks + mi.hblkhd) >> 10;
+}
+static MemReport mem_report() {
+    MemReport r;
+    if (FILE *f = fopen("/proc/self/status", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            if (strncmp(line, "VmHWM:", 6) == 0) r.hwm_kb = strtoull(line + 6, nullptr, 10);
+            else if (strncmp(line, "VmRSS:", 6) == 0) r.rss_kb = strtoull(line + 6, nullptr, 10);
+            else if (strncmp(line, "RssAnon:", 8) == 0) r.anon_kb = strtoull(line + 8, nullptr, 10);
+            else if (strncmp(line, "RssFile:", 8) == 0) r.file_kb = strtoull(line + 8, nullptr, 10);
+            else if (strncmp(line, "RssShmem:", 9) == 0) r.shmem_kb = strtoull(line + 9, nullptr, 10);
+        }
+        fclose(f);
     }
+    const struct mallinfo2 mi = mallinfo2();
+    r.heap_kb = (uint64_t)(mi.uordblks + mi.hblkhd) >> 10;
+    r.heap_free_kb = (uint64_t)mi.fordblks >> 10;
+    return r;
 }
+static uint64_t peak_rss_kb() { return mem_report().hwm_kb; }
 
-// The table's lines, a slab at a time: the entries are staged on the device and fetched SLAB entries at a time, so the host
-// holds one slab of (key, count) pairs and its text whatever the table's size - the reference's map.scan streams into
-// the file the same way (counter/src/lib.rs:220-230).  `ceil_gb` (-m): the slab shrinks with the ceiling.
-static std::string write_table(FILE *out, kt_ctr *ctr, bool acgt, int k, int threads, double ceil_gb, uint64_t *n_out) {
-    uint64_t n = 0;
-    if (kt_ctr_export_stage(ctr, &n) != KT_OK) return kt_last_error();
-    // ~64 bytes of host memory per entry of a slab (12 of pairs, the rest text in flight): a million entries at a time -
-    // 64 MB, far below any ceiling -m accepts (6 .. 128 GB); a sixteenth of the ceiling if that were ever smaller
-    uint64_t slab = (uint64_t)(ceil_gb * (double)(1ull << 30) / 16.0 / 64.0);
-    if (slab > (1ull << 20)) slab = 1ull << 20;
-    if (slab < (1ull << 16)) slab = 1ull << 16;
-    std::vector<uint64_t> keys((size_t)(n < slab ? (n ? n : 1) : slab));
-    std::vector<uint32_t> counts(keys.size());
-    for (uint64_t i0 = 0; i0 < n; i0 += slab) {
-        const uint64_t m = n - i0 < slab ? n - i0 : slab;
-        if (kt_ctr_export_fetch(ctr, i0, m, keys.data(), counts.data()) != KT_OK) return kt_last_error();
-        write_counts(out, keys.data(), counts.data(), m, acgt, k, threads);
+// The table's lines, a slab at a time: the entries are staged on the device and fetched `slab` entries at a time, so the
+// host holds one slab of (key, count) pairs and its text whatever the table's size - the reference's map.scan streams
+// into the file the same way (counter/src/lib.rs:220-230).  `ceil_gb` (-m): the slab shrinks with the ceiling.
+// One writer serves every slab of every pass (and every shard of --devices N): the pair arrays and the text pieces are
+// allocated once and keep their capacity, so what a pass costs in host memory does not depend on how many passes went
+// before it or on how many entries the pass holds (round 4 built them anew per slab: the allocator's retention of the
+// freed blocks moved the process's peak by +-100 MB from run to run).
+class TableWriter {
+  public:
+    TableWriter(bool acgt, int k, int threads, double ceil_gb) : acgt_(acgt), k_(k), threads_(threads) {
+        // ~64 bytes of host memory per entry of a slab (12 of pairs, the rest text in flight): a million entries at a
+        // time - 64 MB, far below any ceiling -m accepts (6 .. 128 GB); a sixteenth of the ceiling if that were smaller
+        slab_ = (uint64_t)(ceil_gb * (double)(1ull << 30) / 16.0 / 64.0);
+        if (slab_ > (1ull << 20)) slab_ = 1ull << 20;
+        if (slab_ < (1ull << 16)) slab_ = 1ull << 16;
     }
-    if (n_out) *n_out = n;
-    return "";
-}
+    std::string write(FILE *out, kt_ctr *ctr, uint64_t *n_out) {
+        uint64_t n = 0;
+        if (kt_ctr_export_stage(ctr, &n) != KT_OK) return kt_last_error();
+        if (n && keys_.empty()) {
+            keys_.resize((size_t)slab_);
+            counts_.resize((size_t)slab_);
+        }
+        for (uint64_t i0 = 0; i0 < n; i0 += slab_) {
+            const uint64_t m = n - i0 < slab_ ? n - i0 : slab_;
+            if (kt_ctr_export_fetch(ctr, i0, m, keys_.data(), counts_.data()) != KT_OK) return kt_last_error();
+            // "{kmer}\t{count}\n" (or the ACGT form), counter/src/lib.rs:220-230
+            const uint64_t *keys = keys_.data();
+            const uint32_t *counts = counts_.data();
+            format_rows(m, threads_, acgt_ ? (size_t)k_ + 13 : 32, pieces_, [&](uint64_t i, std::string &s) {
+                char buf[40];
+                if (acgt_) {
+                    kt_numeric_to_kmer(keys[i], k_, buf);  // counter/src/lib.rs:221-226
+                    s += buf;
+                } else {
+                    const auto rr = std::to_chars(buf, buf + sizeof buf, keys[i]);
+                    s.append(buf, (size_t)(rr.ptr - buf));
+                }
+                s += '\t';
+                const auto r2 = std::to_chars(buf, buf + sizeof buf, counts[i]);
+                s.append(buf, (size_t)(r2.ptr - buf));
+                s += '\n';
+            });
+            const uint64_t h = heap_in_use_kb();  // with a slab's pairs and its text in hand: the writer's high point
+            if (h > heap_peak_kb_) heap_peak_kb_ = h;
+            for (const auto &p : pieces_)
+                if (fwrite(p.data(), 1, p.size(), out) != p.size()) return "Unable to write the table's lines";
+            slabs_++;
+        }
+        entries_ += n;
+        if (n_out) *n_out = n;
+        return "";
+    }
+    // bytes held in the writer's own buffers (capacities: what stays allocated between slabs)
+    uint64_t buffer_bytes() const {
+        uint64_t b = keys_.capacity() * 8 + counts_.capacity() * 4;
+        for (const auto &p : pieces_) b += p.capacity();
+        return b;
+    }
+    uint64_t heap_peak_kb() const { return heap_peak_kb_; }
+    uint64_t slab() const { return slab_; }
+    uint64_t slabs() const { return slabs_; }
 
-static uint64_t peak_rss_kb() {  // VmHWM of this process (KT_CLI_TIMING)
-    FILE *f = fopen("/proc/self/status", "r");
-    if (!f) return 0;
-    char line[256];
-    uint64_t kb = 0;
-    while (fgets(line, sizeof line, f))
-        if (strncmp(line, "VmHWM:", 6) == 0) kb = strtoull(line + 6, nullptr, 10);
-    fclose(f);
-    return kb;
-}
+  private:
+    bool acgt_;
+    int k_, threads_;
+    uint64_t slab_ = 0, slabs_ = 0, entries_ = 0, heap_peak_kb_ = 0;
+    std::vector<uint64_t> keys_;
+    std::vector<uint32_t> counts_;
+    std::vector<std::string> pieces_;
+};
 
 static uint64_t env_u64_host(const char *name, uint64_t dflt) {
     const char *v = getenv(name);
@@ -753,10 +799,17 @@ std::string CountComputer::count() {
     FILE *out = nullptr;
     const std::string path = out_dir_ + "/kmers.counts";
     PhaseTimer pt("ctr count (after the seq_stats pre-pass)");
+    const bool timing = getenv("KT_CLI_TIMING") != nullptr;
+    // One reader, one batch and one table writer serve every pass: a pass rewinds the reader (its threads, cuts and
+    // buffers stay) and reuses the writer's slab, so after the first pass the loop allocates nothing - the host's memory
+    // is the same whether the table takes 2 passes or 200 (the reference's ceiling: counter/src/lib.rs:114-118, 220-230).
+    SeqReader reader;
+    if (!reader.open(in_path_, false)) return reader.error();
+    Batch b;
+    TableWriter writer(acgt_, ksize_, threads_, memory_ceil_gb_);
+    uint64_t heap_after_first = 0, rss_after_first = 0;
     for (uint32_t pass = 0; pass < passes_; pass++) {
-        SeqReader reader;
-        if (!reader.open(in_path_, false)) return reader.error();
-        Batch b;
+        if (pass && !reader.rewind()) return reader.error();
         Lap lap;
         for (;;) {
             const bool more = reader.next_batch(b, cli_batch_bases(batch_bases), cli_batch_reads(1ull << 22));
@@ -776,16 +829,33 @@ std::string CountComputer::count() {
         // - its lines go to kmers.counts, and the table is reused
         if (!out) out = fopen(path.c_str(), "wb");
         if (!out) return "Unable to write to file: " + path;
-        if (getenv("KT_CLI_TIMING")) fprintf(stderr, "[timing] pass %u counted: VmHWM %llu kB\n", pass, (unsigned long long)peak_rss_kb());
-        if (std::string e = write_table(out, ctr_, acgt_, ksize_, threads_, memory_ceil_gb_, nullptr); !e.empty()) return e;
-        if (getenv("KT_CLI_TIMING")) fprintf(stderr, "[timing] pass %u written: VmHWM %llu kB\n", pass, (unsigned long long)peak_rss_kb());
+        uint64_t n_pass = 0;
+        if (std::string e = writer.write(out, ctr_, &n_pass); !e.empty()) return e;
         pt.t[3] += lap();
+        if (timing) {
+            // the ceiling's books, per pass: the program's own buffers by their capacities, the allocator's total, and
+            // the kernel's view of the process (which includes the HIP runtime's ~0.6 GB)
+            const MemReport r = mem_report();
+            const uint64_t own = reader.buffer_bytes() + b.bases.capacity() + b.offsets.capacity() * 8 + writer.buffer_bytes();
+            if (pass == 0) heap_after_first = r.heap_kb, rss_after_first = r.rss_kb;
+            fprintf(stderr, "[timing] pass %u written: entries %llu, own buffers %llu kB, malloc in use %llu kB (peak at a slab boundary %llu kB), "
+                            "malloc free %llu kB, VmRSS %llu kB (anon %llu, file %llu, shmem %llu), VmHWM %llu kB\n",
+                    pass, (unsigned long long)n_pass, (unsigned long long)(own >> 10), (unsigned long long)r.heap_kb,
+                    (unsigned long long)writer.heap_peak_kb(), (unsigned long long)r.heap_free_kb, (unsigned long long)r.rss_kb,
+                    (unsigned long long)r.anon_kb, (unsigned long long)r.file_kb, (unsigned long long)r.shmem_kb,
+                    (unsigned long long)r.hwm_kb);
+        }
         if (kt_ctr_clear(ctr_) != KT_OK) return kt_last_error();
     }
     if (out) fclose(out);
-    if (getenv("KT_CLI_TIMING") && passes_ > 1)
-        fprintf(stderr, "[timing] ctr out of core: %u passes, peak host memory (VmHWM) %llu kB\n", passes_,
-                (unsigned long long)peak_rss_kb());
+    if (timing && passes_ > 1) {
+        const MemReport r = mem_report();
+        fprintf(stderr, "[timing] ctr out of core: %u passes, slabs of %llu entries, malloc peak at a slab boundary %llu kB, growth since the end "
+                        "of pass 0: malloc in use %lld kB, VmRSS %lld kB, peak host memory (VmHWM) %llu kB\n",
+                passes_, (unsigned long long)writer.slab(), (unsigned long long)writer.heap_peak_kb(),
+                (long long)r.heap_kb - (long long)heap_after_first, (long long)r.rss_kb - (long long)rss_after_first,
+                (unsigned long long)r.hwm_kb);
+    }
     return "";
 }
 
@@ -952,10 +1022,11 @@ std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
         FILE *out = fopen(path.c_str(), "wb");
         if (!out) return "Unable to write to file: " + path;
         std::string err;
+        TableWriter writer(acgt_, ksize_, threads_, memory_ceil_gb_);
         for (size_t r = 0; r < shards_.size() && err.empty(); r++) {
             kt_ctr *t = nullptr;
             if (kt_sharded_table(shards_[r], &t) != KT_OK) err = kt_last_error();
-            else err = write_table(out, t, acgt_, ksize_, threads_, memory_ceil_gb_, nullptr);
+            else err = writer.write(out, t, nullptr);
         }
         fclose(out);
         if (getenv("KT_CLI_TIMING"))
@@ -968,7 +1039,8 @@ std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
     Lap lap;
     FILE *out = fopen(path.c_str(), "wb");
     if (!out) return "Unable to write to file: " + path;
-    const std::string e = write_table(out, ctr_, acgt_, ksize_, threads_, memory_ceil_gb_, nullptr);
+    TableWriter writer(acgt_, ksize_, threads_, memory_ceil_gb_);
+    const std::string e = writer.write(out, ctr_, nullptr);
     pt.t[2] += lap();
     fclose(out);
     pt.t[3] += lap();

@@ -384,16 +384,26 @@ int cmd_debug_read(int argc, char **argv, int from) {
     }
     Batch b;
     uint64_t total = 0, count = 0;
-    for (;;) {
-        const bool more = r.next_batch(b, 64, 2, true);  // tiny batches: exercises batch boundaries
-        for (uint64_t i = 0; i < b.n_reads(); i++) {
-            printf("%llu\t%s\t", (unsigned long long)(b.first_record + i), b.ids[i].c_str());
-            fwrite(b.bases.data() + b.offsets[i], 1, b.offsets[i + 1] - b.offsets[i], stdout);
-            printf("\n");
+    // KT_DEBUG_READ_PASSES=N: the records N times over ONE reader (rewind(): the passes of an out-of-core count); every
+    // odd pass before the last is left half-way (a rewind in the middle of the stream, pieces parsed ahead and never taken)
+    const int passes = getenv("KT_DEBUG_READ_PASSES") ? atoi(getenv("KT_DEBUG_READ_PASSES")) : 1;
+    for (int pass = 0; pass < passes; pass++) {
+        if (pass && !r.rewind()) break;
+        const bool cut_short = (pass & 1) && pass + 1 < passes;
+        if (pass) printf("#pass\t%d\n", pass);
+        total = count = 0;
+        for (;;) {
+            const bool more = r.next_batch(b, 64, 2, true);  // tiny batches: exercises batch boundaries
+            for (uint64_t i = 0; i < b.n_reads(); i++) {
+                printf("%llu\t%s\t", (unsigned long long)(b.first_record + i), b.ids[i].c_str());
+                fwrite(b.bases.data() + b.offsets[i], 1, b.offsets[i + 1] - b.offsets[i], stdout);
+                printf("\n");
+            }
+            count += b.n_reads();
+            total += b.bases.size();
+            if (!more || (cut_short && count >= 1000)) break;
         }
-        count += b.n_reads();
-        total += b.bases.size();
-        if (!more) break;
+        if (r.failed()) break;
     }
     if (r.failed()) {
         fprintf(stderr, "Error: %s\n", r.error().c_str());

@@ -56,6 +56,8 @@ struct SeqReader::Parallel {
     std::mutex m;
     std::condition_variable cv;
     size_t next_piece = 0, consume_piece = 0, consume_batch = 0, window = 0;
+    int busy = 0;                  // workers parsing a piece right now
+    std::vector<size_t> buf_bytes = std::vector<size_t>(8, 0);  // (statistics: the workers' piece buffers)
     bool stop = false;
     std::vector<std::thread> workers;
     std::vector<Batch> spare;  // buffers of batches the consumer has taken, for the workers to fill again
@@ -86,12 +88,18 @@ struct SeqReader::Parallel {
     // Looks at a window of the file; a record start is always found within it for records below ~8 MB.
     size_t boundary(size_t from) const {
         if (from == 0) return 0;
+        // (a window that grows: records are a few hundred bytes as a rule, and a reader is opened once per pass of an
+        // out-of-core count - sixteen megabytes per cut were most of what such a pass read beside the pieces)
         std::vector<unsigned char> win;
-        const size_t w0 = from - 1, wn = size - w0 < (16u << 20) ? size - w0 : (16u << 20);
-        if (!read_at(w0, wn, win)) return size;
-        const unsigned char *map = win.data();
-        const size_t wsize = wn;
-        const bool to_eof = w0 + wn == size;
+        for (size_t wmax = 64u << 10;; wmax *= 16) {
+            const size_t w0 = from - 1, wn = size - w0 < wmax ? size - w0 : wmax;
+            if (!read_at(w0, wn, win)) return size;
+            const bool to_eof = w0 + wn == size;
+            const size_t c = boundary_in(win.data(), wn, w0, to_eof);
+            if (c < size || to_eof || wmax >= (16u << 20)) return c;
+        }
+    }
+    size_t boundary_in(const unsigned char *map, size_t wsize, size_t w0, bool to_eof) const {
         const unsigned char *nl = (const unsigned char *)memchr(map, '\n', wsize);
         if (!nl) return size;
         size_t p = (size_t)(nl - map) + 1;
@@ -124,15 +132,17 @@ struct SeqReader::Parallel {
         return size;
     }
 
-    void work() {
+    void work(int self) {
         std::vector<unsigned char> buf;  // this worker's piece of the file, reused
         for (;;) {
             size_t i;
             {
                 std::unique_lock<std::mutex> lk(m);
+                // (a worker that finds no piece left waits: rewind() hands the pieces out again)
                 cv.wait(lk, [&] { return stop || (next_piece < pieces.size() && next_piece < consume_piece + window); });
-                if (stop || next_piece >= pieces.size()) return;
+                if (stop) return;
                 i = next_piece++;
+                busy++;
             }
             SeqReader r;
             std::vector<Batch> out;
@@ -159,6 +169,8 @@ struct SeqReader::Parallel {
                 pieces[i].batches = std::move(out);
                 pieces[i].err = std::move(err);
                 pieces[i].ready = true;
+                busy--;
+                buf_bytes[(size_t)self % buf_bytes.size()] = buf.capacity();
             }
             cv.notify_all();
         }
@@ -268,6 +280,58 @@ bool SeqReader::open(const std::string &path, bool sniff) {
         }
     }
     return true;
+}
+
+// Back to the first record (the passes of an out-of-core count): the parallel reader keeps its cuts, its worker threads
+// and every buffer it has - a second pass allocates nothing -, the stream reader rewinds its file.
+bool SeqReader::rewind() {
+    err_.clear();
+    n_records_ = 0;
+    if (par_) {
+        Parallel &P = *par_;
+        std::unique_lock<std::mutex> lk(P.m);
+        if (!P.started) return true;
+        const size_t n = P.pieces.size();
+        P.next_piece = n;  // nobody takes a new piece while the ones in work are waited for
+        P.cv.wait(lk, [&] { return P.busy == 0; });
+        for (auto &pc : P.pieces) {
+            for (auto &bt : pc.batches) {  // parsed ahead and never taken: the buffers go back to the pool
+                P.spare.emplace_back();
+                P.spare.back().bases.swap(bt.bases);
+                P.spare.back().offsets.swap(bt.offsets);
+            }
+            pc.batches.clear();
+            pc.err.clear();
+            pc.ready = false;
+        }
+        P.next_piece = P.consume_piece = P.consume_batch = 0;
+        P.records = 0;
+        lk.unlock();
+        P.cv.notify_all();
+        return true;
+    }
+    if (!gz_ || gzrewind(gz_) != 0) {
+        err_ = "Unable to rewind the input";
+        return false;
+    }
+    pos_ = end_ = 0;
+    eof_ = false;
+    have_pending_ = false;
+    return true;
+}
+
+// bytes held in the reader's own buffers right now (KT_CLI_TIMING: the memory ceiling's books)
+size_t SeqReader::buffer_bytes() {
+    size_t n = buf_.capacity() + line_.capacity() + pending_.capacity();
+    if (par_) {
+        Parallel &P = *par_;
+        std::lock_guard<std::mutex> lk(P.m);
+        for (const auto &pc : P.pieces)
+            for (const auto &bt : pc.batches) n += bt.bases.capacity() + bt.offsets.capacity() * 8;
+        for (const auto &bt : P.spare) n += bt.bases.capacity() + bt.offsets.capacity() * 8;
+        for (const size_t b : P.buf_bytes) n += b;
+    }
+    return n;
 }
 
 bool SeqReader::fill() {
@@ -392,7 +456,7 @@ bool SeqReader::next_batch_parallel(Batch &b, bool keep_ids) {
         }
         const int T = reader_threads();
         P.window = (size_t)T + 2;
-        for (int t = 0; t < T; t++) P.workers.emplace_back([&P] { P.work(); });
+        for (int t = 0; t < T; t++) P.workers.emplace_back([&P, t] { P.work(t); });
     }
     b.clear();
     b.first_record = P.records;

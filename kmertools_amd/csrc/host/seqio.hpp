@@ -60,6 +60,9 @@ class SeqReader {
     // Appends records until the batch holds >= max_bases bases or max_reads reads.
     // Returns false at end of input (the batch may still hold records) or on a parse error.
     bool next_batch(Batch &b, uint64_t max_bases, uint64_t max_reads, bool keep_ids = false);
+    // Back to the first record, keeping threads and buffers (false: the input cannot be read twice - stdin)
+    bool rewind();
+    size_t buffer_bytes();  // what the reader's own buffers hold right now
     bool failed() const { return !err_.empty(); }
     const std::string &error() const { return err_; }
     uint64_t records_read() const { return n_records_; }

@@ -10,8 +10,28 @@ if str(ROOT) not in sys.path:
 GOLDEN = ROOT / "tests" / "golden"
 
 
-def pytest_configure(config):
-    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+# Collection order: what a run with -x must reach first is parity.  Tier 0: oracle / golden parity of the kernels through
+# the C ABI and the CLI; tier 1: the properties at BASELINE.json's full sizes; tier 2: resource and timing properties
+# (host-memory ceilings, placement timing, child processes that capture graphs) - a resource assertion that trips on a
+# loaded box must not hide the parity suite behind it (round 4's driver run stopped at the fourth test).
+_TIER2 = ("bounded_host_memory", "alloc_placed", "captured_into_a_graph", "launch_info")
+_TIER1 = ("full_size", "cfg2", "cfg3", "cfg4", "cfg5", "many_batches_many_threads")
+
+
+def _tier(item):
+    name = item.name
+    if any(t in name for t in _TIER2):
+        return 2
+    if any(t in name for t in _TIER1):
+        return 1
+    return 0
+
+
+def pytest_collection_modifyitems(session, config, items):
+    file_rank = {"test_oracle_golden.py": 0, "test_host_abi.py": 1, "test_build_checks.py": 2, "test_gpu_parity.py": 3,
+                 "test_pykmertools_dropin.py": 4, "test_cli.py": 5, "test_dist_gloo.py": 6, "test_oracle_sanitize.py": 7}
+    order = {id(it): i for i, it in enumerate(items)}
+    items.sort(key=lambda it: (_tier(it), file_rank.get(it.fspath.basename, 9), order[id(it)]))
 
 
 @pytest.fixture(scope="session")

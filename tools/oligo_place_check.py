@@ -1,5 +1,5 @@
 """oligo k=4 (10 M reads -> 10.9 GB of rows) against where the output lies: slices of one 96 GiB allocation at different
-offsets, and outputs of smaller spans written by several launches (see tools/oligo_ring_test.py)."""
+offsets, and outputs of smaller spans written by several launches (see tools/oligo_ring_check.py)."""
 import sys, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import torch
