@@ -3,7 +3,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).
+N > 1: one rank per GPU over RCCL - either launched by the driver through torch.distributed.run, or, typed as it stands
+(`python bench.py --gpus 8`), bench.py starts torch.distributed.run itself as a child process (launch_ranks).
 A "step" is one pass of the hot path over one batch of synthetic reads that is already
 resident in HBM.
 
@@ -289,9 +290,7 @@ class Env:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
+        if self.world != args.gpus:   # (launched by torch.distributed.run with another count: the launcher's is the truth)
             args.gpus = self.world
         # KT_BENCH_SHARE_GPU=1 (tests only): every rank uses GPU 0 and the collectives go over gloo, so the
         # multi-rank launch path can be exercised on a one-GPU box.  Numbers from such a run mean nothing.
@@ -367,7 +366,10 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
                 o = (offsets[r0:r1 + 1] - offsets[r0]).contiguous()
                 batch_args.append((bases[r0 * L:], o, r1 - r0))
         alg_bytes_per_launch = min(B, n) * (L + bins * esz)
-        dominant = "oligo_sb_kernel<k=%d,canonical,%s,4 waves>" % (k, wl["dtype"])
+        # the kernel's name as rocprofv3 prints it (kt_oligo.hip: k <= 4 runs the dense variant, k = 7 the producer-wave
+        # kernel, 5 and 6 the plain one; template arguments <K, canonical, KT_F64 0 / KT_F32 1 / KT_U32 2, 4 waves>)
+        dominant = "%s<%d, true, %d, 4>" % ("oligo_sb_kernel_dense" if k <= 4 else "oligo_pw_kernel" if k >= 7 else "oligo_sb_kernel",
+                                            k, {"f64": 0, "f32": 1, "u32": 2}[wl["dtype"]])
         parallelism = "reads sharded by rank, no data-path collective"
 
         # Where the output array lies decides how fast it can be written (the same kernel ran at 1.90-2.40 ms on 23
@@ -479,8 +481,10 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
             # the export arrays are named before counting (kt_ctr_export_target): the range build writes its packed
             # (key, count) pairs straight into them and kt_ctr_export has nothing left to copy
             counter.table.export_target(xk, xc, max_distinct)
-        dominant = ("ctr k=%d step: clear + bulk table build (scatter1w, part2, build kernels%s)%s"
-                    % (k, " writing the export arrays" if fused else "",
+        kt_ = "unsigned int" if k <= 16 else "unsigned long"
+        dominant = ("ctr k=%d step: clear + bulk table build (scatter1w_kernel<ReadsSource, %s>, part2_swwc_kernel<%s>, "
+                    "build_kernel<%s, ...>%s)%s"
+                    % (k, kt_, kt_, kt_, " writing the export arrays" if fused else "",
                        " + size + export" + ("" if fused else " (dense_export_kernel)") if with_export else ""))
         parallelism = ("hash-prefix key ownership: route -> exchange of per-owner regions -> partition + range build, "
                        "pipelined in slices; transport: " + counter.transport)
@@ -584,7 +588,14 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         extra["distinct_rank0"] = state["distinct"] if not args.no_export else counter.size_local()
         extra["table_slots_rank0"] = counter.table.capacity()
         if world > 1:
-            extra["exchanged_bytes_per_step_rank0"] = counter.sharded.exchanged_bytes() // (steps + warmup + ramp)
+            # did the library's own communicator see `world` ranks, and what did a rank put on the wires per step?
+            ci = counter.sharded.comm_info()
+            extra["rccl_ranks"] = ci["rccl_ranks"]
+            extra["transport"] = ci["transport"]
+            extra["exchanged_bytes_per_rank"] = counter.sharded.exchanged_bytes() // (steps + warmup + ramp)
+            if not env.share_gpu and ci["rccl_ranks"] != world:
+                sys.exit("bench.py: %d ranks were launched but the library's RCCL communicator reports %d (transport %s)"
+                         % (world, ci["rccl_ranks"], ci["transport"]))
     res = {
         "value": round(value, 3),
         "unit": "Gbases/s",
@@ -636,9 +647,34 @@ def oracle_slice_check(cs):
     return {"rows": cs["rows"], "against": "CPU oracle (oracle/kt_oracle.c)", "criterion": how, "ok": ok}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) typed as it stands: start N ranks of this same command line through
+    torch.distributed.run as a CHILD process - before this process has imported torch or made any HIP call (it never
+    does: replacing a process that has initialised the GPU takes the box down, and nothing here needs to) -, pass the
+    child's output through and leave with its exit code.  A launch that already comes from torch.distributed.run (the
+    driver's own command: WORLD_SIZE is set) does not come through here."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sock:   # a free port of this host
+            sock.bind(("127.0.0.1", 0))
+            port = str(sock.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, str(pathlib.Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:   # rank 0's JSON line (and nothing else: the ranks' diagnostics go to stderr)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     args = parse()
     kt_env = kt_environment()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     env = Env(args)
     names = HEADLINE if args.workload == "headline" else (args.workload,)
     results = []

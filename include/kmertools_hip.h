@@ -348,6 +348,13 @@ int kt_sharded_table(kt_sharded *s, kt_ctr **table);
 /* bytes this rank has sent to other ranks so far */
 int kt_sharded_exchanged_bytes(kt_sharded *s, uint64_t *bytes);
 
+/* what carries the exchange: *n_ranks = the ranks this counter was created for; *rccl_ranks = what the library's own
+ * RCCL communicator reports (ncclCommCount on the communicator kt_sharded_connect_rccl made; 0 when the transport is the
+ * caller's host all-to-all or the counter has a single rank and no communicator); *transport = 0 none (one rank, no
+ * exchange), 1 librccl ncclSend / ncclRecv, 2 the caller's host all-to-all.  A benchmark line that claims N GPUs can
+ * show that RCCL saw N ranks.  (no reference counterpart: statistics) */
+int kt_sharded_comm_info(kt_sharded *s, int *n_ranks, int *rccl_ranks, int *transport);
+
 /* the rank that owns a canonical k-mer in this sharded table (host helper, the function the device uses) */
 int kt_sharded_owner_of(kt_sharded *s, uint64_t kmer, uint32_t *owner);
 

@@ -70,6 +70,7 @@ SYMBOLS = {
     "kt_sharded_finalize": (_i, [_vp]),
     "kt_sharded_table": (_i, [_vp, C.POINTER(_vp)]),
     "kt_sharded_exchanged_bytes": (_i, [_vp, C.POINTER(_u64)]),
+    "kt_sharded_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "kt_sharded_create_local": (_i, [_vp, _i, _u64, _u64, _i, _i, C.POINTER(_vp)]),
     "kt_sharded_connect_rccl": (_i, [_vp, _vp]),
     "kt_sharded_connect_host": (_i, [_vp, _vp, _vp]),

@@ -56,6 +56,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // (optional: statistics only)
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -78,6 +79,7 @@ int load_rccl(Rccl **out) {
             KT_SYM(GetUniqueId, "ncclGetUniqueId");
             KT_SYM(CommInitRank, "ncclCommInitRank");
             KT_SYM(CommDestroy, "ncclCommDestroy");
+            KT_SYM(CommCount, "ncclCommCount");
             KT_SYM(GroupStart, "ncclGroupStart");
             KT_SYM(GroupEnd, "ncclGroupEnd");
             KT_SYM(Send, "ncclSend");
@@ -491,6 +493,21 @@ int kt_sharded_clear(kt_sharded *s) {
 int kt_sharded_exchanged_bytes(kt_sharded *s, uint64_t *bytes) {
     if (!s || !bytes) return kt::fail(KT_ERR_ARG, "kt_sharded_exchanged_bytes: null");
     *bytes = s->exchanged_bytes;
+    return KT_OK;
+}
+
+int kt_sharded_comm_info(kt_sharded *s, int *n_ranks, int *rccl_ranks, int *transport) {
+    if (!s) return kt::fail(KT_ERR_ARG, "kt_sharded_comm_info: null");
+    if (n_ranks) *n_ranks = s->n_ranks;
+    if (transport) *transport = s->fn ? 2 : s->comm ? 1 : 0;
+    if (rccl_ranks) {
+        *rccl_ranks = 0;
+        if (s->comm && s->rccl && s->rccl->CommCount) {
+            int n = 0;
+            KT_NCCL(s->rccl, s->rccl->CommCount(s->comm, &n));
+            *rccl_ranks = n;
+        }
+    }
     return KT_OK;
 }
 

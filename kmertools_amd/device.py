@@ -510,3 +510,10 @@ class Sharded:
         n = C.c_uint64()
         check(_lib.lib().kt_sharded_exchanged_bytes(self._h, C.byref(n)))
         return n.value
+
+    def comm_info(self):
+        """-> dict(n_ranks, rccl_ranks, transport): rccl_ranks is ncclCommCount of the library's own communicator
+        (0 without one), transport "none" / "rccl" / "host" (kt_sharded_comm_info)"""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(_lib.lib().kt_sharded_comm_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"n_ranks": a.value, "rccl_ranks": b.value, "transport": ("none", "rccl", "host")[c.value]}

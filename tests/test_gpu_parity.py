@@ -1457,17 +1457,21 @@ def test_minimiser_python_surface(hctx, oracle):
         kt.MinimiserGenerator(seq, 3, 7)
 
 
-@pytest.mark.parametrize("workload,ranks,presplit", [("comp_oligo_k4", 2, False), ("ctr_k31", 2, False), ("ctr_k31", 8, True),
-                                                     ("ctr_k15", 3, False)])
-def test_bench_two_rank_launch(workload, ranks, presplit):
-    """bench.py through torch.distributed.run with several ranks (all on GPU 0, gloo collectives): the launch
-    contract the driver uses for --gpus N - one JSON line from rank 0, whole-job value, n_gpus = N.  Eight ranks:
-    the 8-GPU ownership intervals, 4 slices x 8 senders of sources per bucket and the pre-split pass (forced: at
-    this size level 2 could take all the bits), three ranks: buckets that do not divide evenly; bench.py's own
-    output check (the counts of all ranks sum to reads x (L - k + 1)) is what certifies the result"""
+@pytest.mark.parametrize("workload,ranks,presplit,plain", [("comp_oligo_k4", 2, False, False), ("ctr_k31", 2, False, True),
+                                                           ("ctr_k31", 8, True, True), ("ctr_k15", 3, False, False)])
+def test_bench_two_rank_launch(workload, ranks, presplit, plain):
+    """bench.py with several ranks (all on GPU 0, gloo collectives) - through torch.distributed.run, the launch contract
+    the driver uses for --gpus N, and (`plain`) typed as it stands, `python bench.py --gpus N`: bench.py then starts the
+    ranks itself as a child process (the plain command used to exit).  One JSON line from rank 0, whole-job
+    value, n_gpus = N.  Eight ranks: the 8-GPU ownership intervals, 4 slices x 8 senders of sources per bucket and the
+    pre-split pass (forced: at this size level 2 could take all the bits), three ranks: buckets that do not divide
+    evenly; bench.py's own output check (the counts of all ranks sum to reads x (L - k + 1)) is what certifies the
+    result.  ctr lines say what carried the exchange and how many bytes a rank sent per step."""
     import json, os, subprocess, sys, pathlib
     root = pathlib.Path(__file__).resolve().parents[1]
     env = dict(os.environ, KT_BENCH_SHARE_GPU="1", KT_BULK_MIN_BASES="0")
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(var, None)
     if presplit:
         env["KT_BULK_MAX_B2"] = "6"
     import socket
@@ -1475,9 +1479,12 @@ def test_bench_two_rank_launch(workload, ranks, presplit):
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
-           "--workload", workload, "--reads", "200000"]
+    tail = [str(root / "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--workload", workload, "--reads", "200000"]
+    if plain:
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -1489,6 +1496,9 @@ def test_bench_two_rank_launch(workload, ranks, presplit):
     if workload.startswith("ctr"):
         k = 31 if workload == "ctr_k31" else 15
         assert j["output_check"]["sum_of_counts"] == ranks * 200000 * (150 - k + 1)
+        # ranks that share a GPU exchange over the host transport (RCCL refuses two ranks on one device): no RCCL
+        # communicator, so no RCCL rank count - on N GPUs the line carries rccl_ranks == N or bench.py exits
+        assert j["transport"] == "host" and j["rccl_ranks"] == 0 and j["exchanged_bytes_per_rank"] > 0
 
 
 def test_alloc_placed_c_abi(torch_mod, ctx):

@@ -30,6 +30,10 @@ def test_header_symbols_exported(klib):
     # and the python binding covers all of them
     assert declared == set(klib.SYMBOLS), declared ^ set(klib.SYMBOLS)
     assert klib.lib().kt_version() >= 100
+    # ... and INTEGRATION.md shows the reference-side (Rust) binding line of every one of them
+    integ = (ROOT / "INTEGRATION.md").read_text()
+    unbound = [name for name in sorted(declared) if "pub fn %s(" % name not in integ]
+    assert not unbound, "INTEGRATION.md has no extern \"C\" line for %s" % unbound
 
 
 def test_host_helpers_match_oracle(klib, oracle):
