@@ -96,6 +96,8 @@ struct Plan {
     uint64_t room1;   // keys of room per level-1 bucket in keys2: cap1 x the number of level-1 outputs that feed it
     uint32_t d_lo, d_hi;  // the level-1 buckets whose ranges this table holds: all B1 of them, or - a shard - its interval
     uint32_t bx;          // hash bits a pre-split pass resolves between level 1 and level 2 (0: none; see finish_typed)
+    uint32_t nxs, xmap;   // level 1 with per-XCD cursors (scatter1x): log2 of the cursor sets, and which set a hardware
+                          // XCC_ID appends to (eight nibbles)
     uint32_t dbg;     // KT_BUILD_DBG: ablation switches of build_kernel (profiling only)
     uint32_t lists;   // the dense build's LDS has room for the claim lists behind the image (build_kernel)
 };
@@ -107,7 +109,10 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *H;        // [G][B1] k-mers of workgroup g in bucket d1
     uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
-    uint64_t *gcur;     // [slices][B1] paged level 1: keys of bucket room handed out so far (page allocator)
+    uint64_t *gcur;     // [slices][B1] paged level 1: keys of bucket room handed out so far (page allocator); with per-XCD
+                        // cursors: the bucket's extent, written by xcd_tails_kernel - either way what level 2 reads up to
+    unsigned long long *dump;  // [1024][2] where scatter1x's copy-out sends the stores that have nothing to write
+    unsigned long long *xcur;  // [slices][8][B1] per-XCD cursors: keys XCD set x has appended to bucket d (scatter1x)
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
     uint32_t *wcur;     // [slices][G][B1] paged level 1: every workgroup's position in its current page of every bucket
     kt_seg_src *srcs;   // [n_src + 1] part2's sources (device copy; the last one: the pre-split pass's output)
@@ -276,6 +281,17 @@ __device__ __forceinline__ void buf_take(K (&dst)[PER], K (&src)[PER]) {
 #undef KT_TAKE8
 }
 
+// wait for loads that are in flight into v[] and will never be used (a loop left early): the registers are INPUTS only, so
+// nothing is copied anywhere - the point is that they are not handed to anything else while a load still targets them
+template <class K, int PER>
+__device__ __forceinline__ void buf_drain(K (&v)[PER]) {
+    static_assert(PER % 8 == 0, "eight registers per asm statement");
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#pragma unroll
+    for (int u = 8; u < PER; u += 8)
+        asm volatile("" ::"v"(v[u]), "v"(v[u + 1]), "v"(v[u + 2]), "v"(v[u + 3]), "v"(v[u + 4]), "v"(v[u + 5]), "v"(v[u + 6]), "v"(v[u + 7]));
+}
+
 // inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS round trips): row_shr 1 / 2 / 4 / 8 inside the
 // rows of 16 lanes, then row_bcast:15 (lane 15 of rows 0 and 2 into rows 1 and 3) and row_bcast:31 (lane 31 into rows 2, 3)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
@@ -292,14 +308,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // call, two barriers, returns the total - in straight-line code: the wave's scan by DPP, the NT / 64 <= 16 wave totals
 // scanned inside one DPP row.  (The general routine's per-thread loops with a run-time trip count cost the partition
 // kernels a few hundred instructions and a dozen spilled registers per call.)
-template <int NT, int PB>
+// (RND = 2^r - 1: every counter is rounded up to a multiple of 2^r first - runs that start on 16-byte boundaries, scatter1x)
+template <int NT, int PB, uint32_t RND = 0>
 __device__ __forceinline__ uint32_t block_excl_scan_n(const uint32_t *cnt, uint32_t *out, uint32_t B, uint32_t *tmp) {
     static_assert(NT % 64 == 0 && NT / 64 <= 16, "wave totals fit one DPP row");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t c[PB], sum = 0;
 #pragma unroll
     for (int j = 0; j < PB; j++) {
-        c[j] = tid * PB + j < B ? cnt[tid * PB + j] : 0u;
+        c[j] = tid * PB + j < B ? (cnt[tid * PB + j] + RND) & ~RND : 0u;
         sum += c[j];
     }
     const uint32_t inc = wave_incl_scan(sum);
@@ -363,6 +380,19 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
         ktseg::stage_prefetched(a, seg_lo + g, sm, t, pf);
         return Walk{ktseg::Window(sm, t, a.k), 0u};
     }
+    // ... and with every read of a unit requested a unit ahead, from inline assembly (scatter1x: ktseg::prefetch_issue / _take)
+    using Pre2 = ktseg::SegPrefetch2;
+    using Taken = ktseg::SegTaken;
+    __device__ uint64_t first_of(uint64_t g) const { return ktd::load_uniform(a.seg_first + ktd::uniform64(seg_lo + g)); }
+    __device__ void prefetch_issue(Pre2 &pf, uint64_t g, uint64_t first_g, uint64_t g_next, uint32_t t, const void *safe) const {
+        ktseg::prefetch_issue(pf, a, seg_lo + g, first_g, seg_lo + g_next, t, safe);
+    }
+    template <int NSTORE>
+    __device__ void prefetch_take(Taken &tk, Pre2 &pf) const { ktseg::prefetch_take<NSTORE>(tk, pf); }
+    __device__ Walk open_taken(uint64_t g, uint64_t first_g, SegShared &sm, uint32_t t, const Taken &tk) const {
+        ktseg::stage_taken(a, seg_lo + g, first_g, sm, t, tk);
+        return Walk{ktseg::Window(sm, t, a.k), 0u};
+    }
     template <int N, class KR>  // KR = uint32_t when k <= 16: half the registers
     __device__ void take(Walk &wk, uint32_t, KR (&keys)[N], uint32_t &ok) const {
         ok = 0;
@@ -414,6 +444,13 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
     struct Pre {};
     __device__ Pre prefetch(uint64_t, uint32_t) const { return Pre{}; }
     __device__ Walk open_pre(uint64_t g, SegShared &sm, uint32_t t, const Pre &) const { return open(g, sm, t); }
+    struct Pre2 {};
+    struct Taken { uint64_t first_next; };
+    __device__ uint64_t first_of(uint64_t) const { return 0; }
+    __device__ void prefetch_issue(Pre2 &, uint64_t, uint64_t, uint64_t, uint32_t, const void *) const {}
+    template <int NSTORE>
+    __device__ void prefetch_take(Taken &tk, Pre2 &) const { tk.first_next = 0; }
+    __device__ Walk open_taken(uint64_t g, uint64_t, SegShared &sm, uint32_t t, const Taken &) const { return open(g, sm, t); }
     template <int N, class KR>
     __device__ void take(Walk &wk, uint32_t t, KR (&out)[N], uint32_t &ok) const {
         ok = 0;
@@ -710,6 +747,13 @@ struct PendList {
     uint64_t *distinct;  // its distinct-key counter
 };
 
+#if KT_ABLATION
+__device__ unsigned long long kt_dbg_phase[16];  // (timing builds: cycles of workgroup thread 0 per phase: [0, 8) build_kernel, [8, 16) scatter1w_kernel)
+#define KT_PH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phs[i] += (uint32_t)(t_ - tph); tph = t_; } while (0)
+#else
+#define KT_PH(i) do { } while (0)
+#endif
+
 constexpr int WIDE_T = 1024, WIDE_GROUPS = WIDE_T / BLOCK;
 #ifndef KT_WIDE_PER64
 #define KT_WIDE_PER64 16
@@ -762,9 +806,14 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
         const uint64_t gfirst = (uint64_t)blockIdx.x * WIDE_GROUPS;
         if (gfirst < n_units) pre = src.prefetch(unit_of(gfirst), t);
     }
+#if KT_ABLATION
+    unsigned long long tph = __builtin_readcyclecounter();
+    uint32_t phs[8] = {};
+#endif
     for (uint64_t g0 = (uint64_t)blockIdx.x * WIDE_GROUPS; g0 < n_units && !stop; g0 += stride) {
         const bool valid = g0 + grp < n_units;  // (a group past the end walks the last unit and keeps nothing)
         auto wk = src.open_pre(unit_of(g0), sm.seg[grp], t, pre);
+        KT_PH(0);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {  // (no early exit in here: the loop must stay unrolled)
             K keys[PER];
@@ -778,7 +827,9 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                 keys[j] = to_stored<K>((uint64_t)keys[j]);
                 if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>(keys[j]), p)], 1u);
             }
+            KT_PH(1);
             ktd::lds_barrier();
+            KT_PH(2);
             const uint32_t nk = block_excl_scan_n<WIDE_T, 1>(sm.cnt, sm.start, p.B1, sm.tmp);  // (B1 <= 1024: one counter per thread)
             // every bucket's run is laid out: what fits goes to the current page, the rest to new pages.  The
             // allocator's answer is only looked at after the placement pass, which hides its round trip.
@@ -800,7 +851,9 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                     sm.cur[d] = cur + c;
                 }
             }
+            KT_PH(3);
             ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
+            KT_PH(4);
 #pragma unroll
             for (int j = 0; j < PER; j++) {
                 if ((ok >> j) & 1u) {
@@ -809,6 +862,7 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                     sm.sorted[pos] = keys[j];
                 }
             }
+            KT_PH(5);
             if (room) {
                 if (got + room > p.cap1 && !pend.slots) {
                     sm.ovf = 1;
@@ -820,14 +874,21 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
                 sm.cur[tid] = g32 + nxt;
             }
             ktd::lds_barrier();
+            KT_PH(6);
             stop = sm.ovf != 0;  // the same for every thread
             if (q == NQ - 1 && g0 + stride < n_units) pre = src.prefetch(unit_of(g0 + stride), t);  // (the keys are placed: their registers are free)
+#if KT_ABLATION
+            if (p.dbg & 0x1000u) stop = true;  // (timing only: no copy-out at all; 0x2000: its stores dropped)
+#endif
             if (!stop) {
                 for (uint32_t i = tid; i < nk; i += WIDE_T) {
                     const K key = sm.sorted[i];
                     const uint32_t d = digit1h(hash_of_stored<K>(key), p);  // (one shift of a stored hash; 32-bit
                                                                             // keys are hashed again: no room for digits)
                     const uint32_t at = (i < sm.split[d] ? sm.to_cur[d] : sm.to_new[d]) + i;
+#if KT_ABLATION
+                    if ((p.dbg & 0x2000u) && key != (K)0x1234567u) continue;
+#endif
                     if (at < p.cap1) {
                         keys1[(uint64_t)d * p.cap1 + at] = key;
                     } else if (pend.slots) {  // the bucket's region is full: counted aside, delivered later
@@ -839,12 +900,307 @@ __global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, u
             }
             // the next round's count, scan and layout touch nothing the copy-out reads, and its placement comes three
             // barriers later: only the staging of a new segment (it shares LDS with the sort buffer) has to wait
+#if KT_ABLATION
+            if (p.dbg & 0x1000u) stop = false;
+#endif
             if (q == NQ - 1) ktd::lds_barrier();
+            KT_PH(7);
         }
     }
+#if KT_ABLATION
+    if (tid == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&kt_dbg_phase[8 + i], (unsigned long long)phs[i]);
+#endif
     ktd::lds_barrier();
     if (sm.ovf) return;
     if (tid < p.B1) wcur[(uint64_t)blockIdx.x * p.B1 + tid] = sm.cur[tid];
+}
+
+// ---- scatter1x: level 1 with ONE CURSOR PER BUCKET AND XCD (round 5) --------------------------------------------------
+// scatter1w's appends go through workgroup-private pages: the open line of a bucket is completed by the same workgroup a
+// round (~18 us) later, and 32 workgroups x 1024 buckets x 128 bytes of open lines are the whole 4 MB L2 of an XCD - the
+// lines leave the L2 half written: 31 GB of write requests for 24 GB of keys, at the 1.5-1.9 TB/s of partial granules
+// (tools/ubench/scatter_runs.hip), a third of the kernel's time and nothing else running meanwhile.  Here the workgroups
+// that share an L2 share the cursor: a workgroup takes its run's place with one returning atomic per (bucket, round) on
+// the cursor set of ITS XCD (the hardware's XCC_ID), so an XCD has B1 open lines (128 KB), a line is completed by its
+// neighbours within a microsecond, and the L2 evicts whole lines - tools/ubench/xcd_append.hip: 128-byte runs 1.85 ->
+// 4.6 TB/s, 64-byte runs 1.36 -> 4.0, the atomics themselves 0.4 ms per 8 GB (agent scope: correct whatever the
+// placement; the XCC_ID only decides which lines a cache shares).  Layout: a bucket's region is cut into lines of LK keys
+// dealt round-robin to the cursor sets - key q of set x lies at ((q / LK) * NX + x) * LK + q % LK - so a line is written
+// by one XCD only, the region stays ONE array for level 2 (and one message for the sharded counter), and what differs
+// between the sets' fills is padded with the empty key by xcd_tails_kernel (a few hundred keys per bucket and set).  No
+// pages, no state carried between launches but the cursors themselves, no split runs in the copy-out.
+// With the stores cheap, what is left is the phases' serial chain - so the workgroup is HALF the size (T = 512: two per CU,
+// 8 K 64-bit or 16 K 32-bit keys per round): the two run out of phase by themselves, one's front end under the other's
+// copy-out (the 64-byte runs that would have cost the private pages dearly cost the shared cursors nothing).
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+__global__ void xcc_census_kernel(uint32_t *mask) {
+    if (threadIdx.x == 0) atomicOr(mask, 1u << xcc_id());
+}
+
+#ifndef KT_S1X_T
+#define KT_S1X_T 1024
+#endif
+// keys of one 16-byte store (2 / 4): every bucket's run of a round starts on a multiple of it - in the sort buffer and in the
+// bucket's stream - and is padded to one with the empty key, so that a lane copies a GROUP with one 16-byte LDS read and one
+// 16-byte store.  Why: 8-byte stores per lane are bound by their ISSUE - ~7 bytes per clock and CU whatever the HBM could
+// take (MI355X_MICROARCH.md, the store-tail row; the same 7.3 here, in tools/ubench/xcd_append.hip and in the kernel's own
+// copy-out) - and a 16-byte store is issued in the time of an 8-byte one.  (4-byte keys stored one per lane were half as
+// fast again.)  The pads cost a few per cent of the keys' bytes (half a group per run), which level 2 skips as it
+// skips the regions' tails.
+template <class K>
+constexpr uint32_t group_keys() { return 16 / sizeof(K); }
+template <class K, int T>
+constexpr uint32_t s1x_slots() { return (uint32_t)T * wide_per<K>() + MAX_B1 * (group_keys<K>() - 1); }  // keys + pads of a round
+template <class K, int T>
+struct Scatter1XShared {
+    union {  // (the staged segments are dead once every thread has loaded its window words: open())
+        SegShared seg[T / BLOCK];
+        K sorted[s1x_slots<K, T>()];
+    };
+    uint32_t cnt[MAX_B1];
+    uint32_t start[MAX_B1];
+    uint32_t delta[MAX_B1];  // (the run's first place in its set's stream of the bucket) - (the run's start in sorted[])
+    uint32_t tmp[16];
+    uint32_t ovf;
+};
+static_assert(sizeof(Scatter1XShared<uint64_t, KT_S1X_T>) <= 160 * 1024 && sizeof(Scatter1XShared<uint32_t, KT_S1X_T>) <= 160 * 1024, "LDS of a CU");
+
+// where key q of cursor set x lies in its bucket's region
+template <class K>
+__device__ __forceinline__ uint64_t xcd_place(uint64_t q, uint32_t x, uint32_t nxs) {
+    constexpr uint32_t LSH = sizeof(K) == 8 ? 4 : 5;  // 16 / 32 keys per 128-byte line
+    return ((((q >> LSH) << nxs) | x) << LSH) | (q & ((1u << LSH) - 1u));
+}
+
+template <class Source, class K, int T>
+__global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, unsigned long long *__restrict__ xcur,
+                                                      uint32_t *__restrict__ ovf, K *__restrict__ keys1, PendList pend,
+                                                      unsigned long long *__restrict__ dump) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Scatter1XShared<K, T> &sm = *reinterpret_cast<Scatter1XShared<K, T> *>(smem_raw);
+    constexpr int PER = wide_per<K>(), NQ = ktseg::PER_THREAD / PER, GROUPS = T / BLOCK, PB = MAX_B1 / T;
+    constexpr uint32_t GK = group_keys<K>(), GSH = GK == 2 ? 1 : 2;
+    // 16-byte stores per thread and round: the round's keys + what the pads can add, in groups, over the threads
+    constexpr int NST = (int)((s1x_slots<K, T>() / GK + T - 1) / T);
+    constexpr K EMPTY = empty_of<K>();
+    typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+    const uint32_t tid = threadIdx.x, grp = tid / BLOCK, t = tid % BLOCK;
+    const uint32_t xset = (p.xmap >> (4u * xcc_id())) & 7u;
+    unsigned long long *const mycur = xcur + (size_t)xset * p.B1;
+#pragma unroll
+    for (int j = 0; j < PB; j++) sm.cnt[tid * PB + j] = 0;  // (every round leaves cnt zeroed for the next one)
+    if (tid == 0) sm.ovf = 0;
+    const uint64_t n_units = src.n_units();
+    bool stop = false;
+    const uint64_t stride = (uint64_t)gridDim.x * GROUPS;
+    auto unit_of = [&](uint64_t g0) { return g0 + grp < n_units ? g0 + grp : n_units - 1; };
+    // Every global read of a unit is requested while the unit before it is still being counted - its bases, the thread's
+    // first read start, and seg_first of the unit after (ktseg::prefetch_issue) - BEFORE the stores of that unit's last
+    // copy-out, and taken behind them with s_waitcnt vmcnt(NST): the reads have landed, the NST stores stay in flight.
+    // For that the copy-out issues exactly NST stores on every path - a group past the end of the round, or past its
+    // region's room, is stored to a dump line instead of being skipped.
+    typename Source::Pre2 pre;
+    typename Source::Taken tk{};
+    uint64_t first_cur = 0;
+    {
+        const uint64_t gfirst = (uint64_t)blockIdx.x * GROUPS;
+        if (gfirst < n_units) {
+            first_cur = src.first_of(unit_of(gfirst));
+            src.prefetch_issue(pre, unit_of(gfirst), first_cur, unit_of(gfirst + stride), t, dump);
+            src.template prefetch_take<0>(tk, pre);
+        }
+    }
+#if KT_ABLATION
+    unsigned long long tph = __builtin_readcyclecounter();
+    uint32_t phs[8] = {};
+#endif
+    for (uint64_t g0 = (uint64_t)blockIdx.x * GROUPS; g0 < n_units && !stop; g0 += stride) {
+        const bool valid = g0 + grp < n_units;  // (a group past the end walks the last unit and keeps nothing)
+        auto wk = src.open_taken(unit_of(g0), first_cur, sm.seg[grp], t, tk);
+        const uint64_t first_next = tk.first_next;
+        KT_PH(0);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {  // (no early exit in here: the loop must stay unrolled)
+            // (the thread index, opaque per round: nothing derived from it - bucket addresses, the cursors' addresses, the
+            // copy-out's indices - is carried across the loop in registers the kernel does not have)
+            uint32_t tl = tid;
+            asm volatile("" : "+v"(tl));
+            K keys[PER];
+            uint32_t ok;
+            src.template take<PER, K>(wk, tl % BLOCK, keys, ok);
+            if (!valid) ok = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
+                keys[j] = to_stored<K>((uint64_t)keys[j]);
+                if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>(keys[j]), p)], 1u);
+            }
+            KT_PH(1);
+            ktd::lds_barrier();
+            KT_PH(2);
+            // the runs of the round in sorted[], every one starting on a group boundary: nk = the slots they take, pads included
+            const uint32_t nk = block_excl_scan_n<T, PB, GK - 1>(sm.cnt, sm.start, p.B1, sm.tmp);
+            // every bucket's run takes its place in the XCD's stream of the bucket: one returning atomic, whose answer is
+            // only looked at behind the placement pass (which hides the round trip)
+            unsigned long long got[PB];
+            uint32_t rc[PB], rs[PB];
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                // (no branch around the atomic - a bucket beyond B1, or without keys this round, adds 0 to a cursor of the
+                // set: under a condition the compiler waits for the answer where the branches meet, i.e. at once, and the
+                // round trip it was meant to hide behind the placement pass is paid in full - measured: a fifth of the kernel)
+                const uint32_t d = tl * PB + j, dc = d & (p.B1 - 1u);
+                rc[j] = d < p.B1 ? sm.cnt[dc] : 0u;
+                rs[j] = sm.start[dc];
+                if (d < p.B1) sm.cnt[d] = 0;  // for the next round's count
+                got[j] = __hip_atomic_fetch_add(&mycur[dc], (unsigned long long)((rc[j] + GK - 1u) & ~(GK - 1u)), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+            }
+            KT_PH(3);
+            ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
+            KT_PH(4);
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                if ((ok >> j) & 1u) {
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
+                    const uint32_t pos = atomicAdd(&sm.start[d], 1u);
+                    sm.sorted[pos] = keys[j];
+                }
+            }
+            KT_PH(5);
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                if (rc[j]) {
+                    // what a run lacks to its last group is the empty key (nobody else writes these slots: the placement's
+                    // cursor stops at the run's last key)
+                    for (uint32_t e = rc[j]; e & (GK - 1u); e++) sm.sorted[rs[j] + e] = EMPTY;
+                    // (a stream far past its room - a sender's heavy-hitter bucket - must not wrap back into it)
+                    const uint32_t q0 = got[j] > 0xE0000000ull ? 0xE0000000u : (uint32_t)got[j];
+                    sm.delta[tl * PB + j] = q0 - rs[j];
+                    if (!pend.slots && xcd_place<K>((uint64_t)q0 + rc[j] - 1u, xset, p.nxs) >= p.cap1) {
+                        sm.ovf = 1;
+                        atomicOr(ovf, 1u);
+                    }
+                }
+            }
+            ktd::lds_barrier();
+            KT_PH(6);
+            stop = sm.ovf != 0;  // the same for every thread
+            const bool nxt = q == NQ - 1 && g0 + stride < n_units;  // (workgroup uniform)
+            if (nxt) {  // (the keys are placed: their registers are free)
+                uint32_t tq = tl;  // (opaque again: what the prefetch derives from the thread index is made here, not kept from the round's top)
+                asm volatile("" : "+v"(tq));
+                src.prefetch_issue(pre, unit_of(g0 + stride), first_next, unit_of(g0 + 2 * stride), tq % BLOCK, dump);
+            }
+            bool skip = stop;
+#if KT_ABLATION
+            if (p.dbg & 0x3000u) skip = true;  // (timing only - 0x1000: no copy-out at all; 0x2000: its stores dropped)
+#endif
+            bool over = false;
+            raw4 *const mydump = reinterpret_cast<raw4 *>(dump) + tl;
+            // group m of the round = slots [m GK, m GK + GK) of sorted[]: one bucket's keys (runs start on group boundaries),
+            // the first of them a key, what follows a pad at most
+            auto group_at = [&](uint32_t m, bool &live, uint32_t &d, uint64_t &at) {
+                const uint32_t i = m << GSH;
+                live = i < nk;
+                const K first = sm.sorted[live ? i : 0u];
+                d = digit1h(hash_of_stored<K>(first), p);  // (one shift of a stored hash; 32-bit keys are hashed again)
+                at = xcd_place<K>((uint64_t)(uint32_t)(sm.delta[d] + i), xset, p.nxs);
+            };
+            if (!skip) {
+                // copy-out, NST groups per thread: one 16-byte LDS read, one 16-byte store each
+#pragma unroll
+                for (int u = 0; u < NST; u++) {
+                    const uint32_t m = tl + (uint32_t)u * T;
+                    bool live;
+                    uint32_t d;
+                    uint64_t at;
+                    group_at(m, live, d, at);
+                    const raw4 v = *reinterpret_cast<const raw4 *>(&sm.sorted[live ? m << GSH : 0u]);
+                    const bool fits = live && at < p.cap1;
+                    over |= live && at >= p.cap1;
+                    raw4 *const dst = fits ? reinterpret_cast<raw4 *>(keys1 + ((uint64_t)d * p.cap1 + at)) : mydump;  // (one store on every path)
+                    *dst = v;
+                }
+                if (nxt) src.template prefetch_take<NST>(tk, pre);
+            } else {
+#if KT_ABLATION
+                if ((p.dbg & 0x2000u) && !stop) {  // (the copy-out's LDS side without its stores)
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int u = 0; u < NST; u++) {
+                        bool live;
+                        uint32_t d;
+                        uint64_t at;
+                        group_at(tl + (uint32_t)u * T, live, d, at);
+                        acc += d + (uint32_t)at;
+                    }
+                    if (acc == 0x1234567u) mydump->x = acc;
+                }
+#endif
+                if (nxt) src.template prefetch_take<0>(tk, pre);
+            }
+            if (nxt) first_cur = first_next;
+            if (over && pend.slots) {
+                // the keys whose bucket's region is full (a sender's skewed batch): counted aside, delivered later - a pass
+                // of its own over the round (sorted[] and delta[] stand until the next placement), behind the take, so that
+                // the copy-out itself has no branch and a fixed number of stores
+#pragma unroll 1
+                for (int u = 0; u < NST; u++) {
+                    const uint32_t m = tl + (uint32_t)u * T;
+                    bool live;
+                    uint32_t d;
+                    uint64_t at;
+                    group_at(m, live, d, at);
+                    if (!live) break;
+                    if (at < p.cap1) continue;
+                    for (uint32_t e = 0; e < GK; e++) {
+                        const K key = sm.sorted[(m << GSH) + e];
+                        if (key == EMPTY) break;
+                        const uint32_t st = kttab::table_add(TableRef{pend.slots, pend.g, pend.flags}, from_stored<K>(key), 1u);
+                        if (st == 0u) atomicOr(pend.flags, 1u);
+                        else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(pend.distinct), 1ull);
+                    }
+                }
+            }
+            // the next round's count, scan and layout touch nothing the copy-out reads (delta[] is written behind the next
+            // placement, two barriers on); only the staging of a new segment (it shares LDS with the sort buffer) has to wait
+            if (q == NQ - 1) ktd::lds_barrier();
+            KT_PH(7);
+        }
+    }
+#if KT_ABLATION
+    if (tid == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&kt_dbg_phase[8 + i], (unsigned long long)phs[i]);
+#endif
+}
+
+// after the last source of a job (or of a slice): a bucket's region is read up to its EXTENT - the lines of the fullest
+// cursor set, times the sets - so what the other sets have not filled of their lines up to there gets the empty key
+// (level 2 skips it), and the extent goes where level 2 and the sharded counter's messages look for the bucket's key count
+template <class K>
+__global__ __launch_bounds__(BLOCK) void xcd_tails_kernel(Plan p, const unsigned long long *__restrict__ xcur,
+                                                          uint64_t *__restrict__ extent, K *__restrict__ keys1) {
+    constexpr uint32_t LSH = sizeof(K) == 8 ? 4 : 5, LK = 1u << LSH;
+    const uint32_t NX = 1u << p.nxs;
+    const uint64_t set_room = (p.cap1 >> (LSH + p.nxs)) << LSH;  // keys a set can place in a region
+    for (uint32_t d = blockIdx.x; d < p.B1; d += gridDim.x) {
+        uint64_t c[8], top = 0;
+        for (uint32_t x = 0; x < NX; x++) {
+            const uint64_t v = xcur[(size_t)x * p.B1 + d];
+            c[x] = v < set_room ? v : set_room;  // (what went past the room was parked or made the pass stop)
+            const uint64_t lines = (c[x] + LK - 1) >> LSH;
+            top = lines > top ? lines : top;
+        }
+        for (uint32_t x = 0; x < NX; x++)
+            for (uint64_t q = c[x] + threadIdx.x; q < (top << LSH); q += BLOCK)
+                keys1[(uint64_t)d * p.cap1 + xcd_place<K>(q, x, p.nxs)] = empty_of<K>();
+        if (threadIdx.x == 0) extent[d] = (top << LSH) << p.nxs;
+    }
 }
 
 // after the last source of a job: the unused tail of every workgroup's last page of every bucket gets the empty key
@@ -1504,6 +1860,9 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
                 ktd::lds_barrier();
                 if (sm.flags[2] != 0) {  // (raised by a flush before the barrier above: the same for every thread)
                     failed = true;
+                    // the next chunk's loads are in flight into knext: they land before the loop is left - with fewer workgroups
+                    // than buckets (KT_P2_GRID) the kernel goes on to its next bucket and loads into the same registers
+                    if (more) buf_drain(knext);
                     break;
                 }
                 const uint64_t sn = seen + c0 + CH;
@@ -1600,12 +1959,6 @@ constexpr int BUILD_T = KT_BUILD_T;
 // claim lists of a dense build: the slot of every key a wave has placed first, in the order it placed them - three keys per
 // lane at most (a range of up to 3072 keys; ranges of hashed distinct keys hold ~2900)
 constexpr uint32_t LIST_CAP = 192, LIST_KEYS = LIST_CAP * (BUILD_T / 64);
-#if KT_ABLATION
-__device__ unsigned long long kt_dbg_phase[16];  // (timing builds: cycles of workgroup thread 0 per phase of build_kernel)
-#define KT_PH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phs[i] += (uint32_t)(t_ - tph); tph = t_; } while (0)
-#else
-#define KT_PH(i) do { } while (0)
-#endif
 
 template <class K>
 struct lds_word;
@@ -2326,7 +2679,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1x;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2338,6 +2691,7 @@ static BulkKnobs read_knobs() {
     k.paged = env_u64("KT_BULK_PAGED", 1);
     k.fixed2 = env_u64("KT_BULK_FIXED2", 1);
     k.s1_wide = env_u64("KT_S1_WIDE", 1);
+    k.s1x = env_u64("KT_S1X", 1);  // level 1 with per-XCD cursors (scatter1x_kernel); 0: workgroup-private pages (scatter1w / scatter1p)
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
     k.p2_grid = env_u64("KT_P2_GRID", 0);  // workgroups of the level-2 launch (0: one per bucket)
@@ -2352,7 +2706,7 @@ static BulkKnobs read_knobs() {
     // hash bits level 2 takes: 10 - what part2_swwc_kernel's one line per fine bucket fits into the LDS (the sort-buffer
     // kernels take 11); shards that need more get the pre-split pass.  (tests: smaller, so that small shards need it too)
     k.max_b2 = env_u64("KT_BULK_MAX_B2", 10);
-    if (k.max_b2 < 1 || k.max_b2 > 11) k.max_b2 = 11;
+    if (k.max_b2 < 1 || k.max_b2 > 11) k.max_b2 = 10;  // (an invalid value: the default)
     k.ext_ovf_blocks = env_u64("KT_EXT_OVF_BLOCKS", 0);  // tests: n + 1 = blocks of scratch behind the export target
     return k;
 }
@@ -2363,6 +2717,7 @@ struct kt_bulk_job {
     Meta m{};
     bool narrow = false;  // 32-bit keys through the partition passes (k <= 16)
     bool paged = false, merge = false, open = false;
+    bool xcd = false;  // paged level 1 appends through per-XCD cursors (scatter1x_kernel + xcd_tails_kernel)
     uint64_t max_keys = 0, added_bound = 0;
     std::vector<SourceRec> srcs;
     // level 1 in slices (the sharded counter, kt_shard.hip): slice i writes the level-1 output i of b_keys1 (B1 regions of
@@ -2386,6 +2741,25 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice
     sm_.gcur = j.m.gcur + (size_t)slice * j.p.B1;
     sm_.wcur = j.m.wcur + (size_t)slice * j.p.G * j.p.B1;
     struct { Meta m; } jj{sm_};
+    if (j.xcd) {
+        constexpr int T = KT_S1X_T;
+        unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;
+        const uint32_t wgs = (uint32_t)ctx->n_cu * (1024 / T) * (uint32_t)(j.kn.g_mult ? j.kn.g_mult : 1);
+        const size_t lds = sizeof(Scatter1XShared<K, T>);
+        if (r.reads) {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1x_kernel<ReadsSource, K, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((scatter1x_kernel<ReadsSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.rs, j.p, xcur,
+                               jj.m.ovf, keys1, j.pend, j.m.dump);
+        } else {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1x_kernel<KeysSource, K, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((scatter1x_kernel<KeysSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.ks, j.p, xcur,
+                               jj.m.ovf, keys1, j.pend, j.m.dump);
+        }
+        KT_HIP(hipGetLastError());
+        return KT_OK;
+    }
     if (j.kn.s1_wide || j.sharded) {
         const uint32_t wgs = j.p.G / 2 ? j.p.G / 2 : 1;  // one resident workgroup per CU (its rows of wcur are [0, wgs))
         const size_t lds = sizeof(Scatter1WShared<K>);
@@ -2452,7 +2826,8 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     Meta &m = j.m;
     K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
     if (j.paged && !j.sharded) {
-        hipLaunchKernelGGL(page_tails_kernel<K>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, p, m.wcur, keys1);
+        if (j.xcd) hipLaunchKernelGGL(xcd_tails_kernel<K>, dim3(p.B1), dim3(BLOCK), 0, ctx->stream, p, (const unsigned long long *)m.xcur, m.gcur, keys1);
+        else hipLaunchKernelGGL(page_tails_kernel<K>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, p, m.wcur, keys1);
         // the one host round trip of the build: did every bucket fit its region?
         uint32_t ovf = 0;
         KT_HIP(hipMemcpyAsync(&ovf, m.ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2684,6 +3059,44 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
 
 }  // namespace
 
+// The cursor sets of scatter1x: one per XCD that runs workgroups of this context's device.  A census launch (once per
+// context) notes which XCC_IDs there are; id -> set is their rank, the number of sets the next power of two (a device
+// in a partitioned mode may show one XCD: one set then, and a region is one plain stream).
+static int xcc_sets(kt_ctx *ctx, uint32_t *nxs, uint32_t *xmap) {
+    if (!ctx->xcc_n) {
+        if (int rc = ctx->s_aux2.reserve(256)) return rc;
+        uint32_t *mask = (uint32_t *)ctx->s_aux2.p, h = 0;
+        KT_HIP(hipMemsetAsync(mask, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(xcc_census_kernel, dim3((uint32_t)ctx->n_cu * 4), dim3(64), 0, ctx->stream, mask);
+        KT_HIP(hipGetLastError());
+        KT_HIP(hipMemcpyAsync(&h, mask, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+        if (!(h & 0xFFu)) h = 1;
+        uint32_t n = 0, map = 0;
+        for (uint32_t id = 0; id < 8; id++)
+            if (h >> id & 1u) map |= (n++) << (4 * id);
+        ctx->xcc_n = n;
+        ctx->xcc_map = map;
+    }
+    uint32_t b = 0;
+    while ((1u << b) < ctx->xcc_n) b++;
+    if (const char *e = getenv("KT_S1X_SETS")) {  // (experiments / tests: fewer sets than XCDs - ids fold onto them)
+        const uint32_t want = (uint32_t)atoi(e);
+        uint32_t wb = 0;
+        while ((1u << wb) < want && wb < 3) wb++;
+        if (wb < b) {
+            uint32_t map = 0;
+            for (uint32_t id = 0; id < 8; id++) map |= (((ctx->xcc_map >> (4 * id)) & 7u) & ((1u << wb) - 1u)) << (4 * id);
+            *nxs = wb;
+            *xmap = map;
+            return KT_OK;
+        }
+    }
+    *nxs = b;
+    *xmap = ctx->xcc_map;
+    return KT_OK;
+}
+
 // Plans the partition of at most `max_keys` k-mers into the table's ranges and reserves the buffers.  *eligible = 0:
 // the table shape or the batch does not suit the bulk path (or HBM is short) and the caller uses the probing path.
 // slice_keys: the most k-mers one level-1 output (slice) takes; n_slices of them; n_src: level-1 outputs that feed one
@@ -2702,6 +3115,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     if (!ctr->job) ctr->job = new (std::nothrow) kt_bulk_job();
     if (!ctr->job) return kt::fail(KT_ERR_NOMEM, "bulk build: host alloc");
     kt_bulk_job &j = *ctr->job;
+    ctr->stage_n = 0;  // (a job changes the table - the sharded counter's adds come through here: kt_ctr_export_stage's entries are stale)
     j.kn = kn;
     j.open = false;
     j.srcs.clear();
@@ -2757,7 +3171,11 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     bool paged = (kn.paged != 0 && !ctr->paged_failed) || sharded;
     const uint64_t PAGE = KT_PAGE_BYTES / ksz;
     // (rounded to a multiple of 128 keys: every region starts on a cache line, whatever the key size)
-    uint64_t cap1 = (slice_keys / p.B1 + slice_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + 127) / 128 * 128;
+    // (per-XCD cursors: no pages; the room beyond the keys' share covers the sets' uneven fills - every set's lines reach as
+    // far as the fullest set's - and the same 1/8 for the hash's own spread; a multiple of 8 sets x 32 keys)
+    const bool xcd = paged && kn.s1x != 0;
+    uint64_t cap1 = xcd ? (slice_keys / p.B1 + slice_keys / p.B1 / 8 + 16 * 256 + 255) / 256 * 256
+                        : (slice_keys / p.B1 + slice_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + 127) / 128 * 128;
     const uint64_t room1 = cap1 * n_src;
     if (room1 * ksz >= (1ull << 31)) {  // (part2 addresses a bucket's fixed regions through 32-bit buffer offsets)
         if (sharded) return kt::fail(KT_ERR_ARG, "sharded counter: batch too large for its level-1 regions (lower max_batch_bases)");
@@ -2778,11 +3196,13 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const size_t off_fs = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fe = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_gc = meta;      meta += ((size_t)n_slices * p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_xc = meta + 0;  meta += ((size_t)n_slices * 8 * p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_du = meta;      meta += 1024 * 16;
     const size_t off_sr = meta;      meta += ((size_t)(n_src + 1) * sizeof(kt_seg_src) + 255) & ~(size_t)255;
     const size_t n_sub = (size_t)nd << p.bx;  // pre-split: sub-bucket bounds and sizes
     const size_t off_xs = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_xe = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
-    const size_t off_xc = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
+    const size_t off_xn = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_ov = meta;      meta += 256;
     const size_t off_fl = meta;      meta += ((n_sub + 1) * 4 + 255) & ~(size_t)255;
     const size_t off_sn = meta;      meta += 256;
@@ -2819,7 +3239,9 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.srcs = (kt_seg_src *)(mb + off_sr);
     m.xstart = (uint64_t *)(mb + off_xs);
     m.xend = (uint64_t *)(mb + off_xe);
-    m.xcount = (uint64_t *)(mb + off_xc);
+    m.xcount = (uint64_t *)(mb + off_xn);
+    m.xcur = (unsigned long long *)(mb + off_xc);
+    m.dump = (unsigned long long *)(mb + off_du);
     m.ovf = (uint32_t *)(mb + off_ov);
     m.fail = (uint32_t *)(mb + off_fl);
     m.spill_n = (uint64_t *)(mb + off_sn);
@@ -2834,7 +3256,19 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)n_slices * p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)n_slices * p.G * p.B1 * 4, ctx->stream));
+        if (xcd) {
+            if (int rc = xcc_sets(ctx, &p.nxs, &p.xmap)) return rc;
+            // (a batch of a few dozen units does not spread evenly over the XCDs - a handful of workgroups, some XCDs with
+            // one more than others - and a set's share of a region is only an eighth of it: such batches append through
+            // one set; what the sets buy, whole lines out of the L2, is nothing they would notice)
+            if (slice_keys < (16ull << 20) && !getenv("KT_S1X_SETS")) {
+                p.nxs = 0;
+                p.xmap = 0;
+            }
+            KT_HIP(hipMemsetAsync(m.xcur, 0, (size_t)n_slices * 8 * p.B1 * 8, ctx->stream));
+        }
     }
+    j.xcd = paged && xcd;
     j.p = p;
     j.m = m;
     j.paged = paged;
@@ -2887,6 +3321,16 @@ int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice) {
     const Plan &p = job->p;
     const uint32_t *wcur = job->m.wcur + (size_t)slice * p.G * p.B1;
     char *keys1 = (char *)ctr->b_keys1.p + (size_t)slice * p.B1 * p.cap1 * job->ksz();
+    if (job->xcd) {
+        const unsigned long long *xcur = job->m.xcur + (size_t)slice * 8 * p.B1;
+        uint64_t *extent = job->m.gcur + (size_t)slice * p.B1;
+        if (job->narrow)
+            hipLaunchKernelGGL(xcd_tails_kernel<uint32_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint32_t *)keys1);
+        else
+            hipLaunchKernelGGL(xcd_tails_kernel<uint64_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint64_t *)keys1);
+        KT_HIP(hipGetLastError());
+        return KT_OK;
+    }
     if (job->narrow)
         hipLaunchKernelGGL(page_tails_kernel<uint32_t>, dim3(p.G), dim3(BLOCK), 0, ctr->ctx->stream, p, wcur, (uint32_t *)keys1);
     else

@@ -379,6 +379,8 @@ int kt_ctr_destroy(kt_ctr *ctr) {
     if (ctr->distinct) (void)hipFree(ctr->distinct);
     if (ctr->range_counts) (void)hipFree(ctr->range_counts);
     ctr->b_ext.release();
+    ctr->b_stage_k.release();
+    ctr->b_stage_c.release();
     ctr->b_keys1.release();
     ctr->b_keys2.release();
     ctr->b_meta.release();
@@ -429,6 +431,7 @@ int kt_ctr_export_target(kt_ctr *ctr, uint64_t *keys_dev, uint32_t *counts_dev, 
     ctr->xt_keys = keys_dev;
     ctr->xt_counts = counts_dev;
     ctr->xt_max = keys_dev ? max_out : 0;
+    ctr->stage_n = 0;  // (what was staged may have been the old target's arrays)
     return KT_OK;
 }
 
@@ -441,6 +444,7 @@ int kt_ctr_add_reads_part(kt_ctr *ctr, const uint8_t *bases, const uint64_t *off
     if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads: null ctr");
     if (n_parts < 1 || part >= n_parts) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads_part: need part < n_parts");
     if (n_reads == 0) return KT_OK;
+    ctr->stage_n = 0;  // the table changes: what kt_ctr_export_stage staged is no longer the table (fetch says so)
     if (!offsets) return kt::fail(KT_ERR_ARG, "kt_ctr_add_reads: null offsets");
     kt_ctx *ctx = ctr->ctx;
     if (int rc = ctx->use()) return rc;
@@ -479,6 +483,7 @@ int kt_ctr_add_pairs(kt_ctr *ctr, const uint64_t *keys, const uint32_t *counts, 
     if (!ctr) return kt::fail(KT_ERR_ARG, "kt_ctr_add_pairs: null ctr");
     if (n == 0) return KT_OK;
     if (!keys) return kt::fail(KT_ERR_ARG, "kt_ctr_add_pairs: null keys");
+    ctr->stage_n = 0;  // (see kt_ctr_add_reads_part)
     kt_ctx *ctx = ctr->ctx;
     if (int rc = ctx->use()) return rc;
     const uint64_t *d_keys = keys;
@@ -633,13 +638,15 @@ int kt_ctr_export_stage(kt_ctr *ctr, uint64_t *n_out) {
             ctr->stage_keys = ctr->xt_keys;
             ctr->stage_counts = ctr->xt_counts;
         } else {
-            if (int rc = ctx->s_aux1.reserve(n * 8)) return rc;
-            if (int rc = ctx->s_aux2.reserve(n * 4)) return rc;
+            // (the table's own staging buffers - the context's scratch is re-reserved by any other call on the context:
+            // host-memory adds and exports, routing, cov, minimisers - ADVICE r4)
+            if (int rc = ctr->b_stage_k.reserve(n * 8)) return rc;
+            if (int rc = ctr->b_stage_c.reserve(n * 4)) return rc;
             uint64_t got = 0;
-            if (int rc = kt_ctr_export(ctr, (uint64_t *)ctx->s_aux1.p, (uint32_t *)ctx->s_aux2.p, n, &got, KT_MEM_DEVICE)) return rc;
+            if (int rc = kt_ctr_export(ctr, (uint64_t *)ctr->b_stage_k.p, (uint32_t *)ctr->b_stage_c.p, n, &got, KT_MEM_DEVICE)) return rc;
             n = got;
-            ctr->stage_keys = (const uint64_t *)ctx->s_aux1.p;
-            ctr->stage_counts = (const uint32_t *)ctx->s_aux2.p;
+            ctr->stage_keys = (const uint64_t *)ctr->b_stage_k.p;
+            ctr->stage_counts = (const uint32_t *)ctr->b_stage_c.p;
         }
     }
     ctr->stage_n = n;

@@ -126,6 +126,16 @@ __device__ __forceinline__ double quot_f64(double c, double d, double y) {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// A load through the SCALAR cache: p must be the same in every lane of the wave (the caller makes it so: uniform64) and
+// point at memory nothing writes while the kernel runs.  Read as constant-address-space memory, which is what makes the
+// compiler take the scalar path - a wave-uniform load of ordinary global memory stays a vector load whenever the
+// kernel also stores (it cannot rule out a clobber), and a vector load's wait drains the wave's stores in flight.
+template <class T>
+__device__ __forceinline__ T load_uniform(const T *p) {
+    typedef const T __attribute__((address_space(4))) *cptr;
+    return *(cptr)(uintptr_t)p;
+}
+
 // uniform (scalar) broadcast of a 64-bit value held by all lanes
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);

@@ -36,6 +36,7 @@ struct kt_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cu = 256;
+    uint32_t xcc_n = 0, xcc_map = 0;  // XCDs that run this device's workgroups, XCC_ID -> dense index in nibbles (kt_bulk.hip's census)
     // device copies of the canonical-bin LUT (u16[4^k], lut[f] = 4 * rank(min(f, rc f)): the byte offset of the
     // bin's u32 counter inside a row), k = 1..7
     uint16_t *lut_dev[kt::KT_MAX_OLIGO_K + 1] = {};
@@ -111,6 +112,7 @@ struct kt_ctr {
     uint64_t stage_n = 0;
     bool xt_too_small = false;         // the last build found the export target smaller than the table (reported by kt_bulk_finish)
     kt::Scratch b_ext;                 // the export-target build's holes and the scratch behind the caller's arrays
+    kt::Scratch b_stage_k, b_stage_c;  // kt_ctr_export_stage's copy of the entries (when they are not the export target's arrays)
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls
     kt_bulk_job *job = nullptr;
     void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}

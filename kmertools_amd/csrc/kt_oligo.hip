@@ -1036,7 +1036,9 @@ static int oligo_launch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offse
     // a stream that is being captured into a graph takes no event records and no event queries: such launches run with
     // what has been decided for the array so far (or the default) and take no part in the measurement
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool capturing = hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+    const hipError_t cap_rc = hipStreamIsCapturing(ctx->stream, &cap);
+    if (cap_rc != hipSuccess) (void)hipGetLastError();  // (the query's failure must not surface as the launch's: the launch just does not measure)
+    const bool capturing = cap_rc != hipSuccess || cap != hipStreamCaptureStatusNone;
     if (k == 4 && !kn.oversub && kn.tune && (tn.paused || capturing)) {
         const kt_ctx::OligoTune::Entry *e = tune_find(tn, out);
         if (tn.forced) per_slot = tn.forced;

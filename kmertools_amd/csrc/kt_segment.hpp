@@ -18,6 +18,7 @@
 #include "kt_device.hpp"
 
 namespace ktseg {
+using ktd::uniform64;
 
 constexpr int BLOCK = 256;
 constexpr uint32_t PER_THREAD = 32;
@@ -199,6 +200,144 @@ __device__ __forceinline__ void stage_prefetched(const SegArgs &a, uint64_t g, S
             if (o >= lim) break;
             const uint32_t rel = (uint32_t)(o - B0);
             atomicOr(&sm.bnd[rel >> 5], 1u << (rel & 31u));
+        }
+    }
+    ktd::lds_barrier();
+}
+
+// ---- the same, with EVERY global read of a unit requested a unit ahead (round 5: kt_bulk.hip's scatter1x) --------------
+// stage_prefetched still starts with a read the thread has to wait for - its first read start, offsets[seg_first[g] + tid] -
+// and that read is YOUNGER than the stores of the previous unit's copy-out: a wave's memory operations complete in issue
+// order, so the wait drains the wave's whole store queue at every unit (the k = 7 lesson of kt_oligo.hip); and the
+// compiler waits vmcnt(0) for the prefetched bases as well - it cannot count the stores issued behind them through the
+// copy-out's control flow.  Here a unit's prefetch carries the bases of unit g, the thread's first read start of unit g
+// (seg_first[g] is known: it came with the prefetch before) and seg_first of the unit after - requested BEFORE the
+// copy-out's stores, from inline assembly (the compiler inserts no wait for what it does not know about), and taken
+// behind them with s_waitcnt vmcnt(number of stores): every read has landed, the stores stay in flight.
+// Rules (the same as kt_bulk.hip's buf_load8_async / buf_take; tools/check_inflight.py reads the assembly at build
+// time): nothing touches the in-flight registers between prefetch_issue and prefetch_take; exactly `NSTORE` vector
+// memory operations are issued between the two on every path; no scratch in the kernel.
+struct SegHalo { uint32_t d[8]; };
+struct SegPrefetch2 {
+    uint64_t a[4];         // item tid of unit g: bases [32 tid, 32 tid + 32) - in flight until prefetch_take
+    uint64_t o0;           // offsets[first(g) + tid] - in flight
+    SegHalo halo;          // the halo item (BLOCK): the same for the whole group, read through the scalar cache
+    uint64_t first_next;   // seg_first of the unit that will be prefetched next (scalar cache)
+    bool whole0, whole1, has_o;  // the item lies wholly inside the batch / the read exists (else: not loaded)
+};
+
+// (`safe`: 32 readable bytes - a lane that has nothing to read reads them instead, so that the loads are issued
+// unconditionally: an asm statement under a condition makes its outputs phi nodes, which the allocator copies at will)
+__device__ __forceinline__ void prefetch_issue(SegPrefetch2 &pf, const SegArgs &a, uint64_t g, uint64_t first_g,
+                                               uint64_t g_next, const uint32_t tid, const void *safe) {
+    const uint64_t total = ktd::load_uniform(a.offsets + a.n_reads);
+    const uint64_t gu = uniform64(g);  // (the unit is the same for the 256 threads of a group)
+    const uint64_t b0 = gu * SEG + 32ull * tid, b1 = gu * SEG + 32ull * BLOCK;
+    pf.whole0 = b0 + 32 <= total;
+    pf.whole1 = b1 + 32 <= total && ((uintptr_t)a.bases & 3u) == 0;  // (a scalar read wants a dword address)
+    const uint64_t r0 = first_g + tid;
+    pf.has_o = r0 < a.n_reads;
+    pf.first_next = ktd::load_uniform(a.seg_first + uniform64(g_next));
+#pragma unroll
+    for (int q = 0; q < 8; q++) pf.halo.d[q] = 0;
+    if (pf.whole1) {
+        typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+        const u32x8 v = ktd::load_uniform(reinterpret_cast<const u32x8 *>(a.bases + b1));
+#pragma unroll
+        for (int q = 0; q < 8; q++) pf.halo.d[q] = v[q];
+    }
+    const void *p0 = pf.whole0 ? (const void *)(a.bases + b0) : safe;
+    const void *po = pf.has_o ? (const void *)(a.offsets + r0) : safe;
+    asm volatile("global_load_dwordx2 %0, %5, off\n\tglobal_load_dwordx2 %1, %5, off offset:8\n\t"
+                 "global_load_dwordx2 %2, %5, off offset:16\n\tglobal_load_dwordx2 %3, %5, off offset:24\n\t"
+                 "global_load_dwordx2 %4, %6, off"
+                 : "=&v"(pf.a[0]), "=&v"(pf.a[1]), "=&v"(pf.a[2]), "=&v"(pf.a[3]), "=&v"(pf.o0) : "v"(p0), "v"(po) : "memory");
+}
+
+// what prefetch_issue requested, once at most NSTORE vector memory operations issued behind it are outstanding
+struct SegTaken {
+    uint32_t d0[8];
+    SegHalo halo;
+    uint64_t o0, first_next;
+    bool whole0, whole1;
+};
+template <int NSTORE>
+__device__ __forceinline__ void prefetch_take(SegTaken &tk, SegPrefetch2 &pf) {
+    uint64_t a[4], o0;
+    // (the in-flight registers are inputs only: with in-out operands the allocator is free to copy them in front of the wait)
+    asm volatile("s_waitcnt vmcnt(%10)\n\tv_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\tv_mov_b64 %3, %8\n\tv_mov_b64 %4, %9"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(o0)
+                 : "v"(pf.a[0]), "v"(pf.a[1]), "v"(pf.a[2]), "v"(pf.a[3]), "v"(pf.o0), "n"(NSTORE)
+                 : "memory");
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        tk.d0[2 * q] = (uint32_t)a[q];
+        tk.d0[2 * q + 1] = (uint32_t)(a[q] >> 32);
+    }
+    tk.halo = pf.halo;
+    tk.o0 = pf.has_o ? o0 : ~0ull;
+    tk.first_next = pf.first_next;
+    tk.whole0 = pf.whole0;
+    tk.whole1 = pf.whole1;
+}
+
+__device__ __forceinline__ void stage_taken(const SegArgs &a, uint64_t g, uint64_t first_g, SegShared &sm,
+                                            const uint32_t tid, const SegTaken &pf) {
+    const uint64_t total = ktd::load_uniform(a.offsets + a.n_reads);
+    const uint64_t B0 = g * SEG;
+    auto encode = [&](uint32_t i, const uint32_t (&din)[8], bool whole) {
+        const uint64_t b = B0 + 32ull * i;
+        uint64_t w = 0;
+        uint32_t iv = 0xFFFFFFFFu;
+        if (b < total) {
+            uint32_t d[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) d[q] = din[q];
+            if (!whole) {  // the batch ends inside this item
+                unsigned char raw[32];
+                for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
+                __builtin_memcpy(d, raw, 32);
+            }
+            uint32_t msb_first = 0, any_raw = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t c8, i4, rw;
+                ktd::swar4(d[q], c8, i4, rw);
+                w = (w << 8) | c8;
+                msb_first = (msb_first << 4) | i4;
+                any_raw |= rw;
+            }
+            iv = __builtin_bitreverse32(msb_first);
+            if (any_raw) {
+                w = 0;
+                iv = 0;
+                for (int j = 0; j < 32; j++) {
+                    const uint32_t e = ktd::nt4((d[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                    w = (w << 2) | (e & 3u);
+                    iv |= (e >> 2) << j;
+                }
+            }
+        }
+        sm.codes[i] = w;
+        sm.inv[i] = iv;
+        sm.bnd[i] = 0;
+    };
+    encode(tid, pf.d0, pf.whole0);
+    if (tid + BLOCK < NITEM) encode(tid + BLOCK, pf.halo.d, pf.whole1);
+    ktd::lds_barrier();
+    {
+        const uint64_t lim = B0 + SEG + 32, r0 = first_g + tid;
+        if (r0 < a.n_reads && pf.o0 < lim) {
+            const uint32_t rel = (uint32_t)(pf.o0 - B0);
+            atomicOr(&sm.bnd[rel >> 5], 1u << (rel & 31u));
+            // more than 256 read starts in a segment (reads below 32 bases): read here, where no loaded value leaves the
+            // loop - one that did would put a wait for every outstanding memory operation behind the loop, on every path
+            for (uint64_t r = r0 + BLOCK; r < a.n_reads; r += BLOCK) {
+                const uint64_t o = a.offsets[r];
+                if (o >= lim) break;
+                const uint32_t rel2 = (uint32_t)(o - B0);
+                atomicOr(&sm.bnd[rel2 >> 5], 1u << (rel2 & 31u));
+            }
         }
     }
     ktd::lds_barrier();

@@ -156,6 +156,7 @@ struct kt_sharded {
     kt_bulk_shape shape{};
     char *recv_keys = nullptr;
     uint64_t *recv_counts = nullptr, *send_status = nullptr;  // send_status: [slice][2] device words {status, unused}
+    uint64_t *go_words = nullptr;  // {0, 1} on the device since creation: the "cannot go on" word of a rank whose copies fail
     size_t recv_key_block = 0, recv_cnt_block = 0;            // bytes / words per (slice, sender)
     uint64_t *fin_send = nullptr, *fin_recv = nullptr;  // n_ranks messages of FIN_CAP keys each
     kt_ctr *pend = nullptr;  // what did not fit the regions, counted: k-mer -> copies (delivered by finalize)
@@ -274,6 +275,11 @@ int sharded_alloc(kt_sharded *s) {
     if (e == hipSuccess) e = hipMalloc((void **)&s->pend_counts, s->pend_cap * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&s->fin_left, 256);
     if (e == hipSuccess) e = hipMalloc((void **)&s->send_status, (size_t)s->n_slices * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->go_words, 256);
+    if (e == hipSuccess) {
+        const uint64_t w[2] = {0, 1};
+        e = hipMemcpy(s->go_words, w, sizeof w, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) return kt::fail(KT_ERR_NOMEM, std::string("sharded counter: hipMalloc: ") + hipGetErrorString(e));
     {   // the exchange's kernels should start the moment their slice is ready, whatever the main stream is running
         int lo = 0, hi = 0;
@@ -463,6 +469,7 @@ int kt_sharded_destroy(kt_sharded *s) {
     if (s->recv_keys) (void)hipFree(s->recv_keys);
     if (s->recv_counts) (void)hipFree(s->recv_counts);
     if (s->send_status) (void)hipFree(s->send_status);
+    if (s->go_words) (void)hipFree(s->go_words);
     if (s->fin_send) (void)hipFree(s->fin_send);
     if (s->fin_recv) (void)hipFree(s->fin_recv);
     if (s->pend_keys) (void)hipFree(s->pend_keys);
@@ -602,13 +609,22 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
     // can everybody go on?  (the finalize buffers serve as the messages: they exist since creation and are idle here)
     if (N > 1) {
         const uint64_t words = HDR_U64 + FIN_CAP + FIN_CAP / 2;
+        // (a rank that cannot even put its word on the device still enters the exchange - leaving here would leave the peers
+        // waiting in it, which is what this round is there to prevent - and sends "cannot" from go_words: two device words
+        // written at creation, [0] = 0, [1] = 1, which no copy of this call has to reach - ADVICE r4)
         std::vector<uint64_t> h((size_t)N, my_code != KT_OK ? 1u : 0u);
-        for (int p = 0; p < N; p++)
-            KT_HIP(hipMemcpyAsync(s->fin_send + (uint64_t)p * words, &h[(size_t)p], 8, hipMemcpyHostToDevice, ctx->stream));
-        KT_HIP(hipStreamSynchronize(ctx->stream));  // (h lives on this frame; the comm stream must see the words)
+        bool words_ok = true;
+        for (int p = 0; p < N && words_ok; p++)
+            words_ok = hipMemcpyAsync(s->fin_send + (uint64_t)p * words, &h[(size_t)p], 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+        if (words_ok) words_ok = hipStreamSynchronize(ctx->stream) == hipSuccess;  // (h lives on this frame; the comm stream must see the words)
+        if (!words_ok) {
+            (void)hipGetLastError();
+            kt::set_error("kt_sharded_add_reads: the status words could not be copied to the device");
+            local_fail(KT_ERR_HIP);
+        }
         std::vector<Piece> pc((size_t)N);
         for (int p = 0; p < N; p++)
-            if (p != me) pc[p] = Piece{s->fin_send + (uint64_t)p * words, 8, s->fin_recv + (uint64_t)p * words, 8};
+            if (p != me) pc[p] = Piece{words_ok ? s->fin_send + (uint64_t)p * words : s->go_words + 1, 8, s->fin_recv + (uint64_t)p * words, 8};
         if (int rc = exchange_v(s, pc)) return rc;  // (a transport that fails fails for everybody)
         KT_HIP(hipStreamSynchronize(s->comm_stream));
         bool peer = false;

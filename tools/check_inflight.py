@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build-time check of the kernels that issue loads from inline assembly (kt_bulk.hip: buf_load8_async / buf_wait /
-buf_take): between an asm load into a register and the asm s_waitcnt behind it, no instruction of the compiler's
+buf_take; kt_segment.hpp: prefetch_issue / prefetch_take): between an asm load into a register and the asm s_waitcnt behind it, no instruction of the compiler's
 own may name that register - a copy or a spill made there would move a value that has not arrived.
 
 usage: check_inflight.py <device assembly .s> <kernel name regex>
@@ -80,7 +80,7 @@ def check(path, pattern):
             continue
         code = s.split(";")[0]
         if in_asm:
-            m = re.match(r"buffer_load_dword(x\d)?\s+(v\[\d+:\d+\]|v\d+)\s*,", code)
+            m = re.match(r"(?:buffer|global)_load_dword(x\d)?\s+(v\[\d+:\d+\]|v\d+)\s*,", code)
             if m:
                 inflight |= regs_of(m.group(2))
                 n_loads += 1
