@@ -6,13 +6,12 @@
 // (one CAS or atomic add per k-mer, kt_ctr.hip) cannot exceed ~20 G k-mers/s.  A batch can instead go through
 // streaming passes (a job: kt_bulk_begin, level 1 over one or more sources, kt_bulk_finish):
 //
-//   scatter1w persistent workgroups (one per CU, four 256-thread groups) run a source's units (8192-base segments of
+//   scatter1x persistent workgroups (one per CU, four 256-thread groups) run a source's units (8192-base segments of
 //             reads, or 8192 keys of an array that another GPU routed here), four at a time; a round's 16 K keys
 //             (32 K 32-bit ones) are counting-sorted in LDS by d1 = top b1 bits of khash(key) and every d1 run is
-//             appended to the bucket's fixed region of the key array through the workgroup's private aligned pages
-//             (one global atomic per page, no counting pass; a partly used page is carried over to the job's next
-//             source).  64-bit keys are stored as khash(key) from here on (to_stored / from_stored).
-//             (scatter1p: the round-1 shape, one 256-thread workgroup per unit; KT_S1_WIDE=0)
+//             appended to the bucket's fixed region of the key array - its place taken with one atomic per run on the
+//             cursor the workgroups of an XCD share (whole cache lines leave the L2), written in 16-byte groups.
+//             64-bit keys are stored as khash(key) from here on (to_stored / from_stored).
 //   part2     one workgroup per level-1 bucket: the bucket is read in 16384-key chunks, each chunk
 //             counting-sorted in LDS by d2 (next b2 hash bits) and its runs appended to the fine buckets, which
 //             own fixed shares of the bucket's region; a bucket whose keys do not spread that evenly is noticed
@@ -114,7 +113,6 @@ struct Meta {           // device arrays carved from ctr->b_meta
     unsigned long long *dump;  // [1024][2] where scatter1x's copy-out sends the stores that have nothing to write
     unsigned long long *xcur;  // [slices][8][B1] per-XCD cursors: keys XCD set x has appended to bucket d (scatter1x)
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
-    uint32_t *wcur;     // [slices][G][B1] paged level 1: every workgroup's position in its current page of every bucket
     kt_seg_src *srcs;   // [n_src + 1] part2's sources (device copy; the last one: the pre-split pass's output)
     uint64_t *xstart, *xend, *xcount;  // [local buckets << bx] pre-split pass: the sub-buckets' bounds in keys2, their sizes
     uint32_t *fail;     // [local buckets << bx] part2_fast_kernel: the bucket did not fit its fixed fine regions
@@ -363,7 +361,7 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
                 if (ktd::owner_of(keys[j], n_parts) != part) ok &= ~(1u << j);
         }
     }
-    // the same k-mers a few at a time (scatter1w): open() stages the segment for the 256 threads of a group (t = index
+    // the same k-mers a few at a time (scatter1x): open() stages the segment for the 256 threads of a group (t = index
     // in the group; whole-workgroup barriers inside), take<N>() hands out the thread's next N window starts
     struct Walk {
         ktseg::Window w;
@@ -373,14 +371,7 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
         ktseg::stage_segment(a, seg_lo + g, sm, t);
         return Walk{ktseg::Window(sm, t, a.k), 0u};
     }
-    // open() with the unit's bytes requested ahead (scatter1w: while the previous unit is still being written out)
-    using Pre = ktseg::SegPrefetch;
-    __device__ Pre prefetch(uint64_t g, uint32_t t) const { return ktseg::prefetch_segment(a, seg_lo + g, t); }
-    __device__ Walk open_pre(uint64_t g, SegShared &sm, uint32_t t, const Pre &pf) const {
-        ktseg::stage_prefetched(a, seg_lo + g, sm, t, pf);
-        return Walk{ktseg::Window(sm, t, a.k), 0u};
-    }
-    // ... and with every read of a unit requested a unit ahead, from inline assembly (scatter1x: ktseg::prefetch_issue / _take)
+    // open() with every read of the unit requested a unit ahead, from inline assembly (ktseg::prefetch_issue / _take)
     using Pre2 = ktseg::SegPrefetch2;
     using Taken = ktseg::SegTaken;
     __device__ uint64_t first_of(uint64_t g) const { return ktd::load_uniform(a.seg_first + ktd::uniform64(seg_lo + g)); }
@@ -441,9 +432,6 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
         uint32_t at;
     };
     __device__ Walk open(uint64_t g, SegShared &, uint32_t) const { return Walk{g * ktseg::SEG, count(), 0u}; }
-    struct Pre {};
-    __device__ Pre prefetch(uint64_t, uint32_t) const { return Pre{}; }
-    __device__ Walk open_pre(uint64_t g, SegShared &sm, uint32_t t, const Pre &) const { return open(g, sm, t); }
     struct Pre2 {};
     struct Taken { uint64_t first_next; };
     __device__ uint64_t first_of(uint64_t) const { return 0; }
@@ -594,147 +582,13 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, uin
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) O[(uint64_t)blockIdx.x * p.B1 + i] = sm.cursor[i];
 }
 
-// ---- scatter1, paged: no hist1 --------------------------------------------------------------------------
-// hist1 is a whole front-end pass whose only purpose is to make scatter1's output offsets exact.  The paged
-// variant drops it: every level-1 bucket owns a fixed region of cap1 keys, and a workgroup appends to a bucket
-// through a private 512-byte page that it replaces from the bucket's allocator (one global atomic per page, not
-// per run).  Pages are aligned and filled front to back; what is left of a workgroup's last pages is filled
-// with the empty key, which part2 skips.  A bucket that runs out of room (a batch dominated by a few k-mers)
-// raises *ovf and the build is redone through hist1 / scan1 / scatter1.
-#ifndef KT_BUILD_NT
-#define KT_BUILD_NT 1  // the table image is written once, whole lines at a time: non-temporal stores (k=31 -5 %).  The
-#endif                 // partition passes' short key runs need the L2 to merge them: there the same hint costs 50 %.
-#ifndef KT_PAGE_BYTES
-#define KT_PAGE_BYTES 512
-#endif
-template <class K>
-constexpr uint32_t page_keys() { return KT_PAGE_BYTES / sizeof(K); }
-
-template <class K>
-struct Scatter1PShared {
-    SegShared seg;
-    K sorted[round_keys<K>()];
-    uint16_t sdig[round_keys<K>()];
-    uint16_t split[MAX_B1];  // this round: sorted[i] of bucket d goes to the current page iff i < split[d]
-    uint32_t cur[MAX_B1];    // where the workgroup's next key of the bucket goes (key offset inside the bucket's
-                             // region); on a page boundary = no room left, a new page is needed
-    uint32_t to_cur[MAX_B1]; // this round: position of sorted[i] = to_cur[d] + i (current page) ...
-    uint32_t to_new[MAX_B1]; //             ... or to_new[d] + i (the pages allocated this round)
-    uint32_t cnt[MAX_B1];
-    uint32_t start[MAX_B1];
-    uint32_t tmp[BLOCK];
-    uint32_t ovf;
-};
-static_assert(sizeof(Scatter1PShared<uint64_t>) <= 80 * 1024 && sizeof(Scatter1PShared<uint32_t>) <= 80 * 1024,
-              "two scatter1 workgroups per CU");
-
-template <class Source, class K>
-__global__ __launch_bounds__(BLOCK) void scatter1p_kernel(Source src, Plan p, uint64_t *__restrict__ gcur,
-                                                          uint32_t *__restrict__ ovf, uint32_t *__restrict__ wcur,
-                                                          K *__restrict__ keys1) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Scatter1PShared<K> &sm = *reinterpret_cast<Scatter1PShared<K> *>(smem_raw);
-    constexpr int ROUNDS = ktseg::SEG / round_keys<K>(), PERR = ktseg::PER_THREAD / ROUNDS;
-    constexpr uint32_t PAGE = page_keys<K>();
-    constexpr int OWN = MAX_B1 / BLOCK;  // buckets a thread looks after: d = tid + it * BLOCK
-    // where this workgroup stands in its current page of every bucket: kept in global memory between the launches
-    // of one job (a job has one launch per source), so a partly used page is carried on instead of being abandoned
-    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cur[i] = wcur[(uint64_t)blockIdx.x * p.B1 + i];
-    if (threadIdx.x == 0) sm.ovf = 0;
-    const uint64_t n_units = src.n_units();
-    bool stop = false;
-    for (uint64_t g = blockIdx.x; g < n_units && !stop; g += gridDim.x) {
-        uint64_t keys[ktseg::PER_THREAD];
-        uint32_t ok;
-        src.collect(g, sm.seg, keys, ok);
-#pragma unroll
-        for (int half = 0; half < ROUNDS; half++) {  // (no early exit in here: the loop must stay unrolled)
-            for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) sm.cnt[i] = 0;
-            ktd::lds_barrier();
-#pragma unroll
-            for (int j = 0; j < PERR; j++)
-            {  // (the keys take their stored form here, where the first digit is needed)
-                keys[half * PERR + j] = (uint64_t)to_stored<K>(keys[half * PERR + j]);
-                if ((ok >> (half * PERR + j)) & 1u)
-                    atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>((K)keys[half * PERR + j]), p)], 1u);
-            }
-            ktd::lds_barrier();
-            const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
-            // every bucket's run is laid out: what fits goes to the current page, the rest to new pages.  The
-            // allocator's answers are only looked at after the placement pass, which hides their round trip.
-            uint64_t got[OWN];
-            uint32_t room[OWN], spl[OWN], nxt[OWN];
-#pragma unroll
-            for (int it = 0; it < OWN; it++) {
-                const uint32_t d = threadIdx.x + it * BLOCK;
-                room[it] = 0;
-                got[it] = 0;
-                spl[it] = 0;
-                nxt[it] = 0;
-                if (d < p.B1) {
-                    const uint32_t c = sm.cnt[d], rs = sm.start[d], cur = sm.cur[d];
-                    const uint32_t left = (0u - cur) & (PAGE - 1u);
-                    sm.to_cur[d] = cur - rs;
-                    spl[it] = rs + (c < left ? c : left);
-                    sm.split[d] = (uint16_t)spl[it];
-                    if (c > left) {
-                        const uint32_t need = c - left;
-                        room[it] = (need + PAGE - 1u) / PAGE * PAGE;  // whole pages; the last one may stay partly used
-                        got[it] = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[d]), (unsigned long long)room[it]);
-                        nxt[it] = need;
-                    } else {
-                        sm.cur[d] = cur + c;
-                    }
-                }
-            }
-            ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
-#pragma unroll
-            for (int j = 0; j < PERR; j++) {
-                if ((ok >> (half * PERR + j)) & 1u) {
-                    const uint64_t m = keys[half * PERR + j];
-                    const uint32_t d = digit1h(hash_of_stored<K>((K)m), p);
-                    const uint32_t pos = atomicAdd(&sm.start[d], 1u);
-                    sm.sorted[pos] = (K)m;
-                    sm.sdig[pos] = (uint16_t)d;
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < OWN; it++) {
-                if (room[it]) {
-                    const uint32_t d = threadIdx.x + it * BLOCK;
-                    if (got[it] + room[it] > p.cap1) {
-                        sm.ovf = 1;
-                        atomicOr(ovf, 1u);
-                    }
-                    sm.to_new[d] = (uint32_t)got[it] - spl[it];
-                    sm.cur[d] = (uint32_t)got[it] + nxt[it];
-                }
-            }
-            ktd::lds_barrier();
-            stop = sm.ovf != 0;  // the same for every thread
-            if (!stop) {
-                for (uint32_t i = threadIdx.x; i < nk; i += BLOCK) {
-                    const uint32_t d = sm.sdig[i];
-                    const uint32_t at = (i < sm.split[d] ? sm.to_cur[d] : sm.to_new[d]) + i;
-                    keys1[(uint64_t)d * p.cap1 + at] = sm.sorted[i];
-                }
-            }
-            ktd::lds_barrier();
-        }
-    }
-    ktd::lds_barrier();
-    if (sm.ovf) return;
-    for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) wcur[(uint64_t)blockIdx.x * p.B1 + i] = sm.cur[i];
-}
-
-// ---- scatter1, paged, wide: the kernel the bulk path runs ------------------------------------------------------
-// scatter1p sorts 4096 64-bit keys (8192 32-bit ones) per round with 1024 buckets: 4-key = 32-byte runs, written by
-// 8 waves per CU that hold their 32 k-mers per thread in ~200 VGPRs.  Here a workgroup is FOUR 256-thread groups,
-// each staging its own segment (or unit of keys), and the thread's walk over its 32 window starts is cut into
-// halves (32-bit keys: taken whole, in 32-bit registers): a round sorts 1024 x 16 (32) keys - 128-byte runs instead
-// of 32-byte ones, a quarter of the rounds per segment, 32 key registers instead of 64, so 16 waves fit a CU (one
-// workgroup, ~150 KB of LDS: the sort buffer takes over the staged segments' space).  Same pages, same allocator, same carried state (wcur) as scatter1p, which stays for comparison
-// (KT_S1_WIDE=0).
+// ---- level 1, the kernel the bulk path runs: scatter1x --------------------------------------------------------------------
+// The exact path above needs hist1, a whole front-end pass whose only purpose is to make scatter1's output offsets
+// exact.  The bulk path drops it: every level-1 bucket owns a fixed REGION of cap1 keys and the workgroups append to it; a
+// bucket that runs out of room (a batch dominated by a few k-mers) raises *ovf and the build is redone through hist1 /
+// scan1 / scatter1.  Rounds 2-4 appended through workgroup-private aligned pages (scatter1p: one 256-thread workgroup per
+// unit, 32-byte runs; scatter1w: 1024 threads, four segments at a time, 128-byte runs, 16 K keys sorted per round) - the
+// shape below keeps scatter1w's rounds and replaces its pages.
 // A sender of the sharded counter (kt_shard.hip) cannot redo its level 1 with exact offsets when a bucket's region
 // overflows - the regions are messages of a fixed size - so there the keys that do not fit are COUNTED in a small
 // table of the sender's own (a batch dominated by a few k-mers: poly-A reads, adapters - few distinct keys, many
@@ -748,173 +602,20 @@ struct PendList {
 };
 
 #if KT_ABLATION
-__device__ unsigned long long kt_dbg_phase[16];  // (timing builds: cycles of workgroup thread 0 per phase: [0, 8) build_kernel, [8, 16) scatter1w_kernel)
+__device__ unsigned long long kt_dbg_phase[16];  // (timing builds: cycles of workgroup thread 0 per phase: [0, 8) build_kernel, [8, 16) scatter1x_kernel)
 #define KT_PH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phs[i] += (uint32_t)(t_ - tph); tph = t_; } while (0)
 #else
 #define KT_PH(i) do { } while (0)
 #endif
 
-constexpr int WIDE_T = 1024, WIDE_GROUPS = WIDE_T / BLOCK;
+#ifndef KT_BUILD_NT
+#define KT_BUILD_NT 1  // the table image is written once, whole lines at a time: non-temporal stores (k=31 -5 %).  The
+#endif                 // partition passes' short key runs need the L2 to merge them: there the same hint costs 50 %.
 #ifndef KT_WIDE_PER64
 #define KT_WIDE_PER64 16
 #endif
 template <class K>
 constexpr int wide_per() { return sizeof(K) == 8 ? KT_WIDE_PER64 : 32; }  // keys per thread and round
-template <class K>
-constexpr uint32_t wide_round() { return (uint32_t)WIDE_T * wide_per<K>(); }
-static_assert(MAX_B1 <= WIDE_T, "one bucket per thread");
-
-template <class K>
-struct Scatter1WShared {
-    union {  // (the staged segments are dead once every thread has loaded its window words: open())
-        SegShared seg[WIDE_GROUPS];
-        K sorted[wide_round<K>()];
-    };
-    uint16_t split[MAX_B1];
-    uint32_t cur[MAX_B1];
-    uint32_t to_cur[MAX_B1];
-    uint32_t to_new[MAX_B1];
-    uint32_t cnt[MAX_B1];
-    uint32_t start[MAX_B1];
-    uint32_t tmp[WIDE_T / 64];
-    uint32_t ovf;
-};
-static_assert(sizeof(Scatter1WShared<uint64_t>) <= 160 * 1024 && sizeof(Scatter1WShared<uint32_t>) <= 160 * 1024, "LDS of a CU");
-
-template <class Source, class K>
-__global__ __launch_bounds__(WIDE_T) void scatter1w_kernel(Source src, Plan p, uint64_t *__restrict__ gcur,
-                                                           uint32_t *__restrict__ ovf, uint32_t *__restrict__ wcur,
-                                                           K *__restrict__ keys1, PendList pend) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Scatter1WShared<K> &sm = *reinterpret_cast<Scatter1WShared<K> *>(smem_raw);
-    constexpr int PER = wide_per<K>(), NQ = ktseg::PER_THREAD / PER;
-    constexpr uint32_t PAGE = page_keys<K>();
-    const uint32_t tid = threadIdx.x, grp = tid / BLOCK, t = tid % BLOCK;
-    if (tid < p.B1) {
-        sm.cur[tid] = wcur[(uint64_t)blockIdx.x * p.B1 + tid];
-        sm.cnt[tid] = 0;  // (from here on every round leaves cnt zeroed for the next one: see below)
-    }
-    if (tid == 0) sm.ovf = 0;
-    const uint64_t n_units = src.n_units();
-    bool stop = false;
-    // the next unit's bytes are asked for while the current one's last round is copied out (round 4: the two dependent
-    // global reads of a unit's staging were waited for with nothing else to do - a fifth of the kernel)
-    const uint64_t stride = (uint64_t)gridDim.x * WIDE_GROUPS;
-    auto unit_of = [&](uint64_t g0) { return g0 + grp < n_units ? g0 + grp : n_units - 1; };
-    typename Source::Pre pre{};
-    {
-        const uint64_t gfirst = (uint64_t)blockIdx.x * WIDE_GROUPS;
-        if (gfirst < n_units) pre = src.prefetch(unit_of(gfirst), t);
-    }
-#if KT_ABLATION
-    unsigned long long tph = __builtin_readcyclecounter();
-    uint32_t phs[8] = {};
-#endif
-    for (uint64_t g0 = (uint64_t)blockIdx.x * WIDE_GROUPS; g0 < n_units && !stop; g0 += stride) {
-        const bool valid = g0 + grp < n_units;  // (a group past the end walks the last unit and keeps nothing)
-        auto wk = src.open_pre(unit_of(g0), sm.seg[grp], t, pre);
-        KT_PH(0);
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {  // (no early exit in here: the loop must stay unrolled)
-            K keys[PER];
-            uint32_t ok;
-            src.template take<PER, K>(wk, t, keys, ok);
-            if (!valid) ok = 0;
-            // (no barrier here: cnt was zeroed by the previous round's layout step, two barriers ago, and nothing a
-            // wave still busy with the previous round's copy-out reads is written before the barrier after the count)
-#pragma unroll
-            for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
-                keys[j] = to_stored<K>((uint64_t)keys[j]);
-                if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>(keys[j]), p)], 1u);
-            }
-            KT_PH(1);
-            ktd::lds_barrier();
-            KT_PH(2);
-            const uint32_t nk = block_excl_scan_n<WIDE_T, 1>(sm.cnt, sm.start, p.B1, sm.tmp);  // (B1 <= 1024: one counter per thread)
-            // every bucket's run is laid out: what fits goes to the current page, the rest to new pages.  The
-            // allocator's answer is only looked at after the placement pass, which hides its round trip.
-            uint64_t got = 0;
-            uint32_t room = 0, spl = 0, nxt = 0;
-            if (tid < p.B1) {
-                const uint32_t d = tid, c = sm.cnt[d], rs = sm.start[d], cur = sm.cur[d];
-                sm.cnt[d] = 0;  // for the next round's count
-                const uint32_t left = (0u - cur) & (PAGE - 1u);
-                sm.to_cur[d] = cur - rs;
-                spl = rs + (c < left ? c : left);
-                sm.split[d] = (uint16_t)spl;
-                if (c > left) {
-                    const uint32_t need = c - left;
-                    room = (need + PAGE - 1u) / PAGE * PAGE;  // whole pages; the last one may stay partly used
-                    got = atomicAdd(reinterpret_cast<unsigned long long *>(&gcur[d]), (unsigned long long)room);
-                    nxt = need;
-                } else {
-                    sm.cur[d] = cur + c;
-                }
-            }
-            KT_PH(3);
-            ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
-            KT_PH(4);
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                if ((ok >> j) & 1u) {
-                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
-                    const uint32_t pos = atomicAdd(&sm.start[d], 1u);
-                    sm.sorted[pos] = keys[j];
-                }
-            }
-            KT_PH(5);
-            if (room) {
-                if (got + room > p.cap1 && !pend.slots) {
-                    sm.ovf = 1;
-                    atomicOr(ovf, 1u);
-                }
-                // (a region far past its room - a sender's heavy-hitter bucket - must not wrap back into it)
-                const uint32_t g32 = got > 0xE0000000ull ? 0xE0000000u : (uint32_t)got;
-                sm.to_new[tid] = g32 - spl;
-                sm.cur[tid] = g32 + nxt;
-            }
-            ktd::lds_barrier();
-            KT_PH(6);
-            stop = sm.ovf != 0;  // the same for every thread
-            if (q == NQ - 1 && g0 + stride < n_units) pre = src.prefetch(unit_of(g0 + stride), t);  // (the keys are placed: their registers are free)
-#if KT_ABLATION
-            if (p.dbg & 0x1000u) stop = true;  // (timing only: no copy-out at all; 0x2000: its stores dropped)
-#endif
-            if (!stop) {
-                for (uint32_t i = tid; i < nk; i += WIDE_T) {
-                    const K key = sm.sorted[i];
-                    const uint32_t d = digit1h(hash_of_stored<K>(key), p);  // (one shift of a stored hash; 32-bit
-                                                                            // keys are hashed again: no room for digits)
-                    const uint32_t at = (i < sm.split[d] ? sm.to_cur[d] : sm.to_new[d]) + i;
-#if KT_ABLATION
-                    if ((p.dbg & 0x2000u) && key != (K)0x1234567u) continue;
-#endif
-                    if (at < p.cap1) {
-                        keys1[(uint64_t)d * p.cap1 + at] = key;
-                    } else if (pend.slots) {  // the bucket's region is full: counted aside, delivered later
-                        const uint32_t st = kttab::table_add(TableRef{pend.slots, pend.g, pend.flags}, from_stored<K>(key), 1u);
-                        if (st == 0u) atomicOr(pend.flags, 1u);
-                        else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(pend.distinct), 1ull);
-                    }
-                }
-            }
-            // the next round's count, scan and layout touch nothing the copy-out reads, and its placement comes three
-            // barriers later: only the staging of a new segment (it shares LDS with the sort buffer) has to wait
-#if KT_ABLATION
-            if (p.dbg & 0x1000u) stop = false;
-#endif
-            if (q == NQ - 1) ktd::lds_barrier();
-            KT_PH(7);
-        }
-    }
-#if KT_ABLATION
-    if (tid == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&kt_dbg_phase[8 + i], (unsigned long long)phs[i]);
-#endif
-    ktd::lds_barrier();
-    if (sm.ovf) return;
-    if (tid < p.B1) wcur[(uint64_t)blockIdx.x * p.B1 + tid] = sm.cur[tid];
-}
 
 // ---- scatter1x: level 1 with ONE CURSOR PER BUCKET AND XCD (round 5) --------------------------------------------------
 // scatter1w's appends go through workgroup-private pages: the open line of a bucket is completed by the same workgroup a
@@ -1200,17 +901,6 @@ __global__ __launch_bounds__(BLOCK) void xcd_tails_kernel(Plan p, const unsigned
             for (uint64_t q = c[x] + threadIdx.x; q < (top << LSH); q += BLOCK)
                 keys1[(uint64_t)d * p.cap1 + xcd_place<K>(q, x, p.nxs)] = empty_of<K>();
         if (threadIdx.x == 0) extent[d] = (top << LSH) << p.nxs;
-    }
-}
-
-// after the last source of a job: the unused tail of every workgroup's last page of every bucket gets the empty key
-template <class K>
-__global__ __launch_bounds__(BLOCK) void page_tails_kernel(Plan p, const uint32_t *__restrict__ wcur, K *__restrict__ keys1) {
-    constexpr uint32_t PAGE = page_keys<K>();
-    for (uint32_t idx = threadIdx.x; idx < p.B1 * PAGE; idx += BLOCK) {
-        const uint32_t d = idx / PAGE, q = idx % PAGE;
-        const uint32_t cur = wcur[(uint64_t)blockIdx.x * p.B1 + d];
-        if (q < ((0u - cur) & (PAGE - 1u)) && (uint64_t)cur + q < p.cap1) keys1[(uint64_t)d * p.cap1 + cur + q] = empty_of<K>();
     }
 }
 
@@ -2678,8 +2368,8 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 };
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
-    uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, s1_wide, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1x;
+    uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2690,8 +2380,6 @@ static BulkKnobs read_knobs() {
     k.g_mult = env_u64("KT_BULK_G_MULT", 1);
     k.paged = env_u64("KT_BULK_PAGED", 1);
     k.fixed2 = env_u64("KT_BULK_FIXED2", 1);
-    k.s1_wide = env_u64("KT_S1_WIDE", 1);
-    k.s1x = env_u64("KT_S1X", 1);  // level 1 with per-XCD cursors (scatter1x_kernel); 0: workgroup-private pages (scatter1w / scatter1p)
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
     k.p2_grid = env_u64("KT_P2_GRID", 0);  // workgroups of the level-2 launch (0: one per bucket)
@@ -2737,10 +2425,7 @@ template <class K>
 int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice = 0) {
     kt_ctx *ctx = ctr->ctx;
     K *keys1 = (K *)ctr->b_keys1.p + (size_t)slice * j.p.B1 * j.p.cap1;
-    Meta sm_ = j.m;  // this slice's allocator state
-    sm_.gcur = j.m.gcur + (size_t)slice * j.p.B1;
-    sm_.wcur = j.m.wcur + (size_t)slice * j.p.G * j.p.B1;
-    struct { Meta m; } jj{sm_};
+    struct { Meta m; } jj{j.m};
     if (j.xcd) {
         constexpr int T = KT_S1X_T;
         unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;
@@ -2760,36 +2445,7 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice
         KT_HIP(hipGetLastError());
         return KT_OK;
     }
-    if (j.kn.s1_wide || j.sharded) {
-        const uint32_t wgs = j.p.G / 2 ? j.p.G / 2 : 1;  // one resident workgroup per CU (its rows of wcur are [0, wgs))
-        const size_t lds = sizeof(Scatter1WShared<K>);
-        if (r.reads) {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1w_kernel<ReadsSource, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1w_kernel<ReadsSource, K>), dim3(wgs), dim3(WIDE_T), lds, ctx->stream, r.rs, j.p,
-                               jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1, j.pend);
-        } else {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1w_kernel<KeysSource, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1w_kernel<KeysSource, K>), dim3(wgs), dim3(WIDE_T), lds, ctx->stream, r.ks, j.p,
-                               jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1, j.pend);
-        }
-        KT_HIP(hipGetLastError());
-        return KT_OK;
-    }
-    if (r.reads) {
-        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<ReadsSource, K>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
-        hipLaunchKernelGGL((scatter1p_kernel<ReadsSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>),
-                           ctx->stream, r.rs, j.p, jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1);
-    } else {
-        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1p_kernel<KeysSource, K>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1PShared<K>)));
-        hipLaunchKernelGGL((scatter1p_kernel<KeysSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1PShared<K>),
-                           ctx->stream, r.ks, j.p, jj.m.gcur, jj.m.ovf, jj.m.wcur, keys1);
-    }
-    KT_HIP(hipGetLastError());
-    return KT_OK;
+    return kt::fail(KT_ERR_ARG, "bulk build: paged level 1 without its cursors");
 }
 
 template <class K>
@@ -2826,8 +2482,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     Meta &m = j.m;
     K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
     if (j.paged && !j.sharded) {
-        if (j.xcd) hipLaunchKernelGGL(xcd_tails_kernel<K>, dim3(p.B1), dim3(BLOCK), 0, ctx->stream, p, (const unsigned long long *)m.xcur, m.gcur, keys1);
-        else hipLaunchKernelGGL(page_tails_kernel<K>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, p, m.wcur, keys1);
+        hipLaunchKernelGGL(xcd_tails_kernel<K>, dim3(p.B1), dim3(BLOCK), 0, ctx->stream, p, (const unsigned long long *)m.xcur, m.gcur, keys1);
         // the one host round trip of the build: did every bucket fit its region?
         uint32_t ovf = 0;
         KT_HIP(hipMemcpyAsync(&ovf, m.ovf, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -3135,7 +2790,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     p.n = 64 - ctr->shift;
     p.m8 = ctr->m8;
 #if KT_ABLATION
-    p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);  // bits 0-7: build_kernel, 8-11: part2, 12-15: scatter1w
+    p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);  // bits 0-7: build_kernel, 8-11: part2, 12-15: scatter1x
 #endif
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
     // a rebuild moves the whole table: small batches are cheaper through the atomics
@@ -3169,13 +2824,11 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     // paged level 1 (no hist1): room per bucket = its share of the most keys there can be + 1/8 + a page per
     // workgroup (every workgroup leaves at most one partly used page per bucket)
     bool paged = (kn.paged != 0 && !ctr->paged_failed) || sharded;
-    const uint64_t PAGE = KT_PAGE_BYTES / ksz;
     // (rounded to a multiple of 128 keys: every region starts on a cache line, whatever the key size)
     // (per-XCD cursors: no pages; the room beyond the keys' share covers the sets' uneven fills - every set's lines reach as
     // far as the fullest set's - and the same 1/8 for the hash's own spread; a multiple of 8 sets x 32 keys)
-    const bool xcd = paged && kn.s1x != 0;
-    uint64_t cap1 = xcd ? (slice_keys / p.B1 + slice_keys / p.B1 / 8 + 16 * 256 + 255) / 256 * 256
-                        : (slice_keys / p.B1 + slice_keys / p.B1 / 8 + ((uint64_t)p.G + 2) * PAGE + 127) / 128 * 128;
+    const bool xcd = paged;
+    uint64_t cap1 = (slice_keys / p.B1 + slice_keys / p.B1 / 8 + 16 * 256 + 255) / 256 * 256;
     const uint64_t room1 = cap1 * n_src;
     if (room1 * ksz >= (1ull << 31)) {  // (part2 addresses a bucket's fixed regions through 32-bit buffer offsets)
         if (sharded) return kt::fail(KT_ERR_ARG, "sharded counter: batch too large for its level-1 regions (lower max_batch_bases)");
@@ -3191,7 +2844,6 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     size_t meta = 0;
     const size_t off_H = meta;       meta += ((size_t)p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_O = meta;       meta += ((size_t)p.G * p.B1 * 8 + 255) & ~(size_t)255;
-    const size_t off_wc = meta;      meta += ((size_t)n_slices * p.G * p.B1 * 4 + 255) & ~(size_t)255;
     const size_t off_bs = meta;      meta += ((size_t)(p.B1 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fs = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fe = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
@@ -3231,7 +2883,6 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     Meta m{};
     m.H = (uint32_t *)(mb + off_H);
     m.O = (uint64_t *)(mb + off_O);
-    m.wcur = (uint32_t *)(mb + off_wc);
     m.bstart = (uint64_t *)(mb + off_bs);
     m.fstart = (uint64_t *)(mb + off_fs);
     m.fend = (uint64_t *)(mb + off_fe);
@@ -3255,7 +2906,6 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
         p.cap2 = kn.fixed2 || p.bx ? room1 / p.B2 / (128 / ksz) * (128 / ksz) : 0;  // (whole cache lines: every fine region starts on one)
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)n_slices * p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
-        KT_HIP(hipMemsetAsync(m.wcur, 0, (size_t)n_slices * p.G * p.B1 * 4, ctx->stream));
         if (xcd) {
             if (int rc = xcc_sets(ctx, &p.nxs, &p.xmap)) return rc;
             // (a batch of a few dozen units does not spread evenly over the XCDs - a handful of workgroups, some XCDs with
@@ -3319,22 +2969,13 @@ int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice) {
     kt_bulk_job *job = ctr->job;
     if (!job || !job->open || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
     const Plan &p = job->p;
-    const uint32_t *wcur = job->m.wcur + (size_t)slice * p.G * p.B1;
     char *keys1 = (char *)ctr->b_keys1.p + (size_t)slice * p.B1 * p.cap1 * job->ksz();
-    if (job->xcd) {
-        const unsigned long long *xcur = job->m.xcur + (size_t)slice * 8 * p.B1;
-        uint64_t *extent = job->m.gcur + (size_t)slice * p.B1;
-        if (job->narrow)
-            hipLaunchKernelGGL(xcd_tails_kernel<uint32_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint32_t *)keys1);
-        else
-            hipLaunchKernelGGL(xcd_tails_kernel<uint64_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint64_t *)keys1);
-        KT_HIP(hipGetLastError());
-        return KT_OK;
-    }
+    const unsigned long long *xcur = job->m.xcur + (size_t)slice * 8 * p.B1;
+    uint64_t *extent = job->m.gcur + (size_t)slice * p.B1;
     if (job->narrow)
-        hipLaunchKernelGGL(page_tails_kernel<uint32_t>, dim3(p.G), dim3(BLOCK), 0, ctr->ctx->stream, p, wcur, (uint32_t *)keys1);
+        hipLaunchKernelGGL(xcd_tails_kernel<uint32_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint32_t *)keys1);
     else
-        hipLaunchKernelGGL(page_tails_kernel<uint64_t>, dim3(p.G), dim3(BLOCK), 0, ctr->ctx->stream, p, wcur, (uint64_t *)keys1);
+        hipLaunchKernelGGL(xcd_tails_kernel<uint64_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint64_t *)keys1);
     KT_HIP(hipGetLastError());
     return KT_OK;
 }

@@ -120,93 +120,10 @@ __device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegS
     stage_segment(a, g, sm, threadIdx.x);
 }
 
-// ---- the same staging with the segment's bytes requested ahead (kt_bulk.hip's level 1) ------------------------------
+// ---- the same staging with EVERY global read of a unit requested a unit ahead (kt_bulk.hip's level 1, scatter1x) -------------
 // stage_segment waits for two dependent global reads in a row - the bases, then (behind a barrier) seg_first -> offsets -
-// while the workgroup has nothing else to do: ~3.5 us per 8192-base unit, a fifth of level 1.  prefetch_segment issues
-// the bases' loads and reads seg_first early (the caller does so while it is still writing out the previous unit);
-// stage_prefetched encodes them, and requests the thread's first offset before the encode so that it travels meanwhile.
-struct SegPrefetch {
-    uint32_t d0[8], d1[8];  // items tid and tid + BLOCK (the halo item: thread 0 only)
-    uint64_t first;         // seg_first[g]
-    bool whole0, whole1;    // the item lies wholly inside the batch (else stage_prefetched reads it byte by byte)
-};
-
-__device__ __forceinline__ SegPrefetch prefetch_segment(const SegArgs &a, uint64_t g, const uint32_t tid) {
-    SegPrefetch pf;
-    const uint64_t total = a.offsets[a.n_reads];
-    const uint64_t b0 = g * SEG + 32ull * tid, b1 = g * SEG + 32ull * (tid + BLOCK);
-    pf.whole0 = b0 + 32 <= total;
-    pf.whole1 = tid + BLOCK < NITEM && b1 + 32 <= total;
-#pragma unroll
-    for (int q = 0; q < 8; q++) pf.d0[q] = pf.d1[q] = 0;
-    if (pf.whole0) __builtin_memcpy(pf.d0, a.bases + b0, 32);
-    if (pf.whole1) __builtin_memcpy(pf.d1, a.bases + b1, 32);
-    pf.first = a.seg_first[g];
-    return pf;
-}
-
-__device__ __forceinline__ void stage_prefetched(const SegArgs &a, uint64_t g, SegShared &sm, const uint32_t tid,
-                                                 const SegPrefetch &pf) {
-    const uint64_t total = a.offsets[a.n_reads];
-    const uint64_t B0 = g * SEG;
-    // the thread's first read start of the segment: requested now, used behind the barrier
-    const uint64_t r0 = pf.first + tid;
-    const uint64_t o0 = r0 < a.n_reads ? a.offsets[r0] : ~0ull;
-    auto encode = [&](uint32_t i, const uint32_t (&din)[8], bool whole) {
-        const uint64_t b = B0 + 32ull * i;
-        uint64_t w = 0;
-        uint32_t iv = 0xFFFFFFFFu;
-        if (b < total) {
-            uint32_t d[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) d[q] = din[q];
-            if (!whole) {  // the batch ends inside this item
-                unsigned char raw[32];
-                for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
-                __builtin_memcpy(d, raw, 32);
-            }
-            uint32_t msb_first = 0, any_raw = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                uint32_t c8, i4, rw;
-                ktd::swar4(d[q], c8, i4, rw);
-                w = (w << 8) | c8;
-                msb_first = (msb_first << 4) | i4;
-                any_raw |= rw;
-            }
-            iv = __builtin_bitreverse32(msb_first);
-            if (any_raw) {
-                w = 0;
-                iv = 0;
-                for (int j = 0; j < 32; j++) {
-                    const uint32_t e = ktd::nt4((d[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-                    w = (w << 2) | (e & 3u);
-                    iv |= (e >> 2) << j;
-                }
-            }
-        }
-        sm.codes[i] = w;
-        sm.inv[i] = iv;
-        sm.bnd[i] = 0;
-    };
-    encode(tid, pf.d0, pf.whole0);
-    if (tid + BLOCK < NITEM) encode(tid + BLOCK, pf.d1, pf.whole1);
-    ktd::lds_barrier();
-    {
-        const uint64_t lim = B0 + SEG + 32;
-        uint64_t o = o0;
-        for (uint64_t r = r0; r < a.n_reads; r += BLOCK) {
-            if (r != r0) o = a.offsets[r];
-            if (o >= lim) break;
-            const uint32_t rel = (uint32_t)(o - B0);
-            atomicOr(&sm.bnd[rel >> 5], 1u << (rel & 31u));
-        }
-    }
-    ktd::lds_barrier();
-}
-
-// ---- the same, with EVERY global read of a unit requested a unit ahead (round 5: kt_bulk.hip's scatter1x) --------------
-// stage_prefetched still starts with a read the thread has to wait for - its first read start, offsets[seg_first[g] + tid] -
+// while the workgroup has nothing else to do: ~3.5 us per 8192-base unit.  Round 4 requested the bases a unit ahead, but
+// still started a unit with a read the thread has to wait for - its first read start, offsets[seg_first[g] + tid] -
 // and that read is YOUNGER than the stores of the previous unit's copy-out: a wave's memory operations complete in issue
 // order, so the wait drains the wave's whole store queue at every unit (the k = 7 lesson of kt_oligo.hip); and the
 // compiler waits vmcnt(0) for the prefetched bases as well - it cannot count the stores issued behind them through the
