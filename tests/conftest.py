@@ -14,7 +14,7 @@ GOLDEN = ROOT / "tests" / "golden"
 # the C ABI and the CLI; tier 1: the properties at BASELINE.json's full sizes; tier 2: resource and timing properties
 # (host-memory ceilings, placement timing, child processes that capture graphs) - a resource assertion that trips on a
 # loaded box must not hide the parity suite behind it (round 4's driver run stopped at the fourth test).
-_TIER2 = ("bounded_host_memory", "alloc_placed", "captured_into_a_graph", "launch_info")
+_TIER2 = ("bounded_host_memory", "alloc_placed", "captured_into_a_graph", "capture_then_launch", "launch_info")
 _TIER1 = ("full_size", "cfg2", "cfg3", "cfg4", "cfg5", "many_batches_many_threads")
 
 

@@ -252,6 +252,24 @@ def test_oligo_launches_can_be_captured_into_a_graph(torch_mod):
     assert r.returncode == 0 and "captured ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+def test_capture_then_launch_trials_without_torch():
+    """round 4 saw a later test's device-wide synchronize wait for ever after a graph capture made through torch in the same
+    process, and moved the capture test into a child process without knowing whose the hang was.  tools/capture_repro.cpp
+    does the same sequence with the HIP runtime and the C ABI alone - 26 launches on a non-blocking side stream,
+    hipStreamBeginCapture / kt_oligo_batch / EndCapture, two replays, rows equal to the plain launch's; then contexts on
+    the NULL stream whose large launches take part in the launch-shape trials (events recorded and polled around them)
+    with hipDeviceSynchronize between - under a watchdog: it does not hang and every round decides its launch shape, so
+    the library's event trials are not what hung (it needs torch's capture in the process: the capture test above stays in
+    a process of its own)"""
+    import subprocess, pathlib
+    exe = pathlib.Path(__file__).resolve().parent.parent / "kmertools_amd" / "bin" / "capture_repro"
+    assert exe.exists(), "kmertools_amd/bin/capture_repro is built by make -C kmertools_amd/csrc (__graft_entry__.build)"
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "captured, replayed twice, rows equal" in r.stdout and "no hang (with a capture before the trials)" in r.stdout
+    assert r.stdout.count("decided 1") == 3, r.stdout
+
+
 @pytest.mark.parametrize("count_min", [True, False])
 def test_oligo_k7_producer_wave_many_tiles_per_workgroup(hctx, oracle, monkeypatch, count_min):
     """comp cgr k=7 runs with a producer wave (four store waves that never load + one wave that reads the input and
