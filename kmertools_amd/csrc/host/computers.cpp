@@ -199,13 +199,33 @@ struct Work {
         pin_ptr_ = nullptr;
         pin_bytes_ = 0;
     }
-    ~Work() { unpin(); }
+    // KT_CLI_PIN_BASES=1 (an experiment, off by default - DESIGN.md 6.1 has what it measured): the batch's bases buffer
+    // page-locked as well, from the item's second batch on.  The parallel reader copies every batch into this buffer,
+    // so its address is stable as long as no batch outgrows its capacity (reserved with slack at the first use).
+    void pin_bases(kt_ctx *ctx) {
+        static const bool on = getenv("KT_CLI_PIN_BASES") != nullptr;
+        if (!on || uses_ < 2) return;
+        void *p = b.bases.data();
+        const size_t bytes = b.bases.capacity();
+        if (p == bpin_ptr_ && bytes == bpin_bytes_) return;
+        if (bpin_ptr_) kt_host_unregister(bpin_ctx_, bpin_ptr_);
+        bpin_ptr_ = nullptr;
+        if (bytes && kt_host_register(ctx, p, bytes) == KT_OK) {
+            bpin_ctx_ = ctx;
+            bpin_ptr_ = p;
+            bpin_bytes_ = bytes;
+        }
+    }
+    ~Work() {
+        unpin();
+        if (bpin_ptr_) kt_host_unregister(bpin_ctx_, bpin_ptr_);
+    }
 
   private:
     uint64_t uses_ = 0;
-    kt_ctx *pin_ctx_ = nullptr;
-    void *pin_ptr_ = nullptr;
-    size_t pin_bytes_ = 0;
+    kt_ctx *pin_ctx_ = nullptr, *bpin_ctx_ = nullptr;
+    void *pin_ptr_ = nullptr, *bpin_ptr_ = nullptr;
+    size_t pin_bytes_ = 0, bpin_bytes_ = 0;
 };
 
 template <class T>
@@ -481,6 +501,7 @@ std::string OligoComputer::vectorise() {
             // normalised rows are f64 (the reference's type, bit-identical); raw counts travel as u32
             w.resize_rows(norm_ ? n * bins : (n * bins + 1) / 2);
             w.pin_rows(dev_.ctx);
+            w.pin_bases(dev_.ctx);
             if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, count_min_, norm_, 1,
                                norm_ ? KT_F64 : KT_U32, w.rows.data(), KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
@@ -533,6 +554,7 @@ std::string OligoCgrComputer::vectorise() {
             const uint64_t n = w.b.n_reads();
             w.resize_rows(n * bins);
             w.pin_rows(dev_.ctx);
+            w.pin_bases(dev_.ctx);
             if (kt_oligo_batch(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, ksize_, 1, norm_, 1, KT_F64, w.rows.data(),
                                KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
@@ -582,6 +604,7 @@ std::string CgrComputer::vectorise() {
             const uint64_t n = w.b.n_reads();
             w.resize_rows(2 * w.b.bases.size() + 2);
             w.pin_rows(dev_.ctx);
+            w.pin_bases(dev_.ctx);
             if (kt_cgr_points(dev_.ctx, bases_ptr(w.b), w.b.offsets.data(), n, (double)vecsize_, w.rows.data(), nullptr,
                               KT_MEM_HOST) != KT_OK)
                 return kt_last_error();
@@ -619,6 +642,12 @@ CountComputer::CountComputer(std::string in_path, std::string out_dir, int ksize
 CountComputer::~CountComputer() {
     release_shards();
     if (ctr_) kt_ctr_destroy(ctr_);
+}
+
+kt_ctr *CountComputer::shard_table(size_t r) const {
+    kt_ctr *t = nullptr;
+    if (!sharded_done_ || r >= shards_.size() || !shards_[r] || kt_sharded_table(shards_[r], &t) != KT_OK) return nullptr;
+    return t;
 }
 
 void CountComputer::release_shards() {
@@ -1031,7 +1060,7 @@ std::string CountComputer::merge(bool /*del: no temp files exist to delete*/) {
         fclose(out);
         if (getenv("KT_CLI_TIMING"))
             fprintf(stderr, "[timing] ctr --devices %d written: VmHWM %llu kB\n", n_devices_, (unsigned long long)peak_rss_kb());
-        release_shards();
+        if (!keep_shards_) release_shards();
         return err;
     }
     if (!ctr_) return "count() has not run";
@@ -1087,6 +1116,8 @@ std::string CovComputer::build_table() {
     ctr_->set_threads(threads_);
     ctr_->set_max_memory(memory_ceil_gb_);
     ctr_->set_device(device_);
+    ctr_->set_devices(n_devices_);
+    ctr_->set_keep_shards(true);
     ctr_->set_pass_hook([this](uint32_t pass, uint32_t passes, kt_ctr *t) { return cov_pass(pass, passes, t); });
     std::string e = ctr_->count();
     if (e.empty()) e = ctr_->merge(true);  // the reference leaves kmers.counts behind as well
@@ -1122,6 +1153,66 @@ std::string CovComputer::compute_coverages() {
         writer.finish();
         fclose(out);
         return "";
+    }
+    if (ctr_ && ctr_->n_shards() > 0) {
+        // --devices N: the table is N shards on N GPUs, each answering for the k-mers of its hash prefixes only.  Every
+        // batch of reads goes past every shard - one thread per shard, each adding raw bin counts to rows of its own
+        // (kt_cov_batch_part skips the k-mers of the other shards) -, the shards' rows are summed, normalised with one
+        // division per cell and written: every k-mer of every read has been binned exactly once (the reference looks the
+        // k-mers up in one map, coverage/src/lib.rs:165-184; its CountComputer built that map out of partitions the same way)
+        const size_t N = ctr_->n_shards();
+        SeqReader reader;
+        if (!reader.open(in_path_, false)) return reader.error();
+        const std::string path = out_dir_ + "/kmers.vectors";
+        FILE *out = fopen(path.c_str(), "wb");
+        if (!out) return "Unable to write to file: " + path;
+        PhaseTimer pt("cov (rows summed over the shards)");
+        AsyncWriter writer(out, pt);
+        std::vector<std::string> pieces;
+        const uint64_t bins = bin_count_;
+        std::vector<std::vector<uint32_t>> part(N);
+        std::vector<std::string> errs(N);
+        Work w;
+        std::string err;
+        for (;;) {
+            const bool more = reader.next_batch(w.b, cli_batch_bases(256ull << 20), cli_batch_reads(bins >= 2048 ? 8192 : 1ull << 19));
+            const uint64_t n = w.b.n_reads();
+            if (n) {
+                std::vector<std::thread> th;
+                for (size_t r = 0; r < N; r++)
+                    th.emplace_back([&, r] {
+                        part[r].assign((size_t)(n * bins), 0u);
+                        kt_ctr *t = ctr_->shard_table(r);
+                        if (!t || kt_cov_batch_part(t, bases_ptr(w.b), w.b.offsets.data(), n, bin_size_, bin_count_, part[r].data(),
+                                                    KT_MEM_HOST, 1, 0) != KT_OK)
+                            errs[r] = t ? kt_last_error() : "cov: a shard's table is gone";
+                    });
+                for (auto &t : th) t.join();
+                for (const auto &e : errs)
+                    if (!e.empty() && err.empty()) err = e;
+                if (!err.empty()) break;
+                w.resize_rows(n * bins);
+                for (uint64_t r = 0; r < n; r++) {
+                    uint64_t total = 0;
+                    for (uint64_t i = 0; i < bins; i++) {
+                        uint64_t c = 0;
+                        for (size_t sh = 0; sh < N; sh++) c += part[sh][r * bins + i];
+                        w.rows[r * bins + i] = (double)c;
+                        total += c;
+                    }
+                    if (norm_) {
+                        const double d = total > 1 ? (double)total : 1.0;  // coverage/src/lib.rs:180-182
+                        for (uint64_t i = 0; i < bins; i++) w.rows[r * bins + i] /= d;
+                    }
+                }
+                emit_matrix(writer, w, bins, norm_, delim_, threads_, pieces, pt);
+            }
+            if (!more) break;
+        }
+        writer.finish();
+        fclose(out);
+        if (err.empty() && reader.failed()) err = reader.error();
+        return err;
     }
     if (!ctr_ || !ctr_->table()) return "build_table() has not run";
     SeqReader reader;

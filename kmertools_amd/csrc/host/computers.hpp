@@ -108,6 +108,10 @@ class CountComputer {
     void set_pass_hook(std::function<std::string(uint32_t pass, uint32_t passes, kt_ctr *table)> h) { pass_hook_ = std::move(h); }
     kt_ctr *table() const { return passes_ == 1 && !sharded_done_ ? ctr_ : nullptr; }  // the resident table (after count())
     kt_ctx *context() const { return dev_.ctx; }
+    // --devices N, for a caller that looks k-mers up afterwards (cov): merge() writes the shards but leaves them on their GPUs
+    void set_keep_shards(bool k) { keep_shards_ = k; }
+    size_t n_shards() const { return sharded_done_ ? shards_.size() : 0; }
+    kt_ctr *shard_table(size_t r) const;  // shard r's table (an ordinary kt_ctr that answers for its own k-mers only)
 
   private:
     std::string in_path_, out_dir_;
@@ -119,7 +123,7 @@ class CountComputer {
     kt_ctr *ctr_ = nullptr;
     int n_devices_ = 1;
     uint32_t passes_ = 1;
-    bool sharded_done_ = false;
+    bool sharded_done_ = false, keep_shards_ = false;
     // --devices N: the shards stay on their GPUs after count(); merge() writes them out one after the other, in slabs
     std::vector<kt_sharded *> shards_;
     std::vector<kt_ctx *> shard_ctx_;
@@ -147,12 +151,13 @@ class CovComputer {
     void set_kmer_path(std::string p) { in_path_kmer_ = std::move(p); }
     void set_max_memory(double gb) { memory_ceil_gb_ = gb; }
     void set_device(int d) { device_ = d; }
+    void set_devices(int n) { n_devices_ = n < 1 ? 1 : n; }  // --devices N: the table sharded over N GPUs, every read looked up in every shard
     std::string build_table();        // coverage/src/lib.rs:69-77: count + merge -> {out_dir}/kmers.counts
     std::string compute_coverages();  // coverage/src/lib.rs:79-163: writes {out_dir}/kmers.vectors
 
   private:
     std::string in_path_, in_path_kmer_, out_dir_, delim_ = " ";
-    int ksize_, threads_ = 0, device_ = 0;
+    int ksize_, threads_ = 0, device_ = 0, n_devices_ = 1;
     uint64_t bin_size_, bin_count_;
     bool norm_ = true;
     double memory_ceil_gb_ = 6.0;

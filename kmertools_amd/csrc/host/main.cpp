@@ -188,6 +188,7 @@ const char *HELP_COV =
     "      --counts                 Disable normalisation and output raw counts\n"
     "  -t, --threads <THREADS>      Thread count for computations 0=auto [default: 0]\n"
     "      --device <DEVICE>        GPU index [default: 0]\n"
+    "      --devices <N>            Shard the table over N GPUs, --device .. --device + N - 1 [default: 1]\n"
     "  -h, --help                   Print help\n";
 
 int make_out_dir(const std::string &out) {
@@ -206,7 +207,7 @@ int cmd_cov(int argc, char **argv, int from) {
     const std::vector<Spec> specs = {{'i', "input", true},    {'a', "alt-input", true}, {'o', "output", true},
                                      {'k', "k-size", true},   {'p', "preset", true},    {'s', "bin-size", true},
                                      {'c', "bin-count", true}, {'m', "memory", true},   {0, "counts", false},
-                                     {'t', "threads", true},  {0, "device", true}};
+                                     {'t', "threads", true},  {0, "device", true},      {0, "devices", true}};
     const auto f = parse_flags(argc, argv, from, specs, HELP_COV);
     const std::string in = required_str(f, "input"), out = required_str(f, "output");
     const int k = (int)ranged(f, "k-size", 7, 31, false, 15);
@@ -232,6 +233,7 @@ int cmd_cov(int argc, char **argv, int from) {
     cov.set_max_memory((double)mem);
     cov.set_delim(preset == "csv" ? "," : preset == "tsv" ? "\t" : " ");
     cov.set_device((int)ranged(f, "device", 0, 63, false, 0));
+    cov.set_devices((int)ranged(f, "devices", 1, 64, false, 1));
     std::string e = cov.build_table();
     if (e.empty()) e = cov.compute_coverages();
     if (!e.empty()) {

@@ -299,6 +299,17 @@ def test_ctr_out_of_core_passes_and_devices(cli, oracle, tmp_path):
     r = run(cli, "ctr", "-i", fq, "-o", d3, "-k", "21", "--devices", "3", env=dict(env, KT_CLI_SHARE_GPU="1"))
     assert r.returncode == 0, r.stderr
     assert sorted((d3 / "kmers.counts").read_text().splitlines()) == want
+    # cov --devices N (coverage/src/lib.rs:69-184: the reference's cov builds its table with the same CountComputer, so
+    # whatever ctr can count cov can look up): the table stays sharded on its GPUs, every batch of reads goes past every
+    # shard (kt_cov_batch_part answers for the shard's own k-mers), the rows are summed - kmers.vectors and kmers.counts
+    # are the oracle's, normalised and raw, with two and with three shards
+    cvd = tmp_path / "covdev"
+    for ndev, extra, norm in ((2, (), True), (3, ("--counts",), False)):
+        r = run(cli, "cov", "-i", fq, "-o", cvd, "-k", "15", "-s", "5", "-c", "6", "--devices", str(ndev), *extra,
+                env=dict(env, KT_CLI_SHARE_GPU="1"))
+        assert r.returncode == 0, r.stderr
+        assert (cvd / "kmers.vectors").read_bytes() == oracle.oligo_text(oc.cov_batch(bases, offsets, 15, 5, 6, norm), norm)
+        assert sorted((cvd / "kmers.counts").read_text().splitlines()) == oracle.counts_lines(k15, c15)
 
 
 @pytest.mark.gpu
