@@ -115,6 +115,8 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
     kt_seg_src *srcs;   // [n_src + 1] part2's sources (device copy; the last one: the pre-split pass's output)
     uint64_t *xstart, *xend, *xcount;  // [local buckets << bx] pre-split pass: the sub-buckets' bounds in keys2, their sizes
+    uint32_t *xcarry;   // [local buckets << bx] pre-split made slice by slice (kt_bulk_presplit_slice): keys a sub-bucket holds so far
+    kt_seg_src *xsrcs;  // [n_src] the slices' source lists of those launches (device copies, one stretch per launch)
     uint32_t *fail;     // [local buckets << bx] part2_fast_kernel: the bucket did not fit its fixed fine regions
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
@@ -1177,7 +1179,10 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
 template <class K, bool BIG, int PB>
 __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) void part2_fast_kernel(
     P2In in, Plan p, K *__restrict__ keys2, uint64_t *__restrict__ fstart, uint64_t *__restrict__ fend,
-    uint32_t *__restrict__ fail) {
+    uint32_t *__restrict__ fail, uint32_t *__restrict__ carry) {
+    // carry (may be null): [buckets][B2] keys every fine bucket holds already - the pass runs in several launches, each over
+    // some of the bucket's sources (the sharded counter's pre-split, slice by slice as the blocks arrive: kt_bulk_presplit_slice);
+    // the fine buckets' cursors start there and are left there, and fstart / fend always describe everything so far
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Part2Shared<K, BIG> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
         }
         const uint64_t lo = (uint64_t)jl * p.room1;
         for (uint32_t i = tid; i < B2; i += P2T) {
-            sm.cur[i] = i * cap2;  // (room1 = B2 * cap2 < 2^32)
+            sm.cur[i] = i * cap2 + (carry ? carry[(uint64_t)jl * B2 + i] : 0u);  // (room1 = B2 * cap2 < 2^32)
             sm.cnt[i] = 0;
             sm.cnt[B2 + i] = 0;
         }
@@ -1339,7 +1344,8 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
                         if (i < B2) {
                             const uint32_t c = sm.cur[i] + cntc[i];
                             sm.cur[i] = c;
-                            if ((float)(c - i * cap2) > allowed) *sm.flag = 1;
+                            // (a pass in several launches has no "share of the bucket seen so far": its check is the room itself)
+                            if (carry ? c - i * cap2 > cap2 : (float)(c - i * cap2) > allowed) *sm.flag = 1;
                         }
                     }
                 }
@@ -1359,6 +1365,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
             for (uint32_t i = tid; i < B2; i += P2T) {
                 fstart[(uint64_t)jl * B2 + i] = lo + (uint64_t)i * cap2;
                 fend[(uint64_t)jl * B2 + i] = lo + sm.cur[i];
+                if (carry) carry[(uint64_t)jl * B2 + i] = sm.cur[i] - i * cap2;
             }
         } else if (tid == 0) {
             fail[jl] = 1u;  // redone by part2_kernel<K, false, BIG> (exact fine boundaries) in the launch behind this one
@@ -2414,6 +2421,10 @@ struct kt_bulk_job {
     bool sharded = false;  // regions are messages: level 1 parks what does not fit (pend) instead of being redone
     PendList pend{};
     std::vector<kt_seg_src> p2_srcs;  // where part2 reads every local bucket from (set by the caller when sharded)
+    // the pre-split made slice by slice (kt_bulk_presplit_slice): sources covered so far, and the launches' source lists
+    // (host copies that outlive their asynchronous upload)
+    uint32_t presplit_srcs = 0;
+    std::vector<std::vector<kt_seg_src>> presplit_lists;
     size_t ksz() const { return narrow ? 4 : 8; }
 };
 
@@ -2556,7 +2567,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
                                                (int)part2_lds));
                     uint32_t grid = pp.d_hi - pp.d_lo;
                     if (j.kn.p2_grid && grid > j.kn.p2_grid) grid = (uint32_t)j.kn.p2_grid;
-                    hipLaunchKernelGGL(fast, dim3(grid), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe, fail);
+                    hipLaunchKernelGGL(fast, dim3(grid), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe, fail, (uint32_t *)nullptr);
                     KT_HIP(hipGetLastError());
                     return KT_OK;
                 };
@@ -2595,7 +2606,25 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         pa.b2 = p.bx;
         pa.B2 = 1u << p.bx;
         pa.cap2 = p.room1 / pa.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
-        if (int rc = run_part2(pa, in, keys2, m.xstart, m.xend)) return rc;
+        if (j.presplit_srcs && j.presplit_srcs == in.n_src) {
+            // pass A has been made already, slice by slice while the blocks arrived (kt_bulk_presplit_slice); what is left of
+            // it is the redo of the buckets that did not fit their fixed sub-regions (none, normally), over all the sources
+            const bool bigr = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 && Part2Shared<K, true>::bytes(pa.B2) <= 160 * 1024;
+            auto redo_launch = [&](auto big) -> int {
+                constexpr bool BIG = decltype(big)::value;
+                const size_t rl = Part2Shared<K, BIG>::bytes(pa.B2);
+                auto redo = part2_kernel<K, false, BIG>;
+                KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
+                hipLaunchKernelGGL(redo, dim3(pa.d_hi - pa.d_lo), dim3(p2t<K, BIG>()), rl, ctx->stream, in, pa, keys2, m.xstart, m.xend,
+                                   (const uint32_t *)m.fail);
+                KT_HIP(hipGetLastError());
+                return KT_OK;
+            };
+            if (int rc = bigr ? redo_launch(std::true_type{}) : redo_launch(std::false_type{})) return rc;
+        } else {
+            if (j.presplit_srcs) return kt::fail(KT_ERR_ARG, "bulk build: the pre-split was made for some of the sources only");
+            if (int rc = run_part2(pa, in, keys2, m.xstart, m.xend)) return rc;
+        }
         const uint32_t n_sub = nd << p.bx;
         hipLaunchKernelGGL(sub_counts_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)m.xstart,
                            (const uint64_t *)m.xend, n_sub, m.xcount);
@@ -2855,6 +2884,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const size_t off_xs = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_xe = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_xn = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
+    const size_t off_xy = meta;      meta += (p.bx ? (n_sub + 1) * 4 + 255 : 0) & ~(size_t)255;
+    const size_t off_xs2 = meta;     meta += (p.bx ? (size_t)n_src * sizeof(kt_seg_src) + 255 : 0) & ~(size_t)255;
     const size_t off_ov = meta;      meta += 256;
     const size_t off_fl = meta;      meta += ((n_sub + 1) * 4 + 255) & ~(size_t)255;
     const size_t off_sn = meta;      meta += 256;
@@ -2892,6 +2923,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.xend = (uint64_t *)(mb + off_xe);
     m.xcount = (uint64_t *)(mb + off_xn);
     m.xcur = (unsigned long long *)(mb + off_xc);
+    m.xcarry = (uint32_t *)(mb + off_xy);
+    m.xsrcs = (kt_seg_src *)(mb + off_xs2);
     m.dump = (unsigned long long *)(mb + off_du);
     m.ovf = (uint32_t *)(mb + off_ov);
     m.fail = (uint32_t *)(mb + off_fl);
@@ -2919,6 +2952,12 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
         }
     }
     j.xcd = paged && xcd;
+    j.presplit_srcs = 0;
+    j.presplit_lists.clear();
+    if (p.bx) {
+        KT_HIP(hipMemsetAsync(m.xcarry, 0, (n_sub + 1) * 4, ctx->stream));
+        KT_HIP(hipMemsetAsync(m.fail, 0, (n_sub + 1) * 4, ctx->stream));
+    }
     j.p = p;
     j.m = m;
     j.paged = paged;
@@ -2989,6 +3028,48 @@ int kt_bulk_slice_info(kt_ctr *ctr, uint32_t slice, uint32_t bucket, kt_bulk_sha
     if (keys) *keys = (char *)ctr->b_keys1.p + ((size_t)slice * p.B1 + bucket) * p.cap1 * job->ksz();
     if (counts) *counts = job->m.gcur + (size_t)slice * p.B1 + bucket;
     return KT_OK;
+}
+
+// The pre-split of a shard (plan_job: bx > 0, the hash bits level 2 cannot take), made for SOME of the bucket's sources -
+// one slice's blocks, as they have arrived - on `stream`: the 2^bx-way pass appends to the sub-buckets where the slices
+// before it stopped (Meta::xcarry).  Called once per slice with that slice's sources, in any order, before
+// kt_bulk_finish, which then only runs the ordinary level 2 over the sub-buckets (and the redo of a bucket that did not
+// fit its fixed sub-regions, over all the sources set with kt_bulk_set_sources).  *needed = 0: this job has no pre-split.
+namespace {
+template <class K>
+int presplit_typed(kt_ctr *ctr, kt_bulk_job &j, const kt_seg_src *d_srcs, uint32_t n, hipStream_t stream) {
+    const Plan &p = j.p;
+    Plan pa = p;
+    pa.b2 = p.bx;
+    pa.B2 = 1u << p.bx;
+    pa.cap2 = p.room1 / pa.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
+    const P2In in{nullptr, nullptr, d_srcs, n};
+    const bool big = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 && Part2Shared<K, true>::bytes(pa.B2) <= 160 * 1024;
+    auto launch = [&](auto bg) -> int {
+        constexpr bool BIG = decltype(bg)::value;
+        const size_t lds = Part2Shared<K, BIG>::bytes(pa.B2);
+        auto fast = part2_fast_kernel<K, BIG, 1>;
+        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fast, dim3(pa.d_hi - pa.d_lo), dim3(p2t<K, BIG>()), lds, stream, in, pa, (K *)ctr->b_keys2.p, j.m.xstart,
+                           j.m.xend, j.m.fail, j.m.xcarry);
+        KT_HIP(hipGetLastError());
+        return KT_OK;
+    };
+    return big ? launch(std::true_type{}) : launch(std::false_type{});
+}
+}  // namespace
+
+int kt_bulk_presplit_slice(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n, hipStream_t stream, int *needed) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->open || !job->sharded) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
+    if (needed) *needed = job->p.bx ? 1 : 0;
+    if (!job->p.bx || !job->p.cap2 || n == 0) return KT_OK;
+    if (job->presplit_srcs + n > job->n_src) return kt::fail(KT_ERR_ARG, "bulk build: more pre-split sources than the job has");
+    job->presplit_lists.emplace_back(srcs, srcs + n);
+    kt_seg_src *d = job->m.xsrcs + job->presplit_srcs;
+    KT_HIP(hipMemcpyAsync(d, job->presplit_lists.back().data(), n * sizeof(kt_seg_src), hipMemcpyHostToDevice, stream));
+    job->presplit_srcs += n;
+    return job->narrow ? presplit_typed<uint32_t>(ctr, *job, d, n, stream) : presplit_typed<uint64_t>(ctr, *job, d, n, stream);
 }
 
 // part2's sources: one per (slice, sender), each the regions of this table's buckets d_lo .. d_hi in bucket order

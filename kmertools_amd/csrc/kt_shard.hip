@@ -163,8 +163,8 @@ struct kt_sharded {
     uint64_t *pend_keys = nullptr, *fin_left = nullptr;  // finalize: the pending table's pairs, exported
     uint32_t *pend_counts = nullptr;
     uint64_t pend_cap = 0;
-    hipStream_t comm_stream = nullptr;
-    std::vector<hipEvent_t> ev_l1, ev_recv;
+    hipStream_t comm_stream = nullptr, ps_stream = nullptr;  // ps_stream: the pre-split of slice i while slice i + 1 travels
+    std::vector<hipEvent_t> ev_l1, ev_recv, ev_ps;
     // transport
     Rccl *rccl = nullptr;
     ncclComm_t comm = nullptr;
@@ -286,10 +286,13 @@ int sharded_alloc(kt_sharded *s) {
         KT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         KT_HIP(hipStreamCreateWithPriority(&s->comm_stream, hipStreamNonBlocking, hi));
     }
+    KT_HIP(hipStreamCreateWithFlags(&s->ps_stream, hipStreamNonBlocking));
     s->ev_l1.resize(s->n_slices);
     s->ev_recv.resize(s->n_slices);
+    s->ev_ps.resize(s->n_slices);
     for (auto &ev : s->ev_l1) KT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (auto &ev : s->ev_recv) KT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto &ev : s->ev_ps) KT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     return KT_OK;
 }
 
@@ -466,6 +469,12 @@ int kt_sharded_destroy(kt_sharded *s) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto ev : s->ev_recv)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : s->ev_ps)
+        if (ev) (void)hipEventDestroy(ev);
+    if (s->ps_stream) {
+        (void)hipStreamSynchronize(s->ps_stream);
+        (void)hipStreamDestroy(s->ps_stream);
+    }
     if (s->recv_keys) (void)hipFree(s->recv_keys);
     if (s->recv_counts) (void)hipFree(s->recv_counts);
     if (s->send_status) (void)hipFree(s->send_status);
@@ -648,6 +657,8 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
 
     std::vector<kt_seg_src> srcs;
     srcs.reserve((size_t)P * N);
+    const char *ps_env = getenv("KT_SHARD_PRESPLIT_SLICED");  // (0: the whole pre-split behind the last block, as in round 4 - A/B, tests)
+    bool pre_sliced = !(ps_env && atoi(ps_env) == 0);
     for (int i = 0; i < P; i++) {
         // level 1 of the slice over this rank's reads: B1 regions, the buckets of owner o one contiguous block
         const uint64_t lo = a.n_seg * (uint64_t)i / (uint64_t)P, hi = a.n_seg * (uint64_t)(i + 1) / (uint64_t)P;
@@ -685,8 +696,23 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
                                           s->recv_counts + ((size_t)i * N + p) * s->recv_cnt_block + 8, sh.cap1});
             }
         }
+        // The pre-split of this slice (N >= 4: the bits level 2 cannot take) leaves as soon as the slice's blocks are in, on
+        // a stream of its own: it runs beside level 1 of the later slices and under the exchange still on the wires, and
+        // the main stream - level 1 of the next slice, whose blocks the peers are waiting for - never stands behind it.
+        // (Round 4 ran the whole pass after the last block had arrived: 11 ms behind an exchange that is the longest
+        // thing in the step; a slice's share, ~2.8 ms, behind the last block is what is left of it.)
+        if (pre_sliced) {
+            KT_HIP(hipStreamWaitEvent(s->ps_stream, s->ev_l1[(size_t)i], 0));
+            KT_HIP(hipStreamWaitEvent(s->ps_stream, s->ev_recv[(size_t)i], 0));
+            int needed = 0;
+            if (int rc = kt_bulk_presplit_slice(s->table, srcs.data() + (size_t)i * N, (uint32_t)N, s->ps_stream, &needed)) return rc;
+            KT_HIP(hipEventRecord(s->ev_ps[(size_t)i], s->ps_stream));
+            if (!needed) pre_sliced = false;
+        }
     }
     for (int i = 0; i < P; i++) KT_HIP(hipStreamWaitEvent(ctx->stream, s->ev_recv[(size_t)i], 0));
+    if (pre_sliced)
+        for (int i = 0; i < P; i++) KT_HIP(hipStreamWaitEvent(ctx->stream, s->ev_ps[(size_t)i], 0));
     // did every rank take part with a sound batch?  (the status words arrived with the blocks)
     bool peer_failed = false;
     if (N > 1) {

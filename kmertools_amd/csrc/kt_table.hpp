@@ -141,6 +141,9 @@ int kt_bulk_slice_reads(kt_ctr *ctr, uint32_t slice, const uint8_t *d_bases, con
 int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice);
 int kt_bulk_slice_info(kt_ctr *ctr, uint32_t slice, uint32_t bucket, kt_bulk_shape *shape, void **keys, uint64_t **counts);
 int kt_bulk_set_sources(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n);
+// the shard's pre-split (the hash bits level 2 cannot take: N >= 4 GPUs) over ONE slice's sources, enqueued on `stream`
+// as soon as the slice's blocks are in - its cursors carry on from the slices before; kt_bulk_finish then skips that pass
+int kt_bulk_presplit_slice(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n, hipStream_t stream, int *needed);
 int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
                       uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_parts, uint32_t part);
 int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n);

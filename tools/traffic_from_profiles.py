@@ -1,11 +1,11 @@
-"""HBM traffic of one ctr step from a committed rocprofv3 summary (profiles/r4_<tag>_rocprof_summary.txt, the separate
+"""HBM traffic of one ctr step from a committed rocprofv3 summary (profiles/r5_<tag>_rocprof_summary.txt, the separate
 FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh): per-dispatch means of the step's kernels x their launches per
 step, summed.  Prints the fetch_kib / write_kib that profiles/traffic.json holds.  usage: traffic_from_profiles.py [tags...]"""
 import pathlib, re, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-STEP_KERNELS = r"seg_index|scatter1|page_tails|part2|build_kernel|ext_scan|ext_patch|hist1|scan1"
+STEP_KERNELS = r"seg_index|scatter1|xcd_tails|part2|build_kernel|ext_scan|ext_patch|hist1|scan1"
 for tag in sys.argv[1:] or ("ctr_k31", "ctr_k31_genome", "ctr_k15"):
-    txt = (ROOT / "profiles" / ("r4_%s_rocprof_summary.txt" % tag)).read_text()
+    txt = (ROOT / "profiles" / ("r5_%s_rocprof_summary.txt" % tag)).read_text()
     rows = []
     for m in re.finditer(r"== (.+)\n((?:  .+\n)+)", txt[txt.index("## PMC"):]):
         if not re.search(STEP_KERNELS, m.group(1)):
