@@ -115,6 +115,8 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
     kt_seg_src *srcs;   // [n_src + 1] part2's sources (device copy; the last one: the pre-split pass's output)
     uint64_t *xstart, *xend, *xcount;  // [local buckets << bx] pre-split pass: the sub-buckets' bounds in keys2, their sizes
+    uint64_t *xout;     // [local buckets << bx] where the level 2 behind the pre-split writes every sub-bucket (presplit_plan_kernel)
+    uint32_t *fail2;    // [local buckets << bx] that level 2's failure words (fail holds the pre-split's meanwhile)
     uint32_t *xcarry;   // [local buckets << bx] pre-split made slice by slice (kt_bulk_presplit_slice): keys a sub-bucket holds so far
     kt_seg_src *xsrcs;  // [n_src] the slices' source lists of those launches (device copies, one stretch per launch)
     uint32_t *fail;     // [local buckets << bx] part2_fast_kernel: the bucket did not fit its fixed fine regions
@@ -958,7 +960,33 @@ struct P2In {
     const uint64_t *bstart;
     const kt_seg_src *srcs;
     uint32_t n_src;
+    // where bucket jl's output begins in keys2 (null: jl * room1).  Set for the level 2 behind a pre-split (presplit_plan_kernel):
+    // the sub-buckets of a parent that a few k-mers dominate are laid out by their sizes inside the parent's room - one of
+    // them may hold more keys than an even share of it
+    const uint64_t *out_starts;
+    __device__ __forceinline__ uint64_t out_of(uint32_t jl, uint64_t room1) const { return out_starts ? out_starts[jl] : (uint64_t)jl * room1; }
 };
+
+// The level 2 behind a pre-split: where every sub-bucket's output goes, and which sub-buckets skip the attempt with fixed
+// fine regions.  A parent bucket whose pre-split did not fit its fixed sub-regions (failA: a few k-mers dominate it) has
+// sub-buckets of very different sizes - one may hold nearly all of the parent's keys, more than the even share (room1 >>
+// bx) the attempt's fixed regions assume: laid out by exact boundaries from the sub-bucket's even place it would run
+// over its neighbours (found by tests: presplit_skewed).  Those sub-buckets are placed back to back inside the PARENT's
+// room, by their sizes, and go straight to the exact pass (failB = 1: the attempt kernels skip them).
+__global__ void presplit_plan_kernel(const uint32_t *__restrict__ failA, const uint64_t *__restrict__ xcount, uint32_t nd, uint32_t bx,
+                                     uint64_t room1, uint64_t line_keys, uint64_t *__restrict__ out_starts, uint32_t *__restrict__ failB) {
+    const uint32_t jl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jl >= nd) return;
+    const uint32_t nsub = 1u << bx;
+    const bool heavy = failA[jl] != 0;
+    uint64_t at = (uint64_t)jl * room1;
+    for (uint32_t i = 0; i < nsub; i++) {
+        const uint32_t js = (jl << bx) + i;
+        failB[js] = heavy ? 1u : 0u;
+        out_starts[js] = heavy ? at : (uint64_t)js * (room1 >> bx);
+        at += (xcount[js] + line_keys - 1) / line_keys * line_keys;  // (every sub-bucket starts on a cache line)
+    }
+}
 
 template <class K, bool FIXED, bool BIG, bool L16 = false>
 __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) void part2_kernel(P2In in, Plan p,
@@ -994,7 +1022,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
             segment(sidx, b, n);
             total += n;
         }
-        const uint64_t lo = in.srcs ? (uint64_t)jl * p.room1 : in.bstart[jl];
+        const uint64_t lo = in.srcs ? in.out_of(jl, p.room1) : in.bstart[jl];
         auto load_chunk = [&](const K *base, uint64_t n, uint64_t c0, K (&dst)[PER]) {
             if constexpr (sizeof(K) == 8 && L16) {  // two keys per load (regions are 16-byte aligned: paged level 1)
                 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -1209,7 +1237,8 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
             segment(sidx, b, n);
             total += n;
         }
-        const uint64_t lo = (uint64_t)jl * p.room1;
+        if (fail[jl] != 0) continue;  // (marked ahead of the attempt - presplit_plan_kernel - or by an earlier launch of a pass in several: the exact pass takes it)
+        const uint64_t lo = in.out_of(jl, p.room1);
         for (uint32_t i = tid; i < B2; i += P2T) {
             sm.cur[i] = i * cap2 + (carry ? carry[(uint64_t)jl * B2 + i] : 0u);  // (room1 = B2 * cap2 < 2^32)
             sm.cnt[i] = 0;
@@ -1453,7 +1482,8 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
             segment(sidx, b, n);
             total += n;
         }
-        const uint64_t lo = (uint64_t)jl * p.room1;
+        if (fail[jl] != 0) continue;  // (marked ahead of the attempt - presplit_plan_kernel - or by an earlier launch of a pass in several: the exact pass takes it)
+        const uint64_t lo = in.out_of(jl, p.room1);
         for (uint32_t i = tid; i < 2 * B2; i += P2T) sm.fc[i] = 0;
         if (tid < 4) sm.flags[tid] = 0;
         ktd::lds_barrier();
@@ -2510,7 +2540,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         }
     }
     // where part2 finds every bucket: the one level-1 output of a table of its own, or what the sharded counter set
-    P2In in{keys1, m.bstart, nullptr, 0};
+    P2In in{keys1, m.bstart, nullptr, 0, nullptr};
     if (j.paged) {
         if (!j.sharded) j.p2_srcs.assign(1, kt_seg_src{keys1, m.gcur, p.cap1, nullptr});
         if (j.p2_srcs.empty() || j.p2_srcs.size() > j.n_src) return kt::fail(KT_ERR_ARG, "bulk build: level-2 sources not set");
@@ -2521,7 +2551,9 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     }
     const uint32_t nd = p.d_hi - p.d_lo;
     // one level-2 launch: `pp` says which hash bits it sorts by and how many buckets it reads, `src` where from
-    auto run_part2 = [&](const Plan &pp, const P2In &src, K *out, uint64_t *fs, uint64_t *fe) -> int {
+    // (`fail`: one word per bucket of the launch - zeroed here, unless `preset`: then the caller has marked the buckets
+    // that skip the attempt with fixed fine regions)
+    auto run_part2 = [&](const Plan &pp, const P2In &src, K *out, uint64_t *fs, uint64_t *fe, uint32_t *fail, bool preset) -> int {
         // (one line per fine bucket wants about a line's worth of keys per bucket and chunk: with few, large fine buckets -
         // the pre-split's 2^bx-way pass - a chunk would be hundreds of generations, and its runs are long anyway: that
         // pass keeps the sort buffer)
@@ -2529,8 +2561,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             // fixed fine regions, whole lines only (part2_swwc_kernel); then the general kernel over the buckets that did not
             // fit their regions (none, normally)
             const size_t lds = SwwcShared<K>::bytes(pp.B2);
-            uint32_t *fail = m.fail;
-            KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
+            if (!preset) KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
             auto swwc = part2_swwc_kernel<K>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(swwc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             uint32_t grid = pp.d_hi - pp.d_lo;
@@ -2558,8 +2589,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             constexpr uint32_t P2T = (uint32_t)p2t<K, BIG>();
             if (pp.cap2 && src.srcs && j.kn.p2_fast && pp.B2 <= 4 * P2T) {
                 // fixed fine regions: the lean kernel, then the general one over the buckets that did not fit (none, normally)
-                uint32_t *fail = m.fail;
-                KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
+                if (!preset) KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
                 auto go = [&](auto pb) -> int {
                     constexpr int PB = decltype(pb)::value;
                     auto fast = part2_fast_kernel<K, BIG, PB>;
@@ -2596,7 +2626,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         return big2 ? launch(std::true_type{}) : launch(std::false_type{});
     };
     if (p.bx == 0) {
-        if (int rc = run_part2(p, in, keys2, m.fstart, m.fend)) return rc;
+        if (int rc = run_part2(p, in, keys2, m.fstart, m.fend, m.fail, false)) return rc;
     } else {
         // The shard of a table spread over many GPUs: level 2 cannot take all the bits level 1 left (plan_job).  Pass A
         // splits every bucket 2^bx ways into keys2 (long runs: close to a copy); pass B is the ordinary level 2 over the
@@ -2623,7 +2653,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             if (int rc = bigr ? redo_launch(std::true_type{}) : redo_launch(std::false_type{})) return rc;
         } else {
             if (j.presplit_srcs) return kt::fail(KT_ERR_ARG, "bulk build: the pre-split was made for some of the sources only");
-            if (int rc = run_part2(pa, in, keys2, m.xstart, m.xend)) return rc;
+            if (int rc = run_part2(pa, in, keys2, m.xstart, m.xend, m.fail, false)) return rc;
         }
         const uint32_t n_sub = nd << p.bx;
         hipLaunchKernelGGL(sub_counts_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)m.xstart,
@@ -2640,8 +2670,13 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         const kt_seg_src from_a{keys2, m.xcount, ~0ull, m.xstart};
         KT_HIP(hipMemcpyAsync(m.srcs + j.n_src, &from_a, sizeof from_a, hipMemcpyHostToDevice, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));  // (from_a lives on this frame)
-        const P2In inb{nullptr, nullptr, m.srcs + j.n_src, 1};
-        if (int rc = run_part2(pb, inb, keys1, m.fstart, m.fend)) return rc;
+        // where every sub-bucket's output goes, and which of them skip the attempt (the children of a parent that a few
+        // k-mers dominate: presplit_plan_kernel)
+        hipLaunchKernelGGL(presplit_plan_kernel, dim3((nd + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)m.fail,
+                           (const uint64_t *)m.xcount, nd, p.bx, p.room1, (uint64_t)(128 / sizeof(K)), m.xout, m.fail2);
+        KT_HIP(hipGetLastError());
+        const P2In inb{nullptr, nullptr, m.srcs + j.n_src, 1, m.xout};
+        if (int rc = run_part2(pb, inb, keys1, m.fstart, m.fend, m.fail2, true)) return rc;
         keys2 = keys1;  // what the builds read
     }
     const uint64_t n_fine = (uint64_t)nd * p.B2;
@@ -2885,6 +2920,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const size_t off_xe = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_xn = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
     const size_t off_xy = meta;      meta += (p.bx ? (n_sub + 1) * 4 + 255 : 0) & ~(size_t)255;
+    const size_t off_xo = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
+    const size_t off_f2 = meta;      meta += (p.bx ? (n_sub + 1) * 4 + 255 : 0) & ~(size_t)255;
     const size_t off_xs2 = meta;     meta += (p.bx ? (size_t)n_src * sizeof(kt_seg_src) + 255 : 0) & ~(size_t)255;
     const size_t off_ov = meta;      meta += 256;
     const size_t off_fl = meta;      meta += ((n_sub + 1) * 4 + 255) & ~(size_t)255;
@@ -2924,6 +2961,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.xcount = (uint64_t *)(mb + off_xn);
     m.xcur = (unsigned long long *)(mb + off_xc);
     m.xcarry = (uint32_t *)(mb + off_xy);
+    m.xout = (uint64_t *)(mb + off_xo);
+    m.fail2 = (uint32_t *)(mb + off_f2);
     m.xsrcs = (kt_seg_src *)(mb + off_xs2);
     m.dump = (unsigned long long *)(mb + off_du);
     m.ovf = (uint32_t *)(mb + off_ov);
@@ -3043,7 +3082,7 @@ int presplit_typed(kt_ctr *ctr, kt_bulk_job &j, const kt_seg_src *d_srcs, uint32
     pa.b2 = p.bx;
     pa.B2 = 1u << p.bx;
     pa.cap2 = p.room1 / pa.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
-    const P2In in{nullptr, nullptr, d_srcs, n};
+    const P2In in{nullptr, nullptr, d_srcs, n, nullptr};
     const bool big = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 && Part2Shared<K, true>::bytes(pa.B2) <= 160 * 1024;
     auto launch = [&](auto bg) -> int {
         constexpr bool BIG = decltype(bg)::value;

@@ -561,7 +561,7 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 # count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
 
 _SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "presplit": (2, 31), "presplit3": (3, 15),
-                "localfail": (2, 31)}   # case -> (ranks, k)
+                "presplit_whole": (2, 31), "presplit_skewed": (2, 31), "presplit_whole_skewed": (2, 31), "localfail": (2, 31)}   # case -> (ranks, k)
 
 
 def _two_rank_worker(rank, port, q, case):
@@ -577,6 +577,8 @@ def _two_rank_worker(rank, port, q, case):
     if case.startswith("presplit"):
         os.environ["KT_BULK_MAX_B2"] = "3"    # level 2 takes 3 bits only: the shards need the pre-split pass (2 bits)
         os.environ["KT_BULK_VERBOSE"] = "1"
+    if case.startswith("presplit_whole"):
+        os.environ["KT_SHARD_PRESPLIT_SLICED"] = "0"   # the whole pre-split behind the last block (round 4's schedule)
     if case == "localfail":
         os.environ["KT_SHARD_FAIL_LOCAL"] = "1:1"   # rank 1's second call fails while it sets the batch up
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -588,7 +590,7 @@ def _two_rank_worker(rank, port, q, case):
         bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
         offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         ctx.synth_reads(4242, n, L, bases, offsets, noise=True, genome_len=200000, first_read=rank * n)
-        if case == "skewed" and rank == 1:
+        if case in ("skewed", "presplit_skewed", "presplit_whole_skewed") and rank == 1:
             bases[: 8000 * L] = ord("A")           # 40 % of rank 1's batch is one k-mer: its owner's regions overflow
         sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD, max_batch_bases=n * L)
         sc.add_reads(bases, offsets, n)
@@ -614,14 +616,17 @@ def _two_rank_worker(rank, port, q, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3", "localfail"])
+@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3", "presplit_whole", "presplit_skewed", "presplit_whole_skewed", "localfail"])
 def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     """the C ABI's sharded counter with two ranks on cuda:0 and the host all-to-all transport over gloo: route on
     the GPU, exchange fixed-size regions, partition + range build of what arrived, finalize; the union of the shards
     is the oracle's table of all reads.  `skewed`: one k-mer floods its owner's regions, so the pending list and
     several finalize rounds run; `narrow3`: three ranks, three slices, k=15 (32-bit keys through the partition);
     `presplit*`: level 2 restricted to 3 hash bits, so that the shards need the pre-split pass that 4- and 8-GPU tables
-    of BASELINE size need (a third trip of the keys: 2^bx-way split, then the ordinary level 2 over the sub-buckets);
+    of BASELINE size need (a third trip of the keys: 2^bx-way split, then the ordinary level 2 over the sub-buckets) - made
+    slice by slice on a stream of its own as the blocks arrive (the default), `presplit_whole`: behind the last block as in
+    round 4, `presplit_skewed`: with a k-mer that floods its sub-bucket's fixed room (the bucket is redone with exact
+    boundaries over all its sources at the end);
     `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call works"""
     import socket
     import torch.multiprocessing as mp
@@ -644,7 +649,7 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     ctr = oracle.Counter(4)
     for rank in range(world):
         hb, ho = oracle.synth_reads(4242, n, L, noise=True, genome_len=200000, first_read=rank * n)
-        if case == "skewed" and rank == 1:
+        if case in ("skewed", "presplit_skewed", "presplit_whole_skewed") and rank == 1:
             hb = hb.copy()
             hb[: 8000 * L] = ord("A")
         ctr.add_reads(hb, ho, k, threads=4)
