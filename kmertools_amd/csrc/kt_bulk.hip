@@ -310,15 +310,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // call, two barriers, returns the total - in straight-line code: the wave's scan by DPP, the NT / 64 <= 16 wave totals
 // scanned inside one DPP row.  (The general routine's per-thread loops with a run-time trip count cost the partition
 // kernels a few hundred instructions and a dozen spilled registers per call.)
-// (RND = 2^r - 1: every counter is rounded up to a multiple of 2^r first - runs that start on 16-byte boundaries, scatter1x)
-template <int NT, int PB, uint32_t RND = 0>
-__device__ __forceinline__ uint32_t block_excl_scan_n(const uint32_t *cnt, uint32_t *out, uint32_t B, uint32_t *tmp) {
+// (RND = 2^r - 1: every counter is rounded up to a multiple of 2^r first - runs that start on 16-byte boundaries, scatter1x;
+// the counters are read through `get(i)`: scatter1y keeps them two to a word)
+template <int NT, int PB, uint32_t RND, class Get>
+__device__ __forceinline__ uint32_t block_excl_scan_f(Get get, uint32_t *out, uint32_t B, uint32_t *tmp) {
     static_assert(NT % 64 == 0 && NT / 64 <= 16, "wave totals fit one DPP row");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t c[PB], sum = 0;
 #pragma unroll
     for (int j = 0; j < PB; j++) {
-        c[j] = tid * PB + j < B ? (cnt[tid * PB + j] + RND) & ~RND : 0u;
+        c[j] = tid * PB + j < B ? (get(tid * PB + j) + RND) & ~RND : 0u;
         sum += c[j];
     }
     const uint32_t inc = wave_incl_scan(sum);
@@ -340,6 +341,10 @@ __device__ __forceinline__ uint32_t block_excl_scan_n(const uint32_t *cnt, uint3
     }
     ktd::lds_barrier();
     return total;
+}
+template <int NT, int PB, uint32_t RND = 0>
+__device__ __forceinline__ uint32_t block_excl_scan_n(const uint32_t *cnt, uint32_t *out, uint32_t B, uint32_t *tmp) {
+    return block_excl_scan_f<NT, PB, RND>([&](uint32_t i) { return cnt[i]; }, out, B, tmp);
 }
 // B <= 4 * NT (every caller: B <= 2048, NT >= 512), dispatched on a workgroup-uniform condition
 template <int NT>
@@ -877,6 +882,238 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
             if (q == NQ - 1) ktd::lds_barrier();
             KT_PH(7);
         }
+    }
+#if KT_ABLATION
+    if (tid == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&kt_dbg_phase[8 + i], (unsigned long long)phs[i]);
+#endif
+}
+
+// ---- scatter1y: two sort buffers, the copy-out of a round spread over the whole of the next one -----------------------------
+// scatter1x's phases add up (section 4.2 of DESIGN.md, round 5): its compute phases issue no stores and its copy-out does
+// nothing else, and a CU cannot issue stores faster than ~7 bytes per clock - a round's 128 KB hold the CU for 7 us.  Here
+// a round is HALF the size (8 K 64-bit / 16 K 32-bit keys: PER2 window starts per thread) and there are TWO sort buffers:
+// the groups of round r leave one 16-byte store at a time from five places inside round r + 1 - the walk, the scan, the
+// placement - so the store queue drains under everything else the CU does, and nobody waits for it.  delta[] follows the
+// buffers (one per parity: the round before reads its own while this round writes its); the round's counters are 16-bit,
+// two to a word - that is what makes room for the second delta[] at 64-bit keys and 1024 buckets; the staged segments
+// borrow the buffer that the round about to begin will fill (its former content left the CU a round ago).  LDS: 2 x (T x
+// PER2 + B1 x (GK - 1)) keys + 14 KB - carved at run time (the pads follow B1); a shape that does not fit 160 KB keeps
+// scatter1x.
+template <class K>
+constexpr int half_per() { return wide_per<K>() / 2; }
+template <class K, int T>
+struct Scatter1YShared {
+    K *sorted[2];
+    // the round's counters: [MAX_B1], or - 64-bit keys, where 2 KB decide whether the second delta[] fits - two 16-bit ones to
+    // a word, [MAX_B1 / 2] (a round has 8 K keys; two buckets per word cost the count's atomics more conflicts: at k=15, 256
+    // buckets, the packed form measured 19.5 against 19.0 ms, so 32-bit keys keep a word per bucket)
+    static constexpr bool PACK = sizeof(K) == 8;
+    uint32_t *cnt2;
+    uint32_t *start;  // [MAX_B1] the runs of the round in sorted[]: the scan's result, the placement's cursors
+    uint32_t *delta[2];  // [MAX_B1] per parity: (the run's first place in its set's stream of the bucket) - (its start in sorted[])
+    uint32_t *tmp, *ovf;
+    __host__ __device__ static constexpr size_t slots(uint32_t B1) { return ((size_t)T * half_per<K>() + (size_t)B1 * (group_keys<K>() - 1) + 63) / 64 * 64; }
+    static constexpr size_t bytes(uint32_t B1) { return 2 * slots(B1) * sizeof(K) + MAX_B1 * (sizeof(K) == 8 ? 2 : 4) + 3 * MAX_B1 * 4 + 16 * 4 + 16; }
+    __device__ Scatter1YShared(unsigned char *raw, uint32_t B1) {
+        sorted[0] = reinterpret_cast<K *>(raw);
+        sorted[1] = sorted[0] + slots(B1);
+        cnt2 = reinterpret_cast<uint32_t *>(sorted[1] + slots(B1));
+        start = cnt2 + (PACK ? MAX_B1 / 2 : MAX_B1);
+        delta[0] = start + MAX_B1;
+        delta[1] = delta[0] + MAX_B1;
+        tmp = delta[1] + MAX_B1;
+        ovf = tmp + 16;
+    }
+};
+static_assert(Scatter1YShared<uint64_t, 1024>::bytes(MAX_B1) <= 160 * 1024, "64-bit keys, 1024 buckets: the largest shape level 1 is asked for");
+
+template <class Source, class K, int T>
+__global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, unsigned long long *__restrict__ xcur,
+                                                      uint32_t *__restrict__ ovf, K *__restrict__ keys1, PendList pend,
+                                                      unsigned long long *__restrict__ dump) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Scatter1YShared<K, T> sm(smem_raw, p.B1);
+    constexpr int PER = half_per<K>(), NQ = ktseg::PER_THREAD / PER, GROUPS = T / BLOCK, PB = MAX_B1 / T;
+    constexpr uint32_t GK = group_keys<K>(), GSH = GK == 2 ? 1 : 2;
+    constexpr int NST = (int)(((size_t)T * PER + (size_t)MAX_B1 * (GK - 1)) / GK + T - 1) / T;  // 16-byte stores per thread and round
+    static_assert(NST == 5 && PB == 1, "the five places the stores leave from");
+    static_assert(GROUPS * sizeof(SegShared) <= (size_t)T * PER * sizeof(K), "the staged segments fit a sort buffer");
+    constexpr K EMPTY = empty_of<K>();
+    typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+    const uint32_t tid = threadIdx.x, grp = tid / BLOCK, t = tid % BLOCK;
+    const uint32_t xset = (p.xmap >> (4u * xcc_id())) & 7u;
+    unsigned long long *const mycur = xcur + (size_t)xset * p.B1;
+    constexpr bool PACK = Scatter1YShared<K, T>::PACK;
+    if (tid < (PACK ? MAX_B1 / 2 : MAX_B1)) sm.cnt2[tid] = 0;  // (every round leaves the counters zeroed for the next one)
+    if (tid == 0) *sm.ovf = 0;
+    const uint64_t n_units = src.n_units();
+    bool stop = false;
+    const uint64_t stride = (uint64_t)gridDim.x * GROUPS;
+    auto unit_of = [&](uint64_t g0) { return g0 + grp < n_units ? g0 + grp : n_units - 1; };
+    typename Source::Pre2 pre;
+    typename Source::Taken tk{};
+    uint64_t first_cur = 0;
+    {
+        const uint64_t gfirst = (uint64_t)blockIdx.x * GROUPS;
+        if (gfirst < n_units) {
+            first_cur = src.first_of(unit_of(gfirst));
+            src.prefetch_issue(pre, unit_of(gfirst), first_cur, unit_of(gfirst + stride), t, dump);
+            src.template prefetch_take<0>(tk, pre);
+        }
+    }
+    uint32_t par = 0;      // parity of the round being made: it fills sorted[par], the round before it lies in sorted[par ^ 1]
+    uint32_t nk_prev = 0;  // slots of the round whose groups are still leaving (0: none)
+    // group u of this thread's share of the round before: out to its place, or - nothing there, or no room - to the dump line
+    auto emit = [&](int u, uint32_t tl, uint32_t pp, bool &over) {
+        uint32_t m = tl + (uint32_t)u * T;
+        asm volatile("" : "+v"(m));  // (pinned to its place in the round)
+        const uint32_t i = m << GSH;
+        const bool live = i < nk_prev;
+        const K *const sb = sm.sorted[pp];
+        const raw4 v = *reinterpret_cast<const raw4 *>(&sb[live ? i : 0u]);
+        const K first = sb[live ? i : 0u];
+        const uint32_t d = digit1h(hash_of_stored<K>(first), p);
+        const uint64_t at = xcd_place<K>((uint64_t)(uint32_t)(sm.delta[pp][d] + i), xset, p.nxs);
+        const bool fits = live && at < p.cap1;
+        over |= live && at >= p.cap1;
+        raw4 *const dst = fits ? reinterpret_cast<raw4 *>(keys1 + ((uint64_t)d * p.cap1 + at)) : reinterpret_cast<raw4 *>(dump) + tl;
+        *dst = v;
+    };
+    // the keys of the round before whose bucket's region is full (a sender's skewed batch): counted aside, delivered later
+    auto park = [&](uint32_t tl, uint32_t pp) {
+        const K *const sb = sm.sorted[pp];
+#pragma unroll 1
+        for (int u = 0; u < NST; u++) {
+            const uint32_t i = (tl + (uint32_t)u * T) << GSH;
+            if (i >= nk_prev) break;
+            const uint32_t d = digit1h(hash_of_stored<K>(sb[i]), p);
+            if (xcd_place<K>((uint64_t)(uint32_t)(sm.delta[pp][d] + i), xset, p.nxs) < p.cap1) continue;
+            for (uint32_t e = 0; e < GK; e++) {
+                const K key = sb[i + e];
+                if (key == EMPTY) break;
+                const uint32_t st = kttab::table_add(TableRef{pend.slots, pend.g, pend.flags}, from_stored<K>(key), 1u);
+                if (st == 0u) atomicOr(pend.flags, 1u);
+                else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(pend.distinct), 1ull);
+            }
+        }
+    };
+#if KT_ABLATION
+    unsigned long long tph = __builtin_readcyclecounter();
+    uint32_t phs[8] = {};
+#endif
+    for (uint64_t g0 = (uint64_t)blockIdx.x * GROUPS; g0 < n_units && !stop; g0 += stride) {
+        const bool valid = g0 + grp < n_units;  // (a group past the end walks the last unit and keeps nothing)
+        // the staged segments borrow the buffer the round about to begin will fill
+        SegShared *const segs = reinterpret_cast<SegShared *>(sm.sorted[par]);
+        auto wk = src.open_taken(unit_of(g0), first_cur, segs[grp], t, tk);
+        const uint64_t first_next = tk.first_next;
+        KT_PH(0);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {  // (no early exit in here: the loop must stay unrolled)
+            uint32_t tl = tid;  // (opaque per round: see scatter1x_kernel)
+            asm volatile("" : "+v"(tl));
+            const uint32_t pp = par ^ 1u;
+            const bool nxt = q == NQ - 1 && g0 + stride < n_units;  // (workgroup uniform)
+            // the next unit's reads leave at the top of the unit's last round and are taken at its end, behind the five stores
+            // and the cursor atomic that follow them on every path: s_waitcnt vmcnt(NST + 1)
+            if (nxt) {
+                uint32_t tq = tl;
+                asm volatile("" : "+v"(tq));
+                src.prefetch_issue(pre, unit_of(g0 + stride), first_next, unit_of(g0 + 2 * stride), tq % BLOCK, dump);
+            }
+            bool over = false;
+            bool skip = stop;
+#if KT_ABLATION
+            if (p.dbg & 0x1000u) skip = true;  // (timing only: no copy-out at all)
+#endif
+            // where the five stores of the round before leave from: the middle and the end of the count, behind the scan, the
+            // middle and the end of the placement - every wave at the same steps, three of them just in front of a barrier
+            // (measured, k=31 / k=15: 13.7 / 19.0 ms; none of them next to a barrier 14.3-14.6 / 18.8; every wave's stores at
+            // steps of its own, spread against the other waves' 15.0 / 18.8 - a wave held up at the store queue in front of
+            // a barrier holds nobody up who is not waiting there anyway)
+            auto emit_at = [&](int slot) {
+                const int u = slot == PER / 2 - 1 ? 0 : slot == PER - 1 ? 1 : slot == PER + PER / 2 ? 3 : slot == 2 * PER - 1 ? 4 : -1;
+                if (!skip && u >= 0) emit(u, tl, pp, over);
+            };
+            K keys[PER];
+            uint32_t ok;
+            src.template take<PER, K>(wk, tl % BLOCK, keys, ok);
+            if (!valid) ok = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
+                keys[j] = to_stored<K>((uint64_t)keys[j]);
+                if ((ok >> j) & 1u) {
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
+                    if constexpr (PACK) atomicAdd(&sm.cnt2[d >> 1], 1u << ((d & 1u) * 16u));
+                    else atomicAdd(&sm.cnt2[d], 1u);
+                }
+                emit_at(j);
+            }
+            KT_PH(1);
+            ktd::lds_barrier();
+            KT_PH(2);
+            uint32_t *const xs = sm.start;
+            auto count_of = [&](uint32_t d) { return PACK ? (sm.cnt2[d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu : sm.cnt2[d]; };
+            const uint32_t nk = block_excl_scan_f<T, PB, GK - 1>(count_of, xs, p.B1, sm.tmp);
+            // (no branch around the atomic: see scatter1x_kernel)
+            const uint32_t d0 = tl, dc = d0 & (p.B1 - 1u);
+            const uint32_t rc = d0 < p.B1 ? count_of(dc) : 0u;
+            const uint32_t rs = xs[dc];
+            // for the next round's count (an atomic: the word's other half is its neighbour's)
+            if (d0 < p.B1) {
+                if constexpr (PACK) atomicAnd(&sm.cnt2[d0 >> 1], (d0 & 1u) ? 0x0000FFFFu : 0xFFFF0000u);
+                else sm.cnt2[d0] = 0;
+            }
+            const unsigned long long got = __hip_atomic_fetch_add(&mycur[dc], (unsigned long long)((rc + GK - 1u) & ~(GK - 1u)),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!skip) emit(2, tl, pp, over);
+            KT_PH(3);
+            ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
+            KT_PH(4);
+            K *const sb = sm.sorted[par];
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                if ((ok >> j) & 1u) {
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
+                    const uint32_t pos = atomicAdd(&xs[d], 1u);
+                    sb[pos] = keys[j];
+                }
+                emit_at(PER + j);
+            }
+            KT_PH(5);
+            if (rc) {
+                for (uint32_t e = rc; e & (GK - 1u); e++) sb[rs + e] = EMPTY;  // what the run lacks to its last group
+                // (a stream far past its room - a sender's heavy-hitter bucket - must not wrap back into it)
+                const uint32_t q0 = got > 0xE0000000ull ? 0xE0000000u : (uint32_t)got;
+                sm.delta[par][tl] = q0 - rs;
+                if (!pend.slots && xcd_place<K>((uint64_t)q0 + rc - 1u, xset, p.nxs) >= p.cap1) {
+                    *sm.ovf = 1;
+                    atomicOr(ovf, 1u);
+                }
+            }
+            if (over && pend.slots) park(tl, pp);
+            if (nxt) {
+                if (!skip) src.template prefetch_take<NST + 1>(tk, pre);
+                else src.template prefetch_take<0>(tk, pre);
+                first_cur = first_next;
+            }
+            ktd::lds_barrier();
+            KT_PH(6);
+            stop = *sm.ovf != 0;  // the same for every thread
+            nk_prev = nk;
+            par ^= 1u;
+            KT_PH(7);
+        }
+    }
+    // the last round's groups
+    if (!stop && nk_prev) {
+        uint32_t tl = tid;
+        asm volatile("" : "+v"(tl));
+        bool over = false;
+#pragma unroll
+        for (int u = 0; u < NST; u++) emit(u, tl, par ^ 1u, over);
+        if (over && pend.slots) park(tl, par ^ 1u);
     }
 #if KT_ABLATION
     if (tid == 0)
@@ -2406,7 +2643,7 @@ struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists;
+        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2417,6 +2654,7 @@ static BulkKnobs read_knobs() {
     k.g_mult = env_u64("KT_BULK_G_MULT", 1);
     k.paged = env_u64("KT_BULK_PAGED", 1);
     k.fixed2 = env_u64("KT_BULK_FIXED2", 1);
+    k.s1y = env_u64("KT_S1Y", 1);  // level 1 with two sort buffers and the copy-out spread over the next round (0: scatter1x)
     k.p2_big64 = env_u64("KT_P2_BIG64", 1);
     k.p2_big32 = env_u64("KT_P2_BIG32", 0);
     k.p2_grid = env_u64("KT_P2_GRID", 0);  // workgroups of the level-2 launch (0: one per bucket)
@@ -2467,6 +2705,25 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice
     kt_ctx *ctx = ctr->ctx;
     K *keys1 = (K *)ctr->b_keys1.p + (size_t)slice * j.p.B1 * j.p.cap1;
     struct { Meta m; } jj{j.m};
+    if (j.xcd && j.kn.s1y && Scatter1YShared<K, 1024>::bytes(j.p.B1) <= 160 * 1024) {  // two sort buffers, the copy-out spread over the next round
+        constexpr int T = 1024;
+        unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;
+        const uint32_t wgs = (uint32_t)ctx->n_cu * (uint32_t)(j.kn.g_mult ? j.kn.g_mult : 1);
+        const size_t lds = Scatter1YShared<K, T>::bytes(j.p.B1);
+        if (r.reads) {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1y_kernel<ReadsSource, K, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((scatter1y_kernel<ReadsSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.rs, j.p, xcur,
+                               jj.m.ovf, keys1, j.pend, j.m.dump);
+        } else {
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1y_kernel<KeysSource, K, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((scatter1y_kernel<KeysSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.ks, j.p, xcur,
+                               jj.m.ovf, keys1, j.pend, j.m.dump);
+        }
+        KT_HIP(hipGetLastError());
+        return KT_OK;
+    }
     if (j.xcd) {
         constexpr int T = KT_S1X_T;
         unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;

@@ -758,19 +758,23 @@ def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap, pa
 
 
 @pytest.mark.parametrize("k", [31, 15])
-@pytest.mark.parametrize("shape", ["wide", "sets8", "sets2", "part2_small", "image"])
+@pytest.mark.parametrize("shape", ["wide", "sets8", "sets2", "one_buffer", "one_buffer_sets8", "part2_small", "image"])
 def test_ctr_bulk_kernel_shapes_and_odd_batches(hctx, oracle, monkeypatch, k, shape):
     """every shape of the partition kernels on batches that do not fill them: one short read, a batch of less than one
     segment, segments in numbers that are not a multiple of the four a level-1 workgroup takes, a read that ends a
-    segment exactly, N runs, an empty read - and an empty batch.  wide = scatter1x + the 1024-thread part2 (default: a small
-    batch appends through ONE cursor set), sets8 / sets2 = the cursor sets of a large batch forced on the small one (one
-    per XCD / the XCDs folded onto two: lines dealt round-robin to the sets, tails padded, a set that runs out of its
-    eighth of a region falls back to exact offsets), part2_small = the 512-thread level 2 for 64-bit keys, image = the
+    segment exactly, N runs, an empty read - and an empty batch.  wide = scatter1y (two sort buffers, the copy-out of a round
+    spread over the next) + the 1024-thread part2 (default: a small batch appends through ONE cursor set), sets8 / sets2 =
+    the cursor sets of a large batch forced on the small one (one per XCD / the XCDs folded onto two: lines dealt
+    round-robin to the sets, tails padded, a set that runs out of its eighth of a region falls back to exact offsets),
+    one_buffer = scatter1x (KT_S1Y=0: the shape 32-bit keys with 1024 buckets keep, whose two buffers do not fit the LDS),
+    part2_small = the 512-thread level 2 for 64-bit keys, image = the
     probing image written at once instead of the dense state"""
     from kmertools_amd import device
     monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
-    if shape.startswith("sets"):
-        monkeypatch.setenv("KT_S1X_SETS", shape[4:])
+    if shape.startswith("one_buffer"):
+        monkeypatch.setenv("KT_S1Y", "0")
+    if "sets" in shape:
+        monkeypatch.setenv("KT_S1X_SETS", shape.split("sets")[1])
     if shape == "part2_small":
         monkeypatch.setenv("KT_P2_BIG64", "0")
         monkeypatch.setenv("KT_P2_BIG32", "1")
