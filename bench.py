@@ -482,7 +482,7 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
             # (key, count) pairs straight into them and kt_ctr_export has nothing left to copy
             counter.table.export_target(xk, xc, max_distinct)
         kt_ = "unsigned int" if k <= 16 else "unsigned long"
-        dominant = ("ctr k=%d step: clear + bulk table build (scatter1w_kernel<ReadsSource, %s>, part2_swwc_kernel<%s>, "
+        dominant = ("ctr k=%d step: clear + bulk table build (scatter1y_kernel<ReadsSource, %s, 1024>, part2_swwc_kernel<%s>, "
                     "build_kernel<%s, ...>%s)%s"
                     % (k, kt_, kt_, kt_, " writing the export arrays" if fused else "",
                        " + size + export" + ("" if fused else " (dense_export_kernel)") if with_export else ""))

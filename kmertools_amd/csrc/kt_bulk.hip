@@ -2101,7 +2101,8 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
         KT_PH(0);
         if (MERGE || dirty) ktd::lds_barrier();  // (a listed range leaves the image empty behind its end barrier)
         KT_PH(1);
-        uint32_t wc = 0;  // DENSE: entries of this wave - listed: counted as they are claimed; else: by the pack pass
+        uint32_t wc = 0;  // DENSE: entries of this wave - listed: the claims of its lanes; else: counted by the pack pass
+        uint32_t m0 = ~0u, m1 = ~0u;  // listed: the slots this lane has claimed (all ones: none)
         {
             // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
             // trip (the CAS itself reports what the slot holds), and a lane that has placed its key moves on to its
@@ -2122,10 +2123,13 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             // the hash bits the insert looks at, in one 32-bit word: bits 3.. = position among the range's S homes, bits
             // 0..2 = which stride (one v_alignbit; the 64-bit shifts are not full-rate instructions)
             const uint32_t sh3 = shift - 3;  // (the bulk path takes tables of 2^15 .. 2^34 hash positions: shift is 30 .. 49)
-            auto hword = [&](K stored) -> uint32_t {
+            // (which of the two forms applies is the table's size: decided outside the loop, insert_batch's HI - left to
+            // the compiler it is a scalar compare and two branches on every trip)
+            auto hword = [&](K stored, auto hi_only) -> uint32_t {
                 const uint64_t h = hash_of_stored<K>(stored);
                 const uint32_t hi32 = (uint32_t)(h >> 32), lo32 = (uint32_t)h;
-                return sh3 >= 32 ? hi32 >> (sh3 - 32) : __builtin_amdgcn_alignbit(hi32, lo32, sh3);
+                if constexpr (decltype(hi_only)::value) return hi32 >> (sh3 - 32);
+                else return __builtin_amdgcn_alignbit(hi32, lo32, sh3);
             };
             auto home_w = [&](uint32_t w) -> uint32_t { return __umul24((w >> 3) & (S - 1), p.m8) >> 3; };
             auto stride_w = [&](uint32_t w) -> uint32_t {
@@ -2137,21 +2141,26 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             // than it has slots cannot fill up, and its loop goes without the walk's counter - two vector and five scalar
             // instructions of a trip that issues ~45, in a loop bound by instruction issue (eight waves per SIMD going
             // round it: 17.2 against 19.2 ms for the kernel).
-            auto insert_batch = [&](auto chk, auto lst) {
+            auto insert_batch = [&](auto chk, auto lst, auto hi_only) {
                 constexpr bool CHECK = decltype(chk)::value, LISTED = decltype(lst)::value;
                 K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
 #if KT_ABLATION
                 if (p.dbg & 1u) cur = EMPTY;
 #endif
-                uint32_t w = hword(cur);
+                uint32_t w = hword(cur, hi_only);
                 uint32_t s = home_w(w), step = stride_w(w), probes = 0;
                 while (cur != EMPTY) {
                     const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
                     bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
-                    if constexpr (LISTED) {  // the claimed slots go to the wave's list (the lanes still in the loop vote)
-                        const uint64_t bal = __ballot(done);
-                        if (done) mylist[wc + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)s;
-                        wc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wc + (uint32_t)__popcll(bal)));
+                    if constexpr (LISTED) {
+                        // the lane remembers the slots it has claimed - three at most, 16 bits each, shifted in: two
+                        // instructions of a loop that is bound by instruction issue.  (Round 4 appended them to the
+                        // wave's list inside the loop: a vote, two bit counts, an address, a 16-bit write, a broadcast
+                        // of the new length - a dozen instructions on every trip in which any lane claimed a slot.)
+                        if (done) {
+                            m1 = __builtin_amdgcn_alignbit(m1, m0, 16);
+                            m0 = (m0 << 16) | s;
+                        }
                     }
                     if (!done && v == cur) {
                         atomicAdd(&scounts[s], 1u);
@@ -2170,7 +2179,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                         q0 = q1;
                         q1 = q2;
                         q2 = EMPTY;
-                        w = hword(cur);
+                        w = hword(cur, hi_only);
                         s = home_w(w);
                         step = stride_w(w);
                         if (CHECK) probes = 0;
@@ -2183,9 +2192,13 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 const bool more = bbase + 4ull * BUILD_T < hi;  // (workgroup uniform; false for hashed distinct keys)
                 K nxt[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
                 if (more) load_head(bbase + 4ull * BUILD_T, hi, nxt);
-                if (listed) insert_batch(std::false_type{}, std::true_type{});
-                else if (roomy) insert_batch(std::false_type{}, std::false_type{});
-                else insert_batch(std::true_type{}, std::false_type{});
+                auto insert = [&](auto hi_only) {
+                    if (listed) insert_batch(std::false_type{}, std::true_type{}, hi_only);
+                    else if (roomy) insert_batch(std::false_type{}, std::false_type{}, hi_only);
+                    else insert_batch(std::true_type{}, std::false_type{}, hi_only);
+                };
+                if (sh3 >= 32) insert(std::true_type{});
+                else insert(std::false_type{});
                 if (!more) break;
                 bbase += 4ull * BUILD_T;
 #pragma unroll
@@ -2193,14 +2206,16 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             }
         }
         if (DENSE && listed) {
-            // wc was the same in every lane still in the loop; a lane that left it earlier holds the value of its last
-            // trip (the loop's exit is divergent): the wave's count is the largest of them
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)wc, o, 64);
-                wc = other > wc ? other : wc;
-            }
-            wc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wc);
+            // the wave's list = its lanes' claimed slots one lane after the other (one scan per range; the wave reads
+            // its own list back below, and LDS executes a wave's accesses in order)
+            const uint32_t c = (uint32_t)((m0 & 0xFFFFu) != 0xFFFFu) + (uint32_t)((m0 >> 16) != 0xFFFFu) +
+                               (uint32_t)((m1 & 0xFFFFu) != 0xFFFFu);
+            const uint32_t inc = wave_incl_scan(c);
+            uint16_t *const at = mylist + (inc - c);
+            if (c > 0) at[0] = (uint16_t)m0;
+            if (c > 1) at[1] = (uint16_t)(m0 >> 16);
+            if (c > 2) at[2] = (uint16_t)m1;
+            wc = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             if (lane == 0) runs[tid >> 6] = wc;  // (known here: no pack pass, no barrier of its own)
         }
         KT_PH(2);
