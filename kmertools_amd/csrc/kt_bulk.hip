@@ -2143,7 +2143,8 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             // round it: 17.2 against 19.2 ms for the kernel).
             auto insert_batch = [&](auto chk, auto lst, auto hi_only) {
                 constexpr bool CHECK = decltype(chk)::value, LISTED = decltype(lst)::value;
-                K cur = head[0], q0 = head[1], q1 = head[2], q2 = head[3];
+                // (a listed range has at most three keys per lane: its queue is one key shorter)
+                K cur = head[0], q0 = head[1], q1 = head[2], q2 = LISTED ? EMPTY : head[3];
 #if KT_ABLATION
                 if (p.dbg & 1u) cur = EMPTY;
 #endif
@@ -2151,28 +2152,27 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                 uint32_t s = home_w(w), step = stride_w(w), probes = 0;
                 while (cur != EMPTY) {
                     const K v = (K)atomicCAS(reinterpret_cast<W *>(&skeys[s]), (W)EMPTY, (W)cur);
-                    bool done = v == EMPTY;  // claimed: first occurrence, stored count stays 0
+                    // claimed: first occurrence, stored count stays 0; dup: the key is there already (cur is not EMPTY
+                    // here, so the two exclude each other - written as two flat tests because the nested form costs
+                    // the loop half a dozen scalar instructions of mask bookkeeping per trip)
+                    const bool claimed = v == EMPTY, dup = v == cur;
+                    bool done = claimed | dup;
+                    if (dup) atomicAdd(&scounts[s], 1u);
                     if constexpr (LISTED) {
                         // the lane remembers the slots it has claimed - three at most, 16 bits each, shifted in: two
                         // instructions of a loop that is bound by instruction issue.  (Round 4 appended them to the
                         // wave's list inside the loop: a vote, two bit counts, an address, a 16-bit write, a broadcast
                         // of the new length - a dozen instructions on every trip in which any lane claimed a slot.)
-                        if (done) {
+                        if (claimed) {
                             m1 = __builtin_amdgcn_alignbit(m1, m0, 16);
                             m0 = (m0 << 16) | s;
                         }
                     }
-                    if (!done && v == cur) {
-                        atomicAdd(&scounts[s], 1u);
+                    s += step;                     // round the range (step 1: kttab::Probe)
+                    if (s >= RS) s -= RS;
+                    if (CHECK && !done && ++probes >= RS) {  // the range is full: the table is too small
+                        spill(from_stored<K>(cur), 1u);
                         done = true;
-                    }
-                    if (!done) {
-                        s += step;                     // round the range (step 1: kttab::Probe)
-                        if (s >= RS) s -= RS;
-                        if (CHECK && ++probes >= RS) {  // the range is full: the table is too small
-                            spill(from_stored<K>(cur), 1u);
-                            done = true;
-                        }
                     }
                     if (done) {
                         cur = q0;
