@@ -2696,7 +2696,7 @@ struct kt_bulk_job {
     bool narrow = false;  // 32-bit keys through the partition passes (k <= 16)
     bool paged = false, merge = false, open = false;
     bool xcd = false;  // paged level 1 appends through per-XCD cursors (scatter1x_kernel + xcd_tails_kernel)
-    uint64_t max_keys = 0, added_bound = 0;
+    uint64_t max_keys = 0, added_bound = 0, cap1_max = 0;
     std::vector<SourceRec> srcs;
     // level 1 in slices (the sharded counter, kt_shard.hip): slice i writes the level-1 output i of b_keys1 (B1 regions of
     // cap1 keys), with its own page allocator state; a table of its own has one slice
@@ -3093,9 +3093,16 @@ static int xcc_sets(kt_ctx *ctx, uint32_t *nxs, uint32_t *xmap) {
 // slice_keys: the most k-mers one level-1 output (slice) takes; n_slices of them; n_src: level-1 outputs that feed one
 // bucket of this table (a table of its own: 1; a shard: slices x senders).  sharded: the sharded counter's job - level 1
 // parks what does not fit its regions in `pend`, the caller sets part2's sources, small batches take the bulk path too.
+uint64_t kt_bulk_region_room(uint64_t slice_keys, uint32_t B1) {
+    return (slice_keys / B1 + slice_keys / B1 / 8 + 16 * 256 + 255) / 256 * 256;
+}
+
+// slice_keys_now (sharded; 0: slice_keys): what a slice of THIS batch holds at most - the regions take their room from it (a
+// region travels at its room), the buffers theirs from slice_keys
 static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_t n_src, bool sharded, const PendList *pend,
-                    int *eligible) {
+                    int *eligible, uint64_t slice_keys_now = 0) {
     *eligible = 0;
+    if (!slice_keys_now || slice_keys_now > slice_keys) slice_keys_now = slice_keys;
     kt_ctx *ctx = ctr->ctx;
     const BulkKnobs kn = read_knobs();
     const uint64_t max_keys = slice_keys * n_slices;
@@ -3164,7 +3171,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     // (per-XCD cursors: no pages; the room beyond the keys' share covers the sets' uneven fills - every set's lines reach as
     // far as the fullest set's - and the same 1/8 for the hash's own spread; a multiple of 8 sets x 32 keys)
     const bool xcd = paged;
-    uint64_t cap1 = (slice_keys / p.B1 + slice_keys / p.B1 / 8 + 16 * 256 + 255) / 256 * 256;
+    uint64_t cap1 = kt_bulk_region_room(slice_keys, p.B1);
     const uint64_t room1 = cap1 * n_src;
     if (room1 * ksz >= (1ull << 31)) {  // (part2 addresses a bucket's fixed regions through 32-bit buffer offsets)
         if (sharded) return kt::fail(KT_ERR_ARG, "sharded counter: batch too large for its level-1 regions (lower max_batch_bases)");
@@ -3245,7 +3252,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.spill_cap = spill_cap;
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
     if (paged) {
-        p.cap1 = cap1;
+        p.cap1 = kt_bulk_region_room(slice_keys_now, p.B1);
+        j.cap1_max = cap1;
         p.room1 = room1;
         p.cap2 = kn.fixed2 || p.bx ? room1 / p.B2 / (128 / ksz) * (128 / ksz) : 0;  // (whole cache lines: every fine region starts on one)
         KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)n_slices * p.B1 * 8, ctx->stream));
@@ -3282,12 +3290,12 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
 }
 
 // ---- the sharded counter's job (kt_shard.hip): level 1 runs where the reads are, level 2 + build where the keys belong ----
-int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_t n_src, kt_ctr *pend) {
+int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint64_t slice_keys_now, uint32_t n_slices, uint32_t n_src, kt_ctr *pend) {
     if (int rc = ktl::table_ready(pend)) return rc;  // (a deferred clear happens now; a full table is reported)
     pend->empty = false;
     const PendList pl{(Slot *)pend->slots, ktl::geom_of(pend), pend->flags, pend->distinct};
     int eligible = 0;
-    if (int rc = plan_job(ctr, slice_keys, n_slices, n_src, true, &pl, &eligible)) return rc;
+    if (int rc = plan_job(ctr, slice_keys, n_slices, n_src, true, &pl, &eligible, slice_keys_now)) return rc;
     if (!eligible) return kt::fail(KT_ERR_ARG, "sharded counter: the table's shape does not suit the partition passes");
     return KT_OK;
 }
@@ -3335,7 +3343,7 @@ int kt_bulk_slice_info(kt_ctr *ctr, uint32_t slice, uint32_t bucket, kt_bulk_sha
     kt_bulk_job *job = ctr->job;
     if (!job || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
     const Plan &p = job->p;
-    if (shape) *shape = kt_bulk_shape{p.B1, p.d_lo, p.d_hi, p.cap1, (uint32_t)job->ksz()};
+    if (shape) *shape = kt_bulk_shape{p.B1, p.d_lo, p.d_hi, p.cap1, (uint32_t)job->ksz(), job->cap1_max};
     if (keys) *keys = (char *)ctr->b_keys1.p + ((size_t)slice * p.B1 + bucket) * p.cap1 * job->ksz();
     if (counts) *counts = job->m.gcur + (size_t)slice * p.B1 + bucket;
     return KT_OK;

@@ -368,9 +368,34 @@ int sharded_new(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t max_batch_
     return KT_OK;
 }
 
-// the first batch fixes the shape of the job (B1, the regions' room, the key size): room for what the peers send
+// window starts of this rank's batch per slice (slice i = segments [n_seg i / P, n_seg (i + 1) / P), a k-mer belongs to the
+// segment it starts in): the most k-mers level 1 can write for the slice - bases that are not ACGT only make it fewer
+__global__ __launch_bounds__(256) void slice_kmers_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint32_t k,
+                                                          uint64_t n_seg, uint32_t P, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long acc[64];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = offsets[r], e = offsets[r + 1];
+        if (e - b < k) continue;
+        const uint64_t a1 = e - k + 1;  // starts [b, a1)
+        for (uint32_t i = 0; i < P; i++) {
+            const uint64_t lo = n_seg * i / P * ktseg::SEG, hi = n_seg * (i + 1) / P * ktseg::SEG;
+            const uint64_t x = b > lo ? b : lo, y = a1 < hi ? a1 : hi;
+            if (y > x) atomicAdd(&acc[i], (unsigned long long)(y - x));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < P && acc[threadIdx.x]) atomicAdd(&out[threadIdx.x], acc[threadIdx.x]);
+}
+
+// the buffers for what the peers send: sized by the largest regions any batch of this counter can have (B1, the key size and
+// max_batch_bases fix them; a batch's own regions - its messages - are as large as its k-mers need)
 int sharded_recv_alloc(kt_sharded *s, const kt_bulk_shape &sh) {
-    if (s->recv_keys && s->shape.cap1 == sh.cap1 && s->shape.key_bytes == sh.key_bytes && s->shape.B1 == sh.B1) return KT_OK;
+    if (s->recv_keys && s->shape.cap1_max == sh.cap1_max && s->shape.key_bytes == sh.key_bytes && s->shape.B1 == sh.B1) {
+        s->shape = sh;
+        return KT_OK;
+    }
     if (s->recv_keys) (void)hipFree(s->recv_keys);
     if (s->recv_counts) (void)hipFree(s->recv_counts);
     s->recv_keys = nullptr;
@@ -382,7 +407,7 @@ int sharded_recv_alloc(kt_sharded *s, const kt_bulk_shape &sh) {
         s->blo.assign({0u, sh.B1});
     }
     const uint32_t mine = sh.d_hi - sh.d_lo;
-    s->recv_key_block = (size_t)mine * sh.cap1 * sh.key_bytes;
+    s->recv_key_block = (size_t)mine * sh.cap1_max * sh.key_bytes;
     s->recv_cnt_block = (size_t)mine + 8;  // one status word (padded to 64 bytes) in front of the counts
     const size_t n_blocks = (size_t)s->n_slices * (size_t)s->n_ranks;
     hipError_t e = hipMalloc((void **)&s->recv_keys, s->recv_key_block * n_blocks + 256);
@@ -605,9 +630,34 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
         if (int rc = ktl::make_seg_args(ctx, d_bases, d_offsets, n_reads, total, s->k, &a)) local_fail(rc);
     }
     const int P = s->n_slices, N = s->n_ranks, me = s->rank;
+    // The regions of this batch - the messages - take their room from the k-mers a slice of it can hold (window starts inside
+    // reads: 120 of 150 bases at k=31), not from max_batch_bases: every rank counts its own and tells the others (below).
+    uint64_t keys_now = 0;
+    if (my_code == KT_OK && total) {
+        std::vector<unsigned long long> h_now((size_t)P, 0ull);
+        unsigned long long *d_now = reinterpret_cast<unsigned long long *>(s->send_status);  // (idle here: P x 16 bytes)
+        hipError_t e = hipMemsetAsync(d_now, 0, (size_t)P * 8, ctx->stream);
+        if (e == hipSuccess) {
+            const uint64_t want = (n_reads + 255) / 256;
+            hipLaunchKernelGGL(slice_kmers_kernel, dim3((unsigned)(want < 2048 ? (want ? want : 1) : 2048)), dim3(256), 0, ctx->stream,
+                               d_offsets, n_reads, (uint32_t)s->k, a.n_seg, (uint32_t)P, d_now);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_now.data(), d_now, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            kt::set_error(std::string("kt_sharded_add_reads: counting the slices' k-mers: ") + hipGetErrorString(e));
+            local_fail(KT_ERR_HIP);
+        }
+        for (int i = 0; i < P; i++) keys_now = h_now[(size_t)i] > keys_now ? h_now[(size_t)i] : keys_now;
+        keys_now = (keys_now + 2 * ktseg::SEG) / ktseg::SEG * ktseg::SEG;
+        if (keys_now > s->slice_keys) keys_now = s->slice_keys;
+    }
+    if (getenv("KT_SHARD_ROOM_BY_BASES")) keys_now = s->slice_keys;  // (A/B, tests: regions as rounds 2-4 sized them)
+    if (!keys_now) keys_now = ktseg::SEG;
     kt_bulk_shape sh{};
     if (my_code == KT_OK) {
-        if (int rc = kt_bulk_begin_sharded(s->table, s->slice_keys, (uint32_t)P, (uint32_t)(P * N), s->pend)) local_fail(rc);
+        if (int rc = kt_bulk_begin_sharded(s->table, s->slice_keys, keys_now, (uint32_t)P, (uint32_t)(P * N), s->pend)) local_fail(rc);
     }
     if (my_code == KT_OK) {
         if (int rc = kt_bulk_slice_info(s->table, 0, 0, &sh, nullptr, nullptr)) local_fail(rc);
@@ -616,12 +666,14 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
         if (int rc = sharded_recv_alloc(s, sh)) local_fail(rc);
     }
     // can everybody go on?  (the finalize buffers serve as the messages: they exist since creation and are idle here)
+    std::vector<uint64_t> peer_keys((size_t)N, keys_now);
     if (N > 1) {
         const uint64_t words = HDR_U64 + FIN_CAP + FIN_CAP / 2;
         // (a rank that cannot even put its word on the device still enters the exchange - leaving here would leave the peers
         // waiting in it, which is what this round is there to prevent - and sends "cannot" from go_words: two device words
         // written at creation, [0] = 0, [1] = 1, which no copy of this call has to reach - ADVICE r4)
-        std::vector<uint64_t> h((size_t)N, my_code != KT_OK ? 1u : 0u);
+        // (the word: bit 0 = cannot go on; from bit 8 up: the k-mers a slice of this rank's batch holds at most - its regions' room)
+        std::vector<uint64_t> h((size_t)N, (my_code != KT_OK ? 1u : 0u) | (keys_now << 8));
         bool words_ok = true;
         for (int p = 0; p < N && words_ok; p++)
             words_ok = hipMemcpyAsync(s->fin_send + (uint64_t)p * words, &h[(size_t)p], 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
@@ -641,7 +693,8 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
             if (p == me) continue;
             uint64_t v = 0;
             KT_HIP(hipMemcpy(&v, s->fin_recv + (uint64_t)p * words, 8, hipMemcpyDeviceToHost));
-            peer |= v != 0;
+            peer |= (v & 0xFFu) != 0;
+            peer_keys[(size_t)p] = v >> 8;
         }
         if (my_code != KT_OK) return kt::fail(my_code, my_error);
         if (peer)
@@ -649,6 +702,13 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
                                         "set-up failed); nothing was counted");
     } else if (my_code != KT_OK) {
         return kt::fail(my_code, my_error);
+    }
+    std::vector<uint64_t> cap1_of((size_t)N, sh.cap1);  // the room of a region in rank p's level-1 outputs
+    for (int p = 0; p < N; p++) {
+        if (p == me) continue;
+        if (!peer_keys[(size_t)p] || peer_keys[(size_t)p] > s->slice_keys)
+            return kt::fail(KT_ERR_ARG, "kt_sharded_add_reads: a peer announced regions larger than the counter was created for");
+        cap1_of[(size_t)p] = kt_bulk_region_room(peer_keys[(size_t)p], sh.B1);
     }
     const uint64_t status_word = 0;
     std::vector<uint64_t> h_status((size_t)P * 2, status_word);
@@ -680,7 +740,7 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
                 uint64_t *rc_ = s->recv_counts + ((size_t)i * N + p) * s->recv_cnt_block;
                 if (piece == 0) pc[p] = Piece{s->send_status + (size_t)i * 2, 8, rc_, 8};
                 else if (piece == 1) pc[p] = Piece{counts, (size_t)s->nb(p) * 8, rc_ + 8, (size_t)s->nb(me) * 8};
-                else pc[p] = Piece{keys, (size_t)s->nb(p) * sh.cap1 * sh.key_bytes, rk, (size_t)s->nb(me) * sh.cap1 * sh.key_bytes};
+                else pc[p] = Piece{keys, (size_t)s->nb(p) * sh.cap1 * sh.key_bytes, rk, (size_t)s->nb(me) * cap1_of[(size_t)p] * sh.key_bytes};
             }
             if (int rc = exchange_v(s, pc)) return rc;
         }
@@ -693,7 +753,7 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
                 srcs.push_back(kt_seg_src{keys, counts, sh.cap1});
             } else {
                 srcs.push_back(kt_seg_src{s->recv_keys + ((size_t)i * N + p) * s->recv_key_block,
-                                          s->recv_counts + ((size_t)i * N + p) * s->recv_cnt_block + 8, sh.cap1});
+                                          s->recv_counts + ((size_t)i * N + p) * s->recv_cnt_block + 8, cap1_of[(size_t)p]});
             }
         }
         // The pre-split of this slice (N >= 4: the bits level 2 cannot take) leaves as soon as the slice's blocks are in, on

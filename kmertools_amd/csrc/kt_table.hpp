@@ -134,8 +134,15 @@ int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible);
 // messages, the buckets [bucket_lo, bucket_hi) of owner o go to GPU o - and level 2 + the range builds on the GPU that
 // owns the buckets, over one source per (slice, sender).  begin: n_slices level-1 outputs of at most slice_keys k-mers
 // each, n_src sources per bucket, the (small, local) table that counts what does not fit a region.
-struct kt_bulk_shape { uint32_t B1, d_lo, d_hi; uint64_t cap1; uint32_t key_bytes; };
-int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_t n_src, kt_ctr *pend);
+// cap1: the room of a level-1 region in THIS job (from the k-mers its batch can hold at most); cap1_max: in any job of the
+// counter (from max_batch_bases) - what the buffers are sized by
+struct kt_bulk_shape { uint32_t B1, d_lo, d_hi; uint64_t cap1; uint32_t key_bytes; uint64_t cap1_max; };
+// keys of room of a level-1 region whose slice holds at most slice_keys k-mers (every rank computes its peers' from the
+// bounds they announce)
+uint64_t kt_bulk_region_room(uint64_t slice_keys, uint32_t B1);
+// slice_keys: the most k-mers a slice of any batch takes (sizes the buffers); slice_keys_now: of this batch (the regions'
+// room, i.e. the size of the messages)
+int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint64_t slice_keys_now, uint32_t n_slices, uint32_t n_src, kt_ctr *pend);
 int kt_bulk_slice_reads(kt_ctr *ctr, uint32_t slice, const uint8_t *d_bases, const uint64_t *d_offsets,
                         const uint64_t *seg_first, uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi);
 int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice);
