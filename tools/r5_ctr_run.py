@@ -45,7 +45,7 @@ try:  # a timing build (KT_ABLATION): cycles of thread 0 per phase, summed over 
     f = _lib.lib().kt_dbg_phases
     buf = (ctypes.c_ulonglong * 16)()
     if f(buf) == 0 and sum(buf):
-        for name, lo in (("build", 0), ("scatter1x", 8)):
+        for name, lo in (("build", 0), ("scatter1y", 8)):
             tot = float(sum(buf[lo:lo + 8]))
             if tot:
                 print("%s phases (share of thread 0's cycles): " % name + " ".join("%d:%.1f%%" % (i, 100 * buf[lo + i] / tot) for i in range(8)))
