@@ -202,9 +202,12 @@ int host_staging(kt_sharded *s, size_t all) {
     return KT_OK;
 }
 
-int exchange_v(kt_sharded *s, const std::vector<Piece> &pc) {
+// block_all: the size of the host transport's equal blocks when the pieces are not the same on every rank (the regions: each
+// sender's room is its own) - a figure every rank computes alike; 0: the largest piece of this rank, which is every rank's
+// when the pieces are symmetric
+int exchange_v(kt_sharded *s, const std::vector<Piece> &pc, size_t block_all = 0) {
     if (s->fn) {
-        size_t block = 0;
+        size_t block = block_all;
         for (int p = 0; p < s->n_ranks; p++) {
             if (p == s->rank) continue;
             if (pc[p].src_bytes > block) block = pc[p].src_bytes;
@@ -742,7 +745,17 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
                 else if (piece == 1) pc[p] = Piece{counts, (size_t)s->nb(p) * 8, rc_ + 8, (size_t)s->nb(me) * 8};
                 else pc[p] = Piece{keys, (size_t)s->nb(p) * sh.cap1 * sh.key_bytes, rk, (size_t)s->nb(me) * cap1_of[(size_t)p] * sh.key_bytes};
             }
-            if (int rc = exchange_v(s, pc)) return rc;
+            // (the host transport's blocks: the largest block any rank sends any other - the same figure on every rank)
+            size_t block_all = 0;
+            if (piece == 2) {
+                uint64_t nb_max = 0, cap_max = 0;
+                for (int p = 0; p < N; p++) {
+                    nb_max = s->nb(p) > nb_max ? s->nb(p) : nb_max;
+                    cap_max = cap1_of[(size_t)p] > cap_max ? cap1_of[(size_t)p] : cap_max;
+                }
+                block_all = (size_t)(nb_max * cap_max * sh.key_bytes);
+            }
+            if (int rc = exchange_v(s, pc, block_all)) return rc;
         }
         KT_HIP(hipEventRecord(s->ev_recv[(size_t)i], s->comm_stream));
         for (int p = 0; p < N; p++) {

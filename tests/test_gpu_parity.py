@@ -561,7 +561,8 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 # count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
 
 _SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "presplit": (2, 31), "presplit3": (3, 15),
-                "presplit_whole": (2, 31), "presplit_skewed": (2, 31), "presplit_whole_skewed": (2, 31), "localfail": (2, 31)}   # case -> (ranks, k)
+                "presplit_whole": (2, 31), "presplit_skewed": (2, 31), "presplit_whole_skewed": (2, 31), "localfail": (2, 31),
+                "uneven3": (3, 21)}   # case -> (ranks, k)
 
 
 def _two_rank_worker(rank, port, q, case):
@@ -593,7 +594,10 @@ def _two_rank_worker(rank, port, q, case):
         if case in ("skewed", "presplit_skewed", "presplit_whole_skewed") and rank == 1:
             bases[: 8000 * L] = ord("A")           # 40 % of rank 1's batch is one k-mer: its owner's regions overflow
         sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD, max_batch_bases=n * L)
-        sc.add_reads(bases, offsets, n)
+        # uneven3: the ranks' batches differ in size, so their regions - sized by each batch's own k-mers - differ, and with
+        # three ranks the level-1 buckets do not divide evenly either: no two messages of the exchange are the same size
+        nr = n // (rank + 1) if case == "uneven3" else n
+        sc.add_reads(bases[: nr * L], offsets[: nr + 1], nr)
         m = 100 if rank == 0 else 0                 # a second "chunk" that only rank 0 has reads for
         if case == "localfail":
             # one rank cannot take part (a local failure ahead of the exchange): EVERY rank must come back with an error -
@@ -632,7 +636,7 @@ def _two_rank_worker(rank, port, q, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3", "presplit_whole", "presplit_skewed", "presplit_whole_skewed", "localfail"])
+@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3", "presplit_whole", "presplit_skewed", "presplit_whole_skewed", "localfail", "uneven3"])
 def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     """the C ABI's sharded counter with two ranks on cuda:0 and the host all-to-all transport over gloo: route on
     the GPU, exchange fixed-size regions, partition + range build of what arrived, finalize; the union of the shards
@@ -643,7 +647,8 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     slice by slice on a stream of its own as the blocks arrive (the default), `presplit_whole`: behind the last block as in
     round 4, `presplit_skewed`: with a k-mer that floods its sub-bucket's fixed room (the bucket is redone with exact
     boundaries over all its sources at the end);
-    `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call works"""
+    `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call works;
+    `uneven3`: three ranks whose batches differ in size (every sender's regions have their own room)"""
     import socket
     import torch.multiprocessing as mp
     from kmertools_amd import device
@@ -668,7 +673,8 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
         if case in ("skewed", "presplit_skewed", "presplit_whole_skewed") and rank == 1:
             hb = hb.copy()
             hb[: 8000 * L] = ord("A")
-        ctr.add_reads(hb, ho, k, threads=4)
+        nr = n // (rank + 1) if case == "uneven3" else n
+        ctr.add_reads(hb[: nr * L], ho[: nr + 1], k, threads=4)
         if rank == 0:
             ctr.add_reads(hb[: 100 * L], ho[:101], k)
     wk, wc = ctr.export()
