@@ -312,7 +312,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // kernels a few hundred instructions and a dozen spilled registers per call.)
 // (RND = 2^r - 1: every counter is rounded up to a multiple of 2^r first - runs that start on 16-byte boundaries, scatter1x;
 // the counters are read through `get(i)`: scatter1y keeps them two to a word)
-template <int NT, int PB, uint32_t RND, class Get>
+// (TAIL = false: without the closing barrier - the caller has one of its own before anybody reads another thread's out[])
+template <int NT, int PB, uint32_t RND, bool TAIL = true, class Get>
 __device__ __forceinline__ uint32_t block_excl_scan_f(Get get, uint32_t *out, uint32_t B, uint32_t *tmp) {
     static_assert(NT % 64 == 0 && NT / 64 <= 16, "wave totals fit one DPP row");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -339,7 +340,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_f(Get get, uint32_t *out, ui
         if (tid * PB + j < B) out[tid * PB + j] = run;
         run += c[j];
     }
-    ktd::lds_barrier();
+    if constexpr (TAIL) ktd::lds_barrier();
     return total;
 }
 template <int NT, int PB, uint32_t RND = 0>
@@ -1055,7 +1056,9 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
             KT_PH(2);
             uint32_t *const xs = sm.start;
             auto count_of = [&](uint32_t d) { return PACK ? (sm.cnt2[d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu : sm.cnt2[d]; };
-            const uint32_t nk = block_excl_scan_f<T, PB, GK - 1>(count_of, xs, p.B1, sm.tmp);
+            // (no closing barrier: the thread reads back its own start only - PB = 1, tl is the thread's index - and the
+            // barrier in front of the placement stands between the scan and everybody else's)
+            const uint32_t nk = block_excl_scan_f<T, PB, GK - 1, false>(count_of, xs, p.B1, sm.tmp);
             // (no branch around the atomic: see scatter1x_kernel)
             const uint32_t d0 = tl, dc = d0 & (p.B1 - 1u);
             const uint32_t rc = d0 < p.B1 ? count_of(dc) : 0u;
