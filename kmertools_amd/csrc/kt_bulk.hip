@@ -128,9 +128,11 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint64_t spill_cap;
 };
 
-__device__ __forceinline__ uint32_t digit1h(uint64_t h, const Plan &p) { return (uint32_t)(h >> (64 - p.b1)); }
+// (both digits lie in the hash's high word - 1 <= b1, b1 + b2 <= 21: plan_job - so they are 32-bit shifts; written on the 64-bit
+// value, with a shift the compiler does not know to be >= 32, each is a 64-bit shift: per key, in every pass)
+__device__ __forceinline__ uint32_t digit1h(uint64_t h, const Plan &p) { return (uint32_t)(h >> 32) >> (32 - p.b1); }
 __device__ __forceinline__ uint32_t digit2h(uint64_t h, const Plan &p) {
-    return (uint32_t)(h >> (64 - p.b1 - p.b2)) & (p.B2 - 1);
+    return ((uint32_t)(h >> 32) >> (32 - p.b1 - p.b2)) & (p.B2 - 1);
 }
 __device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) { return digit1h(ktd::khash(key), p); }
 // What travels through the partition passes ("stored form" of a canonical k-mer): 64-bit keys travel as
@@ -965,6 +967,8 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
     }
     uint32_t par = 0;      // parity of the round being made: it fills sorted[par], the round before it lies in sorted[par ^ 1]
     uint32_t nk_prev = 0;  // slots of the round whose groups are still leaving (0: none)
+    constexpr uint32_t LSH1 = sizeof(K) == 8 ? 4 : 5;  // keys per 128-byte line (xcd_place)
+    const uint32_t cap1_32 = (uint32_t)p.cap1, cap_lines = (uint32_t)(p.cap1 >> LSH1);  // (plan_job: a region is < 2^31 bytes)
     // group u of this thread's share of the round before: out to its place, or - nothing there, or no room - to the dump line
     auto emit = [&](int u, uint32_t tl, uint32_t pp, bool &over) {
         uint32_t m = tl + (uint32_t)u * T;
@@ -975,10 +979,16 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
         const raw4 v = *reinterpret_cast<const raw4 *>(&sb[live ? i : 0u]);
         const K first = sb[live ? i : 0u];
         const uint32_t d = digit1h(hash_of_stored<K>(first), p);
-        const uint64_t at = xcd_place<K>((uint64_t)(uint32_t)(sm.delta[pp][d] + i), xset, p.nxs);
-        const bool fits = live && at < p.cap1;
-        over |= live && at >= p.cap1;
-        raw4 *const dst = fits ? reinterpret_cast<raw4 *>(keys1 + ((uint64_t)d * p.cap1 + at)) : reinterpret_cast<raw4 *>(dump) + tl;
+        // xcd_place in 32 bits (the line index of a stream that ran 2^32 keys past its room still fits), one 64-bit multiply-add
+        // for the place in the key array: the general form - two 64-bit shifts, a 64-bit compare, two multiply-adds - is a
+        // fifth of the kernel's issue cycles, five times per thread and round
+        const uint32_t pos = sm.delta[pp][d] + i;
+        const uint32_t lx = ((pos >> LSH1) << p.nxs) | xset;
+        const bool room = lx < cap_lines;
+        const uint32_t at = (lx << LSH1) | (pos & ((1u << LSH1) - 1u));
+        const bool fits = live && room;
+        over |= live && !room;
+        raw4 *const dst = fits ? reinterpret_cast<raw4 *>(keys1 + ktd::mad64(d, cap1_32, at)) : reinterpret_cast<raw4 *>(dump) + tl;
         *dst = v;
     };
     // the keys of the round before whose bucket's region is full (a sender's skewed batch): counted aside, delivered later
@@ -1460,8 +1470,8 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
     constexpr bool RKD = p2_sdig<K, BIG>();  // the digit is kept beside the rank (32-bit keys: it would cost a second hash)
     const uint32_t tid = threadIdx.x;
     const uint32_t nd = p.d_hi - p.d_lo;
-    const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 64 - p.b1 - p.b2;
-    auto digit = [&](K stored) -> uint32_t { return (uint32_t)(hash_of_stored<K>(stored) >> dshift) & (B2 - 1u); };
+    const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 32 - p.b1 - p.b2;  // (in the hash's high word: digit2h)
+    auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored) >> 32) >> dshift) & (B2 - 1u); };
     for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
         const uint32_t n_seg = in.n_src;
         auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
@@ -1704,8 +1714,8 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
     constexpr uint32_t KPL = LK / GL;                   // keys per lane of a line: 2 (4)
     const uint32_t tid = threadIdx.x;
     const uint32_t nd = p.d_hi - p.d_lo;
-    const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 64 - p.b1 - p.b2;
-    auto digit = [&](K stored) -> uint32_t { return (uint32_t)(hash_of_stored<K>(stored) >> dshift) & (B2 - 1u); };
+    const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 32 - p.b1 - p.b2;  // (in the hash's high word: digit2h)
+    auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored) >> 32) >> dshift) & (B2 - 1u); };
     const uint32_t grp = tid / GL, gl = tid % GL;       // the line group this thread belongs to, its lane in it
     for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
         const uint32_t n_seg = in.n_src;

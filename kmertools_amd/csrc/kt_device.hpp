@@ -126,6 +126,11 @@ __device__ __forceinline__ double quot_f64(double c, double d, double y) {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// a * b + c with 32-bit factors and a 64-bit sum: one v_mad_u64_u32 (written with 64-bit operands the compiler makes two)
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint32_t c) {
+    return (uint64_t)a * (uint64_t)b + (uint64_t)c;
+}
+
 // A load through the SCALAR cache: p must be the same in every lane of the wave (the caller makes it so: uniform64) and
 // point at memory nothing writes while the kernel runs.  Read as constant-address-space memory, which is what makes the
 // compiler take the scalar path - a wave-uniform load of ordinary global memory stays a vector load whenever the
