@@ -20,7 +20,9 @@ All run W warm-up and exactly K timed steps between barrier + synchronize bracke
 Self-certification: the line's `kt_env` lists every KT_* variable the process saw; a variable that can switch
 work off (ablation builds only) makes bench.py exit non-zero before anything is timed.  After each timed loop,
 untimed, the output is checked (`output_check`): oligo rows sum to 1 over the whole output and a 4096-row slice
-is compared with the CPU oracle inside the cpu_baseline leg; ctr's exported counts sum to reads x (L - k + 1).
+is compared with the CPU oracle inside the cpu_baseline leg; ctr's exported counts sum to reads x (L - k + 1), and the
+k-mers of a 20 000-read sample of rank 0's batch, counted by the CPU oracle, are looked up in the shards of all ranks
+(`output_check.sampled_oracle`: each found on exactly one rank - its owner - with at least the sample's count).
 
 Array placement (oligo / cgr workloads, untimed, before the ramp): where an array lies in the HBM moves the store-bound
 kernels by up to 20 %, so the output array - and for one-batch workloads the input array - is the
@@ -30,7 +32,7 @@ objects list every candidate's time and which was kept, candidate 0 being the pl
 `roofline.frac_plain_allocation` is the fraction a plain allocation would have given (candidate 0's probe time);
 `--no-place` takes the plain allocation.  Nothing about the timed steps changes: same kernel, same work, same checks.
 
-ctr's step is what SURVEY.md 8d puts inside it: clear + insert (+ the key exchange at N > 1) +
+ctr's step is what SURVEY.md 8d puts inside it: clear + insert (at N > 1: route pass + exchange of the records + insert) +
 kt_ctr_size + kt_ctr_export into device arrays; algorithmic bytes = L + kmers*16 per read + distinct*12.
 
 `roofline` is for the step's kernels: algorithmic bytes per launch (DESIGN.md "Measurement") / the
@@ -482,19 +484,23 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
             # (key, count) pairs straight into them and kt_ctr_export has nothing left to copy
             counter.table.export_target(xk, xc, max_distinct)
         kt_ = "unsigned int" if k <= 16 else "unsigned long"
-        dominant = ("ctr k=%d step: clear + bulk table build (scatter1y_kernel<ReadsSource, %s, 1024>, part2_swwc_kernel<%s>, "
+        routed = world > 1 or os.environ.get("KT_SHARD_FORCE")
+        dominant = ("ctr k=%d step: clear + %sbulk table build (scatter1y_kernel<%s, %s, 1024>, part2_swwc_kernel<%s>, "
                     "build_kernel<%s, ...>%s)%s"
-                    % (k, kt_, kt_, kt_, " writing the export arrays" if fused else "",
+                    % (k, "route_kernel + " if routed else "", "RecordSource" if routed else "ReadsSource", kt_, kt_, kt_,
+                       " writing the export arrays" if fused else "",
                        " + size + export" + ("" if fused else " (dense_export_kernel)") if with_export else ""))
-        parallelism = ("hash-prefix key ownership: route -> exchange of per-owner regions -> partition + range build, "
-                       "pipelined in slices; transport: " + counter.transport)
+        parallelism = ("one table per GPU" if world == 1 and not os.environ.get("KT_SHARD_FORCE") else
+                       "ownership by the hash prefix of the k-mer's minimiser: route pass (records of <= 8 k-mers as 2-bit bases, "
+                       "one region per owner) -> exchange of the regions in pieces -> the single-GPU partition + range build over "
+                       "the records; transport: " + counter.transport)
         finish = counter.close
         if with_export:
             alg_extra = lambda: state["distinct"] * 12
 
         def step():
             counter.clear()
-            counter.add_reads(bases, offsets, n)   # N > 1: route + exchange + count, in slices (kt_sharded_add_reads)
+            counter.add_reads(bases, offsets, n)   # N > 1: route + exchange + count (kt_sharded_add_reads)
             counter.finalize()
             if with_export:
                 d = counter.size_local()
@@ -575,6 +581,11 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
         want = world * n * kmers_per_read
         check = {"sum_of_counts": int(tot[0].item()), "expected": want, "distinct_all_ranks": int(tot[1].item()),
                  "ok": int(tot[0].item()) == want}
+        # ... and is it the right table?  Rank 0 counts a sample of ITS OWN batch with the CPU oracle (the checker, as in the
+        # cpu_baseline leg - nothing here is timed); every rank looks the sample's k-mers up in its shard (kt_ctr_lookup):
+        # each must be found on exactly one rank - the rank kt_shard_owner_of gives it - with at least the sample's count.
+        check["sampled_oracle"] = sampled_oracle_check(env, counter, bases, offsets, n, L, k)
+        check["ok"] = check["ok"] and check["sampled_oracle"]["ok"]
     if check is not None:
         extra["output_check"] = check
         if wl["kind"] == "oligo" and k == 4:   # the launch shape this process measured for itself (kt_oligo_launch_info)
@@ -587,6 +598,10 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     if wl["kind"] == "ctr":
         extra["distinct_rank0"] = state["distinct"] if not args.no_export else counter.size_local()
         extra["table_slots_rank0"] = counter.table.capacity()
+        if world == 1 and os.environ.get("KT_SHARD_FORCE"):
+            extra["exchanged_bytes_per_rank"] = counter.sharded.exchanged_bytes() // (steps + warmup + ramp)
+            extra["exchanged_bytes_note"] = ("one rank routing into KT_SHARD_FORCE owners' regions: the bytes of the regions a "
+                                             "rank of that many would have sent")
         if world > 1:
             # did the library's own communicator see `world` ranks, and what did a rank put on the wires per step?
             ci = counter.sharded.comm_info()
@@ -627,6 +642,57 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     torch.cuda.empty_cache()
     wl["_check_slice"] = check_slice
     return res, wl
+
+
+def sampled_oracle_check(env, counter, bases, offsets, n, L, k, sample_reads=20000):
+    """untimed: the first `sample_reads` reads of rank 0's batch, counted by the CPU oracle, against the shards of all ranks"""
+    import numpy as np
+    torch, device = env.torch, env.device
+    world, rank = env.world, env.rank
+    on_cpu = world > 1 and env.share_gpu
+    dev = "cpu" if on_cpu else "cuda"
+    m = min(n, sample_reads)
+    if rank == 0:
+        from oracle import kt_oracle as oracle
+        hb = bases[:m * L].cpu().numpy()
+        ho = offsets[:m + 1].cpu().numpy().astype(np.uint64)
+        sk, sc = oracle.count_reads(hb, ho, k, n_parts=4, threads=4)
+        cnt = torch.tensor([len(sk)], dtype=torch.int64, device=dev)
+    else:
+        sk = sc = None
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        env.dist.broadcast(cnt, src=0)
+    nk = int(cnt.item())
+    keys = torch.from_numpy(sk.view(np.int64).copy()).to(dev) if rank == 0 else torch.empty(nk, dtype=torch.int64, device=dev)
+    if world > 1:
+        env.dist.broadcast(keys, src=0)
+    dkeys = keys.cuda()
+    got = torch.zeros(nk, dtype=torch.int32, device="cuda")
+    counter.table.lookup(dkeys, nk, got)
+    torch.cuda.synchronize()
+    found = (got > 0).to(torch.int32)
+    # the keys this rank holds must be its own by the library's host function (a bounded number of them: one ctypes call each)
+    mine = dkeys[found.bool()][:2000].cpu().numpy().view(np.uint64)
+    stray = sum(1 for x in mine if world > 1 and device.shard_owner_of(int(x), k, world) != rank)
+    tot = torch.stack([found.to(torch.int64), got.to(torch.int64)]).to(dev)
+    strays = torch.tensor([stray], dtype=torch.int64, device=dev)
+    if world > 1:
+        env.dist.all_reduce(tot)
+        env.dist.all_reduce(strays)
+    res = {"reads": m, "keys": nk}
+    if rank == 0:
+        want = torch.from_numpy(sc.astype(np.int64)).to(dev)
+        res["found"] = int((tot[0] == 1).sum().item())
+        res["found_on_several_ranks"] = int((tot[0] > 1).sum().item())
+        res["count_below_sample"] = int((tot[1] < want).sum().item())
+    else:
+        res.update(found=nk, found_on_several_ranks=0, count_below_sample=0)
+    res["on_a_rank_that_does_not_own_them"] = int(strays.item())
+    res["against"] = "CPU oracle (oracle/kt_oracle.c) over the first reads of rank 0's batch"
+    res["ok"] = (res["found"] == nk and res["found_on_several_ranks"] == 0 and res["count_below_sample"] == 0
+                 and res["on_a_rank_that_does_not_own_them"] == 0)
+    return res
 
 
 def oracle_slice_check(cs):

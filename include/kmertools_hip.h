@@ -271,13 +271,19 @@ int kt_cov_batch(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, u
                  uint64_t bin_size, uint64_t bin_count, int norm, int out_dtype, void *out,
                  int mem);
 
+/* counts[i] = occurrences of the canonical k-mer keys[i] in the table, 0 when it is absent (`mem` says where keys and
+ * counts live).  replaces: the HashMap get of coverage/src/lib.rs:170 (`kmer_counts.get(&kmer)`), one key at a time. */
+int kt_ctr_lookup(kt_ctr *table, const uint64_t *keys, uint64_t n, uint32_t *counts, int mem);
+
 /* The same lookups against a table that holds only PART of the k-mers - one hash partition of an out-of-core count
- * (kt_ctr_add_reads_part: n_parts passes, the table refilled for each) or one shard of a sharded table (n_parts = 1;
- * the shard answers for the k-mers kt_sharded_owner_of gives it).  Only the k-mers this table answers for are binned
- * (a k-mer of another partition is not "absent": it is skipped), as raw u32 counts ADDED to `counts` (n_reads x
- * bin_count, zeroed by the caller before the first part; `mem` says where it lives).  Summed over the parts every
- * k-mer of every read has been binned exactly once - the rows kt_cov_batch gives with KT_U32; normalisation
- * (count / max(1, sum of the row), coverage/src/lib.rs:180-182) is then one division per cell.
+ * (kt_ctr_add_reads_part: n_parts passes, the table refilled for each) or one shard of a sharded table (n_parts = 1).
+ * Only the k-mers this table answers for are binned (a k-mer of another partition is not "absent": it is skipped), as
+ * raw u32 counts ADDED to `counts` (n_reads x bin_count, zeroed by the caller before the first part; `mem` says where
+ * it lives).  Summed over the parts - modulo 2^32, cell by cell - every k-mer of every read has been binned exactly
+ * once: the rows kt_cov_batch gives with KT_U32; normalisation (count / max(1, sum of the row),
+ * coverage/src/lib.rs:180-182) is then one division per cell.  (A shard does not know which k-mers the other shards
+ * hold without their minimisers: shard 0's pass puts every k-mer into bin 0, and the shard that holds a k-mer moves it
+ * from there to its bin - a shard's own rows mean nothing before they are summed.)
  * replaces: coverage/src/lib.rs:69-92 + :165-184 for inputs whose k-mers do not fit one table. */
 int kt_cov_batch_part(kt_ctr *table, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                       uint64_t bin_size, uint64_t bin_count, uint32_t *counts, int mem, uint32_t n_parts,
@@ -292,29 +298,33 @@ int kt_cov_batch_part(kt_ctr *table, const uint8_t *bases, const uint64_t *offse
 int kt_ctr_route(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                  int k, int n_owners, uint64_t *keys_out, uint64_t *owner_counts, int mem);
 
-/* ---- one table sharded over the GPUs of a node (hash-prefix ownership) -------------------------------------------
+/* ---- k-mer counting sharded over the GPUs of a node (ownership by hash prefix of the k-mer's minimiser) -----------
  * replaces: the `n_parts` partitioning of counter/src/lib.rs:100,127,243-247 and the per-partition merge of
- * :188-231 - the partitions are GPUs.  The N shards are the pieces of ONE table addressed by the top bits of the
- * k-mer's hash: rank o (one process or thread, one kt_ctx, one GPU) holds the hash prefixes (level-1 buckets of the
- * partition passes) [ceil(o B / N), ceil((o + 1) B / N)) of B = 2^b - kt_sharded_owner_of tells which rank owns a
- * k-mer.  kt_sharded_add_reads and kt_sharded_finalize are COLLECTIVE: every rank calls them the same number of times
- * (a rank without reads passes n_reads = 0).  Each rank runs the first partition pass over its own reads - its output
- * regions ARE the messages - exchanges them with every peer (grouped ncclSend / ncclRecv from librccl over xGMI, or
- * the caller's host all-to-all), and runs the second pass and the range builds over what it owns; the batch is cut
- * into slices so that the first pass and the exchange overlap.  Results stay sharded: the union of the ranks' exports
- * is the answer (the reference's output order is unspecified anyway).  With n_ranks == 1 everything degenerates to
- * kt_ctr_add_reads.  A rank that cannot take part in a collective call (a batch larger than agreed, a pending list
- * that overflowed) still completes the exchange, and EVERY rank returns an error - none is left waiting. */
+ * :188-231 - the partitions are GPUs.  Rank o (one process or thread, one kt_ctx, one GPU) counts the k-mers whose
+ * MINIMISER - the canonical m-mer inside the k-mer with the smallest hash (kmer/src/minimiser.rs:61-175 defines a
+ * minimiser; m = kt_shard_minimiser(k)) - hashes into its share of the hash range: owner = mix(min hash) * N >> 32,
+ * kt_sharded_owner_of / kt_shard_owner_of.  Both strands of a k-mer hold the same canonical m-mers, and consecutive
+ * k-mers of a read mostly share their minimiser: a read falls into a few runs of k-mers with one owner each, and what
+ * the ranks send each other is the runs' bases at 2 bits (records of at most 8 k-mers in 10 bytes: ~1.7 bytes per k-mer
+ * at k = 31), not the k-mers at 8 bytes.  Every rank's shard is a whole table of its own (kt_sharded_table).
+ * kt_sharded_add_reads and kt_sharded_finalize are COLLECTIVE: every rank calls them the same number of times (a rank
+ * without reads passes n_reads = 0).  Each rank routes its own reads into one region of records per owner, the ranks
+ * tell each other the regions' sizes, the regions travel in pieces (grouped ncclSend / ncclRecv from librccl over xGMI,
+ * or the caller's host all-to-all) while the partition passes of the ordinary single-GPU pipeline already run over what
+ * has arrived.  Results stay sharded: the union of the ranks' exports is the answer (the reference's output order is
+ * unspecified anyway).  With n_ranks == 1 everything degenerates to kt_ctr_add_reads.  A rank that cannot take part in
+ * a collective call (a batch larger than agreed, a pending table that overflowed) still enters the exchange that
+ * carries the ranks' status, and EVERY rank returns an error - none is left waiting. */
 typedef struct kt_sharded kt_sharded;
 
 /* 128-byte RCCL unique id (ncclGetUniqueId): rank 0 makes it, the caller hands it to the other ranks (any channel:
  * MPI, a file, torch.distributed's store) */
 int kt_rccl_unique_id(uint8_t *id128);
 
-/* capacity_slots: slots per rank's shard (the rank with the fewest hash prefixes gets at least that many; the same
- * value on every rank - the ranks derive the whole table's geometry from it); max_batch_bases: the largest batch any
- * rank will pass to kt_sharded_add_reads - it fixes the size of the exchanged regions, so it must be the same on
- * every rank. */
+/* capacity_slots: slots of this rank's shard (a table of its own: size it for the k-mers one rank will own - about
+ * 1 / n_ranks of the distinct k-mers, more where a few minimisers dominate); max_batch_bases: the largest batch any
+ * rank will pass to kt_sharded_add_reads - it fixes the room of the exchange regions, so it must be the same on every
+ * rank (a mismatch is reported by every rank at the first kt_sharded_add_reads). */
 int kt_sharded_create_rccl(kt_ctx *ctx, int k, uint64_t capacity_slots, uint64_t max_batch_bases, int n_ranks, int rank,
                            const uint8_t *id128, kt_sharded **out);
 
@@ -345,7 +355,8 @@ int kt_sharded_finalize(kt_sharded *s);
 /* this rank's shard, an ordinary table: kt_ctr_size / kt_ctr_export / kt_cov_batch work on it (owned by `s`) */
 int kt_sharded_table(kt_sharded *s, kt_ctr **table);
 
-/* bytes this rank has sent to other ranks so far */
+/* bytes this rank has sent to other ranks so far (a single rank made to route into n regions, KT_SHARD_FORCE = n: the
+ * bytes of the regions a rank of n would have sent) */
 int kt_sharded_exchanged_bytes(kt_sharded *s, uint64_t *bytes);
 
 /* what carries the exchange: *n_ranks = the ranks this counter was created for; *rccl_ranks = what the library's own
@@ -358,13 +369,11 @@ int kt_sharded_comm_info(kt_sharded *s, int *n_ranks, int *rccl_ranks, int *tran
 /* the rank that owns a canonical k-mer in this sharded table (host helper, the function the device uses) */
 int kt_sharded_owner_of(kt_sharded *s, uint64_t kmer, uint32_t *owner);
 
-/* The layout every rank derives from (capacity_slots, n_ranks), without a GPU: the number of hash-prefix bits that
- * ownership goes by, the prefixes [bucket_lo, bucket_hi) of `rank`, the slots of its shard; and the owner of a k-mer
- * under such a layout: (top prefix_bits of the k-mer's hash) * n_ranks >> prefix_bits.
+/* The same without a counter or a GPU: the minimiser length m and the window w = k - m + 1 (m-mers per k-mer) the
+ * sharded counter uses for k-mers of length k, and the rank that owns a k-mer (either strand) among n_ranks.
  * replaces: `min_mer % n_parts`, counter/src/lib.rs:127 */
-int kt_shard_layout(uint64_t capacity_slots, int n_ranks, int rank, uint32_t *prefix_bits, uint32_t *bucket_lo,
-                    uint32_t *bucket_hi, uint64_t *local_slots);
-uint32_t kt_shard_owner_of(uint64_t kmer, uint32_t prefix_bits, uint32_t n_ranks);
+int kt_shard_minimiser(int k, uint32_t *m, uint32_t *w);
+uint32_t kt_shard_owner_of(uint64_t kmer, int k, uint32_t n_ranks);
 
 /* hash partition of a canonical k-mer among n_owners (host helper, same function the device uses): what
  * kt_ctr_add_reads_part and kt_ctr_route split by - the LOW hash bits, independent of a table's slot bits. */

@@ -59,6 +59,7 @@ SYMBOLS = {
     "kt_minimisers": (_i, [_vp, _vp, _vp, _u64, _u64, _i, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64), _i]),
     "kt_cov_batch": (_i, [_vp, _vp, _vp, _u64, _u64, _u64, _i, _i, _vp, _i]),
     "kt_cov_batch_part": (_i, [_vp, _vp, _vp, _u64, _u64, _u64, _vp, _i, _u32, _u32]),
+    "kt_ctr_lookup": (_i, [_vp, _vp, _u64, _vp, _i]),
     "kt_ctr_route": (_i, [_vp, _vp, _vp, _u64, _i, _i, _vp, _vp, _i]),
     "kt_owner_of": (_u32, [_u64, _u32]),
     "kt_rccl_unique_id": (_i, [_vp]),
@@ -75,8 +76,8 @@ SYMBOLS = {
     "kt_sharded_connect_rccl": (_i, [_vp, _vp]),
     "kt_sharded_connect_host": (_i, [_vp, _vp, _vp]),
     "kt_sharded_owner_of": (_i, [_vp, _u64, C.POINTER(_u32)]),
-    "kt_shard_layout": (_i, [_u64, _i, _i, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u64)]),
-    "kt_shard_owner_of": (_u32, [_u64, _u32, _u32]),
+    "kt_shard_minimiser": (_i, [_i, C.POINTER(_u32), C.POINTER(_u32)]),
+    "kt_shard_owner_of": (_u32, [_u64, _i, _u32]),
     "kt_synth_reads": (_i, [_vp, _u64, _u64, _u64, _u32, _i, _u64, _vp, _vp]),
 }
 

@@ -40,6 +40,7 @@
 
 #include "kt_launch.hpp"
 #include "kt_segment.hpp"
+#include "kt_superkmer.hpp"
 #include "kt_table.hpp"
 
 namespace {
@@ -475,6 +476,129 @@ struct KeysSource {  // canonical k-mers that are already an array (routed here 
     }
 };
 
+// The k-mers of RECORDS (kt_superkmer.hpp: at most 8 consecutive k-mers of a read as 8 + k - 1 bases at 2 bits - what the
+// ranks of the sharded counter send each other): unit = one block of 1024 records = 4 per thread, i.e. the same 32 window
+// starts per thread and unit as a segment of reads, a record per 8 of them.  Nothing is staged through LDS: a thread's
+// four records are 32 + 8 contiguous bytes of the block.
+struct RecordSource {
+    const ktsk::RecRun *runs;  // (device) the stretches of whole blocks this source covers, in order
+    const uint64_t *cum;       // (device) [n_runs + 1] blocks in the stretches before run j
+    uint32_t n_runs, k;
+    uint64_t n_blocks;
+    __device__ uint64_t n_units() const { return n_blocks; }
+    // block g of the source and the records it holds (g: the same in every lane of the wave)
+    __device__ void locate(uint64_t g, const uint64_t *&blk, uint32_t &n_in) const {
+        uint32_t lo = 0, hi = n_runs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ktd::load_uniform(cum + mid) <= g) lo = mid;
+            else hi = mid;
+        }
+        const uint64_t b = g - ktd::load_uniform(cum + lo);
+        const uint64_t *const base = ktd::load_uniform(&runs[lo].blocks);
+        const uint64_t left = ktd::load_uniform(&runs[lo].n_rec) - b * ktsk::BLOCK_RECS;
+        blk = base + b * ktsk::BLOCK_WORDS;
+        n_in = left < ktsk::BLOCK_RECS ? (uint32_t)left : ktsk::BLOCK_RECS;
+    }
+    struct Walk {
+        uint64_t a[4], bw;  // the thread's four records: a, and the four b side by side (record c in bits 16c .. 16c + 15)
+        uint32_t at;
+    };
+    // records at and beyond n_in (the unfilled tail of a region's last block) hold nothing
+    static __device__ __forceinline__ uint64_t clip(uint64_t bw, uint32_t t, uint32_t n_in) {
+        const uint32_t have = n_in > 4u * t ? n_in - 4u * t : 0u;
+        return have >= 4u ? bw : bw & ((1ull << (16u * have)) - 1ull);
+    }
+    __device__ Walk open(uint64_t g, SegShared &, uint32_t t) const {
+        const uint64_t *blk;
+        uint32_t n_in;
+        locate(ktd::uniform64(g), blk, n_in);
+        Walk wk;
+#pragma unroll
+        for (int c = 0; c < 4; c++) wk.a[c] = blk[4 * t + c];
+        wk.bw = clip(blk[ktsk::BLOCK_RECS + t], t, n_in);
+        wk.at = 0;
+        return wk;
+    }
+    // the same with the unit's reads requested a unit ahead, from inline assembly (see ktseg::prefetch_issue: five
+    // loads, the same shape as a segment's)
+    struct Pre2 {
+        uint64_t a[4], bw;  // in flight until prefetch_take
+        uint32_t n_in;
+    };
+    struct Taken {
+        uint64_t a[4], bw, first_next;
+        uint32_t n_in;
+    };
+    __device__ uint64_t first_of(uint64_t) const { return 0; }
+    __device__ void prefetch_issue(Pre2 &pf, uint64_t g, uint64_t, uint64_t, uint32_t t, const void *) const {
+        const uint64_t *blk;
+        locate(ktd::uniform64(g), blk, pf.n_in);
+        const void *p0 = blk + 4 * t, *pb = blk + ktsk::BLOCK_RECS + t;
+        asm volatile("global_load_dwordx2 %0, %5, off\n\tglobal_load_dwordx2 %1, %5, off offset:8\n\t"
+                     "global_load_dwordx2 %2, %5, off offset:16\n\tglobal_load_dwordx2 %3, %5, off offset:24\n\t"
+                     "global_load_dwordx2 %4, %6, off"
+                     : "=&v"(pf.a[0]), "=&v"(pf.a[1]), "=&v"(pf.a[2]), "=&v"(pf.a[3]), "=&v"(pf.bw) : "v"(p0), "v"(pb) : "memory");
+    }
+    template <int NSTORE>
+    __device__ void prefetch_take(Taken &tk, Pre2 &pf) const {
+        // (the in-flight registers are inputs only: see ktseg::prefetch_take)
+        asm volatile("s_waitcnt vmcnt(%10)\n\tv_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\tv_mov_b64 %3, %8\n\tv_mov_b64 %4, %9"
+                     : "=&v"(tk.a[0]), "=&v"(tk.a[1]), "=&v"(tk.a[2]), "=&v"(tk.a[3]), "=&v"(tk.bw)
+                     : "v"(pf.a[0]), "v"(pf.a[1]), "v"(pf.a[2]), "v"(pf.a[3]), "v"(pf.bw), "n"(NSTORE)
+                     : "memory");
+        tk.n_in = pf.n_in;
+        tk.first_next = 0;
+    }
+    __device__ Walk open_taken(uint64_t, uint64_t, SegShared &, uint32_t t, const Taken &tk) const {
+        Walk wk;
+#pragma unroll
+        for (int c = 0; c < 4; c++) wk.a[c] = tk.a[c];
+        wk.bw = clip(tk.bw, t, tk.n_in);
+        wk.at = 0;
+        return wk;
+    }
+    // the thread's next N window starts: N / 8 records, eight windows each (bit j of ok: the record has a k-mer there)
+    template <int N, class KR>
+    __device__ void take(Walk &wk, uint32_t, KR (&keys)[N], uint32_t &ok) const {
+        static_assert(N % (int)ktsk::REC_KMERS == 0, "whole records per round");
+        ok = 0;
+#pragma unroll
+        for (int c = 0; c < N / 8; c++) {
+            const uint32_t rec = wk.at / 8u + (uint32_t)c;
+            const uint64_t a = rec == 0 ? wk.a[0] : rec == 1 ? wk.a[1] : rec == 2 ? wk.a[2] : wk.a[3];
+            const uint32_t b = (uint32_t)(wk.bw >> (16u * rec)) & 0xFFFFu;
+            const uint32_t n = b & 15u;
+            ktseg::Window w(a, (uint64_t)(b & 0xFFF0u) << 48, (1u << n) - 1u, k);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                keys[c * 8 + j] = (KR)(w.f < w.r ? w.f : w.r);
+                w.step();
+            }
+            ok |= ((1u << n) - 1u) << (c * 8);
+        }
+        wk.at += N;
+    }
+    __device__ void collect(uint64_t g, SegShared &sm, uint64_t (&keys)[ktseg::PER_THREAD], uint32_t &ok) const {
+        Walk wk = open(g, sm, threadIdx.x);
+        take<(int)ktseg::PER_THREAD, uint64_t>(wk, threadIdx.x, keys, ok);
+    }
+    template <class Sink>
+    __device__ void for_each(uint64_t g, SegShared &sm, Sink &&sink) const {
+        Walk wk = open(g, sm, threadIdx.x);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t b = (uint32_t)(wk.bw >> (16 * c)) & 0xFFFFu;
+            const uint32_t n = b & 15u;
+            ktseg::Window w(wk.a[c], (uint64_t)(b & 0xFFF0u) << 48, (1u << n) - 1u, k);
+            for (uint32_t j = 0; j < n; j++) {
+                sink(w.f < w.r ? w.f : w.r);
+                w.step();
+            }
+        }
+    }
+};
+
 // ---- hist1 --------------------------------------------------------------------------------------
 template <class Source>
 __global__ __launch_bounds__(BLOCK) void hist1_kernel(Source src, Plan p, uint32_t *__restrict__ H) {
@@ -488,6 +612,22 @@ __global__ __launch_bounds__(BLOCK) void hist1_kernel(Source src, Plan p, uint32
     }
     ktd::lds_barrier();
     for (uint32_t i = threadIdx.x; i < p.B1; i += BLOCK) H[(uint64_t)blockIdx.x * p.B1 + i] += cnt[i];  // (a job may have several sources)
+}
+
+// records through the probing path (a batch too small for the partition passes, or small against a table that holds data)
+__global__ __launch_bounds__(BLOCK) void count_records_kernel(RecordSource src, TableRef t, uint64_t *__restrict__ distinct) {
+    __shared__ SegShared sm;  // (not used by this source)
+    uint32_t fresh = 0;
+    const uint64_t n_units = src.n_units();
+    for (uint64_t g = blockIdx.x; g < n_units; g += gridDim.x) {
+        src.for_each(g, sm, [&](uint64_t key) {
+            const uint32_t st = kttab::table_add(t, key, 1u);
+            if (st == 0u) atomicOr(t.flags, 1u);
+            fresh += st == 2u;
+        });
+    }
+    for (int o = 32; o > 0; o >>= 1) fresh += __shfl_down(fresh, o, 64);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(reinterpret_cast<unsigned long long *>(distinct), (unsigned long long)fresh);
 }
 
 // ---- scan1: O[g][d] = (k-mers in buckets < d) + (k-mers of workgroups < g in bucket d) ------------
@@ -2662,12 +2802,23 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
 }  // namespace
 
 // ---- host side: a job = plan + buffers + level 1 over one or more sources + level 2 + range build ----------------
+enum SourceKind { SRC_READS, SRC_KEYS, SRC_RECORDS };
 struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be redone with exact offsets)
-    bool reads;
+    SourceKind kind;
     ReadsSource rs;
     KeysSource ks;
+    RecordSource rc;
     uint64_t n_units;  // upper bound (device-side counts may make it smaller)
 };
+// f(the source of r, as its own type)
+template <class F>
+static int with_source(const SourceRec &r, F &&f) {
+    switch (r.kind) {
+        case SRC_READS: return f(r.rs);
+        case SRC_KEYS: return f(r.ks);
+        default: return f(r.rc);
+    }
+}
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
@@ -2721,6 +2872,9 @@ struct kt_bulk_job {
     // (host copies that outlive their asynchronous upload)
     uint32_t presplit_srcs = 0;
     std::vector<std::vector<kt_seg_src>> presplit_lists;
+    // record sources (kt_bulk_add_records): their descriptors on the device (ctr->b_desc), the host copies the uploads read
+    size_t desc_used = 0;
+    std::vector<std::vector<uint64_t>> desc_host;
     size_t ksz() const { return narrow ? 4 : 8; }
 };
 
@@ -2732,70 +2886,62 @@ template <class K>
 int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice = 0) {
     kt_ctx *ctx = ctr->ctx;
     K *keys1 = (K *)ctr->b_keys1.p + (size_t)slice * j.p.B1 * j.p.cap1;
-    struct { Meta m; } jj{j.m};
-    if (j.xcd && j.kn.s1y && Scatter1YShared<K, 1024>::bytes(j.p.B1) <= 160 * 1024) {  // two sort buffers, the copy-out spread over the next round
-        constexpr int T = 1024;
-        unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;
-        const uint32_t wgs = (uint32_t)ctx->n_cu * (uint32_t)(j.kn.g_mult ? j.kn.g_mult : 1);
-        const size_t lds = Scatter1YShared<K, T>::bytes(j.p.B1);
-        if (r.reads) {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1y_kernel<ReadsSource, K, T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1y_kernel<ReadsSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.rs, j.p, xcur,
-                               jj.m.ovf, keys1, j.pend, j.m.dump);
+    if (!j.xcd) return kt::fail(KT_ERR_ARG, "bulk build: paged level 1 without its cursors");
+    unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;
+    const Plan p = j.p;
+    uint32_t *const ovf = j.m.ovf;
+    unsigned long long *const dump = j.m.dump;
+    const PendList pend = j.pend;
+    // two sort buffers, the copy-out spread over the next round - or, a shape that does not fit the LDS, one buffer
+    const bool two = j.kn.s1y && Scatter1YShared<K, 1024>::bytes(j.p.B1) <= 160 * 1024;
+    const uint32_t mult = (uint32_t)(j.kn.g_mult ? j.kn.g_mult : 1);
+    return with_source(r, [&](const auto &src) -> int {
+        using S = std::decay_t<decltype(src)>;
+        if (two) {
+            constexpr int T = 1024;
+            const size_t lds = Scatter1YShared<K, T>::bytes(p.B1);
+            auto kern = scatter1y_kernel<S, K, T>;
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, pend, dump);
         } else {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1y_kernel<KeysSource, K, T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1y_kernel<KeysSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.ks, j.p, xcur,
-                               jj.m.ovf, keys1, j.pend, j.m.dump);
+            constexpr int T = KT_S1X_T;
+            const size_t lds = sizeof(Scatter1XShared<K, T>);
+            auto kern = scatter1x_kernel<S, K, T>;
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * (1024 / T) * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1,
+                               pend, dump);
         }
         KT_HIP(hipGetLastError());
         return KT_OK;
-    }
-    if (j.xcd) {
-        constexpr int T = KT_S1X_T;
-        unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;
-        const uint32_t wgs = (uint32_t)ctx->n_cu * (1024 / T) * (uint32_t)(j.kn.g_mult ? j.kn.g_mult : 1);
-        const size_t lds = sizeof(Scatter1XShared<K, T>);
-        if (r.reads) {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1x_kernel<ReadsSource, K, T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1x_kernel<ReadsSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.rs, j.p, xcur,
-                               jj.m.ovf, keys1, j.pend, j.m.dump);
-        } else {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1x_kernel<KeysSource, K, T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((scatter1x_kernel<KeysSource, K, T>), dim3(wgs), dim3(T), lds, ctx->stream, r.ks, j.p, xcur,
-                               jj.m.ovf, keys1, j.pend, j.m.dump);
-        }
-        KT_HIP(hipGetLastError());
-        return KT_OK;
-    }
-    return kt::fail(KT_ERR_ARG, "bulk build: paged level 1 without its cursors");
+    });
 }
 
 template <class K>
 int level1_exact(kt_ctr *ctr, kt_bulk_job &j) {  // hist1 over every source, scan1, scatter1 over every source
     kt_ctx *ctx = ctr->ctx;
     K *keys1 = (K *)ctr->b_keys1.p;
-    KT_HIP(hipMemsetAsync(j.m.H, 0, (size_t)j.p.G * j.p.B1 * 4, ctx->stream));
+    const Plan p = j.p;
+    const Meta m = j.m;
+    KT_HIP(hipMemsetAsync(m.H, 0, (size_t)p.G * p.B1 * 4, ctx->stream));
     for (const SourceRec &r : j.srcs) {
-        if (r.reads) hipLaunchKernelGGL(hist1_kernel<ReadsSource>, dim3(j.p.G), dim3(BLOCK), 0, ctx->stream, r.rs, j.p, j.m.H);
-        else hipLaunchKernelGGL(hist1_kernel<KeysSource>, dim3(j.p.G), dim3(BLOCK), 0, ctx->stream, r.ks, j.p, j.m.H);
+        const int rc = with_source(r, [&](const auto &src) -> int {
+            using S = std::decay_t<decltype(src)>;
+            hipLaunchKernelGGL(hist1_kernel<S>, dim3(p.G), dim3(BLOCK), 0, ctx->stream, src, p, m.H);
+            return KT_OK;
+        });
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, j.m.H, j.p, j.m.O, j.m.bstart);
+    hipLaunchKernelGGL(scan1_kernel, dim3(1), dim3(1024), 0, ctx->stream, m.H, p, m.O, m.bstart);
     for (const SourceRec &r : j.srcs) {
-        if (r.reads) {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<ReadsSource, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
-            hipLaunchKernelGGL((scatter1_kernel<ReadsSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>),
-                               ctx->stream, r.rs, j.p, j.m.O, keys1);
-        } else {
-            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scatter1_kernel<KeysSource, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Scatter1Shared<K>)));
-            hipLaunchKernelGGL((scatter1_kernel<KeysSource, K>), dim3(j.p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>),
-                               ctx->stream, r.ks, j.p, j.m.O, keys1);
-        }
+        const int rc = with_source(r, [&](const auto &src) -> int {
+            using S = std::decay_t<decltype(src)>;
+            auto kern = scatter1_kernel<S, K>;
+            KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sizeof(Scatter1Shared<K>)));
+            hipLaunchKernelGGL(kern, dim3(p.G), dim3(BLOCK), sizeof(Scatter1Shared<K>), ctx->stream, src, p, m.O, keys1);
+            return KT_OK;
+        });
+        if (rc) return rc;
     }
     KT_HIP(hipGetLastError());
     return KT_OK;
@@ -3159,7 +3305,6 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     // 256 instead of 512 buckets 23.7 -> 23.3 ms, level 2 14.4 -> 13.8 ms)
     if (fb >= 16 && fb - p.b1 < 9) p.b1 = fb - 9;
     if (kn.b1 && kn.b1 <= 10 && kn.b1 < fb && fb - kn.b1 <= 11) p.b1 = (uint32_t)kn.b1;  // (KT_BULK_B1: the split between the levels, experiments)
-    if (ctr->n_owners > 1) p.b1 = ctr->owner_bits;  // a shard: the level-1 buckets are what the GPUs own (kt_shard.hip)
     p.b2 = fb - p.b1;
     // a pass resolves at most 10 (level 1) / 11 (level 2) hash bits.  The shards of a table spread over N GPUs are
     // addressed by log2(N) more bits than a table of the same size on one GPU, and level 1 - run by the senders - spends
@@ -3171,8 +3316,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     if (p.bx && (!sharded || p.bx > 6)) return KT_OK;
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
-    p.d_lo = ctr->n_owners > 1 ? ctr->bucket_lo : 0;
-    p.d_hi = ctr->n_owners > 1 ? ctr->bucket_hi : p.B1;
+    p.d_lo = 0;
+    p.d_hi = p.B1;
     const uint32_t nd = p.d_hi - p.d_lo;
     // persistent level-1 workgroups (the same for every source of the job): two per CU for the per-unit kernels; the wide
     // kernel launches G / 2 of them, one resident per CU (KT_BULK_G_MULT > 1: more, shorter-lived workgroups)
@@ -3286,6 +3431,8 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     j.xcd = paged && xcd;
     j.presplit_srcs = 0;
     j.presplit_lists.clear();
+    j.desc_used = 0;
+    j.desc_host.clear();
     if (p.bx) {
         KT_HIP(hipMemsetAsync(m.xcarry, 0, (n_sub + 1) * 4, ctx->stream));
         KT_HIP(hipMemsetAsync(m.fail, 0, (n_sub + 1) * 4, ctx->stream));
@@ -3321,7 +3468,7 @@ int kt_bulk_slice_reads(kt_ctr *ctr, uint32_t slice, const uint8_t *d_bases, con
     if (!job || !job->open || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
     if (seg_hi <= seg_lo) return KT_OK;
     SourceRec r{};
-    r.reads = true;
+    r.kind = SRC_READS;
     r.rs.a.bases = d_bases;
     r.rs.a.offsets = d_offsets;
     r.rs.a.seg_first = seg_first;
@@ -3426,7 +3573,7 @@ static int job_add(kt_ctr *ctr, const SourceRec &r, uint64_t bound) {
 int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
                       uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_parts, uint32_t part) {
     SourceRec r{};
-    r.reads = true;
+    r.kind = SRC_READS;
     r.rs.a.bases = d_bases;
     r.rs.a.offsets = d_offsets;
     r.rs.a.seg_first = seg_first;
@@ -3444,10 +3591,75 @@ int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_off
 // level 1 over an array of canonical k-mers (KT_EMPTY_KEY entries are skipped); d_n (may be null) = device-side count
 int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n) {
     SourceRec r{};
-    r.reads = false;
+    r.kind = SRC_KEYS;
     r.ks = KeysSource{d_keys, n_keys, d_n};
     r.n_units = (n_keys + ktseg::SEG - 1) / ktseg::SEG;
     return job_add(ctr, r, n_keys);
+}
+
+// level 1 over records (kt_superkmer.hpp): `runs` (host) = stretches of whole blocks in device memory, in any number;
+// kmers_bound: the k-mers they hold at most (0: not counted against the job's plan - the caller planned for all of them)
+constexpr size_t DESC_BYTES = 1u << 18;
+int kt_bulk_add_records(kt_ctr *ctr, const ktsk::RecRun *runs, uint32_t n_runs, uint64_t kmers_bound) {
+    kt_bulk_job *job = ctr->job;
+    if (!job || !job->open) return kt::fail(KT_ERR_ARG, "bulk build: no open job");
+    if (!n_runs) return KT_OK;
+    // the descriptors: n_runs x {blocks, n_rec}, then n_runs + 1 cumulative block counts
+    std::vector<uint64_t> h((size_t)n_runs * 3 + 1);
+    uint64_t blocks = 0;
+    for (uint32_t i = 0; i < n_runs; i++) {
+        h[2 * (size_t)i] = (uint64_t)(uintptr_t)runs[i].blocks;
+        h[2 * (size_t)i + 1] = runs[i].n_rec;
+        h[2 * (size_t)n_runs + i] = blocks;
+        blocks += (runs[i].n_rec + ktsk::BLOCK_RECS - 1) / ktsk::BLOCK_RECS;
+    }
+    h[3 * (size_t)n_runs] = blocks;
+    if (!blocks) return KT_OK;
+    const size_t bytes = (h.size() * 8 + 255) & ~(size_t)255;
+    if (job->desc_used + bytes > DESC_BYTES) return kt::fail(KT_ERR_ARG, "bulk build: too many record sources in one job");
+    if (!ctr->b_desc.p)
+        if (int rc = ctr->b_desc.reserve(DESC_BYTES)) return rc;
+    char *d = (char *)ctr->b_desc.p + job->desc_used;
+    job->desc_used += bytes;
+    job->desc_host.push_back(std::move(h));  // (alive until the job after next begins: the upload reads it)
+    const std::vector<uint64_t> &hh = job->desc_host.back();
+    KT_HIP(hipMemcpyAsync(d, hh.data(), hh.size() * 8, hipMemcpyHostToDevice, ctr->ctx->stream));
+    SourceRec r{};
+    r.kind = SRC_RECORDS;
+    r.rc.runs = (const ktsk::RecRun *)d;
+    r.rc.cum = (const uint64_t *)d + 2 * (size_t)n_runs;
+    r.rc.n_runs = n_runs;
+    r.rc.k = (uint32_t)ctr->k;
+    r.rc.n_blocks = blocks;
+    r.n_units = blocks;
+    return job_add(ctr, r, kmers_bound);
+}
+
+// the same records, one table_add per k-mer (kt_shard.hip, when kt_bulk_begin says the batch does not suit the passes)
+int kt_ctr_count_records(kt_ctr *ctr, const ktsk::RecRun *runs, uint32_t n_runs) {
+    kt_ctx *ctx = ctr->ctx;
+    if (!n_runs) return KT_OK;
+    std::vector<uint64_t> h((size_t)n_runs * 3 + 1);
+    uint64_t blocks = 0;
+    for (uint32_t i = 0; i < n_runs; i++) {
+        h[2 * (size_t)i] = (uint64_t)(uintptr_t)runs[i].blocks;
+        h[2 * (size_t)i + 1] = runs[i].n_rec;
+        h[2 * (size_t)n_runs + i] = blocks;
+        blocks += (runs[i].n_rec + ktsk::BLOCK_RECS - 1) / ktsk::BLOCK_RECS;
+    }
+    h[3 * (size_t)n_runs] = blocks;
+    if (!blocks) return KT_OK;
+    ctr->stage_n = 0;
+    if (int rc = ktl::table_ready(ctr)) return rc;  // (a dense table gets its probing image, a deferred clear happens now)
+    ctr->empty = false;
+    if (int rc = ctx->s_aux2.reserve(h.size() * 8)) return rc;
+    KT_HIP(hipMemcpyAsync(ctx->s_aux2.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    KT_HIP(hipStreamSynchronize(ctx->stream));  // (h lives on this frame)
+    RecordSource src{(const ktsk::RecRun *)ctx->s_aux2.p, (const uint64_t *)ctx->s_aux2.p + 2 * (size_t)n_runs, n_runs, (uint32_t)ctr->k, blocks};
+    TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
+    hipLaunchKernelGGL(count_records_kernel, dim3(ktl::grid_for(ctx, blocks, 8)), dim3(BLOCK), 0, ctx->stream, src, t, ctr->distinct);
+    KT_HIP(hipGetLastError());
+    return KT_OK;
 }
 
 // level 2 + the range builds; the sources must still be readable (a skewed batch is redone from them)

@@ -38,7 +38,7 @@ struct CovArgs {
     uint32_t bin_count;
     uint32_t *counts;    // n_reads x bin_count, zeroed
     uint32_t n_parts, part;  // n_parts > 1: only the k-mers of hash partition `part` are binned (kt_cov_batch_part)
-    uint32_t shard;          // the table is a shard of a sharded table: only the k-mers it owns are binned
+    uint32_t shard;          // the table is a shard of a sharded table (1; 2: the first shard - see cov_kernel): the rows are summed over the shards
 };
 
 __device__ __forceinline__ uint4 load_slot(const Slot *slots, uint64_t slot) {
@@ -112,16 +112,28 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
                     if (!((ok >> (jj + u)) & 1u)) continue;
                     // (a k-mer that another pass / another shard answers for is not "absent" here: it is skipped)
                     if (c.n_parts > 1 && ktd::owner_of(key[u], c.n_parts) != c.part) continue;
-                    if (c.shard && kttab::probe_of(key[u], c.g).rs == 0) continue;
                     const uint32_t cnt = resolve_count(c, v[u], key[u]);
                     uint32_t bin = c.bin_size ? cnt / c.bin_size : 0u;  // coverage/src/lib.rs:172
                     bin = bin < last_bin ? bin : last_bin;              // :173
                     const uint64_t s = s0 + jj + u;
                     while (s >= next) next = a.offsets[++rid + 1];      // empty reads are stepped over
-                    if (in_lds)
-                        atomicAdd(&rows[(uint32_t)(rid - rbase) * c.bin_count + bin], 1u);
-                    else
-                        atomicAdd(&c.counts[rid * c.bin_count + bin], 1u);
+                    auto add = [&](uint32_t b, uint32_t n) {
+                        if (in_lds) atomicAdd(&rows[(uint32_t)(rid - rbase) * c.bin_count + b], n);
+                        else atomicAdd(&c.counts[rid * c.bin_count + b], n);
+                    };
+                    if (!c.shard) {
+                        add(bin, 1u);
+                    } else {
+                        // one shard of a table spread over several GPUs by minimiser (kt_shard.hip): a k-mer this shard does
+                        // not hold is not "absent" - it may be elsewhere.  Shard 0's pass puts every k-mer into bin 0 (as if
+                        // absent everywhere); the one shard that holds a k-mer moves it from there to its bin.  The shards'
+                        // rows, summed modulo 2^32 (u32 cells), are the rows of the whole table.
+                        if (c.shard == 2u) add(0u, 1u);
+                        if (cnt && bin) {
+                            add(bin, 1u);
+                            add(0u, 0xFFFFFFFFu);
+                        }
+                    }
                 }
             }
         }
@@ -136,6 +148,27 @@ __global__ __launch_bounds__(BLOCK) void cov_kernel(SegArgs a, CovArgs c) {
                 }
             }
         }
+    }
+}
+
+// occurrences of keys[i] in the table (0: absent), one thread per key
+__global__ __launch_bounds__(BLOCK) void lookup_kernel(const Slot *__restrict__ slots, kttab::Geom g, const uint64_t *__restrict__ keys,
+                                                       uint64_t n, uint32_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t key = keys[i];
+        kttab::Probe p = kttab::probe_of(key, g);
+        uint32_t cnt = 0;
+        for (uint32_t probe = 0; probe < p.rs; probe++) {
+            const uint4 v = load_slot(slots, p.slot());
+            const uint64_t kk = ((uint64_t)v.y << 32) | v.x;
+            if (kk == key) {
+                cnt = v.z + 1u;
+                break;
+            }
+            if (kk == KT_EMPTY_KEY) break;
+            p.next();
+        }
+        out[i] = key == KT_EMPTY_KEY ? 0u : cnt;
     }
 }
 
@@ -171,7 +204,7 @@ static int cov_counts(kt_ctr *table, kt_ctx *ctx, const uint8_t *d_bases, const 
     SegArgs a;
     if (int rc = make_seg_args(ctx, d_bases, d_offsets, n_reads, total, table->k, &a)) return rc;
     CovArgs c{(const Slot *)table->slots, ktl::geom_of(table), bin_size > 0xFFFFFFFFull ? 0u : (uint32_t)bin_size,
-              (uint32_t)bin_count, d_counts, n_parts, part, table->n_owners > 1 ? 1u : 0u};
+              (uint32_t)bin_count, d_counts, n_parts, part, table->n_owners > 1 ? (table->owner == 0 ? 2u : 1u) : 0u};
     hipLaunchKernelGGL(cov_kernel, dim3(grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, c);
     KT_HIP(hipGetLastError());
     return KT_OK;
@@ -212,6 +245,33 @@ extern "C" int kt_cov_batch_part(kt_ctr *table, const uint8_t *bases, const uint
         for (uint64_t i = 0; i < n_cells; i++) counts[i] += tmp[i];
     free(tmp);
     if (e != hipSuccess) return kt::fail(KT_ERR_HIP, std::string("kt_cov_batch_part: ") + hipGetErrorString(e));
+    return KT_OK;
+}
+
+extern "C" int kt_ctr_lookup(kt_ctr *table, const uint64_t *keys, uint64_t n, uint32_t *counts, int mem) {
+    if (!table) return kt::fail(KT_ERR_ARG, "kt_ctr_lookup: null table");
+    if (mem != KT_MEM_HOST && mem != KT_MEM_DEVICE) return kt::fail(KT_ERR_ARG, "kt_ctr_lookup: bad mem");
+    if (n == 0) return KT_OK;
+    if (!keys || !counts) return kt::fail(KT_ERR_ARG, "kt_ctr_lookup: null buffer");
+    kt_ctx *ctx = table->ctx;
+    if (int rc = ctx->use()) return rc;
+    if (int rc = table_ready(table)) return rc;  // (a densely packed table gets its probing image first)
+    const uint64_t *d_keys = keys;
+    uint32_t *d_counts = counts;
+    if (mem == KT_MEM_HOST) {
+        if (int rc = ctx->s_aux1.reserve(n * 8)) return rc;
+        if (int rc = ctx->s_aux2.reserve(n * 4)) return rc;
+        KT_HIP(hipMemcpyAsync(ctx->s_aux1.p, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_keys = (const uint64_t *)ctx->s_aux1.p;
+        d_counts = (uint32_t *)ctx->s_aux2.p;
+    }
+    hipLaunchKernelGGL(lookup_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0, ctx->stream,
+                       (const Slot *)table->slots, ktl::geom_of(table), d_keys, n, d_counts);
+    KT_HIP(hipGetLastError());
+    if (mem == KT_MEM_HOST) {
+        KT_HIP(hipMemcpyAsync(counts, d_counts, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return KT_OK;
 }
 

@@ -290,6 +290,17 @@ struct Window {
         f = hi >> sh;
         r = ktd::rev_comp(f, (int)k);
     }
+    // the same walk over bases that are already 2-bit codes (a record of kt_superkmer.hpp): up to 64 bases in (hi_, lo_),
+    // the first in the top bits of hi_; bit j of okm_ = window start j is a k-mer
+    __device__ __forceinline__ Window(uint64_t hi_, uint64_t lo_, uint32_t okm_, uint32_t k) {
+        hi = hi_;
+        lo = lo_;
+        sh = 64u - 2u * k;
+        rsh = 2u * (k - 1);
+        okm = okm_;
+        f = hi >> sh;
+        r = ktd::rev_comp(f, (int)k);
+    }
     // is window start j (0..31) a k-mer: k valid bases, no read start among the k-1 later ones
     __device__ __forceinline__ bool ok(uint32_t j) const { return (okm >> j) & 1u; }
     // slide one base: the next code enters fwd at the bottom, its complement enters rev at the top

@@ -154,6 +154,13 @@ int kt_bulk_presplit_slice(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n, hipS
 int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
                       uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_parts, uint32_t part);
 int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n);
+// level 1 over records of at most 8 consecutive k-mers (kt_superkmer.hpp; what the ranks of the sharded counter send
+// each other): n_runs stretches of whole blocks in device memory (`runs`: host array); kmers_bound = 0: the job was
+// planned for everything these sources hold
+namespace ktsk { struct RecRun; }
+int kt_bulk_add_records(kt_ctr *ctr, const ktsk::RecRun *runs, uint32_t n_runs, uint64_t kmers_bound);
+// ... and the same records through the probing path (one table_add per k-mer), outside any job
+int kt_ctr_count_records(kt_ctr *ctr, const ktsk::RecRun *runs, uint32_t n_runs);
 int kt_bulk_finish(kt_ctr *ctr);
 // kt_ctr.hip: one count for each of the first min(*d_n, cap_keys) keys of an array, through the probing path
 int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_keys, const uint64_t *d_n);

@@ -74,17 +74,16 @@ def owner_of(kmer, n_owners):
     return int(_lib.lib().kt_owner_of(int(kmer), int(n_owners)))
 
 
-def shard_layout(capacity_slots, n_ranks, rank):
-    """-> (prefix_bits, bucket_lo, bucket_hi, local_slots): what a rank of a sharded table derives for itself"""
-    b, lo, hi, n = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
-    check(_lib.lib().kt_shard_layout(int(capacity_slots), int(n_ranks), int(rank), C.byref(b), C.byref(lo), C.byref(hi),
-                                     C.byref(n)))
-    return b.value, lo.value, hi.value, n.value
+def shard_minimiser(k):
+    """-> (m, w): the minimiser length and the window (m-mers per k-mer) the sharded counter uses for k-mers of length k"""
+    m, w = C.c_uint32(), C.c_uint32()
+    check(_lib.lib().kt_shard_minimiser(int(k), C.byref(m), C.byref(w)))
+    return m.value, w.value
 
 
-def shard_owner_of(kmer, prefix_bits, n_ranks):
-    """the rank that owns a k-mer in a sharded table: its hash PREFIX scaled to the number of ranks"""
-    return int(_lib.lib().kt_shard_owner_of(int(kmer), int(prefix_bits), int(n_ranks)))
+def shard_owner_of(kmer, k, n_ranks):
+    """the rank that owns a k-mer (either strand) of length k among n_ranks: by its minimiser's hash (kt_shard_owner_of)"""
+    return int(_lib.lib().kt_shard_owner_of(int(kmer), int(k), int(n_ranks)))
 
 
 def to_csr(seqs):
@@ -384,6 +383,18 @@ class Counter:
     def cov(self, bases, offsets, n_reads, bin_size, bin_count, out, norm=True, dtype="f64", mem=KT_MEM_DEVICE):
         check(_lib.lib().kt_cov_batch(self._h, _ptr(bases), _ptr(offsets), n_reads, int(bin_size), int(bin_count),
                                       int(bool(norm)), _DT[dtype], _ptr(out), mem))
+        return out
+
+    def lookup(self, keys, n, counts, mem=KT_MEM_DEVICE):
+        """counts[i] = occurrences of the canonical k-mer keys[i] (0: absent) - u64 keys, u32 counts"""
+        check(_lib.lib().kt_ctr_lookup(self._h, _ptr(keys), int(n), _ptr(counts), mem))
+        return counts
+
+    def lookup_host(self, keys):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        out = np.zeros(len(keys), np.uint32)
+        if len(keys):
+            self.lookup(keys, len(keys), out, KT_MEM_HOST)
         return out
 
     def cov_part(self, bases, offsets, n_reads, bin_size, bin_count, counts, n_parts=1, part=0, mem=KT_MEM_DEVICE):

@@ -1,9 +1,11 @@
-"""world_size-2 CPU (gloo) test of the multi-GPU counting schedule's host side: ownership by hash prefix
-(kt_shard_layout / kt_shard_owner_of: every rank derives the same layout, the owners partition the k-mers, a rank's
-k-mers have hash prefixes inside its bucket interval) and the host all-to-all transport that kt_sharded_connect_host
-drives (kmertools_amd.dist.host_alltoall over torch.distributed: equal blocks, block p to rank p).
-The GPU kernels are replaced here by the oracle (test infrastructure): every rank fills one block per owner - a status
-word, the key count, the keys, like the library's blocks - the transport moves them, and what arrives is counted."""
+"""world_size-2 CPU (gloo) test of the multi-GPU counting schedule's host side: ownership by the k-mer's minimiser
+(kt_shard_minimiser / kt_shard_owner_of - the library's host functions - against tests/shard_ref.py's restatement: the
+owners partition the k-mers, both strands of a k-mer have one owner), the wire format (records of at most 8 k-mers of
+one owner, 80 bits each, in blocks of 1024), and the host all-to-all transport that kt_sharded_connect_host drives
+(kmertools_amd.dist.host_alltoall over torch.distributed: equal blocks, block p to rank p).
+The GPU kernels are replaced here by shard_ref.py and the oracle (test infrastructure): every rank cuts its reads into
+records, fills one message per owner - a status word, the record count, the blocks, like the library's regions - the
+transport moves them, and what arrives is decoded and counted."""
 import os
 import socket
 
@@ -45,22 +47,44 @@ def _worker(rank, port, q):
         from oracle import kt_oracle as oracle
         bases, offsets = oracle.synth_reads(SEED, N_PER_RANK, L, noise=True, genome_len=20000,
                                             first_read=rank * N_PER_RANK)
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import shard_ref
         canon = _canonical_kmers(oracle, bases, offsets, K)
-        cap = 1 << 20
-        bits, lo, hi, slots = device.shard_layout(cap, WORLD, rank)
-        layouts = [device.shard_layout(cap, WORLD, r) for r in range(WORLD)]
-        assert all(x[0] == bits for x in layouts) and slots >= cap          # every rank derives the same prefix bits
-        assert layouts[0][1] == 0 and layouts[-1][2] == 1 << bits           # the intervals tile the buckets
-        assert all(layouts[r][2] == layouts[r + 1][1] for r in range(WORLD - 1))
-        owners = np.array([device.shard_owner_of(int(x), bits, WORLD) for x in canon], dtype=np.int64)
-        # one block per owner: [status, count, keys...], equal sizes (the host transport's contract)
-        words = 8 + N_PER_RANK * (L - K + 1)                  # (the same on every rank: at most this many k-mers)
+        assert device.shard_minimiser(K) == (shard_ref.mmer_of(K), shard_ref.window_of(K)) == (16, 16)
+        for kk in (1, 7, 8, 9, 10, 11, 14, 15, 16, 21, 22, 23, 31):     # m >= 8 wherever k allows, w a power of two <= 16
+            m, w = device.shard_minimiser(kk)
+            assert (m, w) == (shard_ref.mmer_of(kk), shard_ref.window_of(kk)) and m + w - 1 == kk
+            assert w in (1, 2, 4, 8, 16) and (m >= 8 or w == 1) and m <= 16
+        # the library's host function against the restatement, both strands, several rank counts and k
+        for kk, nr in ((K, WORLD), (K, 8), (21, 3), (15, 5), (10, 2), (6, 4)):
+            sub = canon[:400] & np.uint64((1 << (2 * kk)) - 1)
+            ref = shard_ref.owner_of_kmers(sub, kk, nr)
+            got = np.array([device.shard_owner_of(int(x), kk, nr) for x in sub], dtype=np.int64)
+            rc = np.array([device.shard_owner_of(oracle.rev_comp(int(x), kk), kk, nr) for x in sub], dtype=np.int64)
+            assert np.array_equal(ref, got) and np.array_equal(got, rc) and got.min() >= 0 and got.max() < nr
+        owners = shard_ref.owner_of_kmers(canon, K, WORLD)
+        assert 0.3 < (owners == 0).mean() < 0.7                         # (balanced: the order is a hash of the m-mer)
+        # the records of this rank's reads, one stream per owner
+        streams = [[] for _ in range(WORLD)]
+        n_kmers = 0
+        for i in range(len(offsets) - 1):
+            codes, valid = shard_ref.codes_of(bases[int(offsets[i]):int(offsets[i + 1])].tobytes())
+            for o, start, n in shard_ref.records_of_read(codes, valid, K, WORLD):
+                assert 1 <= n <= shard_ref.REC_KMERS
+                streams[o].append(shard_ref.pack_record(codes, start, n, K))
+                n_kmers += n
+        assert n_kmers == len(canon)                                    # every k-mer is in exactly one record
+        assert len(canon) / sum(len(x) for x in streams) > 4.5          # (and the records are mostly full: ~6 k-mers each)
+        # one message per owner: [status, records, blocks...], equal sizes (the host transport's contract)
+        max_blocks = (N_PER_RANK * (L - K + 1) + shard_ref.BLOCK_RECS - 1) // shard_ref.BLOCK_RECS
+        words = 8 + max_blocks * shard_ref.BLOCK_WORDS
         msg_bytes = words * 8
         send = np.zeros(WORLD * words, np.uint64)
         for o in range(WORLD):
-            mine = canon[owners == o]
-            send[o * words + 1] = len(mine)
-            send[o * words + 8:o * words + 8 + len(mine)] = mine
+            blk = shard_ref.blocks_of_records(streams[o])
+            send[o * words + 1] = len(streams[o])
+            send[o * words + 8:o * words + 8 + len(blk)] = blk
         recv = np.full(WORLD * words, 0xDEAD, np.uint64)
         fn = ktdist.host_alltoall(dist.group.WORLD)          # what kt_sharded_connect_host is given
         assert fn(send.ctypes.data, recv.ctypes.data, msg_bytes) == 0
@@ -68,10 +92,11 @@ def _worker(rank, port, q):
         for p in range(WORLD):
             assert int(recv[p * words]) == 0                  # the sender's status word
             n = int(recv[p * words + 1])
-            got.append(recv[p * words + 8:p * words + 8 + n])
-        got = np.concatenate(got)
+            for a, b in shard_ref.records_of_blocks(recv[p * words + 8:(p + 1) * words], n):
+                got.extend(shard_ref.kmers_of_record(a, b, K))
+        got = np.array(got, dtype=np.uint64)
         # everything received is owned by this rank
-        assert all(device.shard_owner_of(int(x), bits, WORLD) == rank for x in got[:500])
+        assert all(device.shard_owner_of(int(x), K, WORLD) == rank for x in got[:500])
         ctr = oracle.Counter(1)
         ctr.add_pairs(got, np.ones(len(got), np.uint32))
         k_, c_ = ctr.export()

@@ -560,9 +560,29 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 # N > 1 path on one GPU: two ranks share cuda:0, route on the GPU, exchange (gloo, host-staged),
 # count on the GPU.  Union of the shards must equal the oracle's counts of all reads.
 
-_SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "presplit": (2, 31), "presplit3": (3, 15),
-                "presplit_whole": (2, 31), "presplit_skewed": (2, 31), "presplit_whole_skewed": (2, 31), "localfail": (2, 31),
-                "uneven3": (3, 21)}   # case -> (ranks, k)
+_SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "flood": (2, 31), "flood3": (3, 21), "localfail": (2, 31),
+                "uneven3": (3, 21), "empty_rank": (3, 31), "k10": (2, 10), "probing": (2, 25), "five": (5, 27),
+                "unlike": (2, 31)}   # case -> (ranks, k)
+
+
+def _shard_batch(case, rank, n, L, synth):
+    """rank's reads for a sharded-counter case: (bases, offsets, reads to use) - `synth(first_read)` makes n reads"""
+    bases, offsets = synth(rank * n)
+    nr = n
+    if case == "skewed" and rank == 1:
+        bases[: 8000 * L] = ord("A")           # 40 % of rank 1's batch is one k-mer: one owner gets all of its records
+    if case.startswith("flood"):
+        # rank 1: 19 000 reads of one k-mer and 1000 ordinary ones, the others 2000 ordinary reads - the ordinary records fit
+        # the 40-block regions of these cases several times over, the flood is seven times a region's room
+        if rank == 1:
+            bases[: 19000 * L] = ord("A")
+        else:
+            nr = 2000
+    if case == "uneven3":
+        nr = n // (rank + 1)
+    if case == "empty_rank" and rank == 1:
+        nr = 0
+    return bases, offsets, nr
 
 
 def _two_rank_worker(rank, port, q, case):
@@ -572,14 +592,14 @@ def _two_rank_worker(rank, port, q, case):
     world, k = _SHARD_CASES[case]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["KT_BULK_MIN_BASES"] = "0"   # the received k-mers take the partition + range build even at this size
-    if case in ("narrow3", "presplit3"):
+    if case != "probing":
+        os.environ["KT_BULK_MIN_BASES"] = "0"   # what arrives takes the partition + range build even at this size
+    if case in ("narrow3", "flood3"):
         os.environ["KT_SHARD_SLICES"] = "3"
-    if case.startswith("presplit"):
-        os.environ["KT_BULK_MAX_B2"] = "3"    # level 2 takes 3 bits only: the shards need the pre-split pass (2 bits)
-        os.environ["KT_BULK_VERBOSE"] = "1"
-    if case.startswith("presplit_whole"):
-        os.environ["KT_SHARD_PRESPLIT_SLICED"] = "0"   # the whole pre-split behind the last block (round 4's schedule)
+    if case == "five":
+        os.environ["KT_SHARD_SLICES"] = "1"
+    if case.startswith("flood"):
+        os.environ["KT_SHARD_ROOM_BLOCKS"] = "40"   # 40 960 records of room per owner: the flooded owner's region overflows
     if case == "localfail":
         os.environ["KT_SHARD_FAIL_LOCAL"] = "1:1"   # rank 1's second call fails while it sets the batch up
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -588,15 +608,30 @@ def _two_rank_worker(rank, port, q, case):
         torch.cuda.set_device(0)
         ctx = device.Context(0, stream=torch.cuda.current_stream().cuda_stream)
         n, L = 20000, 150
-        bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
-        offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-        ctx.synth_reads(4242, n, L, bases, offsets, noise=True, genome_len=200000, first_read=rank * n)
-        if case in ("skewed", "presplit_skewed", "presplit_whole_skewed") and rank == 1:
-            bases[: 8000 * L] = ord("A")           # 40 % of rank 1's batch is one k-mer: its owner's regions overflow
+
+        def synth(first):
+            bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+            offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            ctx.synth_reads(4242, n, L, bases, offsets, noise=True, genome_len=200000, first_read=first)
+            return bases, offsets
+        bases, offsets, nr = _shard_batch(case, rank, n, L, synth)
+        if case == "unlike":
+            # the ranks made their counters for different batch sizes: EVERY rank must say so at the first batch - in the
+            # same round of the exchange - and none may be left waiting
+            from kmertools_amd import _lib
+            sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD, max_batch_bases=n * L * (1 + 7 * rank))
+            try:
+                sc.add_reads(bases, offsets, n)
+                raise AssertionError("rank %d did not notice that the counters differ" % rank)
+            except _lib.KmertoolsError as e:
+                assert e.code == _lib.KT_ERR_ARG and "differ" in str(e), (rank, e.code, str(e))
+            sc.close()
+            q.put((rank, None, None, 0, 1, True))
+            ctx.close()
+            return
         sc = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD, max_batch_bases=n * L)
-        # uneven3: the ranks' batches differ in size, so their regions - sized by each batch's own k-mers - differ, and with
-        # three ranks the level-1 buckets do not divide evenly either: no two messages of the exchange are the same size
-        nr = n // (rank + 1) if case == "uneven3" else n
+        # uneven3: the ranks' batches differ in size; empty_rank: one rank has no reads at all (it still takes part, and
+        # still counts what the others send it)
         sc.add_reads(bases[: nr * L], offsets[: nr + 1], nr)
         m = 100 if rank == 0 else 0                 # a second "chunk" that only rank 0 has reads for
         if case == "localfail":
@@ -615,43 +650,32 @@ def _two_rank_worker(rank, port, q, case):
         mine = all(sc.sharded.owner_of(int(x)) == rank for x in keys[:300])
         sent = sc.sharded.exchanged_bytes()
         sc.close()
-        if case == "genome":
-            # the regions - the messages - take their room from the k-mers a batch can hold (120 window starts per 150 bases
-            # at k=31), not from its bases: the same batch with the regions of rounds 2-4 sends a fifth more
-            sent_one = []
-            for by_bases in (False, True):
-                if by_bases:
-                    os.environ["KT_SHARD_ROOM_BY_BASES"] = "1"
-                sc2 = ktdist.ShardedCounter(ctx, k, 1 << 23, group=dist.group.WORLD, max_batch_bases=n * L)
-                sc2.add_reads(bases, offsets, n)
-                sc2.finalize()
-                assert sc2.size_global() == total
-                sent_one.append(sc2.sharded.exchanged_bytes())
-                sc2.close()
-            os.environ.pop("KT_SHARD_ROOM_BY_BASES")
-            assert sent_one[0] < 0.9 * sent_one[1], sent_one
         q.put((rank, keys, counts, total, sent, mine))
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["genome", "skewed", "narrow3", "presplit", "presplit3", "presplit_whole", "presplit_skewed", "presplit_whole_skewed", "localfail", "uneven3"])
+@pytest.mark.parametrize("case", sorted(_SHARD_CASES))
 def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
-    """the C ABI's sharded counter with two ranks on cuda:0 and the host all-to-all transport over gloo: route on
-    the GPU, exchange fixed-size regions, partition + range build of what arrived, finalize; the union of the shards
-    is the oracle's table of all reads.  `skewed`: one k-mer floods its owner's regions, so the pending list and
-    several finalize rounds run; `narrow3`: three ranks, three slices, k=15 (32-bit keys through the partition);
-    `presplit*`: level 2 restricted to 3 hash bits, so that the shards need the pre-split pass that 4- and 8-GPU tables
-    of BASELINE size need (a third trip of the keys: 2^bx-way split, then the ordinary level 2 over the sub-buckets) - made
-    slice by slice on a stream of its own as the blocks arrive (the default), `presplit_whole`: behind the last block as in
-    round 4, `presplit_skewed`: with a k-mer that floods its sub-bucket's fixed room (the bucket is redone with exact
-    boundaries over all its sources at the end);
-    `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call works;
-    `uneven3`: three ranks whose batches differ in size (every sender's regions have their own room)"""
+    """the C ABI's sharded counter with several ranks on cuda:0 and the host all-to-all transport over gloo: the route
+    pass on the GPU (owner by minimiser, records of at most 8 k-mers), the exchange of the owners' regions in pieces,
+    the ordinary partition + range build over the records that arrived, finalize; the union of the shards is the oracle's
+    table of all reads and every k-mer lies on the rank its minimiser gives it (the library's host function AND
+    tests/shard_ref.py's restatement).  `skewed`: 40 % of a rank's batch is one k-mer; `flood` / `flood3`: the same with
+    regions of 40 blocks, so that the flooded owner's region overflows - the pending table and several finalize rounds
+    run; `narrow3`: three ranks, three pieces, k=15 (32-bit keys through the partition, w = 8); `k10`: w = 2, `five`: five
+    ranks, one piece, k=27; `probing`: the batch is below the partition passes' size, the records take the probing
+    path; `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call
+    works; `uneven3`: three ranks whose batches differ in size; `empty_rank`: a rank without reads; `unlike`: counters
+    made for different batch sizes - every rank reports it, nobody hangs"""
+    import os
     import socket
+    import sys
     import torch.multiprocessing as mp
     from kmertools_amd import device
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import shard_ref
     world, k = _SHARD_CASES[case]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -666,52 +690,94 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    if case == "unlike":
+        return
     n, L = 20000, 150
     ctr = oracle.Counter(4)
+    n_kmers = 0
     for rank in range(world):
-        hb, ho = oracle.synth_reads(4242, n, L, noise=True, genome_len=200000, first_read=rank * n)
-        if case in ("skewed", "presplit_skewed", "presplit_whole_skewed") and rank == 1:
-            hb = hb.copy()
-            hb[: 8000 * L] = ord("A")
-        nr = n // (rank + 1) if case == "uneven3" else n
+        def synth(first):
+            hb, ho = oracle.synth_reads(4242, n, L, noise=True, genome_len=200000, first_read=first)
+            return hb.copy(), ho
+        hb, ho, nr = _shard_batch(case, rank, n, L, synth)
         ctr.add_reads(hb[: nr * L], ho[: nr + 1], k, threads=4)
+        n_kmers += nr * (L - k + 1)
         if rank == 0:
             ctr.add_reads(hb[: 100 * L], ho[:101], k)
     wk, wc = ctr.export()
     keys = np.concatenate([r[1] for r in res])
     counts = np.concatenate([r[2] for r in res])
     for rank, rk, _, total, sent, mine in res:
-        assert total == len(wk) and sent > 0
-        assert mine                                      # every k-mer of a shard is owned by its rank (hash prefix)
-        bits, lo, hi, _ = device.shard_layout(1 << 23, world, rank)
-        assert all(device.shard_owner_of(int(x), bits, world) == rank for x in rk[:300])
+        assert total == len(wk)
+        assert mine                                      # every k-mer of a shard is owned by its rank (by its minimiser)
+        assert all(device.shard_owner_of(int(x), k, world) == rank for x in rk[:300])
+        assert np.all(shard_ref.owner_of_kmers(rk[:2000], k, world) == rank)
     order = np.argsort(keys)
     assert np.array_equal(keys[order], wk) and np.array_equal(counts[order], wc)
+    if case == "genome":
+        # what crossed between the ranks: 2-bit bases in records of up to 8 k-mers, not k-mers at 8 bytes - less than a third
+        # of the raw keys' bytes even at this size (whole 10 KB blocks per piece; 1.7 bytes per k-mer at BASELINE sizes)
+        # (finalize's one round of fixed-size messages - 1.5 MB per peer, empty here - is not records)
+        sent = sum(r[4] for r in res) - world * (world - 1) * (8 + (1 << 17) + (1 << 16)) * 8
+        assert 0 < sent < 0.25 * 8 * n_kmers * (world - 1) / world, (sent, n_kmers)
+    if case == "empty_rank":
+        # the rank without reads sent no records - only the words ahead of every batch and finalize's one round of (empty)
+        # fixed-size messages - and still owns its share of the k-mers
+        assert res[1][4] <= 2 * (8 + (1 << 17) + (1 << 16)) * 8 + 4096 and len(res[1][1]) > 0
 
 
-def test_sharded_single_rank_through_rccl(torch_mod, ctx, oracle, monkeypatch):
+@pytest.mark.parametrize("owners", [1, 8, 3])
+def test_sharded_single_rank_through_rccl(torch_mod, ctx, oracle, monkeypatch, owners):
     """librccl really is loaded and driven from the C ABI: a one-rank communicator (ncclCommInitRank), and with
-    KT_SHARD_FORCE=1 the routed path (route -> exchange with itself -> level 1 per slice -> range build) instead of
-    the single-GPU shortcut; the table must be the oracle's"""
+    KT_SHARD_FORCE=n the routed path (route into n owners' regions -> level 1 over the regions piece by piece -> range
+    build) instead of the single-GPU shortcut - the launches a rank of n makes, all of them on this GPU; the table must be
+    the oracle's, twice over (the second batch merges into a table that holds data)"""
     torch = torch_mod
     from kmertools_amd import device
     assert len(device.Sharded.unique_id()) == 128
-    monkeypatch.setenv("KT_SHARD_FORCE", "1")
+    monkeypatch.setenv("KT_SHARD_FORCE", str(owners))
     monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
     n, L, k = 30000, 150, 21
     bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
     offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     ctx.synth_reads(77, n, L, bases, offsets, noise=True, genome_len=300000)
     sh = device.Sharded(ctx, k, 1 << 23, n * L, 1, 0, None)
+    hb, ho = oracle.synth_reads(77, n, L, noise=True, genome_len=300000)
+    wk, wc = oracle.count_reads(hb, ho, k, n_parts=4, threads=4)
     for _ in range(2):
         sh.add_reads(bases, offsets, n)
         sh.finalize()
-        hb, ho = oracle.synth_reads(77, n, L, noise=True, genome_len=300000)
-        wk, wc = oracle.count_reads(hb, ho, k, n_parts=4, threads=4)
         gk, gc = sh.table.export_host()
         assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+        sh.add_reads(bases, offsets, n)
+        sh.finalize()
+        gk, gc = sh.table.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+        # what a rank of `owners` would have sent: the regions of the other owners, whole blocks
+        assert (sh.exchanged_bytes() > 0) == (owners > 1)
         sh.clear()
     sh.close()
+
+
+def test_route_pass_records_match_restatement(torch_mod, ctx, oracle, monkeypatch):
+    """the route pass over ragged reads (N runs, lower case, raw codes, reads shorter than k, a 9000-base read, poly-A and
+    ACGT-repeat reads longer than a segment - runs of one owner that span whole threads and segments) into 1 .. 7 owners'
+    regions, counted: the oracle's table for every window / minimiser shape (w = 16, 8, 4, 2, 1; k <= 8: the k-mer is its
+    own minimiser), whatever the cut into records"""
+    torch = torch_mod
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    seqs = ragged_reads(4321, 600) + [b"A" * 20000, b"ACGT" * 3000, b"", b"ACG", b"N" * 100, ragged_reads(5, 1)[0] * 40]
+    bases, offsets = device.to_csr(seqs)
+    for k, owners in ((31, 7), (23, 2), (22, 5), (15, 3), (11, 4), (9, 2), (8, 3), (5, 2), (1, 2), (31, 1)):
+        monkeypatch.setenv("KT_SHARD_FORCE", str(owners))
+        sh = device.Sharded(ctx, k, 1 << 21, int(offsets[-1]), 1, 0, None)
+        sh.add_reads_host(bases, offsets)
+        sh.finalize()
+        gk, gc = sh.table.export_host()
+        wk, wc = oracle.count_reads(bases, offsets, k)
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (k, owners)
+        sh.close()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1508,23 +1574,21 @@ def test_minimiser_python_surface(hctx, oracle):
         kt.MinimiserGenerator(seq, 3, 7)
 
 
-@pytest.mark.parametrize("workload,ranks,presplit,plain", [("comp_oligo_k4", 2, False, False), ("ctr_k31", 2, False, True),
-                                                           ("ctr_k31", 8, True, True), ("ctr_k15", 3, False, False)])
-def test_bench_two_rank_launch(workload, ranks, presplit, plain):
+@pytest.mark.parametrize("workload,ranks,plain", [("comp_oligo_k4", 2, False), ("ctr_k31", 2, True),
+                                                  ("ctr_k31", 8, True), ("ctr_k15", 3, False)])
+def test_bench_two_rank_launch(workload, ranks, plain):
     """bench.py with several ranks (all on GPU 0, gloo collectives) - through torch.distributed.run, the launch contract
     the driver uses for --gpus N, and (`plain`) typed as it stands, `python bench.py --gpus N`: bench.py then starts the
     ranks itself as a child process (the plain command used to exit).  One JSON line from rank 0, whole-job
-    value, n_gpus = N.  Eight ranks: the 8-GPU ownership intervals, 4 slices x 8 senders of sources per bucket and the
-    pre-split pass (forced: at this size level 2 could take all the bits), three ranks: buckets that do not divide
-    evenly; bench.py's own output check (the counts of all ranks sum to reads x (L - k + 1)) is what certifies the
-    result.  ctr lines say what carried the exchange and how many bytes a rank sent per step."""
+    value, n_gpus = N.  Eight ranks: eight owners' regions per rank, 4 pieces x 7 senders of records per rank; three
+    ranks: an odd number of owners; bench.py's own output check (the counts of all ranks sum to reads x (L - k + 1), and
+    a sample of rank 0's reads counted by the oracle is found on the owners' ranks) is what certifies the result.  ctr
+    lines say what carried the exchange and how many bytes a rank sent per step."""
     import json, os, subprocess, sys, pathlib
     root = pathlib.Path(__file__).resolve().parents[1]
     env = dict(os.environ, KT_BENCH_SHARE_GPU="1", KT_BULK_MIN_BASES="0")
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(var, None)
-    if presplit:
-        env["KT_BULK_MAX_B2"] = "6"
     import socket
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))

@@ -1,7 +1,8 @@
 """Soak of the sharded counter with several ranks on ONE GPU (host all-to-all over gloo): every iteration a new counter -
-random k, table size, slices, pre-split on or off - and one to three collective batches whose sizes differ from rank to rank
-(empty ones among them), reads of random lengths, sometimes a k-mer that floods a bucket; the union of the shards must be the
-CPU oracle's table of all the reads.  Every rank derives the iteration's shape from the same seed.
+random k (every minimiser window: w = 16, 8, 4, 2, 1), table size, pieces per exchange, regions small enough to overflow or
+not, batches below or above the partition passes' size - and one to three collective batches whose sizes differ from rank to
+rank (empty ones among them), reads of random lengths, sometimes a k-mer that floods its owner; the union of the shards must be
+the CPU oracle's table of all the reads, and every k-mer must lie on the rank its minimiser gives it.  Every rank derives the iteration's shape from the same seed.
 usage: python tools/fuzz_shard.py [seconds] [seed] [ranks]"""
 import os, sys, time, pathlib, socket
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -29,14 +30,15 @@ def worker(rank, world, port, budget, seed, q):
             if not go[0]:
                 break
             rng = np.random.default_rng([seed, it])          # the same on every rank
-            k = int(rng.choice([11, 15, 16, 17, 21, 27, 31]))
-            slices = int(rng.integers(1, 5))
-            presplit = bool(rng.integers(0, 2))
+            k = int(rng.choice([7, 9, 11, 15, 16, 17, 21, 22, 23, 27, 31]))
+            slices = int(rng.integers(1, 6))
+            presplit = bool(rng.integers(0, 2))   # (here: small regions, so that floods and plain batches overflow them)
             os.environ["KT_SHARD_SLICES"] = str(slices)
             if presplit:
-                os.environ["KT_BULK_MAX_B2"] = str(int(rng.integers(3, 6)))
+                os.environ["KT_SHARD_ROOM_BLOCKS"] = str(int(rng.integers(1, 40)))
             else:
-                os.environ.pop("KT_BULK_MAX_B2", None)
+                os.environ.pop("KT_SHARD_ROOM_BLOCKS", None)
+            os.environ["KT_BULK_MIN_BASES"] = "0" if rng.integers(0, 4) else str(1 << 40)
             n_batches = int(rng.integers(1, 4))
             max_bases = 1 << int(rng.integers(18, 22))
             cap = max(1 << 21, int(2.2 * world * n_batches * max_bases))   # slots: every base a distinct k-mer would still fit
@@ -73,7 +75,11 @@ def worker(rank, world, port, budget, seed, q):
             sc.finalize()
             keys, counts = sc.export_local()
             total = sc.size_global()
+            strays = sum(1 for x in keys[:200] if sc.sharded.owner_of(int(x)) != rank)
             sc.close()
+            if strays:
+                q.put("STRAY k-mers on rank %d it=%d k=%d" % (rank, it, k))
+                os._exit(1)
             gathered = [None] * world
             dist.all_gather_object(gathered, (keys, counts, mine_b, mine_o))
             if rank == 0:
@@ -88,7 +94,7 @@ def worker(rank, world, port, budget, seed, q):
                 order = np.argsort(gk)
                 ok = total == len(wk) and np.array_equal(gk[order], wk) and np.array_equal(gc[order], wc)
                 if not ok:
-                    q.put("MISMATCH it=%d k=%d slices=%d presplit=%s batches=%d got %d want %d" % (it, k, slices, presplit, n_batches, len(gk), len(wk)))
+                    q.put("MISMATCH it=%d k=%d slices=%d small_regions=%s batches=%d got %d want %d" % (it, k, slices, presplit, n_batches, len(gk), len(wk)))
                     os._exit(1)
             it += 1
         if rank == 0:
