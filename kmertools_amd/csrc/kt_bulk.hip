@@ -297,17 +297,7 @@ __device__ __forceinline__ void buf_drain(K (&v)[PER]) {
         asm volatile("" ::"v"(v[u]), "v"(v[u + 1]), "v"(v[u + 2]), "v"(v[u + 3]), "v"(v[u + 4]), "v"(v[u + 5]), "v"(v[u + 6]), "v"(v[u + 7]));
 }
 
-// inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS round trips): row_shr 1 / 2 / 4 / 8 inside the
-// rows of 16 lanes, then row_bcast:15 (lane 15 of rows 0 and 2 into rows 1 and 3) and row_bcast:31 (lane 31 into rows 2, 3)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
+using ktd::wave_incl_scan;
 
 // block_excl_scan for B <= NT * PB with PB (counters per thread) known at compile time: the same contract - all NT threads
 // call, two barriers, returns the total - in straight-line code: the wave's scan by DPP, the NT / 64 <= 16 wave totals

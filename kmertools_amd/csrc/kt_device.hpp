@@ -115,6 +115,18 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS round trips): row_shr 1 / 2 / 4 / 8 inside the
+// rows of 16 lanes, then row_bcast:15 (lane 15 of rows 0 and 2 into rows 1 and 3) and row_bcast:31 (lane 31 into rows 2, 3)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // c / d for integer-valued 0 <= c <= d < 2^32 given y = RN(1 / d): q0 = c*y, r = fma(-q0, d, c) (exact),
 // q = fma(r, y, q0) = RN(c / d) (Markstein) - bit-identical to the reference's `vec[i] /= total`
 // (composition/src/oligo.rs:255-257) at 4 f64 operations per bin instead of a ~14-operation division.

@@ -127,13 +127,14 @@ struct RouteArgs {
 };
 
 struct RouteShared {
-    SegShared seg;
+    SegShared seg2[2];         // (two: a slow wave still cuts records out of a segment's codes while the next is staged)
     uint32_t own4[8][BLOCK];   // the owners of the thread's 32 window starts, four to a word
-    uint32_t cont[BLOCK + 1];  // bit j: window start j carries on the run of window start j - 1 ([BLOCK]: 0, the segment ends)
-    uint32_t link[BLOCK];      // the owner of the thread's last window start (0xFF: not a k-mer)
     uint32_t ext[BLOCK];       // k-mers of the run that reaches the thread's last window start, inside the thread; bit 31: all 32
-    uint32_t cnt[ktsk::MAX_OWNERS], km[ktsk::MAX_OWNERS];
-    unsigned long long base[ktsk::MAX_OWNERS];
+    uint32_t cnt[ktsk::MAX_OWNERS], km[ktsk::MAX_OWNERS];  // records / k-mers of the segment per owner
+    uint32_t cur[ktsk::MAX_OWNERS];   // ... placed so far
+    uint32_t base[ktsk::MAX_OWNERS];  // where they begin in the owner's stream (saturated: >= room = none fit)
+    uint64_t *region[ktsk::MAX_OWNERS];           // the owners' regions
+    uint16_t list[BLOCK / 64][1024];  // the wave's records (finder lane, window start, length), dealt out evenly to its lanes
 };
 
 __device__ __forceinline__ uint32_t low_bits(uint32_t n) { return n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u; }
@@ -150,20 +151,83 @@ __device__ __forceinline__ uint32_t low_bits(uint32_t n) { return n >= 32u ? 0xF
 //   append   count per owner (LDS), one returning atomic per owner and segment on the owner's cursor, then every record
 //            is cut out of the staged codes (a 192-bit funnel shift) and stored at its place: a[pos], b[pos] of its block.
 // A record beyond the region's room is not written: its k-mers are counted in the pending table.
-__global__ __launch_bounds__(BLOCK) void route_kernel(RouteArgs ra) {
+#ifndef KT_ROUTE_ABL
+#define KT_ROUTE_ABL 0  // (timing builds only, tools/build_variant_tu.sh: 1 = no records cut out or written, 2 = no m-mer hashes,
+#endif                  //  4 = no staging of the bases: what each phase of route_kernel costs.  The shipped library: 0.)
+#ifndef KT_ROUTE_WAVES
+#define KT_ROUTE_WAVES 4  // waves per SIMD the kernel is compiled for (4: <= 128 registers)
+#endif
+__global__ __launch_bounds__(BLOCK, KT_ROUTE_WAVES) void route_kernel(RouteArgs ra) {
     __shared__ RouteShared sm;
     const uint32_t tid = threadIdx.x;
     const uint32_t k = ra.a.k, m = ra.m, w = ra.w, N = ra.n_owners;
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
     if (tid < ktsk::MAX_OWNERS) {
         sm.cnt[tid] = 0;
         sm.km[tid] = 0;
     }
-    if (tid == 0) sm.cont[BLOCK] = 0;
-    for (uint64_t g = ra.seg_lo + blockIdx.x; g < ra.seg_hi; g += gridDim.x) {
-        ktseg::stage_segment(ra.a, g, sm.seg);  // (ends with a barrier)
-        const ktseg::Window win(sm.seg, tid, k);
+    if (tid < N) sm.region[tid] = ra.regions + (uint64_t)tid * ra.region_words;
+    const uint32_t room32 = (uint32_t)ra.room;  // (< 2^32 - 2^20: sharded_alloc)
+    // the global reads of a segment - the thread's 32 bases, its first read start, the halo item and the segment's place in
+    // the offsets - are requested a segment ahead (plain loads: nothing here needs them before they have long landed)
+    struct Ahead {
+        uint32_t d0[8];
+        ktseg::SegHalo halo;
+        uint64_t o0, first, first_next;
+        bool whole0, whole1;
+    };
+    auto request = [&](uint64_t g, uint64_t first_g, uint64_t g_next) {
+        Ahead p;
+        const uint64_t total = ktd::load_uniform(ra.a.offsets + ra.a.n_reads);
+        const uint64_t gu = ktd::uniform64(g);
+        const uint64_t b0 = gu * ktseg::SEG + 32ull * tid, b1 = gu * ktseg::SEG + 32ull * BLOCK;
+        p.whole0 = b0 + 32 <= total;
+        p.whole1 = b1 + 32 <= total && ((uintptr_t)ra.a.bases & 3u) == 0;  // (a scalar read wants a dword address)
+        p.first = first_g;
+        p.first_next = ktd::load_uniform(ra.a.seg_first + ktd::uniform64(g_next < ra.a.n_seg ? g_next : ra.a.n_seg));
+#pragma unroll
+        for (int q = 0; q < 8; q++) p.d0[q] = p.halo.d[q] = 0;
+        if (p.whole1) {
+            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+            const u32x8 v = ktd::load_uniform(reinterpret_cast<const u32x8 *>(ra.a.bases + b1));
+#pragma unroll
+            for (int q = 0; q < 8; q++) p.halo.d[q] = v[q];
+        }
+        if (p.whole0) __builtin_memcpy(p.d0, ra.a.bases + b0, 32);
+        const uint64_t r0 = first_g + tid;
+        p.o0 = r0 < ra.a.n_reads ? ra.a.offsets[r0] : ~0ull;
+        return p;
+    };
+    const uint64_t g_first = ra.seg_lo + blockIdx.x;
+    Ahead ah{};
+    if (g_first < ra.seg_hi) ah = request(g_first, ktd::load_uniform(ra.a.seg_first + ktd::uniform64(g_first)), g_first + gridDim.x);
+    uint32_t par = 0;
+    for (uint64_t g = g_first; g < ra.seg_hi; g += gridDim.x, par ^= 1u) {
+        SegShared &seg = sm.seg2[par];
+#if KT_ROUTE_ABL & 4
+        seg.codes[tid] = g * 0x9E3779B97F4A7C15ull + tid;
+        seg.inv[tid] = 0;
+        seg.bnd[tid] = tid & 1 ? 0x10000u : 0u;
+        if (tid == 0) { seg.codes[BLOCK] = g; seg.inv[BLOCK] = 0; seg.bnd[BLOCK] = 0; }
+        ktd::lds_barrier();
+#else
+        {
+            ktseg::SegTaken tk;
+#pragma unroll
+            for (int q = 0; q < 8; q++) tk.d0[q] = ah.d0[q];
+            tk.halo = ah.halo;
+            tk.o0 = ah.o0;
+            tk.first_next = ah.first_next;
+            tk.whole0 = ah.whole0;
+            tk.whole1 = ah.whole1;
+            const uint64_t first_g = ah.first, first_next = ah.first_next;
+            ktseg::stage_taken(ra.a, g, first_g, seg, tid, tk);  // (ends with a barrier)
+            if (g + gridDim.x < ra.seg_hi) ah = request(g + gridDim.x, first_next, g + 2ull * gridDim.x);
+        }
+#endif
+        const ktseg::Window win(seg, tid, k);
         const uint32_t okm = win.okm;
-        const uint64_t c0 = sm.seg.codes[tid], c1 = sm.seg.codes[tid + 1];
+        const uint64_t c0 = seg.codes[tid], c1 = seg.codes[tid + 1];
         uint32_t h[47];
         {
             const uint32_t x[5] = {(uint32_t)(c0 >> 32), (uint32_t)c0, (uint32_t)(c1 >> 32), (uint32_t)c1, 0u};
@@ -174,8 +238,12 @@ __global__ __launch_bounds__(BLOCK) void route_kernel(RouteArgs ra) {
                 const int j = i >> 4, s = 2 * (i & 15);
                 const uint32_t top = s ? __builtin_amdgcn_alignbit(x[j], x[j + 1], 32 - s) : x[j];  // bases i .. i + 15
                 const uint32_t f = top >> msh;
+#if KT_ROUTE_ABL & 2
+                h[i] = f + r;
+#else
                 r = i ? (r >> 2) | ((3u - (f & 3u)) << rsh) : ktsk::rev_comp32(f, m);
                 h[i] = ktsk::mhash(f < r ? f : r);
+#endif
             }
         }
 #pragma unroll
@@ -203,67 +271,97 @@ __global__ __launch_bounds__(BLOCK) void route_kernel(RouteArgs ra) {
             }
             o_last = prev_o;
         }
-        sm.link[tid] = (okm >> 31) ? o_last : 0xFFu;
-        ktd::lds_barrier();
+        // (from here on a wave works alone: the neighbours it talks to are its own lanes - a wave's 2048 window starts begin a
+        // run of their own, one cut more per 2048 bases - and what goes through LDS is ordered by the wave itself)
         {
-            const uint32_t prev = tid ? sm.link[tid - 1] : 0xFFu;
-            eqm |= prev == o_first ? 1u : 0u;  // (0xFF is no owner: the start before was no k-mer, or this is the segment's first)
+            const uint32_t prev = ktd::wave_shr1((okm >> 31) ? o_last : 0xFFu, 0xFFu);  // the owner of the lane before's last start
+            eqm |= prev == o_first ? 1u : 0u;  // (0xFF is no owner: the start before was no k-mer, or this is the wave's first)
         }
         const uint32_t cont = okm & ((okm << 1) | 1u) & eqm;
         const uint32_t rs = okm & ~cont;  // run starts
-        sm.cont[tid] = cont;
         sm.ext[tid] = cont == 0xFFFFFFFFu ? (0x80000000u | 32u) : (uint32_t)__builtin_clz(~cont) + 1u;
-        ktd::lds_barrier();
-        // which window starts begin a record
+        // (the lane behind's word, 0 for the wave's last lane - DPP wave_shl:1; not a shuffle under `lane == 63 ? 0 : ...`: only
+        // the chosen arm of ?: is evaluated, and a lane that sits the shuffle out is not read by its neighbour)
+        const uint32_t cont_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cont, 0x130, 0xf, 0xf, false);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        // which window starts begin a record - and, run by run, what the thread adds to its owners' streams
+        auto owner_at = [&](uint32_t i) { return (sm.own4[i >> 2][tid] >> (8u * (i & 3u))) & 0xFFu; };
         uint32_t recmask = 0;
-        if (cont & 1u) {  // the thread's first window starts carry on a run of the threads before
+        if (cont & 1u) {  // the thread's first window starts carry on a run of the lanes before (lane 0's never do)
             uint32_t carry = 0;
             for (uint32_t j = tid - 1;; j--) {
                 const uint32_t e = sm.ext[j];
                 carry += e & 0xFFFFu;
-                if (!(e >> 31) || j == 0) break;
+                if (!(e >> 31) || (j & 63u) == 0) break;
             }
             const uint32_t l0 = cont == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~cont);
             const uint32_t first = (8u - (carry & 7u)) & 7u;
             recmask = (0x01010101u << first) & low_bits(l0);
+            if (recmask) atomicAdd(&sm.cnt[o_first], (uint32_t)__builtin_popcount(recmask));
+            atomicAdd(&sm.km[o_first], l0);
         }
         for (uint32_t rem = rs; rem; rem &= rem - 1u) {
             const uint32_t s = (uint32_t)__builtin_ctz(rem);
             const uint32_t x = s < 31u ? cont >> (s + 1u) : 0u;
             const uint32_t e = 1u + (uint32_t)__builtin_ctz(~x);  // the run's window starts inside this thread
-            recmask |= (0x01010101u << s) & (low_bits(e) << s);
+            const uint32_t rm = (0x01010101u << s) & (low_bits(e) << s);
+            recmask |= rm;
+            const uint32_t o = owner_at(s);
+            atomicAdd(&sm.cnt[o], (uint32_t)__builtin_popcount(rm));
+            atomicAdd(&sm.km[o], e);
         }
-        const uint64_t cont64 = (uint64_t)cont | ((uint64_t)sm.cont[tid + 1] << 32);
+        const uint64_t cont64 = (uint64_t)cont | ((uint64_t)cont_next << 32);
         auto len_at = [&](uint32_t i) {
             const uint64_t follow = ~(cont64 >> (i + 1u));  // (bits 63 - i .. 63 of the shifted word are 0: a stop bit)
             const uint32_t more = (uint32_t)__builtin_ctzll(follow);
             return 1u + (more < 7u ? more : 7u);
         };
-        auto owner_at = [&](uint32_t i) { return (sm.own4[i >> 2][tid] >> (8u * (i & 3u))) & 0xFFu; };
-        for (uint32_t rem = recmask; rem; rem &= rem - 1u) {
-            const uint32_t i = (uint32_t)__builtin_ctz(rem);
-            const uint32_t o = owner_at(i);
-            atomicAdd(&sm.cnt[o], 1u);
-            atomicAdd(&sm.km[o], len_at(i));
-        }
         ktd::lds_barrier();
+        // one returning atomic per owner and segment - the owners' cursors are a handful of addresses, and an atomic on one
+        // address takes its turn behind every other: per wave (four times as many, a quarter of the waves waiting for each)
+        // the kernel ran three times as long.  Its answer is looked at behind the list's making.
+        unsigned long long got = 0;
         if (tid < N) {
             const uint32_t c = sm.cnt[tid], n = sm.km[tid];
-            sm.base[tid] = c ? atomicAdd(&ra.cursors[tid], (unsigned long long)c) : 0ull;
+            got = c ? atomicAdd(&ra.cursors[tid], (unsigned long long)c) : 0ull;
             if (n) atomicAdd(&ra.kmers[tid], (unsigned long long)n);
             sm.cnt[tid] = 0;
             sm.km[tid] = 0;
+            sm.cur[tid] = 0;  // (every wave is past the segment before: the barrier above)
         }
-        ktd::lds_barrier();
-        if (recmask) {
-            const uint64_t c2 = sm.seg.codes[tid + 2];  // (index <= 257: allocated; only read into by records that reach it)
-            for (uint32_t rem = recmask; rem; rem &= rem - 1u) {
-                const uint32_t i = (uint32_t)__builtin_ctz(rem);
-                const uint32_t o = owner_at(i), len = len_at(i);
-                uint64_t A = c0, B = c1;
+        // The records, dealt out evenly: a thread holds 0 .. 32 of them (4 on average, the fullest lane of a wave 9), so the
+        // lanes that cut them out are not the lanes that found them - every wave lists the records of its window starts
+        // 0 .. 15, then 16 .. 31 (at most 1024 each) in LDS, places by a scan of the lanes' counts, and lane l takes entries
+        // l, l + 64, ...: the owner and the length ride in the entry, the bases come from the staged codes of the finder.
+        uint16_t *const list = sm.list[wv];
+        // (mask: which of the thread's record starts go into this list - all of them, unless the wave has more than 1024)
+        auto make_list = [&](uint32_t mask) -> uint32_t {
+            uint32_t mh = recmask & mask;
+            const uint32_t n_t = (uint32_t)__builtin_popcount(mh);
+            const uint32_t inc = ktd::wave_incl_scan(n_t);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // (the same in every lane)
+            for (uint32_t at = inc - n_t; mh; mh &= mh - 1u, at++) {
+                const uint32_t i = (uint32_t)__builtin_ctz(mh);
+                list[at] = (uint16_t)((lane << 9) | (i << 4) | len_at(i));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            return total;
+        };
+        auto cut_out = [&](uint32_t total) {
+            for (uint32_t r = lane; r < total; r += 64u) {
+                const uint32_t d = list[r];
+                const uint32_t len = d & 15u, i = (d >> 4) & 31u, src = (wv << 6) | (d >> 9);
+                const uint32_t o = (sm.own4[i >> 2][src] >> (8u * (i & 3u))) & 0xFFu;
+                const uint64_t s0 = seg.codes[src], s1 = seg.codes[src + 1];
+                const uint64_t s2 = seg.codes[src + 2];  // (index <= 257: allocated; only records that reach it read into it)
+                uint64_t A = s0, B = s1;
                 if (i) {
-                    A = (c0 << (2u * i)) | (c1 >> (64u - 2u * i));
-                    B = (c1 << (2u * i)) | (c2 >> (64u - 2u * i));
+                    A = (s0 << (2u * i)) | (s1 >> (64u - 2u * i));
+                    B = (s1 << (2u * i)) | (s2 >> (64u - 2u * i));
                 }
                 const uint32_t nb = 2u * (len + k - 1u);  // <= 76 bits of bases
                 if (nb <= 64u) {
@@ -272,26 +370,42 @@ __global__ __launch_bounds__(BLOCK) void route_kernel(RouteArgs ra) {
                 } else {
                     B &= ~0ull << (128u - nb);
                 }
-                const uint64_t pos = sm.base[o] + atomicAdd(&sm.cnt[o], 1u);
-                if (pos < ra.room) {
-                    uint64_t *const blk = ra.regions + (uint64_t)o * ra.region_words + (pos >> 10) * ktsk::BLOCK_WORDS;
-                    const uint32_t idx = (uint32_t)pos & (ktsk::BLOCK_RECS - 1u);
+                const uint32_t pos = sm.base[o] + atomicAdd(&sm.cur[o], 1u);  // (a segment has < 2^14 records: no wrap)
+                if (pos < room32) {
+                    const uint32_t idx = pos & (ktsk::BLOCK_RECS - 1u);
+                    uint64_t *const blk = sm.region[o] + ktd::mad64(pos >> 10, ktsk::BLOCK_WORDS, 0u);
                     blk[idx] = A;
                     reinterpret_cast<uint16_t *>(blk + ktsk::BLOCK_RECS)[idx] = (uint16_t)(((uint32_t)(B >> 52) << 4) | len);
                 } else {
                     // no room in the owner's region (a batch dominated by few k-mers): counted aside, delivered by finalize
                     for (uint32_t j = 0; j < len; j++) {
                         const uint64_t top = j ? (A << (2u * j)) | (B >> (64u - 2u * j)) : A;
-                        const uint64_t f = top >> (64u - 2u * k), r = ktd::rev_comp(f, (int)k);
-                        const uint32_t st = kttab::table_add(TableRef{ra.pend.slots, ra.pend.g, ra.pend.flags}, f < r ? f : r, 1u);
+                        const uint64_t f = top >> (64u - 2u * k), rc = ktd::rev_comp(f, (int)k);
+                        const uint32_t st = kttab::table_add(TableRef{ra.pend.slots, ra.pend.g, ra.pend.flags}, f < rc ? f : rc, 1u);
                         if (st == 0u) atomicOr(ra.pend.flags, 1u);
                         else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(ra.pend.distinct), 1ull);
                     }
                 }
             }
-        }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();  // (the list is rewritten by the next half)
+        };
+#if KT_ROUTE_ABL & 1
+        if (tid < N) sm.base[tid] = (uint32_t)got;
         ktd::lds_barrier();
-        if (tid < N) sm.cnt[tid] = 0;  // (the next segment's staging barriers stand between this and its count)
+        if (recmask == 0x12345u && cont64 == 77u) list[0] = (uint16_t)(len_at(3) + owner_at(2));
+#else
+        // (a wave has ~280 records; more than the list holds - every window start a run of its own: k <= 8 - go in two halves)
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)ktd::wave_incl_scan((uint32_t)__builtin_popcount(recmask)), 63);
+        const bool halves = all > 1024u;
+        const uint32_t total0 = make_list(halves ? 0x0000FFFFu : 0xFFFFFFFFu);
+        if (tid < N) sm.base[tid] = got < (unsigned long long)room32 ? (uint32_t)got : room32;
+        ktd::lds_barrier();
+        cut_out(total0);
+        if (halves) cut_out(make_list(0xFFFF0000u));
+#endif
+        // (no barrier here: the next segment is staged into the other code buffer, its counts go to cnt[] / km[], and what the
+        // cutting-out reads - base[], cur[], region[], the wave's list - is next written behind two of its barriers)
     }
 }
 
@@ -479,6 +593,8 @@ int sharded_alloc(kt_sharded *s) {
     s->room = region_room(s->max_batch_bases, s->w, s->n_owners);
     if (const char *e = getenv("KT_SHARD_ROOM_BLOCKS"))  // tests: regions of that many blocks (a flood that overflows them)
         if (atoll(e) > 0) s->room = (uint64_t)atoll(e) * ktsk::BLOCK_RECS;
+    if (s->room >= 0xFFF00000ull)  // (the route pass keeps a record's place in its owner's stream in 32 bits)
+        return kt::fail(KT_ERR_ARG, "kt_sharded_create: max_batch_bases too large for the exchange regions");
     s->region_words = s->room / ktsk::BLOCK_RECS * ktsk::BLOCK_WORDS;
     hipError_t e = hipMalloc((void **)&s->send, s->region_words * 8 * (size_t)s->n_owners);
     if (e == hipSuccess && s->n_ranks > 1) e = hipMalloc((void **)&s->recv, s->region_words * 8 * (size_t)s->n_ranks);
@@ -774,7 +890,9 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
         ra.pend = PendRef{(Slot *)s->pend->slots, ktl::geom_of(s->pend), s->pend->flags, s->pend->distinct};
         hipError_t e = hipMemsetAsync(s->cursors, 0, 2 * ktsk::MAX_OWNERS * 8, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(route_kernel, dim3(ktl::grid_for(ctx, a.n_seg, 8)), dim3(BLOCK), 0, ctx->stream, ra);
+            const char *ge = getenv("KT_ROUTE_GRID");  // (experiments: workgroups per CU)
+            const uint32_t per_cu = ge && atoi(ge) > 0 ? (uint32_t)atoi(ge) : 16u;
+            hipLaunchKernelGGL(route_kernel, dim3(ktl::grid_for(ctx, a.n_seg, per_cu)), dim3(BLOCK), 0, ctx->stream, ra);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(h_cur.data(), s->cursors, 2 * ktsk::MAX_OWNERS * 8, hipMemcpyDeviceToHost, ctx->stream);

@@ -40,22 +40,23 @@ __host__ __device__ inline uint32_t window_of(uint32_t k) {
 }
 __host__ __device__ inline uint32_t mmer_of(uint32_t k) { return k - window_of(k) + 1; }
 
-// the order of the canonical m-mers: a 32-bit mix (murmur3's finaliser: a bijection, so two m-mers tie only when equal)
-__host__ __device__ __forceinline__ uint32_t mhash(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x85ebca6bu;
-    x ^= x >> 13;
-    x *= 0xc2b2ae35u;
-    x ^= x >> 16;
-    return x;
+// (a[23:0] * b[23:0]) mod 2^32: one full-rate instruction on the device (v_mul_u32_u24; a 32-bit multiply takes four)
+__host__ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu));
+#endif
 }
+// the order of the canonical m-mers: a 32-bit mix of the (at most 32-bit) m-mer - its low 24 bits and its bits 12 .. 31
+// through one 24-bit multiply each (three instructions; not a bijection: two m-mers may tie - the owner is a function of
+// the smallest HASH, whatever m-mer it came from.  Run lengths and balance measured equal to murmur3's finaliser.)
+__host__ __device__ __forceinline__ uint32_t mhash(uint32_t x) { return mul24(x, 0x9E3779u) + mul24(x >> 12, 0x85EBCBu); }
 // the owner from the smallest hash of the window (small values: mixed once more before the top bits are taken)
 __host__ __device__ __forceinline__ uint32_t owner_of_min(uint32_t hmin, uint32_t n_owners) {
-    uint32_t x = hmin * 0x9e3779b1u;
-    x ^= x >> 15;
-    x *= 0x2c1b3c6du;
-    x ^= x >> 12;
-    return (uint32_t)(((uint64_t)x * (uint64_t)n_owners) >> 32);
+    uint32_t x = mul24(hmin, 0x9E3779u) + mul24(hmin >> 8, 0x85EBCBu);
+    x ^= x >> 16;
+    return mul24(x >> 8, n_owners) >> 24;  // (n_owners <= 64)
 }
 
 // reverse complement of an m-mer held in the low 2m bits of a 32-bit word (m <= 16)

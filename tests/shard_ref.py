@@ -22,22 +22,19 @@ def mmer_of(k):
     return k - window_of(k) + 1
 
 
+def _mul24(a, b):
+    return ((a & np.uint64(0xFFFFFF)) * (np.uint64(b) & np.uint64(0xFFFFFF))) & M32
+
+
 def _mhash(x):
     x = x.astype(np.uint64) & M32
-    x ^= x >> np.uint64(16)
-    x = (x * np.uint64(0x85EBCA6B)) & M32
-    x ^= x >> np.uint64(13)
-    x = (x * np.uint64(0xC2B2AE35)) & M32
-    x ^= x >> np.uint64(16)
-    return x
+    return (_mul24(x, 0x9E3779) + _mul24(x >> np.uint64(12), 0x85EBCB)) & M32
 
 
 def _owner_of_min(h, n):
-    x = (h * np.uint64(0x9E3779B1)) & M32
-    x ^= x >> np.uint64(15)
-    x = (x * np.uint64(0x2C1B3C6D)) & M32
-    x ^= x >> np.uint64(12)
-    return ((x * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
+    x = (_mul24(h, 0x9E3779) + _mul24(h >> np.uint64(8), 0x85EBCB)) & M32
+    x ^= x >> np.uint64(16)
+    return (_mul24(x >> np.uint64(8), n) >> np.uint64(24)).astype(np.int64)
 
 
 def _rev_comp(x, m):
