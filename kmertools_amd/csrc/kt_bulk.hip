@@ -91,11 +91,9 @@ struct Plan {
     uint32_t b1, b2;  // hash bits per level; b1 + b2 + LOG2_S == n
     uint32_t B1, B2;
     uint32_t G;       // persistent workgroups of hist1 / scatter1
-    uint64_t cap1;    // paged level 1: keys of room per level-1 bucket in a level-1 output (keys1: one per slice)
+    uint64_t cap1;    // paged level 1: keys of room per level-1 bucket in the level-1 output (keys1)
     uint64_t cap2;    // ... and per fine bucket in keys2 (room1 / B2)
-    uint64_t room1;   // keys of room per level-1 bucket in keys2: cap1 x the number of level-1 outputs that feed it
-    uint32_t d_lo, d_hi;  // the level-1 buckets whose ranges this table holds: all B1 of them, or - a shard - its interval
-    uint32_t bx;          // hash bits a pre-split pass resolves between level 1 and level 2 (0: none; see finish_typed)
+    uint64_t room1;   // keys of room per level-1 bucket in keys2 (= cap1)
     uint32_t nxs, xmap;   // level 1 with per-XCD cursors (scatter1x): log2 of the cursor sets, and which set a hardware
                           // XCC_ID appends to (eight nibbles)
     uint32_t dbg;     // KT_BUILD_DBG: ablation switches of build_kernel (profiling only)
@@ -109,18 +107,12 @@ struct Meta {           // device arrays carved from ctr->b_meta
     uint32_t *H;        // [G][B1] k-mers of workgroup g in bucket d1
     uint64_t *O;        // [G][B1] global offset where workgroup g writes its d1 keys
     uint64_t *bstart;   // [B1 + 1] level-1 bucket boundaries in keys1 (bstart[B1] = #k-mers)
-    uint64_t *gcur;     // [slices][B1] paged level 1: keys of bucket room handed out so far (page allocator); with per-XCD
-                        // cursors: the bucket's extent, written by xcd_tails_kernel - either way what level 2 reads up to
+    uint64_t *gcur;     // [B1] paged level 1: the bucket's extent, written by xcd_tails_kernel - what level 2 reads up to
     unsigned long long *dump;  // [1024][2] where scatter1x's copy-out sends the stores that have nothing to write
-    unsigned long long *xcur;  // [slices][8][B1] per-XCD cursors: keys XCD set x has appended to bucket d (scatter1x)
+    unsigned long long *xcur;  // [8][B1] per-XCD cursors: keys XCD set x has appended to bucket d (scatter1x)
     uint32_t *ovf;      // [0]  paged level 1: a bucket ran out of room
-    kt_seg_src *srcs;   // [n_src + 1] part2's sources (device copy; the last one: the pre-split pass's output)
-    uint64_t *xstart, *xend, *xcount;  // [local buckets << bx] pre-split pass: the sub-buckets' bounds in keys2, their sizes
-    uint64_t *xout;     // [local buckets << bx] where the level 2 behind the pre-split writes every sub-bucket (presplit_plan_kernel)
-    uint32_t *fail2;    // [local buckets << bx] that level 2's failure words (fail holds the pre-split's meanwhile)
-    uint32_t *xcarry;   // [local buckets << bx] pre-split made slice by slice (kt_bulk_presplit_slice): keys a sub-bucket holds so far
-    kt_seg_src *xsrcs;  // [n_src] the slices' source lists of those launches (device copies, one stretch per launch)
-    uint32_t *fail;     // [local buckets << bx] part2_fast_kernel: the bucket did not fit its fixed fine regions
+    kt_seg_src *srcs;   // [1] part2's source (device copy)
+    uint32_t *fail;     // [B1] part2_fast_kernel: the bucket did not fit its fixed fine regions
     uint64_t *fstart;   // [B1 * B2] fine buckets in keys2: [fstart, fend)
     uint64_t *fend;     // [B1 * B2]
     uint64_t *spill_n;  // [1]
@@ -409,15 +401,10 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
         });
     }
 };
-struct KeysSource {  // canonical k-mers that are already an array (routed here from other GPUs): unit = 8192 keys
+struct KeysSource {  // canonical k-mers that are already an array: unit = 8192 keys
     const uint64_t *keys;
     uint64_t n;
-    const uint64_t *n_dev;  // when set: the array holds min(*n_dev, n) keys (the count header of an exchanged region)
-    __device__ uint64_t count() const {
-        if (!n_dev) return n;
-        const uint64_t c = *n_dev;
-        return c < n ? c : n;
-    }
+    __device__ uint64_t count() const { return n; }
     __device__ uint64_t n_units() const { return (count() + ktseg::SEG - 1) / ktseg::SEG; }
     __device__ void collect(uint64_t g, SegShared &, uint64_t (&out)[ktseg::PER_THREAD], uint32_t &ok) const {
         const uint64_t cnt = count();
@@ -731,18 +718,6 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, uin
 // scan1 / scatter1.  Rounds 2-4 appended through workgroup-private aligned pages (scatter1p: one 256-thread workgroup per
 // unit, 32-byte runs; scatter1w: 1024 threads, four segments at a time, 128-byte runs, 16 K keys sorted per round) - the
 // shape below keeps scatter1w's rounds and replaces its pages.
-// A sender of the sharded counter (kt_shard.hip) cannot redo its level 1 with exact offsets when a bucket's region
-// overflows - the regions are messages of a fixed size - so there the keys that do not fit are COUNTED in a small
-// table of the sender's own (a batch dominated by a few k-mers: poly-A reads, adapters - few distinct keys, many
-// copies; kt_sharded_finalize delivers its (k-mer, count) pairs to their owners) and the pass carries on.
-// slots == nullptr: no such table (the pass stops, the build is redone with exact offsets).
-struct PendList {
-    Slot *slots;
-    kttab::Geom g;
-    uint32_t *flags;     // the pending table's own flags: bit 0 = it is full
-    uint64_t *distinct;  // its distinct-key counter
-};
-
 #if KT_ABLATION
 __device__ unsigned long long kt_dbg_phase[16];  // (timing builds: cycles of workgroup thread 0 per phase: [0, 8) build_kernel, [8, 16) scatter1x_kernel)
 #define KT_PH(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phs[i] += (uint32_t)(t_ - tph); tph = t_; } while (0)
@@ -770,7 +745,7 @@ constexpr int wide_per() { return sizeof(K) == 8 ? KT_WIDE_PER64 : 32; }  // key
 // 4.6 TB/s, 64-byte runs 1.36 -> 4.0, the atomics themselves 0.4 ms per 8 GB (agent scope: correct whatever the
 // placement; the XCC_ID only decides which lines a cache shares).  Layout: a bucket's region is cut into lines of LK keys
 // dealt round-robin to the cursor sets - key q of set x lies at ((q / LK) * NX + x) * LK + q % LK - so a line is written
-// by one XCD only, the region stays ONE array for level 2 (and one message for the sharded counter), and what differs
+// by one XCD only, the region stays ONE array for level 2, and what differs
 // between the sets' fills is padded with the empty key by xcd_tails_kernel (a few hundred keys per bucket and set).  No
 // pages, no state carried between launches but the cursors themselves, no split runs in the copy-out.
 // With the stores cheap, what is left is the phases' serial chain - so the workgroup is HALF the size (T = 512: two per CU,
@@ -822,7 +797,7 @@ __device__ __forceinline__ uint64_t xcd_place(uint64_t q, uint32_t x, uint32_t n
 
 template <class Source, class K, int T>
 __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, unsigned long long *__restrict__ xcur,
-                                                      uint32_t *__restrict__ ovf, K *__restrict__ keys1, PendList pend,
+                                                      uint32_t *__restrict__ ovf, K *__restrict__ keys1,
                                                       unsigned long long *__restrict__ dump) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Scatter1XShared<K, T> &sm = *reinterpret_cast<Scatter1XShared<K, T> *>(smem_raw);
@@ -924,7 +899,7 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
                     // (a stream far past its room - a sender's heavy-hitter bucket - must not wrap back into it)
                     const uint32_t q0 = got[j] > 0xE0000000ull ? 0xE0000000u : (uint32_t)got[j];
                     sm.delta[tl * PB + j] = q0 - rs[j];
-                    if (!pend.slots && xcd_place<K>((uint64_t)q0 + rc[j] - 1u, xset, p.nxs) >= p.cap1) {
+                    if (xcd_place<K>((uint64_t)q0 + rc[j] - 1u, xset, p.nxs) >= p.cap1) {
                         sm.ovf = 1;
                         atomicOr(ovf, 1u);
                     }
@@ -943,7 +918,6 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
 #if KT_ABLATION
             if (p.dbg & 0x3000u) skip = true;  // (timing only - 0x1000: no copy-out at all; 0x2000: its stores dropped)
 #endif
-            bool over = false;
             raw4 *const mydump = reinterpret_cast<raw4 *>(dump) + tl;
             // group m of the round = slots [m GK, m GK + GK) of sorted[]: one bucket's keys (runs start on group boundaries),
             // the first of them a key, what follows a pad at most
@@ -965,7 +939,6 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
                     group_at(m, live, d, at);
                     const raw4 v = *reinterpret_cast<const raw4 *>(&sm.sorted[live ? m << GSH : 0u]);
                     const bool fits = live && at < p.cap1;
-                    over |= live && at >= p.cap1;
                     raw4 *const dst = fits ? reinterpret_cast<raw4 *>(keys1 + ((uint64_t)d * p.cap1 + at)) : mydump;  // (one store on every path)
                     *dst = v;
                 }
@@ -988,28 +961,6 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
                 if (nxt) src.template prefetch_take<0>(tk, pre);
             }
             if (nxt) first_cur = first_next;
-            if (over && pend.slots) {
-                // the keys whose bucket's region is full (a sender's skewed batch): counted aside, delivered later - a pass
-                // of its own over the round (sorted[] and delta[] stand until the next placement), behind the take, so that
-                // the copy-out itself has no branch and a fixed number of stores
-#pragma unroll 1
-                for (int u = 0; u < NST; u++) {
-                    const uint32_t m = tl + (uint32_t)u * T;
-                    bool live;
-                    uint32_t d;
-                    uint64_t at;
-                    group_at(m, live, d, at);
-                    if (!live) break;
-                    if (at < p.cap1) continue;
-                    for (uint32_t e = 0; e < GK; e++) {
-                        const K key = sm.sorted[(m << GSH) + e];
-                        if (key == EMPTY) break;
-                        const uint32_t st = kttab::table_add(TableRef{pend.slots, pend.g, pend.flags}, from_stored<K>(key), 1u);
-                        if (st == 0u) atomicOr(pend.flags, 1u);
-                        else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(pend.distinct), 1ull);
-                    }
-                }
-            }
             // the next round's count, scan and layout touch nothing the copy-out reads (delta[] is written behind the next
             // placement, two barriers on); only the staging of a new segment (it shares LDS with the sort buffer) has to wait
             if (q == NQ - 1) ktd::lds_barrier();
@@ -1063,7 +1014,7 @@ static_assert(Scatter1YShared<uint64_t, 1024>::bytes(MAX_B1) <= 160 * 1024, "64-
 
 template <class Source, class K, int T>
 __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, unsigned long long *__restrict__ xcur,
-                                                      uint32_t *__restrict__ ovf, K *__restrict__ keys1, PendList pend,
+                                                      uint32_t *__restrict__ ovf, K *__restrict__ keys1,
                                                       unsigned long long *__restrict__ dump) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Scatter1YShared<K, T> sm(smem_raw, p.B1);
@@ -1100,7 +1051,7 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
     constexpr uint32_t LSH1 = sizeof(K) == 8 ? 4 : 5;  // keys per 128-byte line (xcd_place)
     const uint32_t cap1_32 = (uint32_t)p.cap1, cap_lines = (uint32_t)(p.cap1 >> LSH1);  // (plan_job: a region is < 2^31 bytes)
     // group u of this thread's share of the round before: out to its place, or - nothing there, or no room - to the dump line
-    auto emit = [&](int u, uint32_t tl, uint32_t pp, bool &over) {
+    auto emit = [&](int u, uint32_t tl, uint32_t pp) {
         uint32_t m = tl + (uint32_t)u * T;
         asm volatile("" : "+v"(m));  // (pinned to its place in the round)
         const uint32_t i = m << GSH;
@@ -1117,27 +1068,8 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
         const bool room = lx < cap_lines;
         const uint32_t at = (lx << LSH1) | (pos & ((1u << LSH1) - 1u));
         const bool fits = live && room;
-        over |= live && !room;
         raw4 *const dst = fits ? reinterpret_cast<raw4 *>(keys1 + ktd::mad64(d, cap1_32, at)) : reinterpret_cast<raw4 *>(dump) + tl;
         *dst = v;
-    };
-    // the keys of the round before whose bucket's region is full (a sender's skewed batch): counted aside, delivered later
-    auto park = [&](uint32_t tl, uint32_t pp) {
-        const K *const sb = sm.sorted[pp];
-#pragma unroll 1
-        for (int u = 0; u < NST; u++) {
-            const uint32_t i = (tl + (uint32_t)u * T) << GSH;
-            if (i >= nk_prev) break;
-            const uint32_t d = digit1h(hash_of_stored<K>(sb[i]), p);
-            if (xcd_place<K>((uint64_t)(uint32_t)(sm.delta[pp][d] + i), xset, p.nxs) < p.cap1) continue;
-            for (uint32_t e = 0; e < GK; e++) {
-                const K key = sb[i + e];
-                if (key == EMPTY) break;
-                const uint32_t st = kttab::table_add(TableRef{pend.slots, pend.g, pend.flags}, from_stored<K>(key), 1u);
-                if (st == 0u) atomicOr(pend.flags, 1u);
-                else if (st == 2u) atomicAdd(reinterpret_cast<unsigned long long *>(pend.distinct), 1ull);
-            }
-        }
     };
 #if KT_ABLATION
     unsigned long long tph = __builtin_readcyclecounter();
@@ -1163,7 +1095,6 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
                 asm volatile("" : "+v"(tq));
                 src.prefetch_issue(pre, unit_of(g0 + stride), first_next, unit_of(g0 + 2 * stride), tq % BLOCK, dump);
             }
-            bool over = false;
             bool skip = stop;
 #if KT_ABLATION
             if (p.dbg & 0x1000u) skip = true;  // (timing only: no copy-out at all)
@@ -1175,7 +1106,7 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
             // a barrier holds nobody up who is not waiting there anyway)
             auto emit_at = [&](int slot) {
                 const int u = slot == PER / 2 - 1 ? 0 : slot == PER - 1 ? 1 : slot == PER + PER / 2 ? 3 : slot == 2 * PER - 1 ? 4 : -1;
-                if (!skip && u >= 0) emit(u, tl, pp, over);
+                if (!skip && u >= 0) emit(u, tl, pp);
             };
             K keys[PER];
             uint32_t ok;
@@ -1210,7 +1141,7 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
             }
             const unsigned long long got = __hip_atomic_fetch_add(&mycur[dc], (unsigned long long)((rc + GK - 1u) & ~(GK - 1u)),
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!skip) emit(2, tl, pp, over);
+            if (!skip) emit(2, tl, pp);
             KT_PH(3);
             ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
             KT_PH(4);
@@ -1230,12 +1161,11 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
                 // (a stream far past its room - a sender's heavy-hitter bucket - must not wrap back into it)
                 const uint32_t q0 = got > 0xE0000000ull ? 0xE0000000u : (uint32_t)got;
                 sm.delta[par][tl] = q0 - rs;
-                if (!pend.slots && xcd_place<K>((uint64_t)q0 + rc - 1u, xset, p.nxs) >= p.cap1) {
+                if (xcd_place<K>((uint64_t)q0 + rc - 1u, xset, p.nxs) >= p.cap1) {
                     *sm.ovf = 1;
                     atomicOr(ovf, 1u);
                 }
             }
-            if (over && pend.slots) park(tl, pp);
             if (nxt) {
                 if (!skip) src.template prefetch_take<NST + 1>(tk, pre);
                 else src.template prefetch_take<0>(tk, pre);
@@ -1253,10 +1183,8 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
     if (!stop && nk_prev) {
         uint32_t tl = tid;
         asm volatile("" : "+v"(tl));
-        bool over = false;
 #pragma unroll
-        for (int u = 0; u < NST; u++) emit(u, tl, par ^ 1u, over);
-        if (over && pend.slots) park(tl, par ^ 1u);
+        for (int u = 0; u < NST; u++) emit(u, tl, par ^ 1u);
     }
 #if KT_ABLATION
     if (tid == 0)
@@ -1264,9 +1192,9 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
 #endif
 }
 
-// after the last source of a job (or of a slice): a bucket's region is read up to its EXTENT - the lines of the fullest
+// after the last source of a job: a bucket's region is read up to its EXTENT - the lines of the fullest
 // cursor set, times the sets - so what the other sets have not filled of their lines up to there gets the empty key
-// (level 2 skips it), and the extent goes where level 2 and the sharded counter's messages look for the bucket's key count
+// (level 2 skips it), and the extent goes where level 2 looks for the bucket's key count
 template <class K>
 __global__ __launch_bounds__(BLOCK) void xcd_tails_kernel(Plan p, const unsigned long long *__restrict__ xcur,
                                                           uint64_t *__restrict__ extent, K *__restrict__ keys1) {
@@ -1327,11 +1255,9 @@ struct Part2Shared {
 // processed so far, and as soon as one is heading past its room it stops placing keys, finishes the pass counting
 // only (which is exactly the histogram), and the bucket is redone with the exact boundaries - the price of a
 // wrong guess is the part of the pass done before it was noticed.
-// Where part2 reads a bucket from.  A bucket's keys arrive in SEGMENTS - one per level-1 output that holds keys of the
-// bucket: one for a table of its own; for a shard of the sharded counter one per (slice, sender), the regions the
-// other GPUs' level-1 passes filled and sent (kt_shard.hip).  Segment s of local bucket jl = srcs[s].keys + jl * cap1,
-// min(srcs[s].counts[jl], cap1) keys, empty keys in the page gaps.  (exact level 1, srcs == nullptr: keys1 is dense,
-// bucket j = [bstart[j], bstart[j + 1]).)
+// Where part2 reads a bucket from: its region of the level-1 output - bucket jl = srcs[0].keys + jl * cap1,
+// min(srcs[0].counts[jl], cap1) keys, empty keys in the gaps (the kernels walk a list of such sources; a job has one).
+// (exact level 1, srcs == nullptr: keys1 is dense, bucket j = [bstart[j], bstart[j + 1]).)
 #ifndef KT_P2_LOAD16
 #define KT_P2_LOAD16 0  // two keys per 16-byte load in part2: measured 16.0 against 15.5 ms (k=31) - off
 #endif
@@ -1340,33 +1266,8 @@ struct P2In {
     const uint64_t *bstart;
     const kt_seg_src *srcs;
     uint32_t n_src;
-    // where bucket jl's output begins in keys2 (null: jl * room1).  Set for the level 2 behind a pre-split (presplit_plan_kernel):
-    // the sub-buckets of a parent that a few k-mers dominate are laid out by their sizes inside the parent's room - one of
-    // them may hold more keys than an even share of it
-    const uint64_t *out_starts;
-    __device__ __forceinline__ uint64_t out_of(uint32_t jl, uint64_t room1) const { return out_starts ? out_starts[jl] : (uint64_t)jl * room1; }
+    __device__ __forceinline__ uint64_t out_of(uint32_t jl, uint64_t room1) const { return (uint64_t)jl * room1; }
 };
-
-// The level 2 behind a pre-split: where every sub-bucket's output goes, and which sub-buckets skip the attempt with fixed
-// fine regions.  A parent bucket whose pre-split did not fit its fixed sub-regions (failA: a few k-mers dominate it) has
-// sub-buckets of very different sizes - one may hold nearly all of the parent's keys, more than the even share (room1 >>
-// bx) the attempt's fixed regions assume: laid out by exact boundaries from the sub-bucket's even place it would run
-// over its neighbours (found by tests: presplit_skewed).  Those sub-buckets are placed back to back inside the PARENT's
-// room, by their sizes, and go straight to the exact pass (failB = 1: the attempt kernels skip them).
-__global__ void presplit_plan_kernel(const uint32_t *__restrict__ failA, const uint64_t *__restrict__ xcount, uint32_t nd, uint32_t bx,
-                                     uint64_t room1, uint64_t line_keys, uint64_t *__restrict__ out_starts, uint32_t *__restrict__ failB) {
-    const uint32_t jl = blockIdx.x * blockDim.x + threadIdx.x;
-    if (jl >= nd) return;
-    const uint32_t nsub = 1u << bx;
-    const bool heavy = failA[jl] != 0;
-    uint64_t at = (uint64_t)jl * room1;
-    for (uint32_t i = 0; i < nsub; i++) {
-        const uint32_t js = (jl << bx) + i;
-        failB[js] = heavy ? 1u : 0u;
-        out_starts[js] = heavy ? at : (uint64_t)js * (room1 >> bx);
-        at += (xcount[js] + line_keys - 1) / line_keys * line_keys;  // (every sub-bucket starts on a cache line)
-    }
-}
 
 template <class K, bool FIXED, bool BIG, bool L16 = false>
 __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) void part2_kernel(P2In in, Plan p,
@@ -1379,7 +1280,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
     constexpr int PER = chunk2<K, BIG>() / P2T;  // 16 (32) keys per thread, held in registers
     constexpr uint32_t CH = chunk2<K, BIG>();
     const uint32_t tid = threadIdx.x;
-    const uint32_t nd = p.d_hi - p.d_lo;
+    const uint32_t nd = p.B1;
     for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
         if (only && !only[jl]) continue;  // (the redo pass behind part2_fast_kernel: only the buckets whose attempt failed)
         // the bucket's segments, and where the bucket lives in keys2
@@ -1388,7 +1289,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
             if (in.srcs) {
                 const kt_seg_src &q = in.srcs[sidx];
                 const uint64_t c = q.counts[jl];
-                base = reinterpret_cast<const K *>(q.keys) + (q.starts ? q.starts[jl] : (uint64_t)jl * q.cap1);
+                base = reinterpret_cast<const K *>(q.keys) + (uint64_t)jl * q.cap1;
                 n = c < q.cap1 ? c : q.cap1;
             } else {
                 base = reinterpret_cast<const K *>(in.keys1) + in.bstart[jl];
@@ -1587,10 +1488,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
 template <class K, bool BIG, int PB>
 __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) void part2_fast_kernel(
     P2In in, Plan p, K *__restrict__ keys2, uint64_t *__restrict__ fstart, uint64_t *__restrict__ fend,
-    uint32_t *__restrict__ fail, uint32_t *__restrict__ carry) {
-    // carry (may be null): [buckets][B2] keys every fine bucket holds already - the pass runs in several launches, each over
-    // some of the bucket's sources (the sharded counter's pre-split, slice by slice as the blocks arrive: kt_bulk_presplit_slice);
-    // the fine buckets' cursors start there and are left there, and fstart / fend always describe everything so far
+    uint32_t *__restrict__ fail) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Part2Shared<K, BIG> sm(smem_raw, p.B2);
     constexpr K EMPTY = empty_of<K>();
@@ -1599,7 +1497,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
     constexpr uint32_t CH = chunk2<K, BIG>();
     constexpr bool RKD = p2_sdig<K, BIG>();  // the digit is kept beside the rank (32-bit keys: it would cost a second hash)
     const uint32_t tid = threadIdx.x;
-    const uint32_t nd = p.d_hi - p.d_lo;
+    const uint32_t nd = p.B1;
     const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 32 - p.b1 - p.b2;  // (in the hash's high word: digit2h)
     auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored) >> 32) >> dshift) & (B2 - 1u); };
     for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
@@ -1607,7 +1505,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
         auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
             const kt_seg_src &q = in.srcs[sidx];
             const uint64_t c = q.counts[jl];
-            base = reinterpret_cast<const K *>(q.keys) + (q.starts ? q.starts[jl] : (uint64_t)jl * q.cap1);
+            base = reinterpret_cast<const K *>(q.keys) + (uint64_t)jl * q.cap1;
             n = c < q.cap1 ? c : q.cap1;
         };
         uint64_t total = 0;
@@ -1617,10 +1515,10 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
             segment(sidx, b, n);
             total += n;
         }
-        if (fail[jl] != 0) continue;  // (marked ahead of the attempt - presplit_plan_kernel - or by an earlier launch of a pass in several: the exact pass takes it)
+        if (fail[jl] != 0) continue;  // (marked already: the exact pass takes it)
         const uint64_t lo = in.out_of(jl, p.room1);
         for (uint32_t i = tid; i < B2; i += P2T) {
-            sm.cur[i] = i * cap2 + (carry ? carry[(uint64_t)jl * B2 + i] : 0u);  // (room1 = B2 * cap2 < 2^32)
+            sm.cur[i] = i * cap2;  // (room1 = B2 * cap2 < 2^32)
             sm.cnt[i] = 0;
             sm.cnt[B2 + i] = 0;
         }
@@ -1753,8 +1651,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
                         if (i < B2) {
                             const uint32_t c = sm.cur[i] + cntc[i];
                             sm.cur[i] = c;
-                            // (a pass in several launches has no "share of the bucket seen so far": its check is the room itself)
-                            if (carry ? c - i * cap2 > cap2 : (float)(c - i * cap2) > allowed) *sm.flag = 1;
+                            if ((float)(c - i * cap2) > allowed) *sm.flag = 1;
                         }
                     }
                 }
@@ -1774,7 +1671,6 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
             for (uint32_t i = tid; i < B2; i += P2T) {
                 fstart[(uint64_t)jl * B2 + i] = lo + (uint64_t)i * cap2;
                 fend[(uint64_t)jl * B2 + i] = lo + sm.cur[i];
-                if (carry) carry[(uint64_t)jl * B2 + i] = sm.cur[i] - i * cap2;
             }
         } else if (tid == 0) {
             fail[jl] = 1u;  // redone by part2_kernel<K, false, BIG> (exact fine boundaries) in the launch behind this one
@@ -1843,7 +1739,7 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
     constexpr uint32_t GL = 8;                          // lanes that write one line (16 bytes each)
     constexpr uint32_t KPL = LK / GL;                   // keys per lane of a line: 2 (4)
     const uint32_t tid = threadIdx.x;
-    const uint32_t nd = p.d_hi - p.d_lo;
+    const uint32_t nd = p.B1;
     const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 32 - p.b1 - p.b2;  // (in the hash's high word: digit2h)
     auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored) >> 32) >> dshift) & (B2 - 1u); };
     const uint32_t grp = tid / GL, gl = tid % GL;       // the line group this thread belongs to, its lane in it
@@ -1852,7 +1748,7 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
         auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
             const kt_seg_src &q = in.srcs[sidx];
             const uint64_t c = q.counts[jl];
-            base = reinterpret_cast<const K *>(q.keys) + (q.starts ? q.starts[jl] : (uint64_t)jl * q.cap1);
+            base = reinterpret_cast<const K *>(q.keys) + (uint64_t)jl * q.cap1;
             n = c < q.cap1 ? c : q.cap1;
         };
         uint64_t total = 0;
@@ -1862,7 +1758,7 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
             segment(sidx, b, n);
             total += n;
         }
-        if (fail[jl] != 0) continue;  // (marked ahead of the attempt - presplit_plan_kernel - or by an earlier launch of a pass in several: the exact pass takes it)
+        if (fail[jl] != 0) continue;  // (marked already: the exact pass takes it)
         const uint64_t lo = in.out_of(jl, p.room1);
         for (uint32_t i = tid; i < 2 * B2; i += P2T) sm.fc[i] = 0;
         if (tid < 4) sm.flags[tid] = 0;
@@ -2160,7 +2056,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
     K *const skeys = reinterpret_cast<K *>(smem_raw);
     uint32_t *const scounts = reinterpret_cast<uint32_t *>(smem_raw + (size_t)RS * sizeof(K));
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint64_t n_fine = (uint64_t)(p.d_hi - p.d_lo) * p.B2;  // the ranges this table holds
+    const uint64_t n_fine = (uint64_t)(p.B1) * p.B2;  // the ranges this table holds
     const uint32_t shift = 64 - p.n;
     // (the image in LDS holds keys in their stored form, like the key arrays: to_stored / from_stored; a key's home
     // position inside the range is kttab::probe_of's: home_w below)
@@ -2776,13 +2672,6 @@ __global__ __launch_bounds__(XT) void dense_export_kernel(const Slot *__restrict
     }
 }
 
-// pre-split pass (finish_typed): sizes of the sub-buckets from their bounds
-__global__ void sub_counts_kernel(const uint64_t *__restrict__ fs, const uint64_t *__restrict__ fe, uint32_t n,
-                                  uint64_t *__restrict__ counts) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) counts[i] = fe[i] - fs[i];
-}
-
 uint64_t env_u64(const char *name, uint64_t dflt) {
     const char *s = getenv(name);
     if (!s || !*s) return dflt;
@@ -2812,7 +2701,7 @@ static int with_source(const SourceRec &r, F &&f) {
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, max_b2, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
+        verbose, ext_ovf_blocks, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2835,10 +2724,6 @@ static BulkKnobs read_knobs() {
     k.build_lists = env_u64("KT_BUILD_LISTS", 1);  // 0: the dense build packs the image instead of keeping claim lists (A/B)
     k.dense = env_u64("KT_BULK_DENSE", 1);
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
-    // hash bits level 2 takes: 10 - what part2_swwc_kernel's one line per fine bucket fits into the LDS (the sort-buffer
-    // kernels take 11); shards that need more get the pre-split pass.  (tests: smaller, so that small shards need it too)
-    k.max_b2 = env_u64("KT_BULK_MAX_B2", 10);
-    if (k.max_b2 < 1 || k.max_b2 > 11) k.max_b2 = 10;  // (an invalid value: the default)
     k.ext_ovf_blocks = env_u64("KT_EXT_OVF_BLOCKS", 0);  // tests: n + 1 = blocks of scratch behind the export target
     return k;
 }
@@ -2850,18 +2735,9 @@ struct kt_bulk_job {
     bool narrow = false;  // 32-bit keys through the partition passes (k <= 16)
     bool paged = false, merge = false, open = false;
     bool xcd = false;  // paged level 1 appends through per-XCD cursors (scatter1x_kernel + xcd_tails_kernel)
-    uint64_t max_keys = 0, added_bound = 0, cap1_max = 0;
+    uint64_t max_keys = 0, added_bound = 0;
     std::vector<SourceRec> srcs;
-    // level 1 in slices (the sharded counter, kt_shard.hip): slice i writes the level-1 output i of b_keys1 (B1 regions of
-    // cap1 keys), with its own page allocator state; a table of its own has one slice
-    uint32_t n_slices = 1, n_src = 1;
-    bool sharded = false;  // regions are messages: level 1 parks what does not fit (pend) instead of being redone
-    PendList pend{};
-    std::vector<kt_seg_src> p2_srcs;  // where part2 reads every local bucket from (set by the caller when sharded)
-    // the pre-split made slice by slice (kt_bulk_presplit_slice): sources covered so far, and the launches' source lists
-    // (host copies that outlive their asynchronous upload)
-    uint32_t presplit_srcs = 0;
-    std::vector<std::vector<kt_seg_src>> presplit_lists;
+    kt_seg_src p2_src{};  // where part2 reads every bucket from: the level-1 output (host copy of its one device entry)
     // record sources (kt_bulk_add_records): their descriptors on the device (ctr->b_desc), the host copies the uploads read
     size_t desc_used = 0;
     std::vector<std::vector<uint64_t>> desc_host;
@@ -2873,15 +2749,14 @@ void kt_bulk_job_free(kt_bulk_job *job) { delete job; }
 namespace {
 
 template <class K>
-int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice = 0) {
+int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
     kt_ctx *ctx = ctr->ctx;
-    K *keys1 = (K *)ctr->b_keys1.p + (size_t)slice * j.p.B1 * j.p.cap1;
+    K *keys1 = (K *)ctr->b_keys1.p;
     if (!j.xcd) return kt::fail(KT_ERR_ARG, "bulk build: paged level 1 without its cursors");
-    unsigned long long *xcur = j.m.xcur + (size_t)slice * 8 * j.p.B1;
+    unsigned long long *xcur = j.m.xcur;
     const Plan p = j.p;
     uint32_t *const ovf = j.m.ovf;
     unsigned long long *const dump = j.m.dump;
-    const PendList pend = j.pend;
     // two sort buffers, the copy-out spread over the next round - or, a shape that does not fit the LDS, one buffer
     const bool two = j.kn.s1y && Scatter1YShared<K, 1024>::bytes(j.p.B1) <= 160 * 1024;
     const uint32_t mult = (uint32_t)(j.kn.g_mult ? j.kn.g_mult : 1);
@@ -2892,14 +2767,13 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r, uint32_t slice
             const size_t lds = Scatter1YShared<K, T>::bytes(p.B1);
             auto kern = scatter1y_kernel<S, K, T>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, pend, dump);
+            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, dump);
         } else {
             constexpr int T = KT_S1X_T;
             const size_t lds = sizeof(Scatter1XShared<K, T>);
             auto kern = scatter1x_kernel<S, K, T>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * (1024 / T) * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1,
-                               pend, dump);
+            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * (1024 / T) * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, dump);
         }
         KT_HIP(hipGetLastError());
         return KT_OK;
@@ -2943,7 +2817,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
     Plan &p = j.p;
     Meta &m = j.m;
     K *keys1 = (K *)ctr->b_keys1.p, *keys2 = (K *)ctr->b_keys2.p;
-    if (j.paged && !j.sharded) {
+    if (j.paged) {
         hipLaunchKernelGGL(xcd_tails_kernel<K>, dim3(p.B1), dim3(BLOCK), 0, ctx->stream, p, (const unsigned long long *)m.xcur, m.gcur, keys1);
         // the one host round trip of the build: did every bucket fit its region?
         uint32_t ovf = 0;
@@ -2960,32 +2834,27 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             if (int rc = level1_exact<K>(ctr, j)) return rc;
         }
     }
-    // where part2 finds every bucket: the one level-1 output of a table of its own, or what the sharded counter set
-    P2In in{keys1, m.bstart, nullptr, 0, nullptr};
+    // where part2 finds every bucket: the level-1 output
+    P2In in{keys1, m.bstart, nullptr, 0};
     if (j.paged) {
-        if (!j.sharded) j.p2_srcs.assign(1, kt_seg_src{keys1, m.gcur, p.cap1, nullptr});
-        if (j.p2_srcs.empty() || j.p2_srcs.size() > j.n_src) return kt::fail(KT_ERR_ARG, "bulk build: level-2 sources not set");
-        KT_HIP(hipMemcpyAsync(m.srcs, j.p2_srcs.data(), j.p2_srcs.size() * sizeof(kt_seg_src), hipMemcpyHostToDevice, ctx->stream));
-        KT_HIP(hipStreamSynchronize(ctx->stream));  // (p2_srcs may be reassigned by the caller right after)
+        j.p2_src = kt_seg_src{keys1, m.gcur, p.cap1};
+        KT_HIP(hipMemcpyAsync(m.srcs, &j.p2_src, sizeof(kt_seg_src), hipMemcpyHostToDevice, ctx->stream));
         in.srcs = m.srcs;
-        in.n_src = (uint32_t)j.p2_srcs.size();
+        in.n_src = 1;
     }
-    const uint32_t nd = p.d_hi - p.d_lo;
+    const uint32_t nd = p.B1;
     // one level-2 launch: `pp` says which hash bits it sorts by and how many buckets it reads, `src` where from
-    // (`fail`: one word per bucket of the launch - zeroed here, unless `preset`: then the caller has marked the buckets
-    // that skip the attempt with fixed fine regions)
-    auto run_part2 = [&](const Plan &pp, const P2In &src, K *out, uint64_t *fs, uint64_t *fe, uint32_t *fail, bool preset) -> int {
-        // (one line per fine bucket wants about a line's worth of keys per bucket and chunk: with few, large fine buckets -
-        // the pre-split's 2^bx-way pass - a chunk would be hundreds of generations, and its runs are long anyway: that
-        // pass keeps the sort buffer)
+    // (`fail`: one word per bucket of the launch - zeroed here)
+    auto run_part2 = [&](const Plan &pp, const P2In &src, K *out, uint64_t *fs, uint64_t *fe, uint32_t *fail) -> int {
+        // (one line per fine bucket wants about a line's worth of keys per bucket and chunk: fan-outs below 512 keep the sort buffer)
         if (pp.cap2 && src.srcs && j.kn.p2_swwc && pp.B2 >= 512 && SwwcShared<K>::bytes(pp.B2) <= 160 * 1024) {
             // fixed fine regions, whole lines only (part2_swwc_kernel); then the general kernel over the buckets that did not
             // fit their regions (none, normally)
             const size_t lds = SwwcShared<K>::bytes(pp.B2);
-            if (!preset) KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
+            KT_HIP(hipMemsetAsync(fail, 0, (size_t)pp.B1 * 4, ctx->stream));
             auto swwc = part2_swwc_kernel<K>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(swwc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            uint32_t grid = pp.d_hi - pp.d_lo;
+            uint32_t grid = pp.B1;
             if (j.kn.p2_grid && grid > j.kn.p2_grid) grid = (uint32_t)j.kn.p2_grid;
             hipLaunchKernelGGL(swwc, dim3(grid), dim3(swwc_t<K>()), lds, ctx->stream, src, pp, out, fs, fe, fail);
             KT_HIP(hipGetLastError());
@@ -2995,7 +2864,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
                 const size_t rl = Part2Shared<K, BIG>::bytes(pp.B2);
                 auto redo = part2_kernel<K, false, BIG>;
                 KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-                hipLaunchKernelGGL(redo, dim3(pp.d_hi - pp.d_lo), dim3(p2t<K, BIG>()), rl, ctx->stream, src, pp, out, fs, fe,
+                hipLaunchKernelGGL(redo, dim3(pp.B1), dim3(p2t<K, BIG>()), rl, ctx->stream, src, pp, out, fs, fe,
                                    (const uint32_t *)fail);
                 KT_HIP(hipGetLastError());
                 return KT_OK;
@@ -3010,15 +2879,15 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             constexpr uint32_t P2T = (uint32_t)p2t<K, BIG>();
             if (pp.cap2 && src.srcs && j.kn.p2_fast && pp.B2 <= 4 * P2T) {
                 // fixed fine regions: the lean kernel, then the general one over the buckets that did not fit (none, normally)
-                if (!preset) KT_HIP(hipMemsetAsync(fail, 0, (size_t)(pp.d_hi - pp.d_lo) * 4, ctx->stream));
+                KT_HIP(hipMemsetAsync(fail, 0, (size_t)pp.B1 * 4, ctx->stream));
                 auto go = [&](auto pb) -> int {
                     constexpr int PB = decltype(pb)::value;
                     auto fast = part2_fast_kernel<K, BIG, PB>;
                     KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)part2_lds));
-                    uint32_t grid = pp.d_hi - pp.d_lo;
+                    uint32_t grid = pp.B1;
                     if (j.kn.p2_grid && grid > j.kn.p2_grid) grid = (uint32_t)j.kn.p2_grid;
-                    hipLaunchKernelGGL(fast, dim3(grid), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe, fail, (uint32_t *)nullptr);
+                    hipLaunchKernelGGL(fast, dim3(grid), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe, fail);
                     KT_HIP(hipGetLastError());
                     return KT_OK;
                 };
@@ -3029,77 +2898,24 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
                 auto redo = part2_kernel<K, false, BIG>;
                 KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)part2_lds));
-                hipLaunchKernelGGL(redo, dim3(pp.d_hi - pp.d_lo), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe,
+                hipLaunchKernelGGL(redo, dim3(pp.B1), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe,
                                    (const uint32_t *)fail);
                 KT_HIP(hipGetLastError());
                 return KT_OK;
             }
-            // (16-byte loads where every region starts on a 16-byte boundary: paged level-1 outputs, not the pre-split's)
-            const bool l16 = KT_P2_LOAD16 && sizeof(K) == 8 && pp.cap2 && src.srcs && src.srcs != m.srcs + j.n_src;
+            // (16-byte loads where every region starts on a 16-byte boundary: paged level-1 outputs)
+            const bool l16 = KT_P2_LOAD16 && sizeof(K) == 8 && pp.cap2 && src.srcs;
             auto part2 = !pp.cap2 ? part2_kernel<K, false, BIG> : l16 ? part2_kernel<K, true, BIG, true> : part2_kernel<K, true, BIG>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(part2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)part2_lds));
-            hipLaunchKernelGGL(part2, dim3(pp.d_hi - pp.d_lo), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe,
+            hipLaunchKernelGGL(part2, dim3(pp.B1), dim3(P2T), part2_lds, ctx->stream, src, pp, out, fs, fe,
                                (const uint32_t *)nullptr);
             KT_HIP(hipGetLastError());
             return KT_OK;
         };
         return big2 ? launch(std::true_type{}) : launch(std::false_type{});
     };
-    if (p.bx == 0) {
-        if (int rc = run_part2(p, in, keys2, m.fstart, m.fend, m.fail, false)) return rc;
-    } else {
-        // The shard of a table spread over many GPUs: level 2 cannot take all the bits level 1 left (plan_job).  Pass A
-        // splits every bucket 2^bx ways into keys2 (long runs: close to a copy); pass B is the ordinary level 2 over the
-        // sub-buckets - they are its "level-1 buckets" - and writes where the level-1 outputs were (every one of them
-        // has been sent, and read by pass A, by now); the range builds read from there.
-        Plan pa = p;
-        pa.b2 = p.bx;
-        pa.B2 = 1u << p.bx;
-        pa.cap2 = p.room1 / pa.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
-        if (j.presplit_srcs && j.presplit_srcs == in.n_src) {
-            // pass A has been made already, slice by slice while the blocks arrived (kt_bulk_presplit_slice); what is left of
-            // it is the redo of the buckets that did not fit their fixed sub-regions (none, normally), over all the sources
-            const bool bigr = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 && Part2Shared<K, true>::bytes(pa.B2) <= 160 * 1024;
-            auto redo_launch = [&](auto big) -> int {
-                constexpr bool BIG = decltype(big)::value;
-                const size_t rl = Part2Shared<K, BIG>::bytes(pa.B2);
-                auto redo = part2_kernel<K, false, BIG>;
-                KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl));
-                hipLaunchKernelGGL(redo, dim3(pa.d_hi - pa.d_lo), dim3(p2t<K, BIG>()), rl, ctx->stream, in, pa, keys2, m.xstart, m.xend,
-                                   (const uint32_t *)m.fail);
-                KT_HIP(hipGetLastError());
-                return KT_OK;
-            };
-            if (int rc = bigr ? redo_launch(std::true_type{}) : redo_launch(std::false_type{})) return rc;
-        } else {
-            if (j.presplit_srcs) return kt::fail(KT_ERR_ARG, "bulk build: the pre-split was made for some of the sources only");
-            if (int rc = run_part2(pa, in, keys2, m.xstart, m.xend, m.fail, false)) return rc;
-        }
-        const uint32_t n_sub = nd << p.bx;
-        hipLaunchKernelGGL(sub_counts_kernel, dim3((n_sub + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)m.xstart,
-                           (const uint64_t *)m.xend, n_sub, m.xcount);
-        Plan pb = p;
-        pb.b1 = p.b1 + p.bx;
-        pb.B1 = p.B1 << p.bx;
-        pb.b2 = p.b2 - p.bx;
-        pb.B2 = 1u << pb.b2;
-        pb.d_lo = p.d_lo << p.bx;
-        pb.d_hi = p.d_hi << p.bx;
-        pb.room1 = p.room1 >> p.bx;
-        pb.cap2 = pb.room1 / pb.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
-        const kt_seg_src from_a{keys2, m.xcount, ~0ull, m.xstart};
-        KT_HIP(hipMemcpyAsync(m.srcs + j.n_src, &from_a, sizeof from_a, hipMemcpyHostToDevice, ctx->stream));
-        KT_HIP(hipStreamSynchronize(ctx->stream));  // (from_a lives on this frame)
-        // where every sub-bucket's output goes, and which of them skip the attempt (the children of a parent that a few
-        // k-mers dominate: presplit_plan_kernel)
-        hipLaunchKernelGGL(presplit_plan_kernel, dim3((nd + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)m.fail,
-                           (const uint64_t *)m.xcount, nd, p.bx, p.room1, (uint64_t)(128 / sizeof(K)), m.xout, m.fail2);
-        KT_HIP(hipGetLastError());
-        const P2In inb{nullptr, nullptr, m.srcs + j.n_src, 1, m.xout};
-        if (int rc = run_part2(pb, inb, keys1, m.fstart, m.fend, m.fail2, true)) return rc;
-        keys2 = keys1;  // what the builds read
-    }
+    if (int rc = run_part2(p, in, keys2, m.fstart, m.fend, m.fail)) return rc;
     const uint64_t n_fine = (uint64_t)nd * p.B2;
     // workgroups per CU over the launch; up to two are resident per CU.  Each takes ranges b, b + grid, ... with the next
     // one's bounds and first keys prefetched, so a few ranges per workgroup are enough - and a smaller static share evens
@@ -3190,9 +3006,9 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         uint64_t spilled = 0;
         KT_HIP(hipMemcpyAsync(&spilled, m.spill_n, 8, hipMemcpyDeviceToHost, ctx->stream));
         KT_HIP(hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s%s %s spilled=%llu\n", ctr->k,
+        fprintf(stderr, "[bulk] k=%d keys<=%llu level1=%s level2=%s %s spilled=%llu\n", ctr->k,
                 (unsigned long long)j.max_keys, j.paged ? "paged" : "exact", p.cap2 ? "fixed" : "exact",
-                p.bx ? " +presplit" : "", j.merge ? "merge" : "build", (unsigned long long)spilled);
+                j.merge ? "merge" : "build", (unsigned long long)spilled);
     }
     return KT_OK;
 }
@@ -3239,38 +3055,25 @@ static int xcc_sets(kt_ctx *ctx, uint32_t *nxs, uint32_t *xmap) {
 
 // Plans the partition of at most `max_keys` k-mers into the table's ranges and reserves the buffers.  *eligible = 0:
 // the table shape or the batch does not suit the bulk path (or HBM is short) and the caller uses the probing path.
-// slice_keys: the most k-mers one level-1 output (slice) takes; n_slices of them; n_src: level-1 outputs that feed one
-// bucket of this table (a table of its own: 1; a shard: slices x senders).  sharded: the sharded counter's job - level 1
-// parks what does not fit its regions in `pend`, the caller sets part2's sources, small batches take the bulk path too.
-uint64_t kt_bulk_region_room(uint64_t slice_keys, uint32_t B1) {
-    return (slice_keys / B1 + slice_keys / B1 / 8 + 16 * 256 + 255) / 256 * 256;
+// keys of room of a level-1 region for at most max_keys k-mers in B1 buckets: the bucket's share + 1/8 (the hash's own spread
+// and the cursor sets' uneven fills) + 16 lines per set, a multiple of 256
+static uint64_t region_room(uint64_t max_keys, uint32_t B1) {
+    return (max_keys / B1 + max_keys / B1 / 8 + 16 * 256 + 255) / 256 * 256;
 }
 
-// slice_keys_now (sharded; 0: slice_keys): what a slice of THIS batch holds at most - the regions take their room from it (a
-// region travels at its room), the buffers theirs from slice_keys
-static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_t n_src, bool sharded, const PendList *pend,
-                    int *eligible, uint64_t slice_keys_now = 0) {
+static int plan_job(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     *eligible = 0;
-    if (!slice_keys_now || slice_keys_now > slice_keys) slice_keys_now = slice_keys;
     kt_ctx *ctx = ctr->ctx;
     const BulkKnobs kn = read_knobs();
-    const uint64_t max_keys = slice_keys * n_slices;
-    if (!sharded) {
-        if (kn.bulk == 0) return KT_OK;
-        if (max_keys < kn.min_bases) return KT_OK;  // small batches: atomics are fine
-    }
+    if (kn.bulk == 0) return KT_OK;
+    if (max_keys < kn.min_bases) return KT_OK;  // small batches: atomics are fine
     if (!ctr->job) ctr->job = new (std::nothrow) kt_bulk_job();
     if (!ctr->job) return kt::fail(KT_ERR_NOMEM, "bulk build: host alloc");
     kt_bulk_job &j = *ctr->job;
-    ctr->stage_n = 0;  // (a job changes the table - the sharded counter's adds come through here: kt_ctr_export_stage's entries are stale)
+    ctr->stage_n = 0;  // (a job changes the table: kt_ctr_export_stage's entries are stale)
     j.kn = kn;
     j.open = false;
     j.srcs.clear();
-    j.p2_srcs.clear();
-    j.sharded = sharded;
-    j.n_slices = n_slices;
-    j.n_src = n_src;
-    j.pend = pend ? *pend : PendList{};
     j.merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
     if (j.merge)
         if (int rc = kt_table_image(ctr)) return rc;  // (a densely packed table gets its probing image first)
@@ -3286,7 +3089,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
 #endif
     if (p.n < LOG2_S + 2 || p.n > LOG2_S + 21) return KT_OK;
     // a rebuild moves the whole table: small batches are cheaper through the atomics
-    if (!sharded && j.merge && max_keys < ctr->cap / (kn.merge_div ? kn.merge_div : 1)) return KT_OK;
+    if (j.merge && max_keys < ctr->cap / (kn.merge_div ? kn.merge_div : 1)) return KT_OK;
     const uint32_t fb = p.n - LOG2_S;
     p.b1 = (fb + 1) / 2;
     if (p.b1 > 10) p.b1 = 10;  // level 1 keeps its per-digit LDS arrays at 1024 entries
@@ -3296,38 +3099,24 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     if (fb >= 16 && fb - p.b1 < 9) p.b1 = fb - 9;
     if (kn.b1 && kn.b1 <= 10 && kn.b1 < fb && fb - kn.b1 <= 11) p.b1 = (uint32_t)kn.b1;  // (KT_BULK_B1: the split between the levels, experiments)
     p.b2 = fb - p.b1;
-    // a pass resolves at most 10 (level 1) / 11 (level 2) hash bits.  The shards of a table spread over N GPUs are
-    // addressed by log2(N) more bits than a table of the same size on one GPU, and level 1 - run by the senders - spends
-    // its bits on the whole table: what level 2 cannot take is resolved by a pre-split of every bucket (a third trip of the
-    // keys through HBM, a 2^bx-way split with long runs).
-    // (a table of its own has no pre-split: its level 2 takes up to 11 bits, with the sort-buffer kernel for the 11th)
-    const uint32_t lim2 = sharded ? (uint32_t)kn.max_b2 : 11u;
-    p.bx = p.b2 > lim2 ? p.b2 - lim2 : 0;
-    if (p.bx && (!sharded || p.bx > 6)) return KT_OK;
+    if (p.b2 > 11) return KT_OK;  // (a pass resolves at most 10 (level 1) / 11 (level 2) hash bits)
     p.B1 = 1u << p.b1;
     p.B2 = 1u << p.b2;
-    p.d_lo = 0;
-    p.d_hi = p.B1;
-    const uint32_t nd = p.d_hi - p.d_lo;
+    const uint32_t nd = p.B1;
     // persistent level-1 workgroups (the same for every source of the job): two per CU for the per-unit kernels; the wide
     // kernel launches G / 2 of them, one resident per CU (KT_BULK_G_MULT > 1: more, shorter-lived workgroups)
     p.G = (uint32_t)ctx->n_cu * 2 * (uint32_t)(kn.g_mult ? kn.g_mult : 1);
     // paged level 1 (no hist1): room per bucket = its share of the most keys there can be + 1/8 + a page per
     // workgroup (every workgroup leaves at most one partly used page per bucket)
-    bool paged = (kn.paged != 0 && !ctr->paged_failed) || sharded;
+    bool paged = kn.paged != 0 && !ctr->paged_failed;
     // (rounded to a multiple of 128 keys: every region starts on a cache line, whatever the key size)
     // (per-XCD cursors: no pages; the room beyond the keys' share covers the sets' uneven fills - every set's lines reach as
     // far as the fullest set's - and the same 1/8 for the hash's own spread; a multiple of 8 sets x 32 keys)
     const bool xcd = paged;
-    uint64_t cap1 = kt_bulk_region_room(slice_keys, p.B1);
-    const uint64_t room1 = cap1 * n_src;
-    if (room1 * ksz >= (1ull << 31)) {  // (part2 addresses a bucket's fixed regions through 32-bit buffer offsets)
-        if (sharded) return kt::fail(KT_ERR_ARG, "sharded counter: batch too large for its level-1 regions (lower max_batch_bases)");
-        paged = false;
-    }
-    uint64_t room_in = paged ? cap1 * p.B1 * n_slices : max_keys;  // level-1 outputs
-    if (p.bx && room_in < room1 * nd) room_in = room1 * nd;        // (the pre-split's second pass writes where they were)
-    uint64_t room_out = paged ? room1 * nd : max_keys;             // keys2: the local buckets, every source's share
+    const uint64_t cap1 = region_room(max_keys, p.B1), room1 = cap1;
+    if (room1 * ksz >= (1ull << 31)) paged = false;  // (part2 addresses a bucket's fixed regions through 32-bit buffer offsets)
+    uint64_t room_in = paged ? cap1 * p.B1 : max_keys;  // the level-1 output
+    uint64_t room_out = paged ? room1 * nd : max_keys;  // keys2
 
     // buffers: two key arrays + metadata; if HBM is short, fall back to the incremental path
     // spill list: keys of ranges that hold more distinct keys than slots (they fail in the probing path: table full)
@@ -3338,20 +3127,12 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     const size_t off_bs = meta;      meta += ((size_t)(p.B1 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fs = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
     const size_t off_fe = meta;      meta += (((size_t)nd * p.B2 + 1) * 8 + 255) & ~(size_t)255;
-    const size_t off_gc = meta;      meta += ((size_t)n_slices * p.B1 * 8 + 255) & ~(size_t)255;
-    const size_t off_xc = meta + 0;  meta += ((size_t)n_slices * 8 * p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_gc = meta;      meta += ((size_t)p.B1 * 8 + 255) & ~(size_t)255;
+    const size_t off_xc = meta + 0;  meta += ((size_t)8 * p.B1 * 8 + 255) & ~(size_t)255;
     const size_t off_du = meta;      meta += 1024 * 16;
-    const size_t off_sr = meta;      meta += ((size_t)(n_src + 1) * sizeof(kt_seg_src) + 255) & ~(size_t)255;
-    const size_t n_sub = (size_t)nd << p.bx;  // pre-split: sub-bucket bounds and sizes
-    const size_t off_xs = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
-    const size_t off_xe = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
-    const size_t off_xn = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
-    const size_t off_xy = meta;      meta += (p.bx ? (n_sub + 1) * 4 + 255 : 0) & ~(size_t)255;
-    const size_t off_xo = meta;      meta += (p.bx ? (n_sub + 1) * 8 + 255 : 0) & ~(size_t)255;
-    const size_t off_f2 = meta;      meta += (p.bx ? (n_sub + 1) * 4 + 255 : 0) & ~(size_t)255;
-    const size_t off_xs2 = meta;     meta += (p.bx ? (size_t)n_src * sizeof(kt_seg_src) + 255 : 0) & ~(size_t)255;
+    const size_t off_sr = meta;      meta += 256;
     const size_t off_ov = meta;      meta += 256;
-    const size_t off_fl = meta;      meta += ((n_sub + 1) * 4 + 255) & ~(size_t)255;
+    const size_t off_fl = meta;      meta += (((size_t)nd + 1) * 4 + 255) & ~(size_t)255;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
     const size_t off_sc = meta;      meta += (spill_cap * 4 + 255) & ~(size_t)255;
@@ -3360,7 +3141,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
                ctr->b_meta.reserve(meta) == KT_OK;
     };
     bool have = reserve_all();
-    if (!have && paged && !sharded) {  // the paged layout wants 1/8 more room than the keys: try the exact one before giving up
+    if (!have && paged) {  // the paged layout wants 1/8 more room than the keys: try the exact one before giving up
         paged = false;
         room_in = room_out = max_keys;
         have = reserve_all();
@@ -3370,7 +3151,6 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
         ctr->b_keys1.release();
         ctr->b_keys2.release();
         ctr->b_meta.release();
-        if (sharded) return kt::fail(KT_ERR_NOMEM, "sharded counter: not enough HBM for the partition buffers");
         kt::set_error("");
         return KT_OK;  // not enough HBM for the bulk buffers: incremental path
     }
@@ -3383,14 +3163,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.fend = (uint64_t *)(mb + off_fe);
     m.gcur = (uint64_t *)(mb + off_gc);
     m.srcs = (kt_seg_src *)(mb + off_sr);
-    m.xstart = (uint64_t *)(mb + off_xs);
-    m.xend = (uint64_t *)(mb + off_xe);
-    m.xcount = (uint64_t *)(mb + off_xn);
     m.xcur = (unsigned long long *)(mb + off_xc);
-    m.xcarry = (uint32_t *)(mb + off_xy);
-    m.xout = (uint64_t *)(mb + off_xo);
-    m.fail2 = (uint32_t *)(mb + off_f2);
-    m.xsrcs = (kt_seg_src *)(mb + off_xs2);
     m.dump = (unsigned long long *)(mb + off_du);
     m.ovf = (uint32_t *)(mb + off_ov);
     m.fail = (uint32_t *)(mb + off_fl);
@@ -3400,33 +3173,26 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     m.spill_cap = spill_cap;
     KT_HIP(hipMemsetAsync(m.spill_n, 0, 8, ctx->stream));
     if (paged) {
-        p.cap1 = kt_bulk_region_room(slice_keys_now, p.B1);
-        j.cap1_max = cap1;
+        p.cap1 = cap1;
         p.room1 = room1;
-        p.cap2 = kn.fixed2 || p.bx ? room1 / p.B2 / (128 / ksz) * (128 / ksz) : 0;  // (whole cache lines: every fine region starts on one)
-        KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)n_slices * p.B1 * 8, ctx->stream));
+        p.cap2 = kn.fixed2 ? room1 / p.B2 / (128 / ksz) * (128 / ksz) : 0;  // (whole cache lines: every fine region starts on one)
+        KT_HIP(hipMemsetAsync(m.gcur, 0, (size_t)p.B1 * 8, ctx->stream));
         KT_HIP(hipMemsetAsync(m.ovf, 0, 8, ctx->stream));
         if (xcd) {
             if (int rc = xcc_sets(ctx, &p.nxs, &p.xmap)) return rc;
             // (a batch of a few dozen units does not spread evenly over the XCDs - a handful of workgroups, some XCDs with
             // one more than others - and a set's share of a region is only an eighth of it: such batches append through
             // one set; what the sets buy, whole lines out of the L2, is nothing they would notice)
-            if (slice_keys < (16ull << 20) && !getenv("KT_S1X_SETS")) {
+            if (max_keys < (16ull << 20) && !getenv("KT_S1X_SETS")) {
                 p.nxs = 0;
                 p.xmap = 0;
             }
-            KT_HIP(hipMemsetAsync(m.xcur, 0, (size_t)n_slices * 8 * p.B1 * 8, ctx->stream));
+            KT_HIP(hipMemsetAsync(m.xcur, 0, (size_t)8 * p.B1 * 8, ctx->stream));
         }
     }
     j.xcd = paged && xcd;
-    j.presplit_srcs = 0;
-    j.presplit_lists.clear();
     j.desc_used = 0;
     j.desc_host.clear();
-    if (p.bx) {
-        KT_HIP(hipMemsetAsync(m.xcarry, 0, (n_sub + 1) * 4, ctx->stream));
-        KT_HIP(hipMemsetAsync(m.fail, 0, (n_sub + 1) * 4, ctx->stream));
-    }
     j.p = p;
     j.m = m;
     j.paged = paged;
@@ -3435,119 +3201,7 @@ static int plan_job(kt_ctr *ctr, uint64_t slice_keys, uint32_t n_slices, uint32_
     return KT_OK;
 }
 
-int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
-    return plan_job(ctr, max_keys, 1, 1, false, nullptr, eligible);
-}
-
-// ---- the sharded counter's job (kt_shard.hip): level 1 runs where the reads are, level 2 + build where the keys belong ----
-int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint64_t slice_keys_now, uint32_t n_slices, uint32_t n_src, kt_ctr *pend) {
-    if (int rc = ktl::table_ready(pend)) return rc;  // (a deferred clear happens now; a full table is reported)
-    pend->empty = false;
-    const PendList pl{(Slot *)pend->slots, ktl::geom_of(pend), pend->flags, pend->distinct};
-    int eligible = 0;
-    if (int rc = plan_job(ctr, slice_keys, n_slices, n_src, true, &pl, &eligible, slice_keys_now)) return rc;
-    if (!eligible) return kt::fail(KT_ERR_ARG, "sharded counter: the table's shape does not suit the partition passes");
-    return KT_OK;
-}
-
-// level 1 of slice `slice` over the k-mers that start in segments [seg_lo, seg_hi) of this rank's reads: the slice's
-// B1 regions fill up; finished off by kt_bulk_slice_done (page tails) before the regions are sent
-int kt_bulk_slice_reads(kt_ctr *ctr, uint32_t slice, const uint8_t *d_bases, const uint64_t *d_offsets,
-                        const uint64_t *seg_first, uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi) {
-    kt_bulk_job *job = ctr->job;
-    if (!job || !job->open || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
-    if (seg_hi <= seg_lo) return KT_OK;
-    SourceRec r{};
-    r.kind = SRC_READS;
-    r.rs.a.bases = d_bases;
-    r.rs.a.offsets = d_offsets;
-    r.rs.a.seg_first = seg_first;
-    r.rs.a.n_reads = n_reads;
-    r.rs.a.n_seg = n_seg;
-    r.rs.a.k = (uint32_t)ctr->k;
-    r.rs.seg_lo = seg_lo;
-    r.rs.seg_hi = seg_hi;
-    r.rs.n_parts = 1;
-    r.rs.part = 0;
-    r.n_units = seg_hi - seg_lo;
-    return job->narrow ? level1_paged<uint32_t>(ctr, *job, r, slice) : level1_paged<uint64_t>(ctr, *job, r, slice);
-}
-
-int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice) {
-    kt_bulk_job *job = ctr->job;
-    if (!job || !job->open || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
-    const Plan &p = job->p;
-    char *keys1 = (char *)ctr->b_keys1.p + (size_t)slice * p.B1 * p.cap1 * job->ksz();
-    const unsigned long long *xcur = job->m.xcur + (size_t)slice * 8 * p.B1;
-    uint64_t *extent = job->m.gcur + (size_t)slice * p.B1;
-    if (job->narrow)
-        hipLaunchKernelGGL(xcd_tails_kernel<uint32_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint32_t *)keys1);
-    else
-        hipLaunchKernelGGL(xcd_tails_kernel<uint64_t>, dim3(p.B1), dim3(BLOCK), 0, ctr->ctx->stream, p, xcur, extent, (uint64_t *)keys1);
-    KT_HIP(hipGetLastError());
-    return KT_OK;
-}
-
-// the job's shape, and where slice `slice` keeps the regions and the key counts of level-1 buckets bucket .. B1
-int kt_bulk_slice_info(kt_ctr *ctr, uint32_t slice, uint32_t bucket, kt_bulk_shape *shape, void **keys, uint64_t **counts) {
-    kt_bulk_job *job = ctr->job;
-    if (!job || !job->sharded || slice >= job->n_slices) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
-    const Plan &p = job->p;
-    if (shape) *shape = kt_bulk_shape{p.B1, p.d_lo, p.d_hi, p.cap1, (uint32_t)job->ksz(), job->cap1_max};
-    if (keys) *keys = (char *)ctr->b_keys1.p + ((size_t)slice * p.B1 + bucket) * p.cap1 * job->ksz();
-    if (counts) *counts = job->m.gcur + (size_t)slice * p.B1 + bucket;
-    return KT_OK;
-}
-
-// The pre-split of a shard (plan_job: bx > 0, the hash bits level 2 cannot take), made for SOME of the bucket's sources -
-// one slice's blocks, as they have arrived - on `stream`: the 2^bx-way pass appends to the sub-buckets where the slices
-// before it stopped (Meta::xcarry).  Called once per slice with that slice's sources, in any order, before
-// kt_bulk_finish, which then only runs the ordinary level 2 over the sub-buckets (and the redo of a bucket that did not
-// fit its fixed sub-regions, over all the sources set with kt_bulk_set_sources).  *needed = 0: this job has no pre-split.
-namespace {
-template <class K>
-int presplit_typed(kt_ctr *ctr, kt_bulk_job &j, const kt_seg_src *d_srcs, uint32_t n, hipStream_t stream) {
-    const Plan &p = j.p;
-    Plan pa = p;
-    pa.b2 = p.bx;
-    pa.B2 = 1u << p.bx;
-    pa.cap2 = p.room1 / pa.B2 / (128 / sizeof(K)) * (128 / sizeof(K));
-    const P2In in{nullptr, nullptr, d_srcs, n, nullptr};
-    const bool big = (sizeof(K) == 8 ? j.kn.p2_big64 : j.kn.p2_big32) != 0 && Part2Shared<K, true>::bytes(pa.B2) <= 160 * 1024;
-    auto launch = [&](auto bg) -> int {
-        constexpr bool BIG = decltype(bg)::value;
-        const size_t lds = Part2Shared<K, BIG>::bytes(pa.B2);
-        auto fast = part2_fast_kernel<K, BIG, 1>;
-        KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fast, dim3(pa.d_hi - pa.d_lo), dim3(p2t<K, BIG>()), lds, stream, in, pa, (K *)ctr->b_keys2.p, j.m.xstart,
-                           j.m.xend, j.m.fail, j.m.xcarry);
-        KT_HIP(hipGetLastError());
-        return KT_OK;
-    };
-    return big ? launch(std::true_type{}) : launch(std::false_type{});
-}
-}  // namespace
-
-int kt_bulk_presplit_slice(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n, hipStream_t stream, int *needed) {
-    kt_bulk_job *job = ctr->job;
-    if (!job || !job->open || !job->sharded) return kt::fail(KT_ERR_ARG, "bulk build: no sharded job");
-    if (needed) *needed = job->p.bx ? 1 : 0;
-    if (!job->p.bx || !job->p.cap2 || n == 0) return KT_OK;
-    if (job->presplit_srcs + n > job->n_src) return kt::fail(KT_ERR_ARG, "bulk build: more pre-split sources than the job has");
-    job->presplit_lists.emplace_back(srcs, srcs + n);
-    kt_seg_src *d = job->m.xsrcs + job->presplit_srcs;
-    KT_HIP(hipMemcpyAsync(d, job->presplit_lists.back().data(), n * sizeof(kt_seg_src), hipMemcpyHostToDevice, stream));
-    job->presplit_srcs += n;
-    return job->narrow ? presplit_typed<uint32_t>(ctr, *job, d, n, stream) : presplit_typed<uint64_t>(ctr, *job, d, n, stream);
-}
-
-// part2's sources: one per (slice, sender), each the regions of this table's buckets d_lo .. d_hi in bucket order
-int kt_bulk_set_sources(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n) {
-    kt_bulk_job *job = ctr->job;
-    if (!job || !job->open || !job->sharded || n > job->n_src) return kt::fail(KT_ERR_ARG, "bulk build: bad level-2 sources");
-    job->p2_srcs.assign(srcs, srcs + n);
-    return KT_OK;
-}
+int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible) { return plan_job(ctr, max_keys, eligible); }
 
 static int job_add(kt_ctr *ctr, const SourceRec &r, uint64_t bound) {
     kt_bulk_job *job = ctr->job;
@@ -3578,11 +3232,11 @@ int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_off
     return job_add(ctr, r, (seg_hi - seg_lo) * ktseg::SEG);  // at most one k-mer per base
 }
 
-// level 1 over an array of canonical k-mers (KT_EMPTY_KEY entries are skipped); d_n (may be null) = device-side count
-int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n) {
+// level 1 over an array of canonical k-mers (KT_EMPTY_KEY entries are skipped)
+int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys) {
     SourceRec r{};
     r.kind = SRC_KEYS;
-    r.ks = KeysSource{d_keys, n_keys, d_n};
+    r.ks = KeysSource{d_keys, n_keys};
     r.n_units = (n_keys + ktseg::SEG - 1) / ktseg::SEG;
     return job_add(ctr, r, n_keys);
 }
@@ -3700,7 +3354,7 @@ int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int
     int eligible = 0;
     if (int rc = kt_bulk_begin(ctr, n_keys, &eligible)) return rc;
     if (!eligible) return KT_OK;
-    if (int rc = kt_bulk_add_keys(ctr, d_keys, n_keys, nullptr)) return rc;
+    if (int rc = kt_bulk_add_keys(ctr, d_keys, n_keys)) return rc;
     if (int rc = kt_bulk_finish(ctr)) return rc;
     *done = 1;
     return KT_OK;

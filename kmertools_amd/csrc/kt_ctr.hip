@@ -1,6 +1,6 @@
-// kt_ctr.hip - canonical k-mer counting in an HBM-resident table, plus the hash-prefix
-// routing step used when the table is sharded over several GPUs, plus the debug
-// k-mer generator surface (kt_kmers).
+// kt_ctr.hip - canonical k-mer counting in an HBM-resident table, plus the stand-alone hash
+// partition of a batch's k-mers (kt_ctr_route: what the out-of-core passes split by), plus the
+// debug k-mer generator surface (kt_kmers).
 //
 // Replaces CountComputer::count_chunk / merge (reference counter/src/lib.rs:92-234):
 // the reference's n_parts concurrent hash maps, chunked spill to text files and
@@ -61,22 +61,6 @@ __global__ __launch_bounds__(BLOCK) void add_pairs_kernel(const uint64_t *__rest
         const uint32_t c = counts ? counts[i] : 1u;
         if (key == KT_EMPTY_KEY) continue;
         const uint32_t st = table_add(t, key, c);
-        if (st == 0u) atomicOr(t.flags, 1u);
-        fresh += st == 2u;
-    }
-    publish_fresh(fresh, distinct);
-}
-
-// the same for an array whose length is a device-side count (a region of the sharded counter's exchange)
-__global__ __launch_bounds__(BLOCK) void add_keys_counted_kernel(const uint64_t *__restrict__ keys, uint64_t cap,
-                                                                 const uint64_t *__restrict__ n_dev, TableRef t,
-                                                                 uint64_t *__restrict__ distinct) {
-    const uint64_t n = *n_dev < cap ? *n_dev : cap;
-    uint32_t fresh = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
-        const uint64_t key = keys[i];
-        if (key == KT_EMPTY_KEY) continue;
-        const uint32_t st = table_add(t, key, 1u);
         if (st == 0u) atomicOr(t.flags, 1u);
         fresh += st == 2u;
     }
@@ -326,14 +310,14 @@ extern "C" {
 
 }  // extern "C"
 
-// a table with a given geometry: its own (kt_ctr_create), or the ranges of level-1 buckets [bucket_lo, bucket_hi) of a
-// table spread over n_owners GPUs (kt_shard.hip; g.cap = the slots held here, g.range_base = the first range)
-int kt_ctr_create_geom(kt_ctx *ctx, int k, const kttab::Geom &geom, uint32_t n_owners, uint32_t owner, uint32_t owner_bits,
-                       uint32_t bucket_lo, uint32_t bucket_hi, kt_ctr **out) {
+extern "C" {
+
+int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     if (!ctx || !out) return kt::fail(KT_ERR_ARG, "kt_ctr_create: null");
     *out = nullptr;
     if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_ctr_create: k must be in 1..31");
     if (int rc = ctx->use()) return rc;
+    const kttab::Geom geom = kttab::make_geom(capacity_slots);
     const uint64_t cap = geom.cap;
     kt_ctr *c = new (std::nothrow) kt_ctr();
     if (!c) return kt::fail(KT_ERR_NOMEM, "kt_ctr_create: host alloc");
@@ -342,12 +326,6 @@ int kt_ctr_create_geom(kt_ctx *ctx, int k, const kttab::Geom &geom, uint32_t n_o
     c->cap = cap;
     c->shift = geom.shift;
     c->m8 = geom.m8;
-    c->range_base = geom.range_base;
-    c->n_owners = n_owners;
-    c->owner = owner;
-    c->owner_bits = owner_bits;
-    c->bucket_lo = bucket_lo;
-    c->bucket_hi = bucket_hi;
     hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);
@@ -359,12 +337,6 @@ int kt_ctr_create_geom(kt_ctx *ctx, int k, const kttab::Geom &geom, uint32_t n_o
     }
     *out = c;
     return kt_ctr_clear(c);
-}
-
-extern "C" {
-
-int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
-    return kt_ctr_create_geom(ctx, k, kttab::make_geom(capacity_slots), 1, 0, 0, 0, 1, out);
 }
 
 int kt_ctr_destroy(kt_ctr *ctr) {
@@ -536,20 +508,6 @@ int kt_ctr_reload_pairs(kt_ctr *ctr, const uint64_t *d_keys, const uint32_t *d_c
     TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
     hipLaunchKernelGGL(add_pairs_kernel, dim3(grid_for(ctx, (n + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0, ctx->stream,
                        d_keys, d_counts, n, t, ctr->distinct);
-    KT_HIP(hipGetLastError());
-    return KT_OK;
-}
-
-// table[keys[i]] += 1 for i < min(*d_n, cap_keys), through the probing path (kt_shard.hip, when the bulk build
-// does not apply)
-int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_keys, const uint64_t *d_n) {
-    kt_ctx *ctx = ctr->ctx;
-    if (int rc = ctx->use()) return rc;
-    ctr->empty = false;
-    if (int rc = ensure_cleared(ctr)) return rc;
-    TableRef t{(Slot *)ctr->slots, ktl::geom_of(ctr), ctr->flags};
-    hipLaunchKernelGGL(add_keys_counted_kernel, dim3(grid_for(ctx, (cap_keys + BLOCK - 1) / BLOCK, 8)), dim3(BLOCK), 0,
-                       ctx->stream, d_keys, cap_keys, d_n, t, ctr->distinct);
     KT_HIP(hipGetLastError());
     return KT_OK;
 }

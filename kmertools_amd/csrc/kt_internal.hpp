@@ -73,13 +73,12 @@ struct kt_ctx {
     int canon_lut32(int k, const uint32_t **out);
 };
 
-// where level 2 of the partition passes reads a table's level-1 buckets from: the regions of buckets d_lo, d_lo + 1, ...
-// (cap1 keys of room each, `counts` keys used) of one level-1 output (kt_bulk.hip)
+// where level 2 of the partition passes reads a table's level-1 buckets from: the regions of buckets 0, 1, ... (cap1 keys of
+// room each, `counts` keys used) of the level-1 output (kt_bulk.hip)
 struct kt_seg_src {
     const void *keys;
     const uint64_t *counts;
     uint64_t cap1;
-    const uint64_t *starts;  // null: bucket jl at keys + jl * cap1; else at keys + starts[jl] (the pre-split pass's output)
 };
 
 struct kt_bulk_job;  // kt_bulk.hip: the plan and buffers of a partition + range build in progress
@@ -91,11 +90,9 @@ struct kt_ctr {
     uint64_t cap = 0;          // m8 * 2^(n-3) slots (kttab::Geom)
     uint32_t shift = 0;        // 64 - n
     uint32_t m8 = 8;           // eighths of 2^n (slots per 4096-position range / 512)
-    // a shard of a table spread over n_owners GPUs (kt_shard.hip): `shift` addresses the whole table, this counter holds
-    // the ranges of level-1 buckets [bucket_lo, bucket_hi) of 2^owner_bits (range_base = its first range); a table of
-    // its own has n_owners = 1 and all of them
-    uint64_t range_base = 0;
-    uint32_t n_owners = 1, owner = 0, owner_bits = 0, bucket_lo = 0, bucket_hi = 1;
+    // the table of rank `owner` of a counter sharded over n_owners ranks (kt_shard.hip; a table of its own: 1, 0): a whole
+    // table like any other - only kt_cov_batch_part looks at this (a k-mer that is not here may be on another rank)
+    uint32_t n_owners = 1, owner = 0;
     bool paged_failed = false; // a bulk build overflowed a paged level-1 bucket: exact offsets from now on
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export

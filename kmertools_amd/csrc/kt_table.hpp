@@ -13,8 +13,8 @@
 // their successors), and a full table is noticed after at most one trip round a range.  The price is one compare
 // per probe step, and that a range - not the table - must have room: keep distinct keys below ~0.85 of the slots.
 // Tables of fewer than 8192 slots are a single range of `cap` slots.
-// GPU ownership (ktd::owner_of) uses the LOW 32 bits of the same hash, so a shard's keys still spread over
-// its whole table.
+// The hash partitions of the out-of-core passes (ktd::owner_of) use the LOW 32 bits of the same hash, so a
+// partition's keys still spread over the whole table.
 #pragma once
 #include "kt_device.hpp"
 #include "kt_internal.hpp"
@@ -34,11 +34,9 @@ static_assert(sizeof(Slot) == 16, "slot layout");
 constexpr uint32_t LOG2_RANGE = KT_LOG2_RANGE, RANGE_FULL = 1u << LOG2_RANGE;
 
 struct Geom {
-    uint64_t cap;    // slots held HERE: all of the table, or - a shard of a table spread over several GPUs
-                     // (kt_shard.hip) - the ranges [range_base, range_base + cap / range_slots()) of the whole table
-    uint32_t shift;  // 64 - n, n = hash bits that address the WHOLE table
+    uint64_t cap;    // slots
+    uint32_t shift;  // 64 - n, n = hash bits that address the table
     uint32_t m8;     // slots per range / 1024
-    uint64_t range_base = 0;
     // slots of one range (the whole table when it is smaller than a range)
     __host__ __device__ uint32_t range_slots() const {
         return shift > 64 - LOG2_RANGE ? (uint32_t)cap : m8 << (LOG2_RANGE - 3);
@@ -55,7 +53,7 @@ inline Geom make_geom(uint64_t cap_request) {
     uint32_t m8 = 8;
     if (n >= LOG2_RANGE + 2)
         while (m8 > 5 && p / 8 * (m8 - 1) >= cap_request) m8--;
-    return Geom{p / 8 * m8, 64 - n, m8, 0};
+    return Geom{p / 8 * m8, 64 - n, m8};
 }
 
 struct TableRef {
@@ -76,12 +74,11 @@ __host__ __device__ __forceinline__ Probe probe_of(uint64_t key, const Geom &g) 
     const uint64_t x = ktd::khash(key) >> g.shift;  // n <= 54 bits
     if (g.shift > 64 - LOG2_RANGE) return Probe{0, (uint32_t)x, (uint32_t)g.cap};  // one small range, home = x
     const uint32_t rs = g.m8 << (LOG2_RANGE - 3);
-    const uint64_t r = (x >> LOG2_RANGE) - g.range_base;  // (wraps for a key below this shard's ranges)
-    if (r * rs >= g.cap) return Probe{0, 0, 0};           // a key of another shard: a probe sequence of length 0
+    const uint64_t r = x >> LOG2_RANGE;
     return Probe{r * rs, (((uint32_t)x & (RANGE_FULL - 1)) * g.m8) >> 3, rs};
 }
 
-// table[key] += add; returns 0 = the key's range is full (or the key belongs to another shard), 1 = the key was there,
+// table[key] += add; returns 0 = the key's range is full, 1 = the key was there,
 // 2 = the key is new.
 // A slot's key goes EMPTY -> key exactly once, so a stale (cached) probe can only show EMPTY for a slot that is now
 // taken, and the CAS (device scope, coherent across XCDs) settles that case.  A k-mer seen once costs one probing load
@@ -112,10 +109,6 @@ __device__ __forceinline__ uint32_t table_add(const TableRef &t, uint64_t key, u
 
 }  // namespace kttab
 
-// kt_ctr.hip: a table with a given geometry (kt_shard.hip: one GPU's ranges of a table spread over several)
-int kt_ctr_create_geom(kt_ctx *ctx, int k, const kttab::Geom &geom, uint32_t n_owners, uint32_t owner, uint32_t owner_bits,
-                       uint32_t bucket_lo, uint32_t bucket_hi, kt_ctr **out);
-
 // kt_bulk.hip: adds a whole read batch to the table without global atomics (partition by hash prefix, then every
 // range is built - or rebuilt with what it already holds - in LDS).
 // Returns KT_OK, or an error; `*done` = 0 when the batch / table shape is not eligible and
@@ -125,35 +118,14 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
                   uint64_t total_bases, uint32_t n_parts, uint32_t part, int *done);
 // same, from an array of canonical k-mers (one count each; KT_EMPTY_KEY entries are skipped)
 int kt_bulk_build_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, int *done);
-// The same build in phases, for batches that arrive in pieces (the sharded counter's slices, kt_shard.hip):
+// The same build in phases, for batches that arrive in pieces (the sharded counter's records, kt_shard.hip):
 // begin (plan + buffers for at most max_keys k-mers; *eligible = 0: use the probing path), level 1 over any number of
-// sources (segments [seg_lo, seg_hi) of a read batch / arrays of canonical k-mers, optionally with a device-side
-// count), finish (level 2 + range builds; one host round trip).  Sources must stay readable until finish.
+// sources (segments [seg_lo, seg_hi) of a read batch / arrays of canonical k-mers / records), finish (level 2 + range
+// builds; one host round trip).  Sources must stay readable until finish.
 int kt_bulk_begin(kt_ctr *ctr, uint64_t max_keys, int *eligible);
-// The job of the sharded counter (kt_shard.hip): level 1 runs on the GPU that holds the reads - its B1 regions are the
-// messages, the buckets [bucket_lo, bucket_hi) of owner o go to GPU o - and level 2 + the range builds on the GPU that
-// owns the buckets, over one source per (slice, sender).  begin: n_slices level-1 outputs of at most slice_keys k-mers
-// each, n_src sources per bucket, the (small, local) table that counts what does not fit a region.
-// cap1: the room of a level-1 region in THIS job (from the k-mers its batch can hold at most); cap1_max: in any job of the
-// counter (from max_batch_bases) - what the buffers are sized by
-struct kt_bulk_shape { uint32_t B1, d_lo, d_hi; uint64_t cap1; uint32_t key_bytes; uint64_t cap1_max; };
-// keys of room of a level-1 region whose slice holds at most slice_keys k-mers (every rank computes its peers' from the
-// bounds they announce)
-uint64_t kt_bulk_region_room(uint64_t slice_keys, uint32_t B1);
-// slice_keys: the most k-mers a slice of any batch takes (sizes the buffers); slice_keys_now: of this batch (the regions'
-// room, i.e. the size of the messages)
-int kt_bulk_begin_sharded(kt_ctr *ctr, uint64_t slice_keys, uint64_t slice_keys_now, uint32_t n_slices, uint32_t n_src, kt_ctr *pend);
-int kt_bulk_slice_reads(kt_ctr *ctr, uint32_t slice, const uint8_t *d_bases, const uint64_t *d_offsets,
-                        const uint64_t *seg_first, uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi);
-int kt_bulk_slice_done(kt_ctr *ctr, uint32_t slice);
-int kt_bulk_slice_info(kt_ctr *ctr, uint32_t slice, uint32_t bucket, kt_bulk_shape *shape, void **keys, uint64_t **counts);
-int kt_bulk_set_sources(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n);
-// the shard's pre-split (the hash bits level 2 cannot take: N >= 4 GPUs) over ONE slice's sources, enqueued on `stream`
-// as soon as the slice's blocks are in - its cursors carry on from the slices before; kt_bulk_finish then skips that pass
-int kt_bulk_presplit_slice(kt_ctr *ctr, const kt_seg_src *srcs, uint32_t n, hipStream_t stream, int *needed);
 int kt_bulk_add_reads(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets, const uint64_t *seg_first,
                       uint64_t n_reads, uint64_t n_seg, uint64_t seg_lo, uint64_t seg_hi, uint32_t n_parts, uint32_t part);
-int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys, const uint64_t *d_n);
+int kt_bulk_add_keys(kt_ctr *ctr, const uint64_t *d_keys, uint64_t n_keys);
 // level 1 over records of at most 8 consecutive k-mers (kt_superkmer.hpp; what the ranks of the sharded counter send
 // each other): n_runs stretches of whole blocks in device memory (`runs`: host array); kmers_bound = 0: the job was
 // planned for everything these sources hold
@@ -162,8 +134,6 @@ int kt_bulk_add_records(kt_ctr *ctr, const ktsk::RecRun *runs, uint32_t n_runs, 
 // ... and the same records through the probing path (one table_add per k-mer), outside any job
 int kt_ctr_count_records(kt_ctr *ctr, const ktsk::RecRun *runs, uint32_t n_runs);
 int kt_bulk_finish(kt_ctr *ctr);
-// kt_ctr.hip: one count for each of the first min(*d_n, cap_keys) keys of an array, through the probing path
-int kt_ctr_add_keys_counted(kt_ctr *ctr, const uint64_t *d_keys, uint64_t cap_keys, const uint64_t *d_n);
 // A fresh bulk build leaves the table DENSE: every range holds its entries packed at the front of its slots
 // (kt_ctr.range_counts says how many) instead of a probing image - all that size / export need.  kt_table_image turns
 // it into the probing layout in place (called by whatever has to probe: incremental adds, merges, cov);

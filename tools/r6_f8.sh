@@ -10,7 +10,7 @@ python3 - $out <<'PY'
 import csv, sys, json
 out = sys.argv[1]
 try:
-    j = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
+    j = json.loads([ln for ln in open(out + "/bench.json").read().splitlines() if ln.startswith("{")][-1])
     print("ms_per_step %.3f value %.2f exchanged %s" % (j["ms_per_step"], j["value"], j.get("exchanged_bytes_per_rank")))
 except Exception as e:
     print("no bench line:", e)

@@ -17,4 +17,6 @@ PY
 }
 # NOTE: rocprofv3 must launch python3 directly; env vars are exported instead of using `env`
 run base
-run grid16 KT_ROUTE_GRID=16
+run rw5 KT_LIB=$GRAFT_REPO_ROOT/kmertools_amd/variants/librw5.so KT_ROUTE_GRID=20
+run rw6 KT_LIB=$GRAFT_REPO_ROOT/kmertools_amd/variants/librw6.so KT_ROUTE_GRID=20
+run g32 KT_ROUTE_GRID=32
