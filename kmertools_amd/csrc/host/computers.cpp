@@ -1155,9 +1155,9 @@ std::string CovComputer::compute_coverages() {
         return "";
     }
     if (ctr_ && ctr_->n_shards() > 0) {
-        // --devices N: the table is N shards on N GPUs, each answering for the k-mers of its hash prefixes only.  Every
+        // --devices N: the table is N shards on N GPUs, each holding the k-mers whose minimiser it owns.  Every
         // batch of reads goes past every shard - one thread per shard, each adding raw bin counts to rows of its own
-        // (kt_cov_batch_part skips the k-mers of the other shards) -, the shards' rows are summed, normalised with one
+        // (kt_cov_batch_part: a k-mer a shard does not hold may be on another) -, the shards' rows are summed, normalised with one
         // division per cell and written: every k-mer of every read has been binned exactly once (the reference looks the
         // k-mers up in one map, coverage/src/lib.rs:165-184; its CountComputer built that map out of partitions the same way)
         const size_t N = ctr_->n_shards();
@@ -1195,7 +1195,7 @@ std::string CovComputer::compute_coverages() {
                 for (uint64_t r = 0; r < n; r++) {
                     uint64_t total = 0;
                     for (uint64_t i = 0; i < bins; i++) {
-                        uint64_t c = 0;
+                        uint32_t c = 0;  // (modulo 2^32: a shard's own cells mean nothing before they are summed - kt_cov_batch_part)
                         for (size_t sh = 0; sh < N; sh++) c += part[sh][r * bins + i];
                         w.rows[r * bins + i] = (double)c;
                         total += c;
