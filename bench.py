@@ -598,6 +598,11 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     if wl["kind"] == "ctr":
         extra["distinct_rank0"] = state["distinct"] if not args.no_export else counter.size_local()
         extra["table_slots_rank0"] = counter.table.capacity()
+        if world > 1 or os.environ.get("KT_SHARD_FORCE"):
+            rec, km = counter.sharded.route_stats()   # (rank 0's last batch: what went into every owner's region)
+            if len(km) and km.sum():
+                extra["route"] = {"owners": int(len(km)), "records": int(rec.sum()), "kmers_per_record": round(float(km.sum()) / max(1, int(rec.sum())), 3),
+                                  "owner_kmers_max_over_mean": round(float(km.max()) / float(km.mean()), 4)}
         if world == 1 and os.environ.get("KT_SHARD_FORCE"):
             extra["exchanged_bytes_per_rank"] = counter.sharded.exchanged_bytes() // (steps + warmup + ramp)
             extra["exchanged_bytes_note"] = ("one rank routing into KT_SHARD_FORCE owners' regions: the bytes of the regions a "

@@ -359,6 +359,11 @@ int kt_sharded_table(kt_sharded *s, kt_ctr **table);
  * bytes of the regions a rank of n would have sent) */
 int kt_sharded_exchanged_bytes(kt_sharded *s, uint64_t *bytes);
 
+/* what the route pass of this rank's LAST batch put into every owner's region: records[o] records holding kmers[o] k-mers
+ * (arrays of 64; *n_owners = the owners: n_ranks, or KT_SHARD_FORCE's regions of a single rank).  max / mean of kmers[]
+ * over the owners is the imbalance the minimiser ownership costs.  (no reference counterpart: statistics) */
+int kt_sharded_route_stats(kt_sharded *s, uint32_t *n_owners, uint64_t *records, uint64_t *kmers);
+
 /* what carries the exchange: *n_ranks = the ranks this counter was created for; *rccl_ranks = what the library's own
  * RCCL communicator reports (ncclCommCount on the communicator kt_sharded_connect_rccl made; 0 when the transport is the
  * caller's host all-to-all or the counter has a single rank and no communicator); *transport = 0 none (one rank, no

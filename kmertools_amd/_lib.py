@@ -76,6 +76,7 @@ SYMBOLS = {
     "kt_sharded_connect_rccl": (_i, [_vp, _vp]),
     "kt_sharded_connect_host": (_i, [_vp, _vp, _vp]),
     "kt_sharded_owner_of": (_i, [_vp, _u64, C.POINTER(_u32)]),
+    "kt_sharded_route_stats": (_i, [_vp, C.POINTER(_u32), _vp, _vp]),
     "kt_shard_minimiser": (_i, [_i, C.POINTER(_u32), C.POINTER(_u32)]),
     "kt_shard_owner_of": (_u32, [_u64, _i, _u32]),
     "kt_synth_reads": (_i, [_vp, _u64, _u64, _u64, _u32, _i, _u64, _vp, _vp]),

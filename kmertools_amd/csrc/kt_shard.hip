@@ -478,6 +478,7 @@ struct kt_sharded {
     size_t h_bytes = 0;
     uint64_t exchanged_bytes = 0;  // sent to other ranks so far (statistics; a forced single rank: what would have left)
     uint64_t add_calls = 0;        // kt_sharded_add_reads calls so far (tests: KT_SHARD_FAIL_LOCAL)
+    std::vector<uint64_t> last_records, last_kmers;  // what the last batch's route pass put into every owner's region
     uint64_t *region(uint64_t *buf, int o) const { return buf + (uint64_t)o * region_words; }
 };
 
@@ -793,6 +794,16 @@ int kt_sharded_comm_info(kt_sharded *s, int *n_ranks, int *rccl_ranks, int *tran
     return KT_OK;
 }
 
+int kt_sharded_route_stats(kt_sharded *s, uint32_t *n_owners, uint64_t *records, uint64_t *kmers) {
+    if (!s) return kt::fail(KT_ERR_ARG, "kt_sharded_route_stats: null");
+    if (n_owners) *n_owners = (uint32_t)s->n_owners;
+    for (size_t o = 0; o < (size_t)s->n_owners; o++) {
+        if (records) records[o] = o < s->last_records.size() ? s->last_records[o] : 0;
+        if (kmers) kmers[o] = o < s->last_kmers.size() ? s->last_kmers[o] : 0;
+    }
+    return KT_OK;
+}
+
 int kt_shard_minimiser(int k, uint32_t *m, uint32_t *w) {
     if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_shard_minimiser: k must be in 1..31");
     if (m) *m = ktsk::mmer_of((uint32_t)k);
@@ -905,6 +916,8 @@ int kt_sharded_add_reads(kt_sharded *s, const uint8_t *bases, const uint64_t *of
             fill[(size_t)o] = h_cur[(size_t)o] < s->room ? h_cur[(size_t)o] : s->room;
             kmers[(size_t)o] = h_cur[ktsk::MAX_OWNERS + (size_t)o];
         }
+    s->last_records.assign(h_cur.begin(), h_cur.begin() + V);  // (statistics: kt_sharded_route_stats)
+    s->last_kmers = kmers;
     // ---- can everybody go on, and how much will each send each?  go word p -> rank p: [0] status (0 = fine), [1] records for
     // rank p, [2] their k-mers at most, [3] the room of a region here (all ranks must have made their counters alike),
     // [4] the most records this rank sends any peer (the host transport's equal blocks: every rank takes the largest)

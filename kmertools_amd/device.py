@@ -522,6 +522,14 @@ class Sharded:
         check(_lib.lib().kt_sharded_exchanged_bytes(self._h, C.byref(n)))
         return n.value
 
+    def route_stats(self):
+        """-> (records, kmers): numpy arrays per owner, what the last batch's route pass put into every owner's region"""
+        n = C.c_uint32()
+        rec = np.zeros(64, np.uint64)
+        km = np.zeros(64, np.uint64)
+        check(_lib.lib().kt_sharded_route_stats(self._h, C.byref(n), rec.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p)))
+        return rec[:n.value], km[:n.value]
+
     def comm_info(self):
         """-> dict(n_ranks, rccl_ranks, transport): rccl_ranks is ncclCommCount of the library's own communicator
         (0 without one), transport "none" / "rccl" / "host" (kt_sharded_comm_info)"""

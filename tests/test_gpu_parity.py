@@ -1881,6 +1881,59 @@ def test_ctr_cfg4_per_gpu_shard_properties(torch_mod, ctx, oracle):
     assert int((k2 ^ (k2 >> 29)).sum()) == int((keys ^ (keys >> 29)).sum())
 
 
+def test_ctr_cfg4_routed_into_8_owners_full_size(torch_mod, ctx, oracle, monkeypatch):
+    """BASELINE cfg4's geometry on one GPU: a rank's 25 M x 150 bp reads routed into the regions of 8 owners (KT_SHARD_FORCE=8:
+    what one rank of eight does - route pass, the regions counted piece by piece by the single-GPU pipeline over records), all
+    of them counted here.  What a rank of eight would have put on the wires - 7 of the 8 regions, whole blocks - is under
+    5 GB (the raw k-mers were 21 GB); every k-mer instance is counted once; the table equals the one the
+    ordinary path builds from the same reads (order-independent exact checksums over all 3 G entries); a 1 M-read sub-batch
+    counted by the oracle is in it; the owners' regions are balanced"""
+    from kmertools_amd import device
+    torch = torch_mod
+    n, L, k, seed = 25_000_000, 150, 31, 0x6b6d6572 + 3
+    kpr = L - k + 1
+    torch.cuda.empty_cache()
+    bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads(seed, n, L, bases, offsets)
+    monkeypatch.setenv("KT_SHARD_FORCE", "8")
+    sh = device.Sharded(ctx, k, int(1.9 * n * kpr), n * L, 1, 0, None)
+    keys = torch.empty(n * kpr, dtype=torch.int64, device="cuda")
+    counts = torch.empty(n * kpr, dtype=torch.int32, device="cuda")
+    sh.table.export_target(keys, counts, n * kpr)
+    sh.add_reads(bases, offsets, n)
+    sh.finalize()
+    sent = sh.exchanged_bytes()
+    assert 0 < sent <= 5_000_000_000, sent
+    assert 1.4 < sent / (n * kpr * 7 / 8) < 2.0   # ~1.7 bytes per k-mer on the wires (8 as raw keys), 7 of the 8 regions
+    distinct = sh.table.size()
+    assert sh.table.export(keys, counts, n * kpr) == distinct
+    assert 0.99 * n * kpr < distinct <= n * kpr
+    assert int(counts[:distinct].to(torch.int64).sum()) == n * kpr
+    ka, ca = keys[:distinct], counts[:distinct].to(torch.int64)
+    sums = (int((ka * ca).sum()), int((ka ^ (ka >> 29)).sum()), int(ca.sum()))
+    # a sub-batch against the oracle, looked up where the routed table has it
+    sub = 1_000_000
+    hb, ho = oracle.synth_reads(seed, sub, L, first_read=7_000_000)
+    wk, wc = oracle.count_reads(hb, ho, k, n_parts=64, threads=8)
+    dk = torch.from_numpy(wk.view(np.int64).copy()).cuda()
+    got = torch.zeros(len(wk), dtype=torch.int32, device="cuda")
+    sh.table.lookup(dk, len(wk), got)
+    assert bool((got >= torch.from_numpy(wc.astype(np.int32)).cuda()).all())
+    del dk, got
+    sh.close()
+    # the same reads through the ordinary path: the same table
+    monkeypatch.delenv("KT_SHARD_FORCE")
+    ctr = device.Counter(ctx, k, int(1.9 * n * kpr))
+    ctr.export_target(keys, counts, n * kpr)
+    ctr.add_reads(bases, offsets, n)
+    d2 = ctr.size()
+    assert ctr.export(keys, counts, n * kpr) == d2 == distinct
+    ka, ca = keys[:d2], counts[:d2].to(torch.int64)
+    assert sums == (int((ka * ca).sum()), int((ka ^ (ka >> 29)).sum()), int(ca.sum()))
+    ctr.close()
+
+
 def test_quotient_exhaustive(hctx):
     """the reciprocal + fma normalisation against the IEEE division for every count / divisor pair a read of up to
     32 768 k-mers can produce (total_step 1 and 2: d = total_step * kmers, c <= kmers), and the device division
