@@ -98,6 +98,7 @@ struct Plan {
                           // XCC_ID appends to (eight nibbles)
     uint32_t dbg;     // KT_BUILD_DBG: ablation switches of build_kernel (profiling only)
     uint32_t lists;   // the dense build's LDS has room for the claim lists behind the image (build_kernel)
+    uint32_t kbits;   // 2k for k <= 16 (the table's hash is the bijection ktd::nhash), else 0
 };
 
 template <class K>
@@ -127,7 +128,7 @@ __device__ __forceinline__ uint32_t digit1h(uint64_t h, const Plan &p) { return 
 __device__ __forceinline__ uint32_t digit2h(uint64_t h, const Plan &p) {
     return ((uint32_t)(h >> 32) >> (32 - p.b1 - p.b2)) & (p.B2 - 1);
 }
-__device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) { return digit1h(ktd::khash(key), p); }
+__device__ __forceinline__ uint32_t digit1(uint64_t key, const Plan &p) { return digit1h(ktd::khash_k(key, p.kbits), p); }
 // What travels through the partition passes ("stored form" of a canonical k-mer): 64-bit keys travel as
 // khash(key) - the hash is a bijection (an odd multiply and an xor of the high half into the low half), so the
 // digits and the home slot of every later pass are bit fields of what is already there and the key comes back once,
@@ -144,9 +145,9 @@ __device__ __forceinline__ K to_stored(uint64_t key) {
     else return (K)key;
 }
 template <class K>
-__device__ __forceinline__ uint64_t hash_of_stored(K s) {
+__device__ __forceinline__ uint64_t hash_of_stored(K s, const Plan &p) {
     if constexpr (stores_hash<K>()) return (uint64_t)s;
-    else return ktd::khash((uint64_t)s);
+    else return ktd::khash_k((uint64_t)s, p.kbits);
 }
 template <class K>
 __device__ __forceinline__ uint64_t from_stored(K s) {
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, uin
             {  // (the keys take their stored form here, where the first digit is needed)
                 keys[half * PERR + j] = (uint64_t)to_stored<K>(keys[half * PERR + j]);
                 if ((ok >> (half * PERR + j)) & 1u)
-                    atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>((K)keys[half * PERR + j]), p)], 1u);
+                    atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>((K)keys[half * PERR + j], p), p)], 1u);
             }
             ktd::lds_barrier();
             const uint32_t nk = block_excl_scan(sm.cnt, sm.start, p.B1, sm.tmp);
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(BLOCK) void scatter1_kernel(Source src, Plan p, uin
             for (int j = 0; j < PERR; j++) {
                 if ((ok >> (half * PERR + j)) & 1u) {
                     const uint64_t m = keys[half * PERR + j];
-                    const uint32_t d = digit1h(hash_of_stored<K>((K)m), p);
+                    const uint32_t d = digit1h(hash_of_stored<K>((K)m, p), p);
                     const uint32_t pos = atomicAdd(&sm.fill[d], 1u);
                     sm.sorted[pos] = (K)m;
                     sm.sdig[pos] = (uint16_t)d;
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
 #pragma unroll
             for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
                 keys[j] = to_stored<K>((uint64_t)keys[j]);
-                if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>(keys[j]), p)], 1u);
+                if ((ok >> j) & 1u) atomicAdd(&sm.cnt[digit1h(hash_of_stored<K>(keys[j], p), p)], 1u);
             }
             KT_PH(1);
             ktd::lds_barrier();
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
 #pragma unroll
             for (int j = 0; j < PER; j++) {
                 if ((ok >> j) & 1u) {
-                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j], p), p);
                     const uint32_t pos = atomicAdd(&sm.start[d], 1u);
                     sm.sorted[pos] = keys[j];
                 }
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
                 const uint32_t i = m << GSH;
                 live = i < nk;
                 const K first = sm.sorted[live ? i : 0u];
-                d = digit1h(hash_of_stored<K>(first), p);  // (one shift of a stored hash; 32-bit keys are hashed again)
+                d = digit1h(hash_of_stored<K>(first, p), p);  // (one shift of a stored hash; 32-bit keys are hashed again)
                 at = xcd_place<K>((uint64_t)(uint32_t)(sm.delta[d] + i), xset, p.nxs);
             };
             if (!skip) {
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
         const K *const sb = sm.sorted[pp];
         const raw4 v = *reinterpret_cast<const raw4 *>(&sb[live ? i : 0u]);
         const K first = sb[live ? i : 0u];
-        const uint32_t d = digit1h(hash_of_stored<K>(first), p);
+        const uint32_t d = digit1h(hash_of_stored<K>(first, p), p);
         // xcd_place in 32 bits (the line index of a stream that ran 2^32 keys past its room still fits), one 64-bit multiply-add
         // for the place in the key array: the general form - two 64-bit shifts, a 64-bit compare, two multiply-adds - is a
         // fifth of the kernel's issue cycles, five times per thread and round
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
             for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
                 keys[j] = to_stored<K>((uint64_t)keys[j]);
                 if ((ok >> j) & 1u) {
-                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j], p), p);
                     if constexpr (PACK) atomicAdd(&sm.cnt2[d >> 1], 1u << ((d & 1u) * 16u));
                     else atomicAdd(&sm.cnt2[d], 1u);
                 }
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
 #pragma unroll
             for (int j = 0; j < PER; j++) {
                 if ((ok >> j) & 1u) {
-                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j]), p);
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j], p), p);
                     const uint32_t pos = atomicAdd(&xs[d], 1u);
                     sb[pos] = keys[j];
                 }
@@ -1349,7 +1350,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
                     uint32_t *const cntc = sm.cnt + par * p.B2, *const cntn = sm.cnt + (par ^ 1u) * p.B2;
 #pragma unroll
                     for (int u = 0; u < PER; u++) {
-                        const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
+                        const uint32_t d = digit2h(hash_of_stored<K>(kcur[u], p), p);
                         if (kcur[u] != EMPTY) atomicAdd(&cntc[d], 1u);
                     }
                     ktd::lds_barrier();
@@ -1367,7 +1368,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
 #pragma unroll
                         for (int u = 0; u < PER; u++) {
                             if (kcur[u] != EMPTY) {
-                                const uint32_t d = digit2h(hash_of_stored<K>(kcur[u]), p);
+                                const uint32_t d = digit2h(hash_of_stored<K>(kcur[u], p), p);
                                 const uint32_t pos = atomicAdd(&sm.start[d], 1u);
                                 sm.sorted[pos] = kcur[u];
                                 if constexpr (p2_sdig<K, BIG>()) sm.sdig[pos] = (uint16_t)d;
@@ -1379,7 +1380,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
                             const K key = sm.sorted[i];
                             uint32_t d;
                             if constexpr (p2_sdig<K, BIG>()) d = sm.sdig[i];
-                            else d = digit2h(hash_of_stored<K>(key), p);
+                            else d = digit2h(hash_of_stored<K>(key, p), p);
                             const uint64_t pos = lo + (uint32_t)(cntc[d] + i);
                             if (!attempt || pos < lo + (uint64_t)(d + 1) * p.cap2) keys2[pos] = key;
                         }
@@ -1447,7 +1448,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++)
-                        if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2h(hash_of_stored<K>(kk[u]), p)], 1u);
+                        if (kk[u] != EMPTY) atomicAdd(&sm.cnt[digit2h(hash_of_stored<K>(kk[u], p), p)], 1u);
                 }
             }
             ktd::lds_barrier();
@@ -1499,7 +1500,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
     const uint32_t tid = threadIdx.x;
     const uint32_t nd = p.B1;
     const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 32 - p.b1 - p.b2;  // (in the hash's high word: digit2h)
-    auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored) >> 32) >> dshift) & (B2 - 1u); };
+    auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored, p) >> 32) >> dshift) & (B2 - 1u); };
     for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
         const uint32_t n_seg = in.n_src;
         auto segment = [&](uint32_t sidx, const K *&base, uint64_t &n) {
@@ -1741,7 +1742,7 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
     const uint32_t tid = threadIdx.x;
     const uint32_t nd = p.B1;
     const uint32_t B2 = p.B2, cap2 = (uint32_t)p.cap2, dshift = 32 - p.b1 - p.b2;  // (in the hash's high word: digit2h)
-    auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored) >> 32) >> dshift) & (B2 - 1u); };
+    auto digit = [&](K stored) -> uint32_t { return ((uint32_t)(hash_of_stored<K>(stored, p) >> 32) >> dshift) & (B2 - 1u); };
     const uint32_t grp = tid / GL, gl = tid % GL;       // the line group this thread belongs to, its lane in it
     for (uint32_t jl = blockIdx.x; jl < nd; jl += gridDim.x) {
         const uint32_t n_seg = in.n_src;
@@ -2037,7 +2038,12 @@ struct ExtOut {
 #ifndef KT_BUILD_SGPRS
 #define KT_BUILD_SGPRS 80
 #endif
-template <class K, bool MERGE, bool DENSE, bool EXT = false>
+// DIRECT (32-bit keys, a fresh dense build of a table with exactly 4^k slots, i.e. n = 2k hash bits: plan_job): the
+// table's hash is a bijection of the k-mers onto the slots (ktd::nhash), so a range's image is its COUNTERS alone - a key
+// is one LDS add at the low 13 bits of its hash, no key stored, no compare, no probe chain, no lane waiting for another
+// lane's chain - and the entries come out of the counters that are not zero: key = nhash_inv(range's bits | index).
+// (the reference's `table[kmer] += 1`, counter/src/lib.rs:126-130)
+template <class K, bool MERGE, bool DENSE, bool EXT = false, bool DIRECT = false>
 __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SGPRS), amdgpu_waves_per_eu(8, 8))) void build_kernel(const K *__restrict__ keys2,
                                                         const uint64_t *__restrict__ fstart,
                                                         const uint64_t *__restrict__ fend, Plan p,
@@ -2049,6 +2055,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
                                                         uint32_t *__restrict__ range_counts, ExtOut xo) {
     static_assert(!(MERGE && DENSE), "a dense build starts from an empty table");
     static_assert(!EXT || DENSE, "only a dense build writes to the export arrays");
+    static_assert(!DIRECT || (DENSE && sizeof(K) == 4), "the direct build: 32-bit keys, dense");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using W = typename lds_word<K>::type;
     constexpr K EMPTY = empty_of<K>();
@@ -2132,17 +2139,37 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             }
         } else if (dirty) {
             for (uint32_t i = tid; i < RS; i += BUILD_T) {
-                skeys[i] = EMPTY;
+                if (!DIRECT) skeys[i] = EMPTY;
                 scounts[i] = 0;
             }
         }
-        const bool listed = DENSE && p.lists != 0 && hi - lo <= LIST_KEYS && hi - lo <= RS;  // (workgroup uniform)
+        const bool listed = !DIRECT && DENSE && p.lists != 0 && hi - lo <= LIST_KEYS && hi - lo <= RS;  // (workgroup uniform)
         KT_PH(0);
         if (MERGE || dirty) ktd::lds_barrier();  // (a listed range leaves the image empty behind its end barrier)
         KT_PH(1);
         uint32_t wc = 0;  // DENSE: entries of this wave - listed: the claims of its lanes; else: counted by the pack pass
         uint32_t m0 = ~0u, m1 = ~0u;  // listed: the slots this lane has claimed (all ones: none)
-        {
+        if constexpr (DIRECT) {
+            // every key of the range: one LDS add at the low 13 bits of its hash (RS = 8192: m8 = 8).  Four keys per lane in
+            // flight, the first four requested a range ahead (head[])
+            const uint32_t sh32 = 32u - p.kbits;  // (hash_of_stored's word >> (64 - n), n = kbits: the hash itself)
+            auto bump = [&](K key) {
+                if (key != EMPTY) atomicAdd(&scounts[ktd::nhash((uint32_t)key, p.kbits) & (S - 1u)], 1u);
+            };
+            (void)sh32;
+            uint64_t bbase = lo;
+            for (;;) {
+                const bool more = bbase + 4ull * BUILD_T < hi;  // (workgroup uniform)
+                K nxt[4] = {EMPTY, EMPTY, EMPTY, EMPTY};
+                if (more) load_head(bbase + 4ull * BUILD_T, hi, nxt);
+#pragma unroll
+                for (int u = 0; u < 4; u++) bump(head[u]);
+                if (!more) break;
+                bbase += 4ull * BUILD_T;
+#pragma unroll
+                for (int u = 0; u < 4; u++) head[u] = nxt[u];
+            }
+        } else {
             // Every lane runs its own insert state machine over its keys (lo + tid, + BUILD_T, ...): one probe per
             // trip (the CAS itself reports what the slot holds), and a lane that has placed its key moves on to its
             // next one at once.  ("For each key: probe until placed" makes the wave wait for its longest probe chain on
@@ -2165,7 +2192,7 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             // (which of the two forms applies is the table's size: decided outside the loop, insert_batch's HI - left to
             // the compiler it is a scalar compare and two branches on every trip)
             auto hword = [&](K stored, auto hi_only) -> uint32_t {
-                const uint64_t h = hash_of_stored<K>(stored);
+                const uint64_t h = hash_of_stored<K>(stored, p);
                 const uint32_t hi32 = (uint32_t)(h >> 32), lo32 = (uint32_t)h;
                 if constexpr (decltype(hi_only)::value) return hi32 >> (sh3 - 32);
                 else return __builtin_amdgcn_alignbit(hi32, lo32, sh3);
@@ -2274,8 +2301,16 @@ __global__ __launch_bounds__(BUILD_T) __attribute__((amdgpu_num_sgpr(KT_BUILD_SG
             if (!listed) {
                 for (uint32_t i0 = 0; i0 < share; i0 += 64) {
                     const uint32_t i = wave * share + i0 + lane;
-                    const K kk = skeys[i];
-                    const uint32_t cc = scounts[i];
+                    K kk;
+                    uint32_t cc;
+                    if constexpr (DIRECT) {  // a counter that is not zero is an entry: its key from the slot's index
+                        const uint32_t c1 = scounts[i];
+                        cc = c1 - 1u;        // (stored: occurrences - 1, like the probing builds)
+                        kk = c1 ? (K)ktd::nhash_inv(((uint32_t)fb << LOG2_S) | i, p.kbits) : EMPTY;
+                    } else {
+                        kk = skeys[i];
+                        cc = scounts[i];
+                    }
                     const uint64_t bal = __ballot(kk != EMPTY);
                     if (kk != EMPTY) {
                         const uint32_t at = wave * share + wc + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
@@ -2548,7 +2583,7 @@ __global__ __launch_bounds__(BLOCK) void spill_insert_kernel(const uint64_t *__r
 // dense -> image, in place: one workgroup per range reads the range's packed entries, inserts them into the LDS image
 // (distinct keys: plain CAS probing, counts carried along) and writes the whole range
 __global__ __launch_bounds__(BUILD_T) void materialize_kernel(Slot *__restrict__ slots, uint32_t RS, uint64_t n_ranges,
-                                                              uint32_t shift, uint32_t m8,
+                                                              uint32_t shift, uint32_t m8, uint32_t kbits,
                                                               const uint32_t *__restrict__ range_counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *const skeys = reinterpret_cast<unsigned long long *>(smem_raw);
@@ -2567,7 +2602,7 @@ __global__ __launch_bounds__(BUILD_T) void materialize_kernel(Slot *__restrict__
         for (uint32_t i = tid; i < D; i += BUILD_T) {
             const uint64_t key = dkeys[i];
             const uint32_t cnt = dcounts[i];
-            uint32_t s = (((uint32_t)(ktd::khash(key) >> shift) & (S - 1)) * m8) >> 3;
+            uint32_t s = (((uint32_t)(ktd::khash_k(key, kbits) >> shift) & (S - 1)) * m8) >> 3;
             while (atomicCAS(&skeys[s], (unsigned long long)KT_EMPTY_KEY, (unsigned long long)key) != KT_EMPTY_KEY)
                 s = s + 1 == RS ? 0 : s + 1;  // (D <= RS: a free slot exists)
             scounts[s] = cnt;
@@ -2701,7 +2736,7 @@ static int with_source(const SourceRec &r, F &&f) {
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, build_wgs_ext, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
+        verbose, ext_ovf_blocks, build_wgs_ext, direct, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2723,6 +2758,7 @@ static BulkKnobs read_knobs() {
     k.build_wgs_ext = env_u64("KT_BUILD_WGS_EXT", 16);
     k.build_lists = env_u64("KT_BUILD_LISTS", 1);  // 0: the dense build packs the image instead of keeping claim lists (A/B)
     k.dense = env_u64("KT_BULK_DENSE", 1);
+    k.direct = env_u64("KT_BUILD_DIRECT", 1);  // 0: tables of exactly 4^k slots are built by probing too (A/B, tests)
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
     k.ext_ovf_blocks = env_u64("KT_EXT_OVF_BLOCKS", 0);  // tests: n + 1 = blocks of scratch behind the export target
     return k;
@@ -2937,6 +2973,11 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
                      : to_ext ? build_kernel<K, false, true, true>
                      : dense  ? build_kernel<K, false, true>
                               : build_kernel<K, false, false>;
+        if constexpr (sizeof(K) == 4) {
+            // a table of exactly 4^k slots: the hash is a bijection onto them, the ranges' images are counters alone
+            if (dense && !j.merge && j.kn.direct && p.kbits && p.n == p.kbits && p.m8 == 8)
+                build = to_ext ? build_kernel<K, false, true, true, true> : build_kernel<K, false, true, false, true>;
+        }
         KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(build), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)build_lds));
         hipLaunchKernelGGL(build, dim3((uint32_t)gb), dim3(BUILD_T), build_lds, ctx->stream, (const K *)keys2, m.fstart,
@@ -3083,6 +3124,7 @@ static int plan_job(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     const size_t ksz = j.narrow ? 4 : 8;
     Plan p{};
     p.n = 64 - ctr->shift;
+    p.kbits = ctr->kbits;
     p.m8 = ctr->m8;
 #if KT_ABLATION
     p.dbg = (uint32_t)env_u64("KT_BUILD_DBG", 0);  // bits 0-7: build_kernel, 8-11: part2, 12-15: scatter1x
@@ -3377,7 +3419,7 @@ int kt_table_image(kt_ctr *ctr) {
     uint64_t g = (uint64_t)ctx->n_cu * 4;
     if (g > n_ranges) g = n_ranges;
     hipLaunchKernelGGL(materialize_kernel, dim3((uint32_t)g), dim3(BUILD_T), lds, ctx->stream, (Slot *)ctr->slots, RS, n_ranges,
-                       ctr->shift, ctr->m8, ctr->range_counts);
+                       ctr->shift, ctr->m8, ctr->kbits, ctr->range_counts);
     KT_HIP(hipGetLastError());
     ctr->dense = false;
     return KT_OK;

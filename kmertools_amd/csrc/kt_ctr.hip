@@ -317,7 +317,7 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     *out = nullptr;
     if (k < 1 || k > 31) return kt::fail(KT_ERR_ARG, "kt_ctr_create: k must be in 1..31");
     if (int rc = ctx->use()) return rc;
-    const kttab::Geom geom = kttab::make_geom(capacity_slots);
+    const kttab::Geom geom = kttab::make_geom(capacity_slots, k);
     const uint64_t cap = geom.cap;
     kt_ctr *c = new (std::nothrow) kt_ctr();
     if (!c) return kt::fail(KT_ERR_NOMEM, "kt_ctr_create: host alloc");
@@ -326,6 +326,7 @@ int kt_ctr_create(kt_ctx *ctx, int k, uint64_t capacity_slots, kt_ctr **out) {
     c->cap = cap;
     c->shift = geom.shift;
     c->m8 = geom.m8;
+    c->kbits = geom.kbits;
     hipError_t e = hipMalloc((void **)&c->slots, cap * sizeof(Slot));
     if (e == hipSuccess) e = hipMalloc((void **)&c->flags, 64);
     if (e == hipSuccess) e = hipMalloc((void **)&c->cursor, 64);

@@ -90,6 +90,7 @@ struct kt_ctr {
     uint64_t cap = 0;          // m8 * 2^(n-3) slots (kttab::Geom)
     uint32_t shift = 0;        // 64 - n
     uint32_t m8 = 8;           // eighths of 2^n (slots per 4096-position range / 512)
+    uint32_t kbits = 0;        // 2k when k <= 16: the table's hash is the bijection ktd::nhash (kttab::Geom)
     // the table of rank `owner` of a counter sharded over n_owners ranks (kt_shard.hip; a table of its own: 1, 0): a whole
     // table like any other - only kt_cov_batch_part looks at this (a k-mer that is not here may be on another rank)
     uint32_t n_owners = 1, owner = 0;

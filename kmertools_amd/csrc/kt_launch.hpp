@@ -18,7 +18,7 @@ int total_bases_of(kt_ctx *ctx, const uint64_t *offsets, uint64_t n_reads, int m
 int stage_batch(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                 const uint8_t **d_bases, const uint64_t **d_offsets);
 // the table's geometry as the device functions take it (kt_table.hpp)
-inline kttab::Geom geom_of(const kt_ctr *ctr) { return kttab::Geom{ctr->cap, ctr->shift, ctr->m8}; }
+inline kttab::Geom geom_of(const kt_ctr *ctr) { return kttab::Geom{ctr->cap, ctr->shift, ctr->m8, ctr->kbits}; }
 // makes the table readable: performs a deferred clear, reports KT_ERR_FULL if it overflowed
 int table_ready(kt_ctr *ctr);
 

@@ -37,13 +37,14 @@ struct Geom {
     uint64_t cap;    // slots
     uint32_t shift;  // 64 - n, n = hash bits that address the table
     uint32_t m8;     // slots per range / 1024
+    uint32_t kbits = 0;  // 2k for tables of k <= 16: the hash is ktd::nhash, a bijection of the 2k-bit k-mers (0: ktd::khash)
     // slots of one range (the whole table when it is smaller than a range)
     __host__ __device__ uint32_t range_slots() const {
         return shift > 64 - LOG2_RANGE ? (uint32_t)cap : m8 << (LOG2_RANGE - 3);
     }
 };
 
-inline Geom make_geom(uint64_t cap_request) {
+inline Geom make_geom(uint64_t cap_request, int k = 0) {
     uint64_t p = 1024;
     uint32_t n = 10;
     while (p < cap_request) {
@@ -53,7 +54,7 @@ inline Geom make_geom(uint64_t cap_request) {
     uint32_t m8 = 8;
     if (n >= LOG2_RANGE + 2)
         while (m8 > 5 && p / 8 * (m8 - 1) >= cap_request) m8--;
-    return Geom{p / 8 * m8, 64 - n, m8};
+    return Geom{p / 8 * m8, 64 - n, m8, k >= 1 && k <= 16 ? 2u * (uint32_t)k : 0u};
 }
 
 struct TableRef {
@@ -71,7 +72,7 @@ struct Probe {
 };
 
 __host__ __device__ __forceinline__ Probe probe_of(uint64_t key, const Geom &g) {
-    const uint64_t x = ktd::khash(key) >> g.shift;  // n <= 54 bits
+    const uint64_t x = ktd::khash_k(key, g.kbits) >> g.shift;  // n <= 54 bits
     if (g.shift > 64 - LOG2_RANGE) return Probe{0, (uint32_t)x, (uint32_t)g.cap};  // one small range, home = x
     const uint32_t rs = g.m8 << (LOG2_RANGE - 3);
     const uint64_t r = x >> LOG2_RANGE;

@@ -811,6 +811,54 @@ def test_ctr_odd_capacity_requests(hctx, oracle, monkeypatch, k, cap_request):
         ctr.close()
 
 
+@pytest.mark.parametrize("k", [8, 10, 12, 13])
+def test_ctr_direct_addressed_tables(torch_mod, ctx, oracle, monkeypatch, k):
+    """a table of exactly 4^k slots (k <= 15: the hash of a k-mer is a bijection onto the slots - ktd::nhash - and the bulk
+    build's ranges are counters alone, keys coming back from the slots' indices): the oracle's table from ragged noisy
+    reads with repeats, into the table and into an export target; look-ups, cov and a second batch on top (the dense table
+    becomes a probing image under the same hash, the rebuild merges into it); the same with KT_BUILD_DIRECT=0 (probing
+    build of the same geometry)"""
+    torch = torch_mod
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    rng = np.random.default_rng(k)
+    seqs = ragged_reads(900 + k, 3000) + [b"ACGT" * 400, b"A" * 3000]
+    bases, offsets = device.to_csr(seqs)
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    oc = oracle.Counter(1)
+    oc.add_reads(bases, offsets, k)
+    probe = np.concatenate([wk[:: max(1, len(wk) // 500)], rng.integers(0, 4 ** k, size=300, dtype=np.uint64)])
+    want_probe = np.array([dict(zip(wk.tolist(), wc.tolist())).get(int(x), 0) for x in probe], dtype=np.uint32)
+    for direct in ("1", "0"):
+        monkeypatch.setenv("KT_BUILD_DIRECT", direct)
+        ctr = device.Counter(ctx, k, 4 ** k)
+        assert ctr.capacity() == 4 ** k
+        ctr.add_reads_host(bases, offsets)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (k, direct)
+        assert np.array_equal(ctr.lookup_host(probe), want_probe)
+        assert np.array_equal(ctr.cov_host(bases, offsets, 2, 9, False), oc.cov_batch(bases, offsets, k, 2, 9, False))
+        ctr.add_reads_host(bases, offsets)      # on top: every range rebuilt from what it holds + the batch
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc)
+        ctr.close()
+        # straight into an export target
+        c2 = device.Counter(ctx, k, 4 ** k)
+        xk = torch.zeros(len(wk) + 5, dtype=torch.int64, device="cuda")
+        xc = torch.zeros(len(wk) + 5, dtype=torch.int32, device="cuda")
+        c2.export_target(xk, xc, len(wk) + 5)
+        db = torch.from_numpy(bases).cuda()
+        do = torch.from_numpy(offsets.astype(np.int64)).cuda()
+        c2.add_reads(db, do, len(seqs))
+        d = c2.size()
+        assert d == len(wk) and c2.export(xk, xc, len(wk) + 5) == d
+        gk2 = xk[:d].cpu().numpy().view(np.uint64)
+        order = np.argsort(gk2)
+        assert np.array_equal(gk2[order], wk) and np.array_equal(xc[:d].cpu().numpy().view(np.uint32)[order], wc)
+        assert np.array_equal(c2.lookup_host(probe), want_probe)
+        c2.close()
+
+
 @pytest.mark.parametrize("paged", ["1", "0"])
 @pytest.mark.parametrize("k,log2cap", [(31, 17), (21, 18), (15, 19), (4, 14), (31, 20)])
 def test_ctr_bulk_build_matches_oracle(hctx, oracle, monkeypatch, k, log2cap, paged):
