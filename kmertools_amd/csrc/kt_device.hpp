@@ -75,29 +75,28 @@ __host__ __device__ __forceinline__ uint64_t khash_inv(uint64_t x) {
 #endif
 }
 
-// The table hash of a k-mer of k <= 16 (kbits = 2k <= 32 bits): a BIJECTION of the 2k-bit words - two rounds of an odd
-// multiply and a fold of the high half into the low half, inside 2k bits - placed in the top bits of the 64-bit hash word.  A
-// table of exactly 4^k slots is then addressed by the k-mer's own hash: every canonical k-mer has a slot of its own, no
-// key is stored or compared (kt_bulk.hip, the direct build; SURVEY 7 (iii): the reference's `+= 1`,
-// counter/src/lib.rs:126-130), and the key comes back from the slot's index (nhash_inv).  kbits = 0: khash.
-__host__ __device__ __forceinline__ uint32_t nhash(uint32_t x, uint32_t kbits) {
-    const uint32_t mask = kbits >= 32u ? 0xFFFFFFFFu : (1u << kbits) - 1u, half = kbits >> 1;
-    x = (x * 0x9E3779B1u) & mask;
-    x ^= x >> half;
-    x = (x * 0x85EBCA6Bu) & mask;
-    x ^= x >> half;
-    return x;
+// The table hash of a k-mer of k <= 16 (kbits = 2k <= 32 bits): a BIJECTION of the 2k-bit words - an odd multiply and
+// a fold of the high half into the low half, inside 2k bits (the partition digits are its top bits: the multiply's, as
+// with khash; the fold spreads the position inside a range) - placed in the top bits of the 64-bit hash word.  A table of
+// exactly 4^k slots is then addressed by the k-mer's own hash: every canonical k-mer has a slot of its own, no key is
+// stored or compared (kt_bulk.hip, the direct build; SURVEY 7 (iii): the reference's `+= 1`, counter/src/lib.rs:126-130),
+// and the key comes back from the slot's index (nhash_inv).  kbits = 0: khash.  (Two rounds measured +2.2 ms on ctr k=15's
+// partition passes - the hash is evaluated six times per k-mer there - for no better balance.)
+// (held top-aligned in a 32-bit word - nhash_top: the product shifted up by 32 - 2k, which is also the mask; what the fold
+// drags below the 2k valid bits is never looked at - so that the hash word of the partition passes is four 32-bit
+// instructions and its digits one more shift each)
+__host__ __device__ __forceinline__ uint32_t nhash_top(uint32_t x, uint32_t kbits) {
+    const uint32_t t = (x * 0x9E3779B1u) << (32u - kbits);
+    return t ^ (t >> (kbits >> 1));
 }
-__host__ __device__ __forceinline__ uint32_t nhash_inv(uint32_t x, uint32_t kbits) {
-    const uint32_t mask = kbits >= 32u ? 0xFFFFFFFFu : (1u << kbits) - 1u, half = kbits >> 1;
-    x ^= x >> half;                     // (half >= kbits / 2: the fold is its own inverse)
-    x = (x * 0xA5CB9243u) & mask;       // 0x85EBCA6B^-1 mod 2^32
-    x ^= x >> half;
-    x = (x * 0x0E8B2F51u) & mask;       // 0x9E3779B1^-1 mod 2^32
-    return x;
+__host__ __device__ __forceinline__ uint32_t nhash(uint32_t x, uint32_t kbits) { return nhash_top(x, kbits) >> (32u - kbits); }
+__host__ __device__ __forceinline__ uint32_t nhash_inv(uint32_t y, uint32_t kbits) {
+    uint32_t t = y << (32u - kbits);
+    t ^= t >> (kbits >> 1);             // (the fold is its own inverse: twice the shift is the whole word)
+    return ((t >> (32u - kbits)) * 0x0E8B2F51u) & (kbits >= 32u ? 0xFFFFFFFFu : (1u << kbits) - 1u);  // 0x9E3779B1^-1 mod 2^32
 }
 __host__ __device__ __forceinline__ uint64_t khash_k(uint64_t key, uint32_t kbits) {
-    return kbits ? (uint64_t)nhash((uint32_t)key, kbits) << (64u - kbits) : khash(key);
+    return kbits ? (uint64_t)nhash_top((uint32_t)key, kbits) << 32 : khash(key);
 }
 
 // owner of a canonical k-mer among n owners: LOW 32 bits of the hash, multiply-shift (the
