@@ -23,6 +23,7 @@ def worker(rank, world, port, budget, seed, q):
     t0 = time.time()
     it = 0
     try:
+      try:
         while True:
             # (rank 0 decides when to stop: every rank must leave in the same iteration)
             go = [time.time() - t0 < budget]
@@ -34,13 +35,13 @@ def worker(rank, world, port, budget, seed, q):
             slices = int(rng.integers(1, 6))
             presplit = bool(rng.integers(0, 2))   # (here: small regions, so that floods and plain batches overflow them)
             os.environ["KT_SHARD_SLICES"] = str(slices)
-            if presplit:
-                os.environ["KT_SHARD_ROOM_BLOCKS"] = str(int(rng.integers(1, 40)))
-            else:
-                os.environ.pop("KT_SHARD_ROOM_BLOCKS", None)
             os.environ["KT_BULK_MIN_BASES"] = "0" if rng.integers(0, 4) else str(1 << 40)
             n_batches = int(rng.integers(1, 4))
             max_bases = 1 << int(rng.integers(18, 22))
+            if presplit:   # regions that ordinary reads fit (0.2 records per base and owner's share) and a flood does not
+                os.environ["KT_SHARD_ROOM_BLOCKS"] = os.environ.get("KT_FUZZ_ROOM_BLOCKS", str(int(0.2 * max_bases / world / 1024) + 4))
+            else:
+                os.environ.pop("KT_SHARD_ROOM_BLOCKS", None)
             cap = max(1 << 21, int(2.2 * world * n_batches * max_bases))   # slots: every base a distinct k-mer would still fit
             sc = ktdist.ShardedCounter(ctx, k, cap, group=dist.group.WORLD, max_batch_bases=max_bases)
             mine_b, mine_o = [], []
@@ -99,6 +100,10 @@ def worker(rank, world, port, budget, seed, q):
             it += 1
         if rank == 0:
             q.put("fuzz_shard ok iterations %d seed %d ranks %d" % (it, seed, world))
+      except BaseException as e:  # noqa: BLE001 - say what happened before the process goes (the parent waits on the queue)
+        import traceback
+        q.put("rank %d it=%d: %s" % (rank, it, "".join(traceback.format_exception_only(type(e), e)).strip()[-400:]))
+        raise
     finally:
         ctx.close()
         dist.destroy_process_group()
@@ -119,7 +124,7 @@ if __name__ == "__main__":
     for p in procs:
         p.start()
     try:
-        print(q.get(timeout=budget + 600))
+        print(q.get(timeout=budget + 180))
     finally:
         for p in procs:
             p.join(timeout=60)
