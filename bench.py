@@ -545,11 +545,17 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
     # committed under profiles/; see profiles/traffic.json) - null when not collected
     torch.cuda.synchronize()
     first_ms = [a.elapsed_time(b) for a, b in rev]
-    traffic = None
+    traffic, traffic_file, traffic_head = None, None, None
     try:
-        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(name + ("_genome" if genome else ""))
+        key = name + ("_genome" if genome else "")
+        if wl["kind"] == "ctr" and world == 1 and os.environ.get("KT_SHARD_FORCE") == "8" and not genome:
+            key = name + "_forced8"   # (the one-GPU run of the 8-rank path has a profile of its own)
+        elif wl["kind"] == "ctr" and (world > 1 or os.environ.get("KT_SHARD_FORCE")):
+            key = None                # (no committed counter profile of this configuration)
+        tj = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(key) if key else None
         if tj and not reduced and not (wl["kind"] == "ctr" and args.no_export):
             traffic = int((tj["fetch_kib"] * tj.get("fetch_correction", 1) + tj["write_kib"]) * 1024)
+            traffic_file, traffic_head = tj.get("source"), tj.get("profile_head")
     except (OSError, ValueError, KeyError):
         traffic = None
 
@@ -632,6 +638,7 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
                      # (nothing in this run measures HBM traffic: the figure is read from a committed file)
                      "traffic_source": ("profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE from separate rocprofv3 --pmc "
                                         "passes of this command, committed; not measured in this run") if traffic else None,
+                     "traffic_profile": traffic_file, "traffic_profile_head": traffic_head,
                      "kernel": dominant, "kernel_ms": round(kern_ms, 4),
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }

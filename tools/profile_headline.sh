@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage (GPU box): tools/profile_headline.sh  -> the default bench.py command (the driver's) under rocprofv3
+# usage (GPU box): tools/profile_headline.sh <round tag, e.g. r6>  -> the default bench.py command (the driver's) under rocprofv3
 # --kernel-trace --stats, its JSON line, and FETCH_SIZE / WRITE_SIZE of the oligo kernel from separate --pmc passes
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/prof_r4_headline; rm -rf $out; mkdir -p $out
+tag=${1:-r6}
+out=gpurun_out/prof_${tag}_headline; rm -rf $out; mkdir -p $out
 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats -d $out -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu > $out/bench_under_trace.json 2> $out/kt.err
 {
