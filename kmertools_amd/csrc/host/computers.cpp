@@ -1175,7 +1175,11 @@ std::string CovComputer::compute_coverages() {
         Work w;
         std::string err;
         for (;;) {
-            const bool more = reader.next_batch(w.b, cli_batch_bases(256ull << 20), cli_batch_reads(bins >= 2048 ? 8192 : 1ull << 19));
+            // (a batch holds N shards' u32 rows, the library's temporary of one shard's rows and the f64 rows: its reads are
+            // bounded so that all of it stays under 1 GiB whatever the number of shards and bins - ADVICE r5)
+            const uint64_t by_memory = std::max<uint64_t>(1024, (1ull << 30) / (bins * (4 * (uint64_t)N + 12)));
+            const bool more = reader.next_batch(w.b, cli_batch_bases(256ull << 20),
+                                                std::min<uint64_t>(cli_batch_reads(bins >= 2048 ? 8192 : 1ull << 19), by_memory));
             const uint64_t n = w.b.n_reads();
             if (n) {
                 std::vector<std::thread> th;

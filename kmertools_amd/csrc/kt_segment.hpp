@@ -132,8 +132,10 @@ __device__ __forceinline__ void stage_segment(const SegArgs &a, uint64_t g, SegS
 // copy-out's stores, from inline assembly (the compiler inserts no wait for what it does not know about), and taken
 // behind them with s_waitcnt vmcnt(number of stores): every read has landed, the stores stay in flight.
 // Rules (the same as kt_bulk.hip's buf_load8_async / buf_take; tools/check_inflight.py reads the assembly at build
-// time): nothing touches the in-flight registers between prefetch_issue and prefetch_take; exactly `NSTORE` vector
-// memory operations are issued between the two on every path; no scratch in the kernel.
+// time): nothing touches the in-flight registers between prefetch_issue and prefetch_take - a spill or a reload of one of
+// them there would move garbage (scratch elsewhere in the kernel is harmless: csrc/Makefile) -; at least `NSTORE` vector
+// memory operations are issued between the two on every path (the copy-out stores unconditionally: a group with nothing to
+// write goes to a dump line - the checker counts the instructions of the layout, the GPU suite checks the paths).
 struct SegHalo { uint32_t d[8]; };
 struct SegPrefetch2 {
     uint64_t a[4];         // item tid of unit g: bases [32 tid, 32 tid + 32) - in flight until prefetch_take

@@ -4,7 +4,7 @@
 // k-mer would do, the partition is not observable in the output.  Here the owner of a k-mer is a function of its
 // MINIMISER: of the w = k - m + 1 m-mers inside the k-mer, each taken in canonical form (the smaller of the m-mer and its
 // reverse complement, kmer/src/minimiser.rs:61-175 orders by that value; here the order is a hash of it so that the
-// owners are balanced), the one with the smallest hash h.  owner = mix(min h) * n_owners >> 32.  A k-mer and its reverse
+// owners are balanced), the one with the smallest hash h.  owner = top bits of mix(min h) scaled to n_owners.  A k-mer and its reverse
 // complement hold the same canonical m-mers, so both strands of a k-mer have one owner; consecutive k-mers of a read
 // mostly share their minimiser, so a read falls into a few RUNS of k-mers with one owner each (a "super-k-mer": n
 // k-mers in n + k - 1 bases), and what travels is bases at 2 bits, not k-mers at 8 bytes.

@@ -3,11 +3,19 @@
 buf_take; kt_segment.hpp: prefetch_issue / prefetch_take): between an asm load into a register and the asm s_waitcnt behind it, no instruction of the compiler's
 own may name that register - a copy or a spill made there would move a value that has not arrived.
 
-usage: check_inflight.py <device assembly .s> <kernel name regex>
+usage: check_inflight.py <device assembly .s> <kernel name regex> [<regex of the kernels whose counted waits are checked>]
 
 The walk is in layout order, which is the order of execution for these loops (the load block lies in front of the
 wait block in the chunk loop's body; code the compiler placed out of line is not followed).  Exit status 1 and a
-listing when something is found."""
+listing when something is found.
+
+A wait `s_waitcnt vmcnt(N)` with N > 0 is only sound when at least N vector-memory operations are issued between the asm
+loads and the wait on every path (the loads have landed once at most N YOUNGER operations are outstanding).  The walk
+counts the vector-memory instructions it passes between the last asm load and the wait and fails when there are fewer than
+N - which catches a store that was removed or moved, not one that was put under a condition (the count is of the layout,
+not of a path): the kernels issue those stores unconditionally by construction (a group with nothing to write goes to a
+dump line), and the GPU suite is what checks that.  Only for the kernels the third argument names: where the loads sit at
+the bottom of a loop and the wait at its top (the level-2 kernels) the layout between them is not what runs between them."""
 import re
 import sys
 
@@ -49,13 +57,14 @@ def dead_high_addend(lines, i, code, inflight):
     return False
 
 
-def check(path, pattern):
+def check(path, pattern, count_pattern=None):
     bad = []
     fn = None
     in_asm = False
     inflight = set()
     pending_clear = False
     n_loads = n_waits = 0
+    vmem_since = 0      # vector-memory instructions passed since the last asm load into a register that is still in flight
     lines = open(path).read().split("\n")
     for ln, line in enumerate(lines, 1):
         s = line.strip()
@@ -84,13 +93,21 @@ def check(path, pattern):
             if m:
                 inflight |= regs_of(m.group(2))
                 n_loads += 1
+                vmem_since = 0
             elif re.match(r"s_waitcnt\s+vmcnt", code):
+                mw = re.match(r"s_waitcnt\s+vmcnt\((\d+)\)", code)
+                if mw and inflight and count_pattern and re.search(count_pattern, fn) and int(mw.group(1)) > vmem_since:
+                    bad.append((fn, ln, "%s behind only %d vector-memory instruction(s)" % (code.strip(), vmem_since), sorted(inflight)[:4]))
                 pending_clear = True
                 n_waits += 1
+            elif re.match(r"(?:buffer|global|flat|scratch)_(?:load|store|atomic)", code):
+                vmem_since += 1
             continue
         if re.match(r"s_waitcnt\s+vmcnt\(0\)", code):  # (one of the compiler's own: everything has landed)
             inflight.clear()
             continue
+        if re.match(r"\s*(?:buffer|global|flat|scratch)_(?:load|store|atomic)", code):
+            vmem_since += 1
         hit = regs_of(code) & inflight
         if hit and dead_high_addend(lines, ln - 1, code, inflight):
             hit = set()
@@ -100,7 +117,7 @@ def check(path, pattern):
 
 
 if __name__ == "__main__":
-    bad, n_loads, n_waits = check(sys.argv[1], sys.argv[2])
+    bad, n_loads, n_waits = check(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     if n_loads == 0 or n_waits == 0:
         print("check_inflight: no asm loads / waits found in kernels matching %r - the check is not looking at anything" % sys.argv[2])
         sys.exit(1)
