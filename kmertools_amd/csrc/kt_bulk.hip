@@ -2796,6 +2796,7 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
     // two sort buffers, the copy-out spread over the next round - or, a shape that does not fit the LDS, one buffer
     const bool two = j.kn.s1y && Scatter1YShared<K, 1024>::bytes(j.p.B1) <= 160 * 1024;
     const uint32_t mult = (uint32_t)(j.kn.g_mult ? j.kn.g_mult : 1);
+    const uint32_t cus = (uint32_t)ctx->n_cu > 2 * ctr->l1_spare_cus ? (uint32_t)ctx->n_cu - ctr->l1_spare_cus : (uint32_t)ctx->n_cu;
     return with_source(r, [&](const auto &src) -> int {
         using S = std::decay_t<decltype(src)>;
         if (two) {
@@ -2803,13 +2804,13 @@ int level1_paged(kt_ctr *ctr, kt_bulk_job &j, const SourceRec &r) {
             const size_t lds = Scatter1YShared<K, T>::bytes(p.B1);
             auto kern = scatter1y_kernel<S, K, T>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, dump);
+            hipLaunchKernelGGL(kern, dim3(cus * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, dump);
         } else {
             constexpr int T = KT_S1X_T;
             const size_t lds = sizeof(Scatter1XShared<K, T>);
             auto kern = scatter1x_kernel<S, K, T>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu * (1024 / T) * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, dump);
+            hipLaunchKernelGGL(kern, dim3(cus * (1024 / T) * mult), dim3(T), lds, ctx->stream, src, p, xcur, ovf, keys1, dump);
         }
         KT_HIP(hipGetLastError());
         return KT_OK;

@@ -94,6 +94,9 @@ struct kt_ctr {
     // the table of rank `owner` of a counter sharded over n_owners ranks (kt_shard.hip; a table of its own: 1, 0): a whole
     // table like any other - only kt_cov_batch_part looks at this (a k-mer that is not here may be on another rank)
     uint32_t n_owners = 1, owner = 0;
+    // CUs the level-1 launches of a bulk job leave free (kt_shard.hip: the exchange's kernels run beside them on the comm stream,
+    // and a level-1 workgroup takes a whole CU's LDS for the length of the launch)
+    uint32_t l1_spare_cus = 0;
     bool paged_failed = false; // a bulk build overflowed a paged level-1 bucket: exact offsets from now on
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export

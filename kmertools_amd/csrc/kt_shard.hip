@@ -696,6 +696,14 @@ int kt_sharded_connect_rccl(kt_sharded *s, const uint8_t *id128) {
     else r = s->rccl->GetUniqueId(&id);  // (a single rank made to take the routed path: tests)
     if (r == ncclSuccess) r = s->rccl->CommInitRank(&s->comm, s->n_ranks, id, s->rank);
     if (r != ncclSuccess) return kt::fail(KT_ERR_HIP, std::string("ncclCommInitRank: ") + s->rccl->GetErrorString(r));
+    if (s->n_ranks > 1) {
+        // The pieces travel (RCCL's send / receive kernels, comm stream) while level 1 counts the pieces before them - and a
+        // level-1 workgroup holds a whole CU's LDS for the length of its launch: on a chip that level 1 fills, the exchange's
+        // kernels would wait for a launch to end.  Level 1 leaves a few CUs free (KT_SHARD_COMM_CUS, default 16 of 256: +6 %
+        // of level 1's 11.5 ms, against an exchange that would otherwise not overlap at all).  NOT measured: no multi-GPU box.
+        const char *e = getenv("KT_SHARD_COMM_CUS");
+        s->table->l1_spare_cus = e ? (uint32_t)atoi(e) : 16u;
+    }
     return KT_OK;
 }
 
