@@ -562,7 +562,7 @@ def test_ctr_k31_large_checksums(torch_mod, ctx, oracle):
 
 _SHARD_CASES = {"genome": (2, 31), "skewed": (2, 31), "narrow3": (3, 15), "flood": (2, 31), "flood3": (3, 21), "localfail": (2, 31),
                 "uneven3": (3, 21), "empty_rank": (3, 31), "k10": (2, 10), "probing": (2, 25), "five": (5, 27),
-                "unlike": (2, 31)}   # case -> (ranks, k)
+                "unlike": (2, 31), "eight": (8, 31), "uniform": (2, 31)}   # case -> (ranks, k)
 
 
 def _shard_batch(case, rank, n, L, synth):
@@ -612,7 +612,7 @@ def _two_rank_worker(rank, port, q, case):
         def synth(first):
             bases = torch.empty(n * L, dtype=torch.uint8, device="cuda")
             offsets = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-            ctx.synth_reads(4242, n, L, bases, offsets, noise=True, genome_len=200000, first_read=first)
+            ctx.synth_reads(4242, n, L, bases, offsets, noise=case != "uniform", genome_len=0 if case == "uniform" else 200000, first_read=first)
             return bases, offsets
         bases, offsets, nr = _shard_batch(case, rank, n, L, synth)
         if case == "unlike":
@@ -666,7 +666,7 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     regions of 40 blocks, so that the flooded owner's region overflows - the pending table and several finalize rounds
     run; `narrow3`: three ranks, three pieces, k=15 (32-bit keys through the partition, w = 8); `k10`: w = 2, `five`: five
     ranks, one piece, k=27; `probing`: the batch is below the partition passes' size, the records take the probing
-    path; `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call
+    path; `eight`: eight ranks; `uniform`: i.i.d. reads without noise (BASELINE's distribution); `localfail`: one rank's batch set-up fails (injected) - every rank returns an error, nobody hangs, the next call
     works; `uneven3`: three ranks whose batches differ in size; `empty_rank`: a rank without reads; `unlike`: counters
     made for different batch sizes - every rank reports it, nobody hangs"""
     import os
@@ -697,7 +697,7 @@ def test_two_ranks_one_gpu_sharded_ctr(oracle, case):
     n_kmers = 0
     for rank in range(world):
         def synth(first):
-            hb, ho = oracle.synth_reads(4242, n, L, noise=True, genome_len=200000, first_read=first)
+            hb, ho = oracle.synth_reads(4242, n, L, noise=case != "uniform", genome_len=0 if case == "uniform" else 200000, first_read=first)
             return hb.copy(), ho
         hb, ho, nr = _shard_batch(case, rank, n, L, synth)
         ctr.add_reads(hb[: nr * L], ho[: nr + 1], k, threads=4)

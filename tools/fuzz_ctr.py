@@ -78,7 +78,7 @@ while time.time() < t_end:
         ctr.close()
     else:
         if mode == "sharded":
-            os.environ["KT_SHARD_FORCE"] = "1"
+            os.environ["KT_SHARD_FORCE"] = str(int(rng.integers(1, 10)))   # a single rank routing into 1 .. 9 owners' regions
             os.environ["KT_SHARD_SLICES"] = str(int(rng.integers(1, 6)))
             sh = device.Sharded(ctx, k, cap, max(int(ho[-1]) for _, ho in batches) + 1, 1, 0, None)
             os.environ["KT_SHARD_FORCE"] = "0"
