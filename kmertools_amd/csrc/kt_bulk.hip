@@ -1675,6 +1675,7 @@ __global__ __launch_bounds__((p2t<K, BIG>()), (p2t<K, BIG>() == 1024 ? 4 : 2)) v
             }
         } else if (tid == 0) {
             fail[jl] = 1u;  // redone by part2_kernel<K, false, BIG> (exact fine boundaries) in the launch behind this one
+            atomicAdd(&fail[p.B1], 1u);  // (how many of the job's buckets: finish_typed reports it, kt_shard.hip sizes its next job by it)
         }
         ktd::lds_barrier();
     }
@@ -1927,7 +1928,10 @@ __global__ __launch_bounds__((swwc_t<K>()), (swwc_t<K>() / 256)) void part2_swwc
             }
         }
         ktd::lds_barrier();
-        if ((failed || sm.flags[2] != 0) && tid == 0) fail[jl] = 1u;  // redone by part2_kernel<K, false, BIG> in the launch behind this one
+        if ((failed || sm.flags[2] != 0) && tid == 0) {
+            fail[jl] = 1u;  // redone by part2_kernel<K, false, BIG> in the launch behind this one
+            atomicAdd(&fail[p.B1], 1u);
+        }
         ktd::lds_barrier();
     }
 }
@@ -2888,7 +2892,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             // fixed fine regions, whole lines only (part2_swwc_kernel); then the general kernel over the buckets that did not
             // fit their regions (none, normally)
             const size_t lds = SwwcShared<K>::bytes(pp.B2);
-            KT_HIP(hipMemsetAsync(fail, 0, (size_t)pp.B1 * 4, ctx->stream));
+            KT_HIP(hipMemsetAsync(fail, 0, ((size_t)pp.B1 + 1) * 4, ctx->stream));
             auto swwc = part2_swwc_kernel<K>;
             KT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(swwc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             uint32_t grid = pp.B1;
@@ -2916,7 +2920,7 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
             constexpr uint32_t P2T = (uint32_t)p2t<K, BIG>();
             if (pp.cap2 && src.srcs && j.kn.p2_fast && pp.B2 <= 4 * P2T) {
                 // fixed fine regions: the lean kernel, then the general one over the buckets that did not fit (none, normally)
-                KT_HIP(hipMemsetAsync(fail, 0, (size_t)pp.B1 * 4, ctx->stream));
+                KT_HIP(hipMemsetAsync(fail, 0, ((size_t)pp.B1 + 1) * 4, ctx->stream));
                 auto go = [&](auto pb) -> int {
                     constexpr int PB = decltype(pb)::value;
                     auto fast = part2_fast_kernel<K, BIG, PB>;
@@ -3015,9 +3019,12 @@ int finish_typed(kt_ctr *ctr, kt_bulk_job &j) {
         KT_HIP(hipGetLastError());
         // did the blocks fit (flag 4: keys spread too unevenly over the workgroups)?  One 4-byte read; the caller's
         // next step - kt_ctr_size, kt_ctr_export - waits for these kernels anyway.
-        uint32_t fl = 0;
+        uint32_t fl = 0, l2_redone = 0;
         KT_HIP(hipMemcpyAsync(&fl, ctr->flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KT_HIP(hipMemcpyAsync(&l2_redone, m.fail + p.B1, 4, hipMemcpyDeviceToHost, ctx->stream));  // (rides on the same round trip)
         KT_HIP(hipStreamSynchronize(ctx->stream));
+        ctr->l2_redone = l2_redone;
+        ctr->l2_buckets = p.B1;
         if (fl & 6u) {
             // 4: the blocks did not fit (or could not all be patched): the ranges are built the ordinary way and
             //    kt_ctr_export copies them out.
@@ -3175,7 +3182,7 @@ static int plan_job(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     const size_t off_du = meta;      meta += 1024 * 16;
     const size_t off_sr = meta;      meta += 256;
     const size_t off_ov = meta;      meta += 256;
-    const size_t off_fl = meta;      meta += (((size_t)nd + 1) * 4 + 255) & ~(size_t)255;
+    const size_t off_fl = meta;      meta += (((size_t)nd + 2) * 4 + 255) & ~(size_t)255;
     const size_t off_sn = meta;      meta += 256;
     const size_t off_sk = meta;      meta += (spill_cap * 8 + 255) & ~(size_t)255;
     const size_t off_sc = meta;      meta += (spill_cap * 4 + 255) & ~(size_t)255;

@@ -97,6 +97,9 @@ struct kt_ctr {
     // CUs the level-1 launches of a bulk job leave free (kt_shard.hip: the exchange's kernels run beside them on the comm stream,
     // and a level-1 workgroup takes a whole CU's LDS for the length of the launch)
     uint32_t l1_spare_cus = 0;
+    // of the last bulk job into an export target: level-1 buckets whose keys did not fit their fixed fine regions and went
+    // through the exact pass (of l2_buckets) - a caller that plans its jobs itself (kt_shard.hip) gives the next one more room
+    uint32_t l2_redone = 0, l2_buckets = 0;
     bool paged_failed = false; // a bulk build overflowed a paged level-1 bucket: exact offsets from now on
     bool empty = true;         // nothing inserted since the last clear (bulk build allowed)
     bool needs_clear = true;   // slots hold stale data: clear before the incremental path / export
