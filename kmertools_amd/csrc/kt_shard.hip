@@ -51,7 +51,7 @@ constexpr int MAX_RANKS = (int)ktsk::MAX_OWNERS;
 constexpr uint64_t HDR_U64 = 8;  // 64-byte header of a finalize message: [0] keys in it (may exceed the capacity: clamp),
                                  // [1] keys still pending at the sender, [2] the sender's status (0 = fine)
 constexpr uint64_t FIN_CAP = 1u << 17;  // keys per peer and finalize round (1 MiB messages)
-constexpr uint32_t GO_WORDS = 8;        // the words the ranks exchange before data moves (go_word below)
+constexpr uint32_t GO_WORDS = 8;        // the words the ranks exchange before data moves (kt_sharded_add_reads)
 
 // ---- librccl, resolved at run time -----------------------------------------------------------------------------
 struct Rccl {
@@ -140,16 +140,20 @@ struct RouteShared {
 __device__ __forceinline__ uint32_t low_bits(uint32_t n) { return n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u; }
 
 // One workgroup per 8192-base segment of the rank's reads (grid-stride), a thread per 32 window starts - the front end of
-// every other k-mer kernel (kt_segment.hpp) - and then:
+// every other k-mer kernel (kt_segment.hpp), its global reads requested a segment ahead, the staged codes in one of two
+// buffers - and then, every WAVE on its own (its 2048 window starts begin a run of their own: one cut per 2048 bases):
 //   hashes   the canonical m-mers that start at the thread's 32 + w - 1 bases, from the two staged code words (32-bit
 //            words, one funnel shift each), hashed; the minimum over every window of w of them in log2(w) in-place passes
 //   owners   of the 32 window starts; a window start CONTINUES the run of the one before it when both are k-mers of one
-//            owner (the neighbour thread's last one through LDS; a segment begins a run: one cut per 8192 bases)
-//   records  start where a run starts and every 8 k-mers from there (the run's start may lie in an earlier thread: the
-//            threads' run lengths are looked back through LDS - one step unless a run spans whole threads); a record's
-//            length is what follows of its run, 8 at most, read off the thread's and the next thread's continuation bits
-//   append   count per owner (LDS), one returning atomic per owner and segment on the owner's cursor, then every record
-//            is cut out of the staged codes (a 192-bit funnel shift) and stored at its place: a[pos], b[pos] of its block.
+//            owner (the lane before's last one by DPP)
+//   records  start where a run starts and every 8 k-mers from there (the run's start may lie in an earlier lane: the
+//            lanes' run lengths are looked back through LDS - one step unless a run spans whole lanes); a record's
+//            length is what follows of its run, 8 at most, read off the lane's and the next lane's continuation bits
+//   append   counts per owner (LDS); ONE workgroup barrier; one returning atomic per owner and SEGMENT on the owner's
+//            cursor (per wave - four times the atomics on the same handful of addresses - the kernel ran three times as
+//            long), its answer looked at behind the making of the wave's record list; one more barrier; then the wave's
+//            records, listed in LDS by a scan of the lanes' counts, are dealt out evenly to its lanes (a lane finds 0 .. 32
+//            records, 4 on average), cut out of the staged codes (a 192-bit funnel shift) and stored: a[pos], b[pos].
 // A record beyond the region's room is not written: its k-mers are counted in the pending table.
 #ifndef KT_ROUTE_ABL
 #define KT_ROUTE_ABL 0  // (timing builds only, tools/build_variant_tu.sh: 1 = no records cut out or written, 2 = no m-mer hashes,
