@@ -402,6 +402,101 @@ struct ReadsSource {  // the k-mers of a read batch: unit = one 8192-base segmen
         });
     }
 };
+// The same k-mers from reads that a pass of their own has PACKED (pack_segments_kernel: what stage_segment makes of a
+// segment - 32 bases as a 64-bit word of codes, the invalid-base mask, the read-start mask: 16 bytes per 32 bases - written
+// out instead of kept in LDS): level 1 then stages nothing - a thread's window words are its item and the next one, 32
+// contiguous bytes - and has no barrier of its own per unit.
+struct PackedSource {
+    const uint4 *items;  // item i = bases [32 i, 32 i + 32): {codes lo, codes hi, invalid mask, read-start mask}; one terminator behind the last
+    uint64_t seg_lo, seg_hi;
+    uint32_t k;
+    __device__ uint64_t n_units() const { return seg_hi - seg_lo; }
+    struct Walk {
+        ktseg::Window w;
+        uint32_t at;
+    };
+    static __device__ __forceinline__ Walk walk_of(const uint64_t (&a)[4], uint32_t k) {
+        // a[0] = codes of item t, a[1] = {inv, bnd} of item t, a[2] / a[3] the same of item t + 1
+        const uint64_t iv = (a[1] & 0xFFFFFFFFull) | (a[3] << 32), bd = (a[1] >> 32) | (a[3] & 0xFFFFFFFF00000000ull);
+        return Walk{ktseg::Window(a[0], a[2], iv, bd, k), 0u};
+    }
+    __device__ Walk open(uint64_t g, SegShared &, uint32_t t) const {
+        const uint64_t *p = reinterpret_cast<const uint64_t *>(items + (seg_lo + g) * BLOCK + t);
+        const uint64_t a[4] = {p[0], p[1], p[2], p[3]};
+        return walk_of(a, k);
+    }
+    struct Pre2 {
+        uint64_t a[4], o0;  // in flight until prefetch_take
+    };
+    struct Taken {
+        uint64_t a[4], first_next;
+    };
+    __device__ uint64_t first_of(uint64_t) const { return 0; }
+    __device__ void prefetch_issue(Pre2 &pf, uint64_t g, uint64_t, uint64_t, uint32_t t, const void *safe) const {
+        const void *p0 = items + (ktd::uniform64(seg_lo + g) * BLOCK + t);
+        asm volatile("global_load_dwordx2 %0, %5, off\n\tglobal_load_dwordx2 %1, %5, off offset:8\n\t"
+                     "global_load_dwordx2 %2, %5, off offset:16\n\tglobal_load_dwordx2 %3, %5, off offset:24\n\t"
+                     "global_load_dwordx2 %4, %6, off"
+                     : "=&v"(pf.a[0]), "=&v"(pf.a[1]), "=&v"(pf.a[2]), "=&v"(pf.a[3]), "=&v"(pf.o0) : "v"(p0), "v"(safe) : "memory");
+    }
+    template <int NSTORE>
+    __device__ void prefetch_take(Taken &tk, Pre2 &pf) const {
+        uint64_t o0;
+        asm volatile("s_waitcnt vmcnt(%10)\n\tv_mov_b64 %0, %5\n\tv_mov_b64 %1, %6\n\tv_mov_b64 %2, %7\n\tv_mov_b64 %3, %8\n\tv_mov_b64 %4, %9"
+                     : "=&v"(tk.a[0]), "=&v"(tk.a[1]), "=&v"(tk.a[2]), "=&v"(tk.a[3]), "=&v"(o0)
+                     : "v"(pf.a[0]), "v"(pf.a[1]), "v"(pf.a[2]), "v"(pf.a[3]), "v"(pf.o0), "n"(NSTORE)
+                     : "memory");
+        tk.first_next = 0;
+    }
+    __device__ Walk open_taken(uint64_t, uint64_t, SegShared &, uint32_t, const Taken &tk) const { return walk_of(tk.a, k); }
+    template <int N, class KR>
+    __device__ void take(Walk &wk, uint32_t, KR (&keys)[N], uint32_t &ok) const {
+        ok = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            keys[j] = (KR)(wk.w.f < wk.w.r ? wk.w.f : wk.w.r);
+            ok |= (wk.w.ok(wk.at + j) ? 1u : 0u) << j;
+            wk.w.step();
+        }
+        wk.at += N;
+    }
+    __device__ void collect(uint64_t g, SegShared &sm, uint64_t (&keys)[ktseg::PER_THREAD], uint32_t &ok) const {
+        Walk wk = open(g, sm, threadIdx.x);
+        take<(int)ktseg::PER_THREAD, uint64_t>(wk, threadIdx.x, keys, ok);
+    }
+    template <class Sink>
+    __device__ void for_each(uint64_t g, SegShared &sm, Sink &&sink) const {
+        Walk wk = open(g, sm, threadIdx.x);
+#pragma unroll 4
+        for (uint32_t j = 0; j < ktseg::PER_THREAD; j++) {
+            if (wk.w.ok(j)) sink(wk.w.f < wk.w.r ? wk.w.f : wk.w.r);
+            wk.w.step();
+        }
+    }
+};
+
+// what stage_segment makes of the segments [seg_lo, seg_hi), written out: item (g, t) at items[g * 256 + t]
+__global__ __launch_bounds__(BLOCK) void pack_segments_kernel(SegArgs a, uint64_t seg_lo, uint64_t seg_hi, uint4 *__restrict__ items) {
+    __shared__ SegShared sm2[2];  // (two: a wave still reading its item of one segment does not hold up the staging of the next)
+    const uint32_t tid = threadIdx.x;
+    const uint64_t g_first = seg_lo + blockIdx.x;
+    ktseg::SegAhead ah{};
+    if (g_first < seg_hi)
+        ah = ktseg::request_ahead(a, g_first, ktd::load_uniform(a.seg_first + ktd::uniform64(g_first)), g_first + gridDim.x, tid);
+    uint32_t par = 0;
+    for (uint64_t g = g_first; g < seg_hi; g += gridDim.x, par ^= 1u) {
+        SegShared &sm = sm2[par];
+        const uint64_t first_next = ah.first_next;
+        ktseg::stage_ahead(a, g, sm, tid, ah);
+        if (g + gridDim.x < seg_hi) ah = ktseg::request_ahead(a, g + gridDim.x, first_next, g + 2ull * gridDim.x, tid);
+        const uint64_t c = sm.codes[tid];
+        typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
+        const raw4 v = {(uint32_t)c, (uint32_t)(c >> 32), sm.inv[tid], sm.bnd[tid]};
+        *reinterpret_cast<raw4 *>(items + g * BLOCK + tid) = v;
+    }
+    if (blockIdx.x == 0 && tid == 0) items[a.n_seg * BLOCK] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);  // behind the last item: nothing
+}
+
 struct KeysSource {  // canonical k-mers that are already an array: unit = 8192 keys
     const uint64_t *keys;
     uint64_t n;
@@ -2720,12 +2815,13 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
 }  // namespace
 
 // ---- host side: a job = plan + buffers + level 1 over one or more sources + level 2 + range build ----------------
-enum SourceKind { SRC_READS, SRC_KEYS, SRC_RECORDS };
+enum SourceKind { SRC_READS, SRC_KEYS, SRC_RECORDS, SRC_PACKED };
 struct SourceRec {  // what level 1 ran over (kept so that a skewed batch can be redone with exact offsets)
     SourceKind kind;
     ReadsSource rs;
     KeysSource ks;
     RecordSource rc;
+    PackedSource ps;
     uint64_t n_units;  // upper bound (device-side counts may make it smaller)
 };
 // f(the source of r, as its own type)
@@ -2734,13 +2830,14 @@ static int with_source(const SourceRec &r, F &&f) {
     switch (r.kind) {
         case SRC_READS: return f(r.rs);
         case SRC_KEYS: return f(r.ks);
+        case SRC_PACKED: return f(r.ps);
         default: return f(r.rc);
     }
 }
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
     uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
-        verbose, ext_ovf_blocks, build_wgs_ext, direct, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
+        verbose, ext_ovf_blocks, build_wgs_ext, direct, pack, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
@@ -2762,7 +2859,8 @@ static BulkKnobs read_knobs() {
     k.build_wgs_ext = env_u64("KT_BUILD_WGS_EXT", 16);
     k.build_lists = env_u64("KT_BUILD_LISTS", 1);  // 0: the dense build packs the image instead of keeping claim lists (A/B)
     k.dense = env_u64("KT_BULK_DENSE", 1);
-    k.direct = env_u64("KT_BUILD_DIRECT", 1);  // 0: tables of exactly 4^k slots are built by probing too (A/B, tests)
+    k.direct = env_u64("KT_BUILD_DIRECT", 1);
+    k.pack = env_u64("KT_BULK_PACK", 1);  // 0: level 1 stages the reads itself (ReadsSource) instead of reading packed items  // 0: tables of exactly 4^k slots are built by probing too (A/B, tests)
     k.verbose = env_u64("KT_BULK_VERBOSE", 0);
     k.ext_ovf_blocks = env_u64("KT_EXT_OVF_BLOCKS", 0);  // tests: n + 1 = blocks of scratch behind the export target
     return k;
@@ -3391,7 +3489,29 @@ int kt_bulk_build(kt_ctr *ctr, const uint8_t *d_bases, const uint64_t *d_offsets
     uint64_t *seg_first = (uint64_t *)ctx->s_aux0.p;
     hipLaunchKernelGGL(ktseg::seg_index_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                        d_offsets, n_reads, seg_first, n_seg);
-    if (int rc = kt_bulk_add_reads(ctr, d_bases, d_offsets, seg_first, n_reads, n_seg, 0, n_seg, n_parts, part)) return rc;
+    // A pass of its own packs the reads (16 bytes per 32 bases: codes, invalid-base mask, read-start mask - what stage_segment
+    // makes of them) and level 1 reads the packed items: it stages nothing through LDS and has no barrier of its own per unit.
+    // ctr k=31: pack 1.5 + level 1 11.0 ms against 13.2-13.4 with the staging inside level 1; k=15: 3.1 + 14.7 against 18.3.
+    // (Not for the hash partitions of an out-of-core count - every pass would pack the same reads again - and not when the
+    // half byte per base of HBM is not to be had.)
+    bool packed = ctr->job->kn.pack && n_parts <= 1 && ctr->job->paged;
+    if (packed && ctr->b_pack.reserve((n_seg * BLOCK + 1) * sizeof(uint4)) != KT_OK) {
+        kt::set_error("");
+        packed = false;
+    }
+    if (packed) {
+        SegArgs a{d_bases, d_offsets, seg_first, n_reads, n_seg, (uint32_t)ctr->k};
+        hipLaunchKernelGGL(pack_segments_kernel, dim3(ktl::grid_for(ctx, n_seg, 8)), dim3(BLOCK), 0, ctx->stream, a, (uint64_t)0, n_seg,
+                           (uint4 *)ctr->b_pack.p);
+        KT_HIP(hipGetLastError());
+        SourceRec r{};
+        r.kind = SRC_PACKED;
+        r.ps = PackedSource{(const uint4 *)ctr->b_pack.p, 0, n_seg, (uint32_t)ctr->k};
+        r.n_units = n_seg;
+        if (int rc = job_add(ctr, r, n_seg * ktseg::SEG)) return rc;
+    } else if (int rc = kt_bulk_add_reads(ctr, d_bases, d_offsets, seg_first, n_reads, n_seg, 0, n_seg, n_parts, part)) {
+        return rc;
+    }
     if (int rc = kt_bulk_finish(ctr)) return rc;
     *done = 1;
     return KT_OK;

@@ -358,6 +358,7 @@ int kt_ctr_destroy(kt_ctr *ctr) {
     ctr->b_keys2.release();
     ctr->b_meta.release();
     ctr->b_desc.release();
+    ctr->b_pack.release();
     kt_bulk_job_free(ctr->job);
     delete ctr;
     return KT_OK;

@@ -118,6 +118,7 @@ struct kt_ctr {
     kt::Scratch b_ext;                 // the export-target build's holes and the scratch behind the caller's arrays
     kt::Scratch b_stage_k, b_stage_c;  // kt_ctr_export_stage's copy of the entries (when they are not the export target's arrays)
     kt::Scratch b_keys1, b_keys2, b_meta;  // bulk-build buffers (kt_bulk.hip), kept across calls
+    kt::Scratch b_pack;                    // ... the reads packed for level 1 (PackedSource, KT_BULK_PACK)
     kt::Scratch b_desc;                    // ... and the descriptors of its record sources (kt_bulk_add_records)
     kt_bulk_job *job = nullptr;
     void *slots = nullptr;     // [cap] of {u64 key (KT_EMPTY_KEY = free), u32 count, u32 pad}

@@ -262,6 +262,52 @@ __device__ __forceinline__ void stage_taken(const SegArgs &a, uint64_t g, uint64
     ktd::lds_barrier();
 }
 
+// The same a segment ahead with PLAIN loads (route_kernel, pack_segments_kernel: kernels whose stores are long gone by the
+// time the next segment is staged, so the compiler's own wait costs nothing): request_ahead right behind the staging of
+// segment g asks for segment g_next's reads, stage_ahead stages them when their turn comes.
+struct SegAhead {
+    uint32_t d0[8];
+    SegHalo halo;
+    uint64_t o0, first, first_next;
+    bool whole0, whole1;
+};
+// g: the segment asked for (the same for the 256 threads), first_g = seg_first[g], g_after: the segment that will be asked
+// for next (its seg_first comes along)
+__device__ __forceinline__ SegAhead request_ahead(const SegArgs &a, uint64_t g, uint64_t first_g, uint64_t g_after, const uint32_t tid) {
+    SegAhead p;
+    const uint64_t total = ktd::load_uniform(a.offsets + a.n_reads);
+    const uint64_t gu = uniform64(g);
+    const uint64_t b0 = gu * SEG + 32ull * tid, b1 = gu * SEG + 32ull * BLOCK;
+    p.whole0 = b0 + 32 <= total;
+    p.whole1 = b1 + 32 <= total && ((uintptr_t)a.bases & 3u) == 0;  // (a scalar read wants a dword address)
+    p.first = first_g;
+    p.first_next = ktd::load_uniform(a.seg_first + uniform64(g_after < a.n_seg ? g_after : a.n_seg));
+#pragma unroll
+    for (int q = 0; q < 8; q++) p.d0[q] = p.halo.d[q] = 0;
+    if (p.whole1) {
+        typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+        const u32x8 v = ktd::load_uniform(reinterpret_cast<const u32x8 *>(a.bases + b1));
+#pragma unroll
+        for (int q = 0; q < 8; q++) p.halo.d[q] = v[q];
+    }
+    if (p.whole0) __builtin_memcpy(p.d0, a.bases + b0, 32);
+    const uint64_t r0 = first_g + tid;
+    p.o0 = r0 < a.n_reads ? a.offsets[r0] : ~0ull;
+    return p;
+}
+// stages segment g from what request_ahead(.., g, ..) brought (ends with a barrier, like stage_segment)
+__device__ __forceinline__ void stage_ahead(const SegArgs &a, uint64_t g, SegShared &sm, const uint32_t tid, const SegAhead &ah) {
+    SegTaken tk;
+#pragma unroll
+    for (int q = 0; q < 8; q++) tk.d0[q] = ah.d0[q];
+    tk.halo = ah.halo;
+    tk.o0 = ah.o0;
+    tk.first_next = ah.first_next;
+    tk.whole0 = ah.whole0;
+    tk.whole1 = ah.whole1;
+    stage_taken(a, g, ah.first, sm, tid, tk);
+}
+
 // The thread's walk over its 32 window starts [32*tid, 32*tid + 32) of a staged segment: a
 // 128-bit shift register held in two VGPR pairs: fwd = top 2k bits, rev rolls like the
 // reference's generator (kmer/src/kmer.rs:91-93).
@@ -287,6 +333,18 @@ struct Window {
         rsh = 2u * (k - 1);
         // which of the 32 window starts are k-mers, all at once: start j is one iff none of bases j .. j + k - 1 is
         // invalid and no read starts at j + 1 .. j + k - 1 (testing every start on its own was 8 instructions x 32)
+        const uint64_t bad = or_span(iv, k) | (k > 1 ? or_span(bd >> 1, k - 1) : 0ull);
+        okm = ~(uint32_t)bad;
+        f = hi >> sh;
+        r = ktd::rev_comp(f, (int)k);
+    }
+    // the same from the words themselves (two packed items of kt_bulk.hip's PackedSource): iv / bd = the invalid-base and
+    // read-start masks of the 64 bases
+    __device__ __forceinline__ Window(uint64_t hi_, uint64_t lo_, uint64_t iv, uint64_t bd, uint32_t k) {
+        hi = hi_;
+        lo = lo_;
+        sh = 64u - 2u * k;
+        rsh = 2u * (k - 1);
         const uint64_t bad = or_span(iv, k) | (k > 1 ? or_span(bd >> 1, k - 1) : 0ull);
         okm = ~(uint32_t)bad;
         f = hi >> sh;

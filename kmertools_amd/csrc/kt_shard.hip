@@ -174,37 +174,10 @@ __global__ __launch_bounds__(BLOCK, KT_ROUTE_WAVES) void route_kernel(RouteArgs 
     const uint32_t room32 = (uint32_t)ra.room;  // (< 2^32 - 2^20: sharded_alloc)
     // the global reads of a segment - the thread's 32 bases, its first read start, the halo item and the segment's place in
     // the offsets - are requested a segment ahead (plain loads: nothing here needs them before they have long landed)
-    struct Ahead {
-        uint32_t d0[8];
-        ktseg::SegHalo halo;
-        uint64_t o0, first, first_next;
-        bool whole0, whole1;
-    };
-    auto request = [&](uint64_t g, uint64_t first_g, uint64_t g_next) {
-        Ahead p;
-        const uint64_t total = ktd::load_uniform(ra.a.offsets + ra.a.n_reads);
-        const uint64_t gu = ktd::uniform64(g);
-        const uint64_t b0 = gu * ktseg::SEG + 32ull * tid, b1 = gu * ktseg::SEG + 32ull * BLOCK;
-        p.whole0 = b0 + 32 <= total;
-        p.whole1 = b1 + 32 <= total && ((uintptr_t)ra.a.bases & 3u) == 0;  // (a scalar read wants a dword address)
-        p.first = first_g;
-        p.first_next = ktd::load_uniform(ra.a.seg_first + ktd::uniform64(g_next < ra.a.n_seg ? g_next : ra.a.n_seg));
-#pragma unroll
-        for (int q = 0; q < 8; q++) p.d0[q] = p.halo.d[q] = 0;
-        if (p.whole1) {
-            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-            const u32x8 v = ktd::load_uniform(reinterpret_cast<const u32x8 *>(ra.a.bases + b1));
-#pragma unroll
-            for (int q = 0; q < 8; q++) p.halo.d[q] = v[q];
-        }
-        if (p.whole0) __builtin_memcpy(p.d0, ra.a.bases + b0, 32);
-        const uint64_t r0 = first_g + tid;
-        p.o0 = r0 < ra.a.n_reads ? ra.a.offsets[r0] : ~0ull;
-        return p;
-    };
     const uint64_t g_first = ra.seg_lo + blockIdx.x;
-    Ahead ah{};
-    if (g_first < ra.seg_hi) ah = request(g_first, ktd::load_uniform(ra.a.seg_first + ktd::uniform64(g_first)), g_first + gridDim.x);
+    ktseg::SegAhead ah{};
+    if (g_first < ra.seg_hi)
+        ah = ktseg::request_ahead(ra.a, g_first, ktd::load_uniform(ra.a.seg_first + ktd::uniform64(g_first)), g_first + gridDim.x, tid);
     uint32_t par = 0;
     for (uint64_t g = g_first; g < ra.seg_hi; g += gridDim.x, par ^= 1u) {
         SegShared &seg = sm.seg2[par];
@@ -216,17 +189,9 @@ __global__ __launch_bounds__(BLOCK, KT_ROUTE_WAVES) void route_kernel(RouteArgs 
         ktd::lds_barrier();
 #else
         {
-            ktseg::SegTaken tk;
-#pragma unroll
-            for (int q = 0; q < 8; q++) tk.d0[q] = ah.d0[q];
-            tk.halo = ah.halo;
-            tk.o0 = ah.o0;
-            tk.first_next = ah.first_next;
-            tk.whole0 = ah.whole0;
-            tk.whole1 = ah.whole1;
-            const uint64_t first_g = ah.first, first_next = ah.first_next;
-            ktseg::stage_taken(ra.a, g, first_g, seg, tid, tk);  // (ends with a barrier)
-            if (g + gridDim.x < ra.seg_hi) ah = request(g + gridDim.x, first_next, g + 2ull * gridDim.x);
+            const uint64_t first_next = ah.first_next;
+            ktseg::stage_ahead(ra.a, g, seg, tid, ah);  // (ends with a barrier)
+            if (g + gridDim.x < ra.seg_hi) ah = ktseg::request_ahead(ra.a, g + gridDim.x, first_next, g + 2ull * gridDim.x, tid);
         }
 #endif
         const ktseg::Window win(seg, tid, k);

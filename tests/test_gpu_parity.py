@@ -811,6 +811,30 @@ def test_ctr_odd_capacity_requests(hctx, oracle, monkeypatch, k, cap_request):
         ctr.close()
 
 
+@pytest.mark.parametrize("k", [31, 16, 15, 5, 1])
+def test_ctr_level1_over_packed_reads_and_over_staged_reads(hctx, oracle, monkeypatch, k):
+    """the bulk build's level 1 reads the reads as a pass of their own packed them (pack_segments_kernel -> PackedSource: the
+    default) or stages them itself (KT_BULK_PACK=0: ReadsSource): ragged noisy reads - N runs, lower case, raw codes, reads
+    shorter than k, empty reads, reads that cross segments, a batch that ends inside a 32-base item - give the oracle's
+    table either way, also with a second batch merged on top"""
+    from kmertools_amd import device
+    monkeypatch.setenv("KT_BULK_MIN_BASES", "0")
+    seqs = ragged_reads(77 + k, 1500) + [b"ACGTN" * 1700, b"", b"AC", ragged_reads(3, 9)[8][:13]]
+    bases, offsets = device.to_csr(seqs)
+    assert len(bases) % 32 != 0 and len(bases) > 5 * 8192
+    wk, wc = oracle.count_reads(bases, offsets, k)
+    for pack in ("1", "0"):
+        monkeypatch.setenv("KT_BULK_PACK", pack)
+        ctr = device.Counter(hctx, k, 1 << 21)
+        ctr.add_reads_host(bases, offsets)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, wc), (k, pack)
+        ctr.add_reads_host(bases, offsets)
+        gk, gc = ctr.export_host()
+        assert np.array_equal(gk, wk) and np.array_equal(gc, 2 * wc), (k, pack)
+        ctr.close()
+
+
 @pytest.mark.parametrize("k", [8, 10, 12, 13])
 def test_ctr_direct_addressed_tables(torch_mod, ctx, oracle, monkeypatch, k):
     """a table of exactly 4^k slots (k <= 15: the hash of a k-mer is a bijection onto the slots - ktd::nhash - and the bulk
