@@ -485,9 +485,11 @@ def run_workload(env, name, args, genome=0, steps=None, warmup=None):
             counter.table.export_target(xk, xc, max_distinct)
         kt_ = "unsigned int" if k <= 16 else "unsigned long"
         routed = world > 1 or os.environ.get("KT_SHARD_FORCE")
+        packed = os.environ.get("KT_BULK_PACK", "1") != "0"
         dominant = ("ctr k=%d step: clear + %sbulk table build (scatter1y_kernel<%s, %s, 1024>, part2_swwc_kernel<%s>, "
                     "build_kernel<%s, ...>%s)%s"
-                    % (k, "route_kernel + " if routed else "", "RecordSource" if routed else "ReadsSource", kt_, kt_, kt_,
+                    % (k, "route_kernel + " if routed else "pack_segments_kernel + " if packed else "",
+                       "RecordSource" if routed else "PackedSource" if packed else "ReadsSource", kt_, kt_, kt_,
                        " writing the export arrays" if fused else "",
                        " + size + export" + ("" if fused else " (dense_export_kernel)") if with_export else ""))
         parallelism = ("one table per GPU" if world == 1 and not os.environ.get("KT_SHARD_FORCE") else

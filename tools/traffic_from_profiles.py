@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-CTR_KERNELS = r"seg_index|route_kernel|scatter1|xcd_tails|part2|build_kernel|ext_scan|ext_patch|hist1|scan1"
+CTR_KERNELS = r"seg_index|pack_segments|route_kernel|scatter1|xcd_tails|part2|build_kernel|ext_scan|ext_patch|hist1|scan1"
 # traffic.json key -> (summary tag, kernels of the workload's step, kernel whose launch count = steps (None: per launch of it))
 WORKLOADS = {
     "ctr_k31": ("ctr_k31", CTR_KERNELS, "build_kernel"),
