@@ -147,7 +147,8 @@ __device__ __forceinline__ K to_stored(uint64_t key) {
 template <class K>
 __device__ __forceinline__ uint64_t hash_of_stored(K s, const Plan &p) {
     if constexpr (stores_hash<K>()) return (uint64_t)s;
-    else return ktd::khash_k((uint64_t)s, p.kbits);
+    else if constexpr (sizeof(K) == 4) return (uint64_t)ktd::nhash_top((uint32_t)s, p.kbits) << 32;  // (k <= 16: kbits = 2k, never 0 -
+    else return ktd::khash_k((uint64_t)s, p.kbits);  // khash_k's test of it is a branch per key and pass: plan_job)
 }
 template <class K>
 __device__ __forceinline__ uint64_t from_stored(K s) {
@@ -1080,6 +1081,13 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
 // borrow the buffer that the round about to begin will fill (its former content left the CU a round ago).  LDS: 2 x (T x
 // PER2 + B1 x (GK - 1)) keys + 14 KB - carved at run time (the pads follow B1); a shape that does not fit 160 KB keeps
 // scatter1x.
+#ifndef KT_S1Y_BATCH
+#define KT_S1Y_BATCH 1   // 0: the placement asks for a cursor and waits for it, key by key; 2: batched with 64-bit keys too (A/B builds)
+#endif
+// (ctr k=15, 16 keys per thread and round: level 1 15.2 -> 12.9 ms; 64-bit keys, 8 per thread: 10.38 -> 10.30 ms over packed reads,
+// 2.31 -> 2.37 ms per piece over records - so 32-bit keys only)
+template <class K>
+constexpr bool s1y_batch() { return KT_S1Y_BATCH == 2 || (KT_S1Y_BATCH == 1 && sizeof(K) == 4); }
 template <class K>
 constexpr int half_per() { return wide_per<K>() / 2; }
 template <class K, int T>
@@ -1211,7 +1219,11 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
 #pragma unroll
             for (int j = 0; j < PER; j++) {  // (the keys take their stored form here, where the first digit is needed)
                 keys[j] = to_stored<K>((uint64_t)keys[j]);
-                if ((ok >> j) & 1u) {
+                if constexpr (s1y_batch<K>()) {  // (a key that does not count adds 0: no branch, no exec-mask bookkeeping per key)
+                    const uint32_t d = digit1h(hash_of_stored<K>(keys[j], p), p), one = (ok >> j) & 1u;
+                    if constexpr (PACK) atomicAdd(&sm.cnt2[d >> 1], one << ((d & 1u) * 16u));
+                    else atomicAdd(&sm.cnt2[d], one);
+                } else if ((ok >> j) & 1u) {
                     const uint32_t d = digit1h(hash_of_stored<K>(keys[j], p), p);
                     if constexpr (PACK) atomicAdd(&sm.cnt2[d >> 1], 1u << ((d & 1u) * 16u));
                     else atomicAdd(&sm.cnt2[d], 1u);
@@ -1242,14 +1254,31 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
             ktd::lds_barrier();  // start[] was read above; the placement pass uses it as its cursors
             KT_PH(4);
             K *const sb = sm.sorted[par];
+            if constexpr (s1y_batch<K>()) {
+                // the placement's cursor atomics leave together, all PER of them, and the keys follow as the answers come in: a
+                // key that does not count adds 0 to its cursor (no branch around the atomic: under one the compiler waits for
+                // every answer where it is asked for - PER LDS round trips one after the other, four waves per SIMD to hide them)
+                uint32_t at[PER];
 #pragma unroll
-            for (int j = 0; j < PER; j++) {
-                if ((ok >> j) & 1u) {
+                for (int j = 0; j < PER; j++) {
                     const uint32_t d = digit1h(hash_of_stored<K>(keys[j], p), p);
-                    const uint32_t pos = atomicAdd(&xs[d], 1u);
-                    sb[pos] = keys[j];
+                    at[j] = atomicAdd(&xs[d], (ok >> j) & 1u);
                 }
-                emit_at(PER + j);
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    if ((ok >> j) & 1u) sb[at[j]] = keys[j];
+                    emit_at(PER + j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    if ((ok >> j) & 1u) {
+                        const uint32_t d = digit1h(hash_of_stored<K>(keys[j], p), p);
+                        const uint32_t pos = atomicAdd(&xs[d], 1u);
+                        sb[pos] = keys[j];
+                    }
+                    emit_at(PER + j);
+                }
             }
             KT_PH(5);
             if (rc) {
@@ -2836,14 +2865,13 @@ static int with_source(const SourceRec &r, F &&f) {
 }
 
 struct BulkKnobs {  // the KT_BULK_* / KT_S1_* / KT_P2_* / KT_BUILD_* environment, read once per job (kt_bulk_begin)
-    uint64_t bulk, min_bases, narrow, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
+    uint64_t bulk, min_bases, merge_div, g_mult, paged, fixed2, p2_big64, p2_big32, build_wgs, dense,
         verbose, ext_ovf_blocks, build_wgs_ext, direct, pack, p2_fast, p2_grid, p2_swwc, b1, build_lists, s1y;
 };
 static BulkKnobs read_knobs() {
     BulkKnobs k;
     k.bulk = env_u64("KT_BULK", 1);
     k.min_bases = env_u64("KT_BULK_MIN_BASES", 4ull << 20);
-    k.narrow = env_u64("KT_BULK_NARROW", 1);
     k.merge_div = env_u64("KT_BULK_MERGE_DIV", 8);
     k.g_mult = env_u64("KT_BULK_G_MULT", 1);
     k.paged = env_u64("KT_BULK_PAGED", 1);
@@ -3224,7 +3252,7 @@ static int plan_job(kt_ctr *ctr, uint64_t max_keys, int *eligible) {
     j.merge = !ctr->empty;  // the table holds data: every range is rebuilt from what it has + the batch
     if (j.merge)
         if (int rc = kt_table_image(ctr)) return rc;  // (a densely packed table gets its probing image first)
-    j.narrow = ctr->k <= 16 && kn.narrow;
+    j.narrow = ctr->k <= 16 && ctr->kbits != 0;  // (kt_ctr_create: every table of k <= 16 hashes with ktd::nhash)
     j.max_keys = max_keys;
     j.added_bound = 0;
     const size_t ksz = j.narrow ? 4 : 8;
