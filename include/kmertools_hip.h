@@ -248,8 +248,9 @@ int kt_cgr_points(kt_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, ui
  * (minimiser, window start, window end) the reference yields; read i owns entries
  * [ev_offsets[i], ev_offsets[i+1]) of kmers/starts/ends (starts/ends are read-local, ends
  * exclusive).  wsize = 0 means "the read's own length" (one minimiser per read,
- * misc/src/minimisers.rs:44-48); otherwise msize <= wsize (windows of more than 4096 m-mers take a one-read-per-
- * thread path: correct, and parallel across reads only).
+ * misc/src/minimisers.rs:44-48); otherwise msize <= wsize (windows of more than 4096 m-mers: a two-level
+ * sliding minimum in front of the same kernel, three scratch arrays of one m-mer per base; windows of 2^30 bases and
+ * more take a one-read-per-thread path: correct, and parallel across reads only).
  * 1 <= msize <= 31.  Quirks of the iterator are kept (a change on the last base swallows the
  * final window; a last run shorter than the window reports UINT64_MAX).  Reads shorter than msize
  * yield nothing with wsize = 0 (the reference's capacity arithmetic underflows there).

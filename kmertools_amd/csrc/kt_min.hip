@@ -277,10 +277,13 @@ constexpr unsigned long long ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MAS
 
 // HG = granules of halo in front of the tile: windows of up to HG * 1024 m-mers (1: tiles of 7168 positions;
 // 4: tiles of 4096, for the rare wide windows)
-template <class V, bool EMIT, int HG>
+// MODE (windows of more than MAX_HG * 1024 m-mers - the two-level sliding minimum, see kt_minimisers): 1 = the tile's
+// sliding minimum over a.W (= 4096) m-mers goes to act[] and nothing else happens; 2 = the active minimiser of every
+// position comes from act[] (strided_min_kernel has made it) and the tile does everything but the sliding minimum
+template <class V, bool EMIT, int HG, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__restrict__ tile_count, Chain chain,
                                                          Event *__restrict__ ev, uint8_t *__restrict__ ev_type,
-                                                         uint64_t *__restrict__ ev_offsets) {
+                                                         uint64_t *__restrict__ ev_offsets, V *__restrict__ act) {
     __shared__ TileShared<V> sm;
     __shared__ uint64_t sh_u64;
     constexpr V VNONE = (V)~(V)0;
@@ -396,8 +399,17 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         return loc == FAR ? far_value : (uint64_t)(range0 + (int64_t)loc);
     };
 
+    if constexpr (MODE == 2) {
+        // the active minimisers of the owned positions and of the one in front of them, as the passes before left them
+#pragma unroll
+        for (int32_t j = 0; j < (int32_t)PER; j++) {
+            const int32_t li = l0 + j;
+            sm.a[ph((uint32_t)li)] = ((inside >> j) & 1u) && li + 1 >= (int32_t)HALO ? act[range0 + (int64_t)li] : VNONE;
+        }
+        __syncthreads();
+    }
     // ---- canonical m-mers of this thread's positions -> sm.a ----
-    {
+    if constexpr (MODE != 2) {
         V f = 0, r = 0;
         const V mask = (V)(((uint64_t)1 << (2 * m)) - 1ull);
         const uint32_t rsh = 2 * (uint32_t)(m - 1);
@@ -424,10 +436,10 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
             sm.a[ph((uint32_t)(l0 + j))] = v;
         }
     }
-    __syncthreads();
+    if constexpr (MODE != 2) __syncthreads();
 
     // ---- sliding minimum over W m-mers: doubling, then two overlapping power-of-two windows ----
-    {
+    if constexpr (MODE != 2) {
         // only windows ending at local index >= HALO - 1 are ever read; the values they are built from reach
         // back less than 2 W positions, so the threads further in front (most of the halo wave) just keep step
         const bool needed = (uint32_t)l0 + PER + 2 * W + 2 > HALO;
@@ -455,6 +467,15 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
             span *= 2;
         }
         if (span < W) combine(W - span);
+    }
+
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int32_t j = 0; j < (int32_t)PER; j++) {
+            const int32_t li = l0 + j;
+            if (((inside >> j) & 1u) && li >= (int32_t)HALO) act[range0 + (int64_t)li] = sm.a[ph((uint32_t)li)];
+        }
+        return;
     }
 
     // ---- events of the positions this workgroup owns (local index >= HALO) ----
@@ -583,6 +604,17 @@ __global__ __launch_bounds__(BLOCK) void min_tile_kernel(MinArgs a, uint64_t *__
         const uint64_t o = a.offsets[r];
         if (o >= t0 + TILE || o >= a.total) break;
         ev_offsets[r] = base + sm.rank[(uint32_t)((int64_t)o - range0)];
+    }
+}
+
+// out[p] = min(in[p], in2[p - d]) (nothing in front of the batch): one step of the second level of the sliding minimum
+template <class V>
+__global__ __launch_bounds__(256) void strided_min_kernel(const V *__restrict__ in, const V *__restrict__ in2, V *__restrict__ out,
+                                                          uint64_t n, uint64_t d) {
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (uint64_t)gridDim.x * 256) {
+        const V u = in[p];
+        const V o = p >= d ? in2[p - d] : (V)~(V)0;
+        out[p] = u < o ? u : o;
     }
 }
 
@@ -765,6 +797,47 @@ __global__ void set_last_kernel(uint64_t *__restrict__ ev_offsets, uint64_t n_re
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- windows of more than 4096 m-mers on the tile path: the sliding minimum in two levels --------------------------------
+// H = 4096 (what a tile's halo reaches).  Level 1: A0(p) = min of the H m-mers ending at p - the tile kernel itself (MODE 1),
+// written out.  Level 2, with W = J H + R: B_J(p) = min over j < J of A0(p - j H) by doubling on the stride-H sequence
+// (log2 J elementwise passes, out[p] = min(in[p], in[p - d])), and the window's first H m-mers are A0(p - (W - H)):
+// act(p) = min(B_J(p), A0(p - (W - H))).  Windows that reach across a run's start come out wrong and are never looked at
+// (an event needs run_len >= w), exactly as inside a tile.  Three arrays of one m-mer per base, in ctx->s_aux0.
+template <class V>
+int wide_window_act(kt_ctx *ctx, const MinArgs &a_in, V **act_out) {
+    const uint64_t total = a_in.total, H = (uint64_t)MAX_HG * GRAN, W = a_in.W;
+    const size_t one = align256(total * sizeof(V));
+    if (int rc = ctx->s_aux0.reserve(3 * one + 256)) return rc;
+    char *base = (char *)ctx->s_aux0.p;
+    V *A0 = (V *)base, *bufs[2] = {(V *)(base + one), (V *)(base + 2 * one)};
+    MinArgs a = a_in;
+    a.W = (uint32_t)H;
+    a.w = (uint32_t)H + a.m - 1;
+    const uint64_t n_tiles = (total + (RANGE - H) - 1) / (RANGE - H);
+    hipLaunchKernelGGL((min_tile_kernel<V, false, (int)MAX_HG, 1>), dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a,
+                       (uint64_t *)nullptr, Chain{}, (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr, A0);
+    KT_HIP(hipGetLastError());
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 64u);
+    int which = 0;
+    V *cur = A0;
+    auto step = [&](const V *in2, uint64_t d) {
+        hipLaunchKernelGGL(strided_min_kernel<V>, dim3(grid), dim3(256), 0, ctx->stream, (const V *)cur, in2, bufs[which], total, d);
+        cur = bufs[which];
+        which ^= 1;
+    };
+    const uint64_t J = W / H;
+    uint64_t span = 1;
+    while (span * 2 <= J) {
+        step(cur, span * H);
+        span *= 2;
+    }
+    if (span < J) step(cur, (J - span) * H);
+    step(A0, W - H);
+    KT_HIP(hipGetLastError());
+    *act_out = cur;
+    return KT_OK;
+}
+
 }  // namespace
 
 using namespace ktl;
@@ -778,7 +851,13 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     if (msize < 1 || msize > 31) return kt::fail(KT_ERR_ARG, "kt_minimisers: msize must be in 1..31");
     if (wsize != 0 && wsize < (uint64_t)msize)
         return kt::fail(KT_ERR_ARG, "kt_minimisers: wsize must be 0 or >= msize");
-    const bool wide = wsize != 0 && wsize - (uint64_t)msize + 1 > MAX_HG * GRAN;  // one thread per read (min_serial_kernel)
+    // windows of more than 4096 m-mers: the two-level sliding minimum (wide_window_act) in front of the tile kernel; the
+    // iterator itself, one read per thread (min_serial_kernel), is what is left for windows of 2^30 bases and more, and
+    // what KT_MIN_SERIAL=1 asks for (the tests run both against the oracle)
+    const bool beyond = wsize != 0 && wsize - (uint64_t)msize + 1 > MAX_HG * GRAN;
+    const char *ser = getenv("KT_MIN_SERIAL");
+    const bool wide = beyond && (wsize >= (1ull << 30) || (ser && ser[0] == '1'));
+    const bool two_level = beyond && !wide;
     if (n_reads == 0) return KT_OK;
     if (!offsets || !ev_offsets) return kt::fail(KT_ERR_ARG, "kt_minimisers: null offsets");
     if (capacity && (!kmers || !starts || !ends)) return kt::fail(KT_ERR_ARG, "kt_minimisers: null output");
@@ -804,7 +883,7 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     // internal buffers (one scratch allocation): granule index/carries, per-tile counts/bases, scan partials
     const uint64_t n_gran = (total + GRAN - 1) / GRAN;
     // halo granules in front of every tile: one for windows of up to 1024 m-mers, four for wider ones
-    const int hg = (wsize == 0 || wsize - (uint64_t)msize + 1 <= GRAN) ? 1 : (int)MAX_HG;
+    const int hg = (wsize == 0 || two_level || wsize - (uint64_t)msize + 1 <= GRAN) ? 1 : (int)MAX_HG;
     const uint64_t tile_len = RANGE - (uint64_t)hg * GRAN;
     const uint64_t n_tiles = (total + tile_len - 1) / tile_len;
     const uint64_t n_scan = (n_reads > n_gran ? n_reads : n_gran) + 1;
@@ -868,13 +947,25 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
             MinArgs a{d_bases, d_offsets, gfirst, carry, n_reads, total, n_gran,
                       (uint32_t)wsize, (uint32_t)msize, (uint32_t)(wsize - (uint64_t)msize + 1)};
             const bool narrow = msize <= 16;
+            uint32_t *act32 = nullptr;
+            uint64_t *act64 = nullptr;
+            if (two_level) {
+                if (int rc = narrow ? wide_window_act<uint32_t>(ctx, a, &act32) : wide_window_act<uint64_t>(ctx, a, &act64)) return rc;
+            }
             Chain chain{(unsigned long long *)tcount, (unsigned long long *)(d_total + 1), d_total, n_tiles, capacity};
             if (capacity == 0) {
                 // count only: per-tile counts, then their sum
-                auto kern = narrow ? (hg == 1 ? min_tile_kernel<uint32_t, false, 1> : min_tile_kernel<uint32_t, false, MAX_HG>)
-                                   : (hg == 1 ? min_tile_kernel<uint64_t, false, 1> : min_tile_kernel<uint64_t, false, MAX_HG>);
-                hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, tcount, chain,
-                                   (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr);
+                if (narrow) {
+                    auto kern = two_level ? min_tile_kernel<uint32_t, false, 1, 2>
+                                          : (hg == 1 ? min_tile_kernel<uint32_t, false, 1> : min_tile_kernel<uint32_t, false, MAX_HG>);
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, tcount, chain,
+                                       (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr, act32);
+                } else {
+                    auto kern = two_level ? min_tile_kernel<uint64_t, false, 1, 2>
+                                          : (hg == 1 ? min_tile_kernel<uint64_t, false, 1> : min_tile_kernel<uint64_t, false, MAX_HG>);
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, tcount, chain,
+                                       (Event *)nullptr, (uint8_t *)nullptr, (uint64_t *)nullptr, act64);
+                }
                 if (int rc = device_excl_scan<false>(ctx, tcount, n_tiles, tbase, partial, d_total)) return rc;
                 KT_HIP(hipMemcpyAsync(&n_ev, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
                 KT_HIP(hipStreamSynchronize(ctx->stream));
@@ -885,10 +976,17 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
                 uint8_t *ev_type = (uint8_t *)ctx->s_aux2.p + align256(capacity * sizeof(Event));
                 KT_HIP(hipMemsetAsync(tcount, 0, n_tiles * 8, ctx->stream));
                 KT_HIP(hipMemsetAsync(d_total, 0, 16, ctx->stream));
-                auto kern = narrow ? (hg == 1 ? min_tile_kernel<uint32_t, true, 1> : min_tile_kernel<uint32_t, true, MAX_HG>)
-                                   : (hg == 1 ? min_tile_kernel<uint64_t, true, 1> : min_tile_kernel<uint64_t, true, MAX_HG>);
-                hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, (uint64_t *)nullptr, chain,
-                                   ev, ev_type, d_evoff);
+                if (narrow) {
+                    auto kern = two_level ? min_tile_kernel<uint32_t, true, 1, 2>
+                                          : (hg == 1 ? min_tile_kernel<uint32_t, true, 1> : min_tile_kernel<uint32_t, true, MAX_HG>);
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, (uint64_t *)nullptr, chain,
+                                       ev, ev_type, d_evoff, act32);
+                } else {
+                    auto kern = two_level ? min_tile_kernel<uint64_t, true, 1, 2>
+                                          : (hg == 1 ? min_tile_kernel<uint64_t, true, 1> : min_tile_kernel<uint64_t, true, MAX_HG>);
+                    hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(BLOCK), 0, ctx->stream, a, (uint64_t *)nullptr, chain,
+                                       ev, ev_type, d_evoff, act64);
+                }
                 hipLaunchKernelGGL(min_tail_kernel, dim3((uint32_t)((n_reads + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                    d_evoff, n_reads, d_total);
                 KT_HIP(hipGetLastError());

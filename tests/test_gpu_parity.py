@@ -1582,15 +1582,21 @@ def test_minimisers_arguments(hctx):
     assert len(k) == 0 and list(evo) == [0]
 
 
-@pytest.mark.parametrize("w,m", [(5000, 7), (4200, 17), (9000, 31), (20000, 10)])
-def test_minimisers_windows_wider_than_4096(hctx, oracle, w, m):
-    """windows of more than 4096 m-mers run the iterator itself, one read per thread (min_serial_kernel): reads
-    shorter than, equal to and several times the window, N runs, lower case, the quirks on the last base"""
+@pytest.mark.parametrize("w,m,serial", [(5000, 7, "0"), (4200, 17, "0"), (9000, 31, "0"), (20000, 10, "0"), (4096 + 7, 8, "0"),
+                                        (8192 + 6, 7, "0"), (12288 + 30, 31, "0"), (70_000, 12, "0"), (33_000, 20, "0"),
+                                        (5000, 7, "1"), (4200, 17, "1"), (9000, 31, "1"), (20000, 10, "1")])
+def test_minimisers_windows_wider_than_4096(hctx, oracle, monkeypatch, w, m, serial):
+    """windows of more than 4096 m-mers: the sliding minimum in two levels in front of the tile kernel (4096-m-mer minima
+    from the tiles, doubling over the stride-4096 sequence: wide_window_act - windows of exactly one, two, three and
+    seventeen times 4096 m-mers and in between), and the iterator itself, one read per thread (KT_MIN_SERIAL=1:
+    min_serial_kernel) - reads shorter than, equal to and several times the window, N runs, lower case, the quirks on the
+    last base, ties all along"""
     from kmertools_amd import device
+    monkeypatch.setenv("KT_MIN_SERIAL", serial)
     rng = np.random.default_rng(w + m)
     alpha = np.frombuffer(b"ACGT", np.uint8)
     seqs = []
-    for L in [0, 1, m - 1, m, w - 1, w, w + 1, w + m, 2 * w + 17, 3 * w, 60, 25_000, 61_000]:
+    for L in [0, 1, m - 1, m, w - 1, w, w + 1, w + m, 2 * w + 17, 3 * w, 60, 25_000, 61_000] + ([4 * w + 4095] if w > 30_000 else []):
         s = alpha[rng.integers(0, 4, size=L)].copy()
         if L > 200 and rng.random() < 0.7:
             for at in rng.integers(0, L, size=3):
