@@ -476,23 +476,46 @@ struct PackedSource {
     }
 };
 
-// what stage_segment makes of the segments [seg_lo, seg_hi), written out: item (g, t) at items[g * 256 + t]
+// what stage_segment makes of the segments [seg_lo, seg_hi), written out: item (g, t) at items[g * 256 + t].  A thread's codes
+// and invalid-base mask come straight from the 32 bytes it has read; only the read starts cross threads (the thread that reads
+// read r's offset sets a bit in another thread's item): one LDS word per item, two sets of them - a thread clears its word of
+// the set the NEXT segment will use in front of this segment's barrier - so a segment costs one barrier.  The reads of a
+// segment are asked for while the one before it is packed (ktseg::request_ahead).
 __global__ __launch_bounds__(BLOCK) void pack_segments_kernel(SegArgs a, uint64_t seg_lo, uint64_t seg_hi, uint4 *__restrict__ items) {
-    __shared__ SegShared sm2[2];  // (two: a wave still reading its item of one segment does not hold up the staging of the next)
+    __shared__ uint32_t bnd2[2][BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint64_t g_first = seg_lo + blockIdx.x;
+    const uint64_t total = ktd::load_uniform(a.offsets + a.n_reads);
     ktseg::SegAhead ah{};
     if (g_first < seg_hi)
         ah = ktseg::request_ahead(a, g_first, ktd::load_uniform(a.seg_first + ktd::uniform64(g_first)), g_first + gridDim.x, tid);
+    bnd2[0][tid] = 0;
+    ktd::lds_barrier();
     uint32_t par = 0;
     for (uint64_t g = g_first; g < seg_hi; g += gridDim.x, par ^= 1u) {
-        SegShared &sm = sm2[par];
-        const uint64_t first_next = ah.first_next;
-        ktseg::stage_ahead(a, g, sm, tid, ah);
+        const uint64_t B0 = g * ktseg::SEG, first_g = ah.first, first_next = ah.first_next, o0 = ah.o0;
+        uint64_t w;
+        uint32_t iv;
+        ktseg::encode_item(a, total, B0 + 32ull * tid, ah.d0, ah.whole0, w, iv);
         if (g + gridDim.x < seg_hi) ah = ktseg::request_ahead(a, g + gridDim.x, first_next, g + 2ull * gridDim.x, tid);
-        const uint64_t c = sm.codes[tid];
+        uint32_t *const bnd = bnd2[par];
+        bnd2[par ^ 1u][tid] = 0;  // (last read a barrier ago, by this thread; next written behind the barrier below)
+        {
+            const uint64_t lim = B0 + ktseg::SEG, r0 = first_g + tid;
+            if (r0 < a.n_reads && o0 < lim) {
+                const uint32_t rel = (uint32_t)(o0 - B0);
+                atomicOr(&bnd[rel >> 5], 1u << (rel & 31u));
+                for (uint64_t r = r0 + BLOCK; r < a.n_reads; r += BLOCK) {  // more than 256 read starts in a segment
+                    const uint64_t o = a.offsets[r];
+                    if (o >= lim) break;
+                    const uint32_t rel2 = (uint32_t)(o - B0);
+                    atomicOr(&bnd[rel2 >> 5], 1u << (rel2 & 31u));
+                }
+            }
+        }
+        ktd::lds_barrier();
         typedef uint32_t raw4 __attribute__((ext_vector_type(4)));
-        const raw4 v = {(uint32_t)c, (uint32_t)(c >> 32), sm.inv[tid], sm.bnd[tid]};
+        const raw4 v = {(uint32_t)w, (uint32_t)(w >> 32), iv, bnd[tid]};
         *reinterpret_cast<raw4 *>(items + g * BLOCK + tid) = v;
     }
     if (blockIdx.x == 0 && tid == 0) items[a.n_seg * BLOCK] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0u);  // behind the last item: nothing

@@ -200,43 +200,51 @@ __device__ __forceinline__ void prefetch_take(SegTaken &tk, SegPrefetch2 &pf) {
     tk.whole1 = pf.whole1;
 }
 
+// the 32 bases at batch position b (din: their bytes when the item lies wholly inside the batch) as a word of 2-bit codes,
+// first base on top, and the mask of the bases that are not nucleotides (all ones past the batch's end)
+__device__ __forceinline__ void encode_item(const SegArgs &a, uint64_t total, uint64_t b, const uint32_t (&din)[8], bool whole,
+                                            uint64_t &w, uint32_t &iv) {
+    w = 0;
+    iv = 0xFFFFFFFFu;
+    if (b < total) {
+        uint32_t d[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) d[q] = din[q];
+        if (!whole) {  // the batch ends inside this item
+            unsigned char raw[32];
+            for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
+            __builtin_memcpy(d, raw, 32);
+        }
+        uint32_t msb_first = 0, any_raw = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint32_t c8, i4, rw;
+            ktd::swar4(d[q], c8, i4, rw);
+            w = (w << 8) | c8;
+            msb_first = (msb_first << 4) | i4;
+            any_raw |= rw;
+        }
+        iv = __builtin_bitreverse32(msb_first);
+        if (any_raw) {
+            w = 0;
+            iv = 0;
+            for (int j = 0; j < 32; j++) {
+                const uint32_t e = ktd::nt4((d[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+                w = (w << 2) | (e & 3u);
+                iv |= (e >> 2) << j;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void stage_taken(const SegArgs &a, uint64_t g, uint64_t first_g, SegShared &sm,
                                             const uint32_t tid, const SegTaken &pf) {
     const uint64_t total = ktd::load_uniform(a.offsets + a.n_reads);
     const uint64_t B0 = g * SEG;
     auto encode = [&](uint32_t i, const uint32_t (&din)[8], bool whole) {
-        const uint64_t b = B0 + 32ull * i;
-        uint64_t w = 0;
-        uint32_t iv = 0xFFFFFFFFu;
-        if (b < total) {
-            uint32_t d[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) d[q] = din[q];
-            if (!whole) {  // the batch ends inside this item
-                unsigned char raw[32];
-                for (int j = 0; j < 32; j++) raw[j] = (b + j < total) ? a.bases[b + j] : (unsigned char)'N';
-                __builtin_memcpy(d, raw, 32);
-            }
-            uint32_t msb_first = 0, any_raw = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                uint32_t c8, i4, rw;
-                ktd::swar4(d[q], c8, i4, rw);
-                w = (w << 8) | c8;
-                msb_first = (msb_first << 4) | i4;
-                any_raw |= rw;
-            }
-            iv = __builtin_bitreverse32(msb_first);
-            if (any_raw) {
-                w = 0;
-                iv = 0;
-                for (int j = 0; j < 32; j++) {
-                    const uint32_t e = ktd::nt4((d[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-                    w = (w << 2) | (e & 3u);
-                    iv |= (e >> 2) << j;
-                }
-            }
-        }
+        uint64_t w;
+        uint32_t iv;
+        encode_item(a, total, B0 + 32ull * i, din, whole, w, iv);
         sm.codes[i] = w;
         sm.inv[i] = iv;
         sm.bnd[i] = 0;
