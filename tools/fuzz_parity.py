@@ -105,4 +105,24 @@ while time.time() < t_end:
         g = [(int(kk[j]), int(ss[j]), int(ee[j])) for j in range(int(evo[i]), int(evo[i + 1]))]
         assert g == oracle.minimisers(s, w, m), ("min", seed, i, w, m)
     cases["min"] += 1
+    # min, windows of more than 4096 m-mers (the two-level sliding minimum), a few long reads with N runs and repeats
+    if rng.random() < 0.3:
+        m = int(rng.integers(1, 32))
+        w = m - 1 + int(rng.choice([4097, 4096 + int(rng.integers(1, 4096)), 8192, 8193, 3 * 4096 + int(rng.integers(0, 4096)),
+                                    int(rng.integers(17_000, 40_000))]))
+        ls = []
+        for L in (int(rng.integers(0, 2 * w)), int(rng.integers(w, 3 * w)), w, w + 1, int(rng.integers(1, 300))):
+            t = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=L)].copy()
+            if L > 100 and rng.random() < 0.5:
+                at = int(rng.integers(0, L - 50)); t[at:at + int(rng.integers(1, 5))] = ord("N")
+            if L > 1000 and rng.random() < 0.3:
+                per = int(rng.integers(1, 40)); at = int(rng.integers(0, L // 2)); span = int(rng.integers(1, L // 2))
+                t[at:at + span] = np.resize(t[at:at + per].copy(), span)
+            ls.append(t.tobytes())
+        lb, lo = oracle.to_csr(ls)
+        evo, kk, ss, ee = ctx.minimisers_host(lb, lo, w, m)
+        for i, s in enumerate(ls):
+            g = [(int(kk[j]), int(ss[j]), int(ee[j])) for j in range(int(evo[i]), int(evo[i + 1]))]
+            assert g == oracle.minimisers(s, w, m), ("min wide", seed, i, w, m)
+        cases["min_wide"] = cases.get("min_wide", 0) + 1
 print("fuzz ok", cases, "seed", seed)

@@ -16,7 +16,8 @@ for r in csv.DictReader(open(sys.argv[1] + "/kt_kernel_stats.csv")):
 PY
 }
 # NOTE: rocprofv3 must launch python3 directly; env vars are exported instead of using `env`
+# (the variants of the round - waves per workgroup, ablations - were builds with -DKT_ROUTE_WAVES / -DKT_ROUTE_ABL:
+# tools/build_variant_tu.sh <name> kt_shard -D..., then `run <name> KT_LIB=.../variants/lib<name>.so`)
 run base
-run rw5 KT_LIB=$GRAFT_REPO_ROOT/kmertools_amd/variants/librw5.so KT_ROUTE_GRID=20
-run rw6 KT_LIB=$GRAFT_REPO_ROOT/kmertools_amd/variants/librw6.so KT_ROUTE_GRID=20
+run g20 KT_ROUTE_GRID=20
 run g32 KT_ROUTE_GRID=32
