@@ -856,8 +856,8 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     // what KT_MIN_SERIAL=1 asks for (the tests run both against the oracle)
     const bool beyond = wsize != 0 && wsize - (uint64_t)msize + 1 > MAX_HG * GRAN;
     const char *ser = getenv("KT_MIN_SERIAL");
-    const bool wide = beyond && (wsize >= (1ull << 30) || (ser && ser[0] == '1'));
-    const bool two_level = beyond && !wide;
+    bool wide = beyond && (wsize >= (1ull << 30) || (ser && ser[0] == '1'));
+    bool two_level = beyond && !wide;
     if (n_reads == 0) return KT_OK;
     if (!offsets || !ev_offsets) return kt::fail(KT_ERR_ARG, "kt_minimisers: null offsets");
     if (capacity && (!kmers || !starts || !ends)) return kt::fail(KT_ERR_ARG, "kt_minimisers: null output");
@@ -865,6 +865,11 @@ extern "C" int kt_minimisers(kt_ctx *ctx, const uint8_t *bases, const uint64_t *
     uint64_t total = 0;
     if (int rc = total_bases_of(ctx, offsets, n_reads, mem, &total)) return rc;
     if (total && !bases) return kt::fail(KT_ERR_ARG, "kt_minimisers: null bases");
+    if (two_level && ctx->s_aux0.reserve(3 * align256(total * (msize <= 16 ? 4 : 8)) + 256) != KT_OK) {
+        kt::set_error("");  // (no room for the three arrays of the two-level minimum: the iterator needs one)
+        two_level = false;
+        wide = true;
+    }
 
     const uint8_t *d_bases = bases;
     const uint64_t *d_offsets = offsets;
