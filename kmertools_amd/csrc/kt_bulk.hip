@@ -1104,6 +1104,9 @@ __global__ __launch_bounds__(T, 4) void scatter1x_kernel(Source src, Plan p, uns
 // borrow the buffer that the round about to begin will fill (its former content left the CU a round ago).  LDS: 2 x (T x
 // PER2 + B1 x (GK - 1)) keys + 14 KB - carved at run time (the pads follow B1); a shape that does not fit 160 KB keeps
 // scatter1x.
+#ifndef KT_S1Y_CARRY
+#define KT_S1Y_CARRY 1   // 0: a bucket's odd key leaves with an empty key beside it, every round (A/B builds)
+#endif
 #ifndef KT_S1Y_BATCH
 #define KT_S1Y_BATCH 1   // 0: the placement asks for a cursor and waits for it, key by key; 2: batched with 64-bit keys too (A/B builds)
 #endif
@@ -1175,6 +1178,13 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
     }
     uint32_t par = 0;      // parity of the round being made: it fills sorted[par], the round before it lies in sorted[par ^ 1]
     uint32_t nk_prev = 0;  // slots of the round whose groups are still leaving (0: none)
+    // CARRY (64-bit keys: two to a group): a bucket's odd key does not leave with an empty key beside it - 7 % of what level 1
+    // wrote and level 2 read at 1024 buckets - but waits in the sort buffer it lies in (which stays as it is for the whole of
+    // the next round: it is the one being copied out) and is counted and placed again by the bucket's thread in the next round.
+    // The copy-out knows the group by the empty key in its second place and sends it to the dump line; the space taken in the
+    // stream is the run's even part; what is left at the end of the launch goes out key by key, an empty key beside it.
+    constexpr bool CARRY = KT_S1Y_CARRY && GK == 2;
+    uint32_t rs_prev = 0, rc_prev = 0;  // this thread's bucket in the round before: where its run starts in sorted[], its keys
     constexpr uint32_t LSH1 = sizeof(K) == 8 ? 4 : 5;  // keys per 128-byte line (xcd_place)
     const uint32_t cap1_32 = (uint32_t)p.cap1, cap_lines = (uint32_t)(p.cap1 >> LSH1);  // (plan_job: a region is < 2^31 bytes)
     // group u of this thread's share of the round before: out to its place, or - nothing there, or no room - to the dump line
@@ -1182,9 +1192,10 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
         uint32_t m = tl + (uint32_t)u * T;
         asm volatile("" : "+v"(m));  // (pinned to its place in the round)
         const uint32_t i = m << GSH;
-        const bool live = i < nk_prev;
+        bool live = i < nk_prev;
         const K *const sb = sm.sorted[pp];
         const raw4 v = *reinterpret_cast<const raw4 *>(&sb[live ? i : 0u]);
+        if constexpr (CARRY) live = live && (v[2] & v[3]) != 0xFFFFFFFFu;  // (a run's odd key: it stays)
         const K first = sb[live ? i : 0u];
         const uint32_t d = digit1h(hash_of_stored<K>(first, p), p);
         // xcd_place in 32 bits (the line index of a stream that ran 2^32 keys past its room still fits), one 64-bit multiply-add
@@ -1253,6 +1264,14 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
                 }
                 emit_at(j);
             }
+            K carried = EMPTY;
+            uint32_t has_carry = 0;
+            if constexpr (CARRY) {
+                has_carry = rc_prev & 1u;
+                carried = sm.sorted[pp][has_carry ? rs_prev + rc_prev - 1u : 0u];
+                if constexpr (PACK) atomicAdd(&sm.cnt2[tl >> 1], has_carry << ((tl & 1u) * 16u));  // (has_carry: tl is a bucket)
+                else atomicAdd(&sm.cnt2[tl], has_carry);
+            }
             KT_PH(1);
             ktd::lds_barrier();
             KT_PH(2);
@@ -1270,7 +1289,8 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
                 if constexpr (PACK) atomicAnd(&sm.cnt2[d0 >> 1], (d0 & 1u) ? 0x0000FFFFu : 0xFFFF0000u);
                 else sm.cnt2[d0] = 0;
             }
-            const unsigned long long got = __hip_atomic_fetch_add(&mycur[dc], (unsigned long long)((rc + GK - 1u) & ~(GK - 1u)),
+            const uint32_t take = CARRY ? rc & ~1u : (rc + GK - 1u) & ~(GK - 1u);  // the keys of the run that leave
+            const unsigned long long got = __hip_atomic_fetch_add(&mycur[dc], (unsigned long long)take,
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!skip) emit(2, tl, pp);
             KT_PH(3);
@@ -1303,17 +1323,24 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
                     emit_at(PER + j);
                 }
             }
+            if constexpr (CARRY) {  // the bucket's odd key of the round before: placed like any other key of its bucket
+                const uint32_t posc = atomicAdd(&xs[dc], has_carry);
+                if (has_carry) sb[posc] = carried;
+            }
             KT_PH(5);
             if (rc) {
                 for (uint32_t e = rc; e & (GK - 1u); e++) sb[rs + e] = EMPTY;  // what the run lacks to its last group
                 // (a stream far past its room - a sender's heavy-hitter bucket - must not wrap back into it)
                 const uint32_t q0 = got > 0xE0000000ull ? 0xE0000000u : (uint32_t)got;
                 sm.delta[par][tl] = q0 - rs;
-                if (xcd_place<K>((uint64_t)q0 + rc - 1u, xset, p.nxs) >= p.cap1) {
+                const uint32_t leaving = CARRY ? take : rc;
+                if (leaving && xcd_place<K>((uint64_t)q0 + leaving - 1u, xset, p.nxs) >= p.cap1) {
                     *sm.ovf = 1;
                     atomicOr(ovf, 1u);
                 }
             }
+            rs_prev = rs;
+            rc_prev = rc;
             if (nxt) {
                 if (!skip) src.template prefetch_take<NST + 1>(tk, pre);
                 else src.template prefetch_take<0>(tk, pre);
@@ -1333,6 +1360,24 @@ __global__ __launch_bounds__(T, 4) void scatter1y_kernel(Source src, Plan p, uns
         asm volatile("" : "+v"(tl));
 #pragma unroll
         for (int u = 0; u < NST; u++) emit(u, tl, par ^ 1u);
+    }
+    if constexpr (CARRY) {
+        // what the last round left waiting: one group per bucket with an odd key, an empty key beside it
+        if (!stop && (rc_prev & 1u)) {
+            const K key = sm.sorted[par ^ 1u][rs_prev + rc_prev - 1u];
+            const uint32_t d = tid & (p.B1 - 1u);
+            const unsigned long long got = __hip_atomic_fetch_add(&mycur[d], 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t pos = got > 0xE0000000ull ? 0xE0000000u : (uint32_t)got;
+            const uint32_t lx = ((pos >> LSH1) << p.nxs) | xset;
+            if (lx < cap_lines) {
+                const uint32_t at = (lx << LSH1) | (pos & ((1u << LSH1) - 1u));
+                K *const dst = keys1 + ktd::mad64(d, cap1_32, at);
+                dst[0] = key;
+                dst[1] = EMPTY;
+            } else {
+                atomicOr(ovf, 1u);
+            }
+        }
     }
 #if KT_ABLATION
     if (tid == 0)
